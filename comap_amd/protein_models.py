@@ -1,0 +1,147 @@
+"""Empirical substitution-model tables used to build the generator Q handed to the engine.
+
+The engine itself (C-ABI, ``include/comap_mi355x.h``) takes Q, pi, rates and weights as
+plain arrays; nothing in this file is on the device path.  The reference obtains these
+tables from Bio++ (``model = JTT92`` in examples/Proteins/Benchmark/CoMap/comap.bpp:40,
+which Bio++ implements with the DCmut estimate of Kosiol & Goldman 2005); Bio++ is not in
+the reference tree, so the table below is typed in from the literature (PAML's
+``jones-dcmut.dat`` layout: lower-triangular exchangeabilities, then frequencies; amino
+acid order A R N D C Q E G H I L K M F P S T W Y V).  It is validated by reproducing the
+reference's committed ``Myo.infos`` / ``Myo_unif.vec`` fixtures (tests/test_golden_myoglobin.py).
+"""
+import numpy as np
+
+AA_ORDER = "ARNDCQEGHILKMFPSTWYV"
+
+_JTT_DCMUT_LOWER = """
+0.531678
+0.557967 0.451095
+0.827445 0.154899 5.549530
+0.574478 1.019843 0.313311 0.105625
+0.556725 3.021995 0.768834 0.521646 0.091304
+1.066681 0.318483 0.578115 7.766557 0.053907 3.417706
+1.740159 1.359652 0.773313 1.272434 0.546389 0.231294 1.115632
+0.219970 3.210671 4.025778 1.032342 0.724998 5.684080 0.243768 0.201696
+0.361684 0.239195 0.491003 0.115968 0.150559 0.078270 0.111773 0.053769 0.181788
+0.310007 0.372261 0.137289 0.061486 0.164593 0.709004 0.097485 0.069492 0.540571 2.335139
+0.369437 6.529255 2.529517 0.282466 0.049009 2.966732 1.731684 0.269840 0.525096 0.202562 0.146481
+0.469395 0.431045 0.330720 0.190001 0.409202 0.456901 0.175084 0.130379 0.329660 4.831666 3.856906 0.624581
+0.138293 0.065314 0.073481 0.032522 0.678335 0.045683 0.043829 0.050212 0.453428 0.777090 2.500294 0.024521 0.436181
+1.959599 0.710489 0.121804 0.127164 0.123653 1.608126 0.191994 0.208081 1.141961 0.098580 1.060504 0.216345 0.164215 0.148483
+3.887095 1.001551 5.057964 0.589268 2.155331 0.548807 0.312449 1.874296 0.743458 0.405119 0.592511 0.474478 0.285564 0.943971 2.788406
+4.582565 0.650282 2.351311 0.425159 0.469823 0.523825 0.331584 0.316862 0.477355 2.553806 0.272514 0.965641 2.114728 0.138904 1.176961 4.777647
+0.084329 1.257961 0.027700 0.057466 1.104181 0.172206 0.114381 0.544180 0.128193 0.134510 0.530324 0.089134 0.201334 0.537922 0.069965 0.310927 0.080556
+0.139492 0.235601 0.700693 0.453952 2.114852 0.254745 0.063452 0.052500 5.848400 0.303445 0.241094 0.087904 0.189870 5.484236 0.113850 0.628608 0.201094 0.747889
+2.924161 0.171995 0.164525 0.315261 0.621323 0.179771 0.465271 0.470140 0.121827 9.533943 1.761439 0.124066 3.038533 0.593478 0.211561 0.408532 1.143980 0.239697 0.165473
+"""
+
+_JTT_DCMUT_FREQ = """
+0.076862 0.051057 0.042546 0.051269 0.020279 0.041061 0.061820 0.074714 0.022983 0.052569
+0.091111 0.059498 0.023414 0.040530 0.050532 0.068225 0.058518 0.014336 0.032303 0.066374
+"""
+
+# Grantham (1974) chemical distance, upper triangle in AA_ORDER (used by the weighted
+# fixtures Myo_*_grantham.vec: nijt=...(weight=AAdist(type=grantham, sym=yes)),
+# examples/Proteins/Benchmark/CoMap/analyse.sh:31-43).
+_GRANTHAM_UPPER = """
+112 111 126 195  91 107  60  86  94  96 106  84 113  27  99  58 148 112  64
+     86  96 180  43  54 125  29  97 102  26  91  97 103 110  71 101  77  96
+         23 139  46  42  80  68 149 153  94 142 158  91  46  65 174 143 133
+            154  61  45  94  81 168 172 101 160 177 108  65  85 181 160 152
+                154 170 159 174 198 198 202 196 205 169 112 149 215 194 192
+                     29  87  24 109 113  53 101 116  76  68  42 130  99  96
+                         98  40 134 138  56 126 140  93  80  65 152 122 121
+                             98 135 138 127 127 153  42  56  59 184 147 109
+                                 94  99  32  87 100  77  89  47 115  83  84
+                                      5 102  10  21  95 142  89  61  33  29
+                                        107  15  22  98 145  92  61  36  32
+                                             95 102 103 121  78 110  85  97
+                                                 28  87 135  81  67  36  21
+                                                    114 155 103  40  22  50
+                                                         74  38 147 110  68
+                                                             58 177 144 124
+                                                                128  92  69
+                                                                     37  88
+                                                                         55
+"""
+
+
+def _lower_to_sym(txt, n=20):
+    vals = [float(x) for x in txt.split()]
+    assert len(vals) == n * (n - 1) // 2
+    S = np.zeros((n, n))
+    k = 0
+    for i in range(1, n):
+        for j in range(i):
+            S[i, j] = S[j, i] = vals[k]
+            k += 1
+    return S
+
+
+def _upper_to_sym(txt, n=20):
+    vals = [float(x) for x in txt.split()]
+    assert len(vals) == n * (n - 1) // 2
+    S = np.zeros((n, n))
+    k = 0
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            S[i, j] = S[j, i] = vals[k]
+            k += 1
+    return S
+
+
+def reversible_generator(exch, freq):
+    """Q = S.diag(pi), rows summing to 0, scaled so that -sum_i pi_i Q_ii = 1.
+
+    pi is renormalised to sum to one first (the published JTT frequencies sum to 1.000001).
+    Returns (Q row-major [S,S], pi)."""
+    pi = np.asarray(freq, dtype=np.float64)
+    pi = pi / pi.sum()
+    Q = np.asarray(exch, dtype=np.float64) * pi[None, :]
+    np.fill_diagonal(Q, 0.0)
+    np.fill_diagonal(Q, -Q.sum(axis=1))
+    scale = -(pi * np.diag(Q)).sum()
+    return Q / scale, pi
+
+
+def jtt92():
+    """JTT92 (DCmut) generator and equilibrium frequencies."""
+    S = _lower_to_sym(_JTT_DCMUT_LOWER)
+    f = np.array([float(x) for x in _JTT_DCMUT_FREQ.split()])
+    return reversible_generator(S, f)
+
+
+def grantham_distance():
+    return _upper_to_sym(_GRANTHAM_UPPER)
+
+
+def gtr(a, b, c, d, e, theta, theta1, theta2):
+    """Bio++ GTR parameterisation (states A C G T):
+    exchangeabilities a=C<->T... as in bpp-phyl GTR: S(A,C)=d, S(A,G)=1(kappa slot)...
+    Implemented as: r_AC=d, r_AG=1, r_AT=b, r_CG=c, r_CT=a, r_GT=e ;
+    piA=theta1(1-theta), piC=(1-theta2)theta, piG=theta2 theta, piT=(1-theta1)(1-theta)."""
+    pi = np.array([theta1 * (1 - theta), (1 - theta2) * theta, theta2 * theta, (1 - theta1) * (1 - theta)])
+    S = np.array([[0, d, 1.0, b], [d, 0, c, a], [1.0, c, 0, e], [b, a, e, 0]], dtype=np.float64)
+    return reversible_generator(S, pi)
+
+
+def synthetic_reversible(nstates, seed):
+    """Seeded random reversible generator (throughput work is model-independent)."""
+    rng = np.random.default_rng(seed)
+    S = rng.gamma(0.7, 1.0, size=(nstates, nstates))
+    S = (S + S.T) / 2
+    f = rng.dirichlet(np.full(nstates, 5.0))
+    return reversible_generator(S, f)
+
+
+def gamma_rates(alpha, ncat):
+    """Equiprobable discrete Gamma(alpha, beta=alpha), class value = mean of the class
+    (pinned by max PR in Myo.infos)."""
+    from scipy.stats import gamma as _g
+    from scipy.special import gammainc
+    q = _g.ppf(np.arange(1, ncat) / ncat, a=alpha, scale=1.0 / alpha)
+    cuts = np.concatenate([[0.0], q, [np.inf]])
+    inc = gammainc(alpha + 1.0, cuts * alpha)
+    rates = (inc[1:] - inc[:-1]) * ncat
+    probs = np.full(ncat, 1.0 / ncat)
+    return rates, probs

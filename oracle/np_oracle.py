@@ -1,0 +1,278 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the reference hot path (second, independent
+oracle next to oracle/oracle.c).  Nothing under comap_amd/ may import this module; only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg use oracle/.
+
+The arithmetic restated here lives in Bio++ (bpp-core / bpp-seq / bpp-phyl >= 3.0.0,
+/root/reference/CMakeLists.txt:107), which is NOT vendored in the reference and is absent from
+this image, so the published algorithms are restated and pinned against
+the reference's own committed fixtures examples/Proteins/Benchmark/CoMap/Myo_{unif,decomp,naive}
+[_grantham].vec and Myo.infos (tests/golden/myoglobin.npz, tests/test_golden_myoglobin.py).
+Parity for pair statistics / null / Mica MI is UNPINNED by reference outputs (none are
+committed); those follow the in-tree formulas cited per function.
+
+Tree convention everywhere in this repo: nodes in post-order, root last; parent[root] = -1;
+branch index b == id of the branch's lower node (rows of the reference .vec files).
+"""
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- tree
+def parse_newick(txt):
+    """Newick -> (parent[int], blen[float], names[list|None per node]) in post-order, root last.
+    Node ids are assigned as nodes close (confirmed on Myo_unif.vec rows)."""
+    txt = txt.strip()
+    assert txt.endswith(";")
+    pos = 0
+    parent, blen, names = [], [], []
+
+    def parse_node():
+        nonlocal pos
+        children = []
+        name = None
+        if txt[pos] == "(":
+            pos += 1
+            while True:
+                children.append(parse_node())
+                if txt[pos] == ",":
+                    pos += 1
+                    continue
+                if txt[pos] == ")":
+                    pos += 1
+                    break
+                raise ValueError("bad newick at %d" % pos)
+        start = pos
+        while txt[pos] not in ":,();":
+            pos += 1
+        label = txt[start:pos].strip()
+        if not children:
+            name = label
+        length = 0.0
+        if txt[pos] == ":":
+            pos += 1
+            start = pos
+            while txt[pos] not in ",();":
+                pos += 1
+            length = float(txt[start:pos])
+        nid = len(parent)
+        parent.append(-1)
+        blen.append(length)
+        names.append(name)
+        for c in children:
+            parent[c] = nid
+        return nid
+
+    parse_node()
+    return np.array(parent, dtype=np.int32), np.array(blen, dtype=np.float64), names
+
+
+def unroot(parent, blen, names):
+    """DRHomogeneousTreeLikelihood(checkRooted=true) unroots a bifurcating root
+    (CoETools.cpp:124): the two root branches are merged and node ids re-assigned in post-order."""
+    n = len(parent)
+    root = n - 1
+    kids = [i for i in range(n) if parent[i] == root]
+    if len(kids) != 2:
+        return parent, blen, names
+    # remove the root, attach first internal child as new root (Bio++ TreeTemplate::unroot keeps son0 or son1
+    # whichever is internal; branch lengths are summed)
+    a, b = kids
+    new_root = a if any(parent[i] == a for i in range(n)) else b
+    other = b if new_root == a else a
+    children = {i: [j for j in range(n) if parent[j] == i] for i in range(n)}
+    children[new_root] = children[new_root] + [other]
+    bl = blen.copy()
+    bl[other] = blen[a] + blen[b]
+    order = []
+
+    def visit(u):
+        for c in children[u]:
+            if c != root:
+                visit(c)
+        order.append(u)
+
+    visit(new_root)
+    remap = {old: new for new, old in enumerate(order)}
+    p2 = np.full(len(order), -1, dtype=np.int32)
+    b2 = np.zeros(len(order))
+    n2 = [None] * len(order)
+    for old in order:
+        new = remap[old]
+        n2[new] = names[old]
+        if old == new_root:
+            continue
+        par = new_root if old == other else parent[old]
+        p2[new] = remap[par]
+        b2[new] = bl[old]
+    return p2, b2, n2
+
+
+def children_lists(parent):
+    ch = [[] for _ in parent]
+    for i, p in enumerate(parent):
+        if p >= 0:
+            ch[p].append(i)
+    return ch
+
+
+# ----------------------------------------------------------------------------- model
+def eigen_reversible(Q, pi):
+    """Q = V diag(lam) Vinv through the symmetrised generator (reversible models)."""
+    s = np.sqrt(pi)
+    A = (s[:, None] * Q) / s[None, :]
+    A = (A + A.T) / 2
+    lam, U = np.linalg.eigh(A)
+    V = U / s[:, None]
+    Vinv = U.T * s[None, :]
+    return lam, V, Vinv
+
+
+def transition_matrix(lam, V, Vinv, t):
+    return (V * np.exp(lam * t)[None, :]) @ Vinv
+
+
+def count_matrix_uniformization(Q, Bm, t):
+    """J(t) = int_0^t e^{Qs} B e^{Q(t-s)} ds by uniformization (Bio++
+    UniformizationSubstitutionCount, the reference's default nijt, doc/comap.texi:155).
+    Returns J (not yet divided by P)."""
+    S = Q.shape[0]
+    mu = np.max(np.abs(np.diag(Q)))
+    R = np.eye(S) + Q / mu
+    mt = mu * t
+    nmax = int(np.ceil(4 + 6 * np.sqrt(mt) + mt)) + 10
+    # s_n = sum_{l=0}^{n} R^l B R^{n-l};  s_{n+1} = R s_n + B R^{n+1}
+    Rn = np.eye(S)
+    s = Bm.copy()
+    J = np.zeros((S, S))
+    # Pois(n+1; mt) = e^{-mt} mt^{n+1}/(n+1)!
+    logp = -mt + np.log(mt)  # n = 0 -> Pois(1)
+    for n in range(nmax + 1):
+        J += np.exp(logp) / mu * s
+        Rn = Rn @ R
+        s = R @ s + Bm @ Rn
+        logp += np.log(mt) - np.log(n + 2)
+    return J
+
+
+def count_matrix_decomposition(lam, V, Vinv, Bm, t):
+    """J = V [ (Vinv B V) o Phi(t) ] Vinv (DecompositionSubstitutionCount)."""
+    e = np.exp(lam * t)
+    dl = lam[:, None] - lam[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        Phi = np.where(np.abs(dl) > 1e-12 * (1 + np.abs(lam[:, None])), (e[:, None] - e[None, :]) / dl, t * e[:, None])
+    return V @ ((Vinv @ Bm @ V) * Phi) @ Vinv
+
+
+def rate_matrix_register(Q, W=None):
+    """B = Q o [x != y] o W  (total register; W == 1 unweighted)."""
+    Bm = Q.copy()
+    np.fill_diagonal(Bm, 0.0)
+    if W is not None:
+        Bm = Bm * W
+    return Bm
+
+
+def conditional_counts(J, P, nonneg):
+    """N = J / P with Bio++'s guards: NaN/Inf -> 0; unweighted negatives -> 0."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        N = J / P
+    N[~np.isfinite(N)] = 0.0
+    if nonneg:
+        N[N < 0] = 0.0
+    return N
+
+
+# ----------------------------------------------------------------------------- likelihood + mapping
+def leaf_partials(codes, masks, S):
+    """codes: [N] uint8 per site; masks: [ncodes] uint32 bitmask of compatible states -> [N,S] 0/1."""
+    m = masks[codes]
+    return ((m[:, None] >> np.arange(S)[None, :]) & 1).astype(np.float64)
+
+
+def map_sites(parent, blen, leaf_of_taxon, aln, masks, Q, pi, rates, probs, Bk_list, method="unif",
+              nonneg=None, naive_W=None):
+    """DR likelihood + computeSubstitutionVectors(average=yes, joint=yes).
+
+    aln: [T, N] uint8 codes (taxon-major).  Returns dict(counts[N,B,K], logL[N], post_rate[N],
+    rate_class[N], norm[N])."""
+    parent = np.asarray(parent)
+    nn = len(parent)
+    root = nn - 1
+    B = nn - 1
+    T, N = aln.shape
+    S = len(pi)
+    C = len(rates)
+    K = len(Bk_list) if method != "naive" else 1
+    ch = children_lists(parent)
+    lam, V, Vinv = eigen_reversible(Q, pi)
+    taxon_of_leaf = {int(n): t for t, n in enumerate(leaf_of_taxon)}
+
+    D = [None] * nn          # D[n]: [C, N, S]
+    M = [None] * nn          # M[e] = P_e D_e : [C, N, S]
+    P = np.zeros((nn, C, S, S))
+    for e in range(B):
+        for c in range(C):
+            P[e, c] = transition_matrix(lam, V, Vinv, blen[e] * rates[c])
+    for n in range(nn):
+        if not ch[n]:
+            lp = leaf_partials(aln[taxon_of_leaf[n]], masks, S)
+            D[n] = np.broadcast_to(lp[None], (C, N, S)).copy()
+        else:
+            acc = np.ones((C, N, S))
+            for e in ch[n]:
+                acc = acc * M[e]
+            D[n] = acc
+        if n != root:
+            M[n] = np.einsum("cxz,cnz->cnx", P[n], D[n])
+    Lc = np.einsum("cnx,x->cn", D[root], pi)                 # [C,N]
+    L = (probs[:, None] * Lc).sum(0)
+    post = probs[:, None] * Lc
+    post_rate = (rates[:, None] * post).sum(0) / L
+    rate_class = np.argmax(post, axis=0).astype(np.int32)
+
+    # outside pass
+    Up = [None] * nn      # message arriving at node n from above, [C,N,S] (includes pi at root)
+    Up[root] = np.broadcast_to(pi[None, None, :], (C, N, S)).copy()
+    counts = np.zeros((N, B, K))
+    for f in range(nn - 1, -1, -1):
+        if not ch[f]:
+            continue
+        for n in ch[f]:
+            U = Up[f].copy()
+            for m in ch[f]:
+                if m != n:
+                    U = U * M[m]
+            for k in range(K):
+                tot = np.zeros(N)
+                for c in range(C):
+                    t = blen[n] * rates[c]
+                    if method == "naive":
+                        Nm = np.ones((S, S)) if naive_W is None else naive_W.copy()
+                        np.fill_diagonal(Nm, 0.0)
+                    else:
+                        if method == "unif":
+                            J = count_matrix_uniformization(Q, Bk_list[k], t)
+                        else:
+                            J = count_matrix_decomposition(lam, V, Vinv, Bk_list[k], t)
+                        Nm = conditional_counts(J, P[n, c], nonneg if nonneg is not None else True)
+                    JJ = P[n, c] * Nm
+                    tot += probs[c] * np.einsum("nx,xy,ny->n", U[c], JJ, D[n][c])
+                counts[:, n, k] = tot / L
+            if ch[n]:
+                Up[n] = np.einsum("cxz,cnx->cnz", P[n], U)
+    norm = np.sqrt((counts.sum(axis=2) ** 2).sum(axis=1))
+    return dict(counts=counts, logL=np.log(L), post_rate=post_rate, rate_class=rate_class, norm=norm)
+
+
+# ----------------------------------------------------------------------------- statistics (CoMap/Statistics.h)
+def stat_correlation(x, y):
+    """CorrelationStatistic::getValueForPair, Statistics.h:164-174 -> VectorTools::cor (A.7)."""
+    dx = x - x.mean()
+    dy = y - y.mean()
+    n = len(x)
+    cov = (dx * dy).sum() / (n - 1)
+    return cov / (np.sqrt((dx * dx).sum() / (n - 1)) * np.sqrt((dy * dy).sum() / (n - 1)))
+
+
+def stat_compensation(x, y):
+    """CompensationStatistic::getValueForPair, Statistics.h:247-265 (x,y per-branch totals)."""
+    return 1.0 - np.sqrt(((x + y) ** 2).sum()) / (np.sqrt((x * x).sum()) + np.sqrt((y * y).sum()))
