@@ -1,0 +1,565 @@
+// C-ABI of the engine (include/comap_mi355x.h).  Host-side orchestration only: uploads the prepared model,
+// owns the per-wave workspace, launches the HIP kernels.  There is no CPU compute path: without a HIP device every
+// compute entry point fails with CMX_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/comap_mi355x.h"
+#include "cmx_device.h"
+#include "cmx_host_model.h"
+
+using namespace cmx;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+}  // namespace
+
+struct cmx_ctx {
+  int device = 0;
+  bool has_model = false;
+  HostModel hm;
+  DevModel dm{};
+  Workspace ws{};
+  int cu_count = 0, waves = 0, grid_blocks = 0;
+  size_t ws_bytes = 0;
+  std::vector<void*> model_allocs;
+  std::map<std::string, DevBuf> scratch;
+  uint32_t* d_default_masks = nullptr;
+  mutable std::string err;
+};
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) {                                                                                  \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                        \
+      return CMX_ERR_DEVICE;                                                                                 \
+    }                                                                                                        \
+  } while (0)
+
+namespace {
+
+cmx_status fail(cmx_ctx* ctx, cmx_status s, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return s;
+}
+
+template <class T>
+cmx_status upload(cmx_ctx* ctx, const std::vector<T>& h, const T** d) {
+  void* p = nullptr;
+  const size_t bytes = sizeof(T) * (h.empty() ? 1 : h.size());
+  HIP_TRY(ctx, hipMalloc(&p, bytes));
+  ctx->model_allocs.push_back(p);
+  if (!h.empty()) HIP_TRY(ctx, hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+  *d = static_cast<const T*>(p);
+  return CMX_OK;
+}
+
+// grow-only named scratch buffers (allocated on first use, released with the context)
+cmx_status scratch(cmx_ctx* ctx, const char* name, size_t bytes, void** out) {
+  DevBuf& b = ctx->scratch[name];
+  if (b.bytes < bytes) {
+    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
+    b.bytes = bytes;
+  }
+  *out = b.p;
+  return CMX_OK;
+}
+
+struct TmpDev {  // RAII device temporaries for the host-pointer entry points
+  std::vector<void*> ptrs;
+  ~TmpDev() { for (void* p : ptrs) (void)hipFree(p); }
+  hipError_t alloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e == hipSuccess) ptrs.push_back(*p);
+    return e;
+  }
+};
+
+cmx_status need_model(cmx_ctx* ctx) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!ctx->has_model) return fail(ctx, CMX_ERR_INVALID, "this context was created without a model/tree");
+  return CMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cmx_version(void) { return "comap_mi355x 0.1 (gfx950)"; }
+
+const char* cmx_last_error(const cmx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int device, cmx_ctx** out) {
+  if (!out) return CMX_ERR_INVALID;
+  *out = nullptr;
+  cmx_ctx* ctx = new cmx_ctx();
+  ctx->device = device;
+  auto bail = [&](cmx_status s) {
+    g_create_error = ctx->err;
+    cmx_ctx_destroy(ctx);
+    return s;
+  };
+  if ((model == nullptr) != (tree == nullptr)) {
+    ctx->err = "model and tree must be given together (both NULL creates a context for cmx_mi_columns only)";
+    return bail(CMX_ERR_INVALID);
+  }
+  if (model) {
+    int code = CMX_OK;
+    std::string msg = build_host_model(model, tree, &ctx->hm, &code);
+    if (!msg.empty()) {
+      ctx->err = msg;
+      return bail((cmx_status)code);
+    }
+    ctx->has_model = true;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    ctx->err = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+               "); this engine has no CPU path";
+    return bail(CMX_ERR_DEVICE);
+  }
+  if (device < 0 || device >= ndev) {
+    ctx->err = "device index out of range";
+    return bail(CMX_ERR_INVALID);
+  }
+  auto dev_init = [&]() -> cmx_status {
+    HIP_TRY(ctx, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(ctx, CMX_ERR_UNSUPPORTED, std::string("built for gfx950 only, device is ") + prop.gcnArchName);
+    ctx->cu_count = prop.multiProcessorCount;
+    std::vector<uint32_t> dm(256);
+    for (int i = 0; i < 256; ++i) dm[i] = i < 32 ? (1u << i) : 0xffffffffu;
+    const uint32_t* p = nullptr;
+    cmx_status s = upload(ctx, dm, &p);
+    if (s != CMX_OK) return s;
+    ctx->d_default_masks = const_cast<uint32_t*>(p);
+    if (!ctx->has_model) return CMX_OK;
+    const HostModel& h = ctx->hm;
+    DevModel& d = ctx->dm;
+    d.S = h.S; d.C = h.C; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.root = h.root;
+#define UP(field) if ((s = upload(ctx, h.field, &d.field)) != CMX_OK) return s
+    UP(int_post); UP(first_child); UP(next_sib); UP(taxon_of); UP(slot); UP(parent);
+    UP(PP); UP(JP); UP(LPT); UP(LJT); UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
+#undef UP
+    // ambiguity masks default: code c >= S compatible with every state; fix the table for this S
+    for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
+    // per-wave workspace: 2 waves per SIMD on every CU
+    ctx->grid_blocks = ctx->cu_count * 2;
+    ctx->waves = ctx->grid_blocks * kWavesPerBlock;
+    const size_t w = (size_t)ctx->waves;
+    const size_t bD = w * h.NI * h.S * kWave * sizeof(double);
+    const size_t bC = w * 2 * h.B * h.K * kWave * sizeof(double);
+    const size_t bS = w * h.nn * kWave, bA = w * h.T * kWave;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.D, bD));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.U, bD));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.cnt, bC));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.st, bS));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.aln, bA));
+    ctx->ws.waves = ctx->waves;
+    ctx->ws_bytes = 2 * bD + bC + bS + bA;
+    return CMX_OK;
+  };
+  cmx_status s = dev_init();
+  if (s != CMX_OK) return bail(s);
+  *out = ctx;
+  return CMX_OK;
+}
+
+void cmx_ctx_destroy(cmx_ctx* ctx) {
+  if (!ctx) return;
+  for (void* p : ctx->model_allocs) (void)hipFree(p);
+  for (auto& kv : ctx->scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+  if (ctx->ws.D) (void)hipFree(ctx->ws.D);
+  if (ctx->ws.U) (void)hipFree(ctx->ws.U);
+  if (ctx->ws.cnt) (void)hipFree(ctx->ws.cnt);
+  if (ctx->ws.st) (void)hipFree(ctx->ws.st);
+  if (ctx->ws.aln) (void)hipFree(ctx->ws.aln);
+  delete ctx;
+}
+
+cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info) {
+  if (!ctx || !info) return CMX_ERR_INVALID;
+  std::memset(info, 0, sizeof(*info));
+  info->nstates = ctx->hm.S; info->nclasses = ctx->hm.C; info->ntypes = ctx->hm.K; info->nnodes = ctx->hm.nn;
+  info->nbranches = ctx->hm.B; info->ntaxa = ctx->hm.T; info->ninternal = ctx->hm.NI;
+  info->device = ctx->device; info->cu_count = ctx->cu_count; info->waves = ctx->waves;
+  info->workspace_bytes = ctx->ws_bytes;
+  return CMX_OK;
+}
+
+cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P) {
+  if (!ctx || !P || !ctx->has_model) return CMX_ERR_INVALID;
+  std::memcpy(P, ctx->hm.P.data(), sizeof(double) * ctx->hm.P.size());
+  return CMX_OK;
+}
+
+cmx_status cmx_synchronize(cmx_ctx* ctx) {
+  if (!ctx) return CMX_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  return CMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ mapping
+cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
+                             double* d_counts, size_t ldc, double* d_logL, double* d_post_rate, int32_t* d_rate_class,
+                             double* d_norm, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!d_aln || nsites == 0 || ld < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: bad alignment arguments");
+  if (d_counts && ldc < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: ldc < nsites");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MapArgs a{};
+  a.m = ctx->dm; a.ws = ctx->ws;
+  a.aln = d_aln; a.ld = ld; a.nsites = nsites; a.masks = d_masks ? d_masks : ctx->d_default_masks;
+  a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
+  a.norm = d_norm;
+  const size_t blocks_needed = ((nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int grid = (int)std::min<size_t>(blocks_needed, (size_t)ctx->grid_blocks);
+  HIP_TRY(ctx, launch_map(a, kModeObserved, grid, (hipStream_t)stream));
+  return CMX_OK;
+}
+
+cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t ld, const uint32_t* masks,
+                         size_t nmasks, double* counts, double* logL, double* post_rate, int32_t* rate_class,
+                         double* norm) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!aln || nsites == 0 || ld < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: bad alignment arguments");
+  const HostModel& h = ctx->hm;
+  // every code must be a state or a known mask (the reference throws BadCharException at alignment parsing)
+  for (int t = 0; t < h.T; ++t)
+    for (size_t i = 0; i < nsites; ++i) {
+      const unsigned c = aln[(size_t)t * ld + i];
+      if (c >= (unsigned)h.S && masks && c >= nmasks) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: alignment code without a mask");
+    }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  TmpDev tmp;
+  uint8_t* d_aln = nullptr;
+  uint32_t* d_masks = nullptr;
+  double *d_counts = nullptr, *d_logL = nullptr, *d_pr = nullptr, *d_norm = nullptr;
+  int32_t* d_rc = nullptr;
+  const size_t BK = (size_t)h.B * h.K;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_aln, (size_t)h.T * nsites));
+  HIP_TRY(ctx, hipMemcpy2D(d_aln, nsites, aln, ld, nsites, h.T, hipMemcpyHostToDevice));
+  if (masks) {
+    std::vector<uint32_t> mk(256, h.S >= 32 ? 0xffffffffu : ((1u << h.S) - 1u));
+    for (size_t i = 0; i < nmasks && i < 256; ++i) mk[i] = masks[i];
+    HIP_TRY(ctx, tmp.alloc((void**)&d_masks, 256 * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemcpy(d_masks, mk.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  if (counts) HIP_TRY(ctx, tmp.alloc((void**)&d_counts, BK * nsites * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_logL, nsites * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_pr, nsites * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_norm, nsites * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_rc, nsites * sizeof(int32_t)));
+  s = cmx_map_sites_dev(ctx, d_aln, nsites, nsites, d_masks, d_counts, nsites, d_logL, d_pr, d_rc, d_norm, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  if (counts) {  // branch-major [B*K][N] -> site-major [N][B][K] (reference layout mapping[i][b][k])
+    std::vector<double> bm(BK * nsites);
+    HIP_TRY(ctx, hipMemcpy(bm.data(), d_counts, bm.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < BK; ++r)
+      for (size_t i = 0; i < nsites; ++i) counts[i * BK + r] = bm[r * nsites + i];
+  }
+  if (logL) HIP_TRY(ctx, hipMemcpy(logL, d_logL, nsites * sizeof(double), hipMemcpyDeviceToHost));
+  if (post_rate) HIP_TRY(ctx, hipMemcpy(post_rate, d_pr, nsites * sizeof(double), hipMemcpyDeviceToHost));
+  if (norm) HIP_TRY(ctx, hipMemcpy(norm, d_norm, nsites * sizeof(double), hipMemcpyDeviceToHost));
+  if (rate_class) HIP_TRY(ctx, hipMemcpy(rate_class, d_rc, nsites * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ simulator
+cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln_out, int32_t* classes_out) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!aln_out || n == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_simulate: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const HostModel& h = ctx->hm;
+  TmpDev tmp;
+  uint8_t *d_aln = nullptr, *d_st = nullptr;
+  int32_t* d_cls = nullptr;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_aln, (size_t)h.T * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_st, (size_t)h.nn * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_cls, n * sizeof(int32_t)));
+  HIP_TRY(ctx, launch_simulate(ctx->dm, seed, g0, n, d_aln, n, d_cls, d_st, nullptr));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(aln_out, d_aln, (size_t)h.T * n, hipMemcpyDeviceToHost));
+  if (classes_out) HIP_TRY(ctx, hipMemcpy(classes_out, d_cls, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pair statistics
+static cmx_status check_kind(cmx_ctx* ctx, int kind) {
+  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_DISCRETE_MI) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
+  return CMX_OK;
+}
+
+cmx_status cmx_pair_stats_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts1, size_t n1,
+                              size_t ld1, const double* d_counts2, size_t n2, size_t ld2, double* d_out, size_t ldo,
+                              void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
+  const bool intra = d_counts2 == nullptr;
+  if (intra) { n2 = n1; ld2 = ld1; }
+  if (!d_counts1 || !d_out || n1 == 0 || n2 == 0 || ld1 < n1 || ld2 < n2 || ldo < n2)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_pair_stats: bad arguments");
+  const HostModel& h = ctx->hm;
+  if (h.B < 2) return fail(ctx, CMX_ERR_INVALID, "cmx_pair_stats: need at least two branches");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  const int Bp = (h.B + 3) / 4 * 4;
+  const size_t ldx1 = (n1 + 15) / 16 * 16, ldx2 = (n2 + 15) / 16 * 16;
+  double *X1, *s1, *r1, *X2, *s2, *r2;
+  if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx1, (void**)&X1)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pair_s1", sizeof(double) * n1, (void**)&s1)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pair_r1", sizeof(double) * n1, (void**)&r1)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_pair_prep(kind, param, d_counts1, n1, ld1, h.B, h.K, X1, ldx1, Bp, s1, r1, st));
+  if (intra) { X2 = X1; s2 = s1; r2 = r1; }
+  else {
+    if ((s = scratch(ctx, "pair_X2", sizeof(double) * Bp * ldx2, (void**)&X2)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_s2", sizeof(double) * n2, (void**)&s2)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_r2", sizeof(double) * n2, (void**)&r2)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_pair_prep(kind, param, d_counts2, n2, ld2, h.B, h.K, X2, ldx2, Bp, s2, r2, st));
+  }
+  HIP_TRY(ctx, launch_pair_gram(kind, h.B, Bp, X1, s1, r1, n1, ldx1, X2, s2, r2, n2, intra ? ldx1 : ldx2, intra ? 1 : 0,
+                                d_out, ldo, st));
+  return CMX_OK;
+}
+
+static void to_branch_major(const double* sm, size_t n, size_t BK, std::vector<double>* bm) {
+  bm->resize(BK * n);
+  for (size_t i = 0; i < n; ++i)
+    for (size_t r = 0; r < BK; ++r) (*bm)[r * n + i] = sm[i * BK + r];
+}
+
+cmx_status cmx_pair_stats(cmx_ctx* ctx, int kind, const double* params, const double* counts1, size_t n1,
+                          const double* counts2, size_t n2, double* out) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!counts1 || !out || n1 == 0 || (counts2 && n2 == 0)) return fail(ctx, CMX_ERR_INVALID, "cmx_pair_stats: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t BK = (size_t)ctx->hm.B * ctx->hm.K;
+  if (!counts2) n2 = n1;
+  TmpDev tmp;
+  std::vector<double> bm;
+  double *d1 = nullptr, *d2 = nullptr, *d_out = nullptr;
+  to_branch_major(counts1, n1, BK, &bm);
+  HIP_TRY(ctx, tmp.alloc((void**)&d1, bm.size() * sizeof(double)));
+  HIP_TRY(ctx, hipMemcpy(d1, bm.data(), bm.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (counts2) {
+    to_branch_major(counts2, n2, BK, &bm);
+    HIP_TRY(ctx, tmp.alloc((void**)&d2, bm.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(d2, bm.data(), bm.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(ctx, tmp.alloc((void**)&d_out, n1 * n2 * sizeof(double)));
+  s = cmx_pair_stats_dev(ctx, kind, params, d1, n1, n1, d2, n2, n2, d_out, n2, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, d_out, n1 * n2 * sizeof(double), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ null distribution
+cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin,
+                              size_t rep_end, size_t rep_ram, const uint8_t* d_supplied, double* d_stat,
+                              int32_t* d_rcmin, double* d_prmin, double* d_nmin, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
+  if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MapArgs a{};
+  a.m = ctx->dm; a.ws = ctx->ws;
+  a.masks = ctx->d_default_masks;
+  a.nsites = (rep_end - rep_begin) * rep_ram;
+  a.stat_kind = kind;
+  a.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  a.seed = seed; a.rep_begin = rep_begin; a.rep_ram = rep_ram; a.supplied = d_supplied;
+  a.null_stat = d_stat; a.null_rcmin = d_rcmin; a.null_prmin = d_prmin; a.null_nmin = d_nmin;
+  const size_t blocks_needed = ((a.nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int grid = (int)std::min<size_t>(blocks_needed, (size_t)ctx->grid_blocks);
+  HIP_TRY(ctx, launch_map(a, kModeNull, grid, (hipStream_t)stream));
+  return CMX_OK;
+}
+
+cmx_status cmx_null_intra(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin, size_t rep_end,
+                          size_t rep_ram, const uint8_t* supplied, double* stat, int32_t* rcmin, double* prmin,
+                          double* nmin) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (rep_end <= rep_begin || rep_ram == 0 || !stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = (rep_end - rep_begin) * rep_ram;
+  TmpDev tmp;
+  uint8_t* d_sup = nullptr;
+  double *d_stat, *d_pr, *d_nm;
+  int32_t* d_rc;
+  if (supplied) {
+    const size_t bytes = (rep_end - rep_begin) * 2 * (size_t)ctx->hm.T * rep_ram;
+    for (size_t i = 0; i < bytes; ++i)
+      if (supplied[i] >= (unsigned)ctx->hm.S) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra: supplied alignments must be fully resolved");
+    HIP_TRY(ctx, tmp.alloc((void**)&d_sup, bytes));
+    HIP_TRY(ctx, hipMemcpy(d_sup, supplied, bytes, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(ctx, tmp.alloc((void**)&d_stat, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_pr, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_nm, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_rc, n * sizeof(int32_t)));
+  s = cmx_null_intra_dev(ctx, kind, params, seed, rep_begin, rep_end, rep_ram, d_sup, d_stat, d_rc, d_pr, d_nm, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(stat, d_stat, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (rcmin) HIP_TRY(ctx, hipMemcpy(rcmin, d_rc, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (prmin) HIP_TRY(ctx, hipMemcpy(prmin, d_pr, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (nmin) HIP_TRY(ctx, hipMemcpy(nmin, d_nm, n * sizeof(double), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ p-values
+cmx_status cmx_intra_pvalues_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, const double* d_norms, size_t n,
+                                 int nclasses, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
+                                 double* d_pvalue, int32_t* d_nsim, void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!d_stat || !d_norms || !d_pvalue || !d_nsim || n == 0 || ldo < n || nclasses < 1 || nclasses > 64 ||
+      (nnull > 0 && (!d_null_stat || !d_null_nmin)) || nnull > 0xfffffff0ull)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_intra_pvalues: bad arguments (nclasses must be in 1..64)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  cmx_status s;
+  double *maxnorm, *sa, *sb;
+  uint32_t *ca, *cb, *hist;
+  const size_t nn = nnull ? nnull : 1;
+  if ((s = scratch(ctx, "pv_max", sizeof(double), (void**)&maxnorm)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_sa", sizeof(double) * nn, (void**)&sa)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_sb", sizeof(double) * nn, (void**)&sb)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_ca", sizeof(uint32_t) * nn, (void**)&ca)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_cb", sizeof(uint32_t) * nn, (void**)&cb)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_hist", sizeof(uint32_t) * 66, (void**)&hist)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_max_reduce(d_norms, n, maxnorm, st));
+  HIP_TRY(ctx, launch_null_classify(d_null_stat, d_null_nmin, nnull, maxnorm, nclasses, ca, hist, st));
+  if (nnull > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(sa, d_null_stat, sizeof(double) * nnull, hipMemcpyDeviceToDevice, st));
+    size_t tmp_bytes = 0;
+    HIP_TRY(ctx, sort_null_by_class(nullptr, tmp_bytes, sa, sb, ca, cb, nnull, st));
+    void* tmp;
+    if ((s = scratch(ctx, "pv_sorttmp", tmp_bytes, &tmp)) != CMX_OK) return s;
+    HIP_TRY(ctx, sort_null_by_class(tmp, tmp_bytes, sa, sb, ca, cb, nnull, st));
+  }
+  HIP_TRY(ctx, launch_pvalues(d_stat, ldo, d_norms, n, maxnorm, nclasses, sa, hist, d_pvalue, d_nsim, st));
+  return CMX_OK;
+}
+
+cmx_status cmx_intra_pvalues(cmx_ctx* ctx, const double* stat, const double* norms, size_t n, int nclasses,
+                             const double* null_stat, const double* null_nmin, size_t nnull, double* pvalue,
+                             int32_t* nsim) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!stat || !norms || !pvalue || !nsim || n == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_intra_pvalues: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  TmpDev tmp;
+  double *d_stat, *d_norms, *d_ns = nullptr, *d_nm = nullptr, *d_pv;
+  int32_t* d_nsim;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_stat, n * n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_norms, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_pv, n * n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_nsim, n * n * sizeof(int32_t)));
+  HIP_TRY(ctx, hipMemcpy(d_stat, stat, n * n * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_norms, norms, n * sizeof(double), hipMemcpyHostToDevice));
+  if (nnull) {
+    HIP_TRY(ctx, tmp.alloc((void**)&d_ns, nnull * sizeof(double)));
+    HIP_TRY(ctx, tmp.alloc((void**)&d_nm, nnull * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(d_ns, null_stat, nnull * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_nm, null_nmin, nnull * sizeof(double), hipMemcpyHostToDevice));
+  }
+  cmx_status s = cmx_intra_pvalues_dev(ctx, d_stat, n, d_norms, n, nclasses, d_ns, d_nm, nnull, d_pv, d_nsim, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(pvalue, d_pv, n * n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(nsim, d_nsim, n * n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Mica MI
+cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* d_masks, const uint8_t* d_aln1,
+                              size_t n1, size_t ld1, const uint8_t* d_aln2, size_t n2, size_t ld2, double* d_mi,
+                              double* d_hjoint, size_t ldo, double* d_h1, double* d_h2, void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (nalpha != 4 && nalpha != 20) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mi_columns: alphabet size must be 4 or 20");
+  const bool intra = d_aln2 == nullptr;
+  if (intra) { d_aln2 = d_aln1; n2 = n1; ld2 = ld1; }
+  if (!d_masks) {  // no ambiguity table: every code >= nalpha is "unknown" (compatible with all states)
+    std::vector<uint32_t> mk(256, (1u << nalpha) - 1u);
+    for (int i = 0; i < nalpha; ++i) mk[i] = 1u << i;
+    void* p = nullptr;
+    cmx_status s = scratch(ctx, "mi_masks", 256 * sizeof(uint32_t), &p);
+    if (s != CMX_OK) return s;
+    HIP_TRY(ctx, hipMemcpy(p, mk.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    d_masks = static_cast<const uint32_t*>(p);
+  }
+  if (!d_aln1 || !d_mi || !d_hjoint || ntaxa < 1 || n1 == 0 || n2 == 0 || ld1 < n1 || ld2 < n2 || ldo < n2)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_mi_columns: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, launch_mi_columns(nalpha, ntaxa, d_masks, d_aln1, n1, ld1, d_aln2, n2, ld2, intra ? 1 : 0, d_mi, d_hjoint,
+                                 ldo, d_h1, intra ? nullptr : d_h2, (hipStream_t)stream));
+  return CMX_OK;
+}
+
+cmx_status cmx_mi_columns(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks, const uint8_t* aln1,
+                          size_t n1, const uint8_t* aln2, size_t n2, double* mi, double* hjoint, double* h1, double* h2) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!aln1 || !mi || !hjoint || n1 == 0 || ntaxa < 1 || nalpha < 2 || nalpha > 31) return fail(ctx, CMX_ERR_INVALID, "cmx_mi_columns: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!aln2) n2 = n1;
+  std::vector<uint32_t> mk(256, (1u << nalpha) - 1u);
+  for (int i = 0; i < nalpha; ++i) mk[i] = 1u << i;
+  if (masks) for (size_t i = 0; i < nmasks && i < 256; ++i) mk[i] = masks[i];
+  for (size_t i = 0; i < 256; ++i) if (mk[i] == 0) mk[i] = (1u << nalpha) - 1u;
+  TmpDev tmp;
+  uint32_t* d_masks;
+  uint8_t *d1, *d2 = nullptr;
+  double *d_mi, *d_hj, *d_h1, *d_h2 = nullptr;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_masks, 256 * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipMemcpy(d_masks, mk.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, tmp.alloc((void**)&d1, (size_t)ntaxa * n1));
+  HIP_TRY(ctx, hipMemcpy(d1, aln1, (size_t)ntaxa * n1, hipMemcpyHostToDevice));
+  if (aln2) {
+    HIP_TRY(ctx, tmp.alloc((void**)&d2, (size_t)ntaxa * n2));
+    HIP_TRY(ctx, hipMemcpy(d2, aln2, (size_t)ntaxa * n2, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, tmp.alloc((void**)&d_h2, n2 * sizeof(double)));
+  }
+  HIP_TRY(ctx, tmp.alloc((void**)&d_mi, n1 * n2 * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_hj, n1 * n2 * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_h1, n1 * sizeof(double)));
+  cmx_status s = cmx_mi_columns_dev(ctx, nalpha, ntaxa, d_masks, d1, n1, n1, d2, n2, n2, d_mi, d_hj, n2, d_h1, d_h2, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(mi, d_mi, n1 * n2 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(hjoint, d_hj, n1 * n2 * sizeof(double), hipMemcpyDeviceToHost));
+  if (h1) HIP_TRY(ctx, hipMemcpy(h1, d_h1, n1 * sizeof(double), hipMemcpyDeviceToHost));
+  if (h2) HIP_TRY(ctx, hipMemcpy(h2, aln2 ? d_h2 : d_h1, n2 * sizeof(double), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+// Host-side model preparation (see cmx_host_model.h).  Plain C++17, no device code.
+#include "cmx_host_model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace cmx {
+namespace {
+
+using Mat = std::vector<double>;
+
+Mat matmul(int n, const Mat& A, const Mat& B) {
+  Mat C((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < n; ++k) {
+      const double a = A[(size_t)i * n + k];
+      for (int j = 0; j < n; ++j) C[(size_t)i * n + j] += a * B[(size_t)k * n + j];
+    }
+  return C;
+}
+
+// cyclic Jacobi eigen-solver for a symmetric matrix (n <= 64 here); columns of U are eigenvectors
+void jacobi(int n, Mat A, Mat* U, std::vector<double>* lam) {
+  U->assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) (*U)[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 200; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; ++i) {
+      diag += A[(size_t)i * n + i] * A[(size_t)i * n + i];
+      for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+    }
+    if (off <= 1e-40 * (diag + 1e-300)) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - s * akq;
+          A[(size_t)k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - s * aqk;
+          A[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double ukp = (*U)[(size_t)k * n + p], ukq = (*U)[(size_t)k * n + q];
+          (*U)[(size_t)k * n + p] = c * ukp - s * ukq;
+          (*U)[(size_t)k * n + q] = s * ukp + c * ukq;
+        }
+      }
+  }
+  lam->resize(n);
+  for (int i = 0; i < n; ++i) (*lam)[i] = A[(size_t)i * n + i];
+}
+
+// row-major SxS -> 4x4-block packed (tile t = (bi, bj), element k = (k/4, k%4)); layout consumed by matvec_s
+void pack_blocks(int S, const double* M, double* out) {
+  const int NB = S / 4;
+  for (int t = 0; t < NB * NB; ++t)
+    for (int k = 0; k < 16; ++k) out[t * 16 + k] = M[(size_t)(4 * (t / NB) + k / 4) * S + 4 * (t % NB) + k % 4];
+}
+
+}  // namespace
+
+std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostModel* hm, int* code) {
+  *code = CMX_ERR_INVALID;
+  if (!model || !tree) return "model and tree are required";
+  const int S = model->nstates, C = model->nclasses;
+  const int K = model->Bk ? model->ntypes : 1;
+  if (S != 4 && S != 20) {
+    *code = CMX_ERR_UNSUPPORTED;
+    return "nstates must be 4 (nucleotides) or 20 (proteins); got " + std::to_string(S);
+  }
+  if (C < 1 || C > 64) return "nclasses out of range";
+  if (K < 1 || K > 64) return "ntypes out of range";
+  if (!model->Q || !model->pi || !model->rates || !model->probs) return "Q, pi, rates and probs are required";
+  const int nn = tree->nnodes, T = tree->ntaxa;
+  if (nn < 3 || T < 2 || !tree->parent || !tree->blen || !tree->leaf_of_taxon) return "tree is incomplete";
+  if (nn > 65535) return "tree too large";
+  hm->S = S; hm->C = C; hm->K = K; hm->nn = nn; hm->B = nn - 1; hm->T = T; hm->root = nn - 1;
+  hm->parent.assign(tree->parent, tree->parent + nn);
+  hm->blen.assign(tree->blen, tree->blen + nn);
+  // ---- tree checks: post-order, root last
+  if (hm->parent[nn - 1] != -1) return "parent[root] must be -1 with the root last";
+  for (int i = 0; i < nn - 1; ++i) {
+    if (hm->parent[i] <= i || hm->parent[i] >= nn) return "nodes must be in post-order (parent id > child id)";
+    if (!(hm->blen[i] >= 0.0) || !std::isfinite(hm->blen[i])) return "branch lengths must be finite and >= 0";
+  }
+  hm->first_child.assign(nn, -1);
+  hm->next_sib.assign(nn, -1);
+  std::vector<int> last(nn, -1), nchild(nn, 0);
+  for (int i = 0; i < nn - 1; ++i) {
+    const int p = hm->parent[i];
+    if (hm->first_child[p] < 0) hm->first_child[p] = i; else hm->next_sib[last[p]] = i;
+    last[p] = i;
+    nchild[p]++;
+  }
+  hm->taxon_of.assign(nn, -1);
+  for (int t = 0; t < T; ++t) {
+    const int n = tree->leaf_of_taxon[t];
+    if (n < 0 || n >= nn || nchild[n] != 0) return "leaf_of_taxon must name leaves";
+    if (hm->taxon_of[n] >= 0) return "leaf_of_taxon has duplicates";
+    hm->taxon_of[n] = t;
+  }
+  hm->slot.assign(nn, -1);
+  hm->int_post.clear();
+  for (int i = 0; i < nn; ++i) {
+    if (nchild[i] == 0) {
+      if (hm->taxon_of[i] < 0) return "every leaf needs an alignment row";
+    } else {
+      if (nchild[i] < 2 && i != nn - 1) return "internal nodes need at least two children";
+      hm->slot[i] = (int)hm->int_post.size();
+      hm->int_post.push_back(i);
+    }
+  }
+  if (nchild[nn - 1] < 2) return "the root needs at least two children";
+  hm->NI = (int)hm->int_post.size();
+  // ---- model checks
+  hm->pi.assign(model->pi, model->pi + S);
+  hm->rates.assign(model->rates, model->rates + C);
+  hm->probs.assign(model->probs, model->probs + C);
+  double spi = 0, spr = 0;
+  for (double v : hm->pi) { if (!(v > 0)) return "pi must be positive"; spi += v; }
+  for (double v : hm->probs) { if (!(v >= 0)) return "probs must be >= 0"; spr += v; }
+  if (std::fabs(spi - 1.0) > 1e-6 || std::fabs(spr - 1.0) > 1e-6) return "pi and probs must sum to one";
+  for (double v : hm->rates) if (!(v >= 0) || !std::isfinite(v)) return "rates must be finite and >= 0";
+  const size_t S2 = (size_t)S * S;
+  Mat Q(model->Q, model->Q + S2);
+  for (int x = 0; x < S; ++x) {
+    double rs = 0;
+    for (int y = 0; y < S; ++y) {
+      rs += Q[(size_t)x * S + y];
+      const double a = hm->pi[x] * Q[(size_t)x * S + y], b = hm->pi[y] * Q[(size_t)y * S + x];
+      if (std::fabs(a - b) > 1e-9 * (std::fabs(a) + std::fabs(b) + 1e-300) + 1e-14)
+        return "Q must be reversible with respect to pi (pi_x Q_xy == pi_y Q_yx)";
+    }
+    if (std::fabs(rs) > 1e-9) return "rows of Q must sum to zero";
+  }
+  std::vector<Mat> Bk(K);
+  for (int k = 0; k < K; ++k) {
+    if (model->Bk) Bk[k].assign(model->Bk + k * S2, model->Bk + (k + 1) * S2);
+    else { Bk[k] = Q; for (int x = 0; x < S; ++x) Bk[k][(size_t)x * S + x] = 0.0; }
+  }
+  // ---- eigen-decomposition through the symmetrised generator
+  Mat A(S2), U;
+  std::vector<double> lam;
+  for (int x = 0; x < S; ++x)
+    for (int y = 0; y < S; ++y) A[(size_t)x * S + y] = std::sqrt(hm->pi[x]) * Q[(size_t)x * S + y] / std::sqrt(hm->pi[y]);
+  for (int x = 0; x < S; ++x)
+    for (int y = x + 1; y < S; ++y) A[(size_t)x * S + y] = A[(size_t)y * S + x] = 0.5 * (A[(size_t)x * S + y] + A[(size_t)y * S + x]);
+  jacobi(S, A, &U, &lam);
+  Mat V(S2), Vi(S2);
+  for (int x = 0; x < S; ++x)
+    for (int j = 0; j < S; ++j) {
+      V[(size_t)x * S + j] = U[(size_t)x * S + j] / std::sqrt(hm->pi[x]);
+      Vi[(size_t)j * S + x] = U[(size_t)x * S + j] * std::sqrt(hm->pi[x]);
+    }
+  std::vector<Mat> W(K);  // Vinv B_k V
+  for (int k = 0; k < K; ++k) W[k] = matmul(S, matmul(S, Vi, Bk[k]), V);
+  // ---- per (class, branch) matrices
+  const int B = hm->B;
+  hm->P.assign((size_t)C * B * S2, 0.0);
+  hm->PN.assign((size_t)C * B * K * S2, 0.0);
+  Mat E(S2), Phi(S2);
+  for (int c = 0; c < C; ++c)
+    for (int b = 0; b < B; ++b) {
+      const double t = hm->blen[b] * hm->rates[c];
+      double* P = &hm->P[((size_t)c * B + b) * S2];
+      for (int x = 0; x < S; ++x)
+        for (int j = 0; j < S; ++j) E[(size_t)x * S + j] = V[(size_t)x * S + j] * std::exp(lam[j] * t);
+      Mat Pm = matmul(S, E, Vi);
+      std::memcpy(P, Pm.data(), sizeof(double) * S2);
+      for (int k = 0; k < K; ++k) {
+        double* PNk = &hm->PN[(((size_t)c * B + b) * K + k) * S2];
+        if (model->count_method == CMX_COUNT_NAIVE) {
+          for (size_t i = 0; i < S2; ++i)
+            PNk[i] = (i / S == i % S) ? 0.0 : P[i] * (model->naive_weights ? model->naive_weights[i] : 1.0);
+          continue;
+        }
+        // J = V [ (Vinv B V) o Phi ] Vinv; Phi through expm1 (accurate O(t^2) diagonal on 1e-6 branches)
+        for (int i = 0; i < S; ++i)
+          for (int j = 0; j < S; ++j) {
+            const double d = (lam[i] - lam[j]) * t;
+            const double phi = std::fabs(d) < 1e-14 ? t * std::exp(lam[i] * t) : t * std::exp(lam[j] * t) * std::expm1(d) / d;
+            Phi[(size_t)i * S + j] = W[k][(size_t)i * S + j] * phi;
+          }
+        Mat J = matmul(S, matmul(S, V, Phi), Vi);
+        for (size_t i = 0; i < S2; ++i) {
+          double nxy = J[i] / P[i];  // conditional count; Bio++ guards: non-finite -> 0, unweighted negatives -> 0
+          if (std::isnan(nxy) || std::isinf(nxy)) nxy = 0.0;
+          if (model->clamp_negative && nxy < 0.0) nxy = 0.0;
+          PNk[i] = P[i] * nxy;
+        }
+      }
+    }
+  // ---- device layouts
+  const int NI = hm->NI;
+  hm->PP.assign((size_t)C * NI * S2, 0.0);
+  hm->JP.assign((size_t)C * NI * K * S2, 0.0);
+  hm->LPT.assign((size_t)C * T * S2, 0.0);
+  hm->LJT.assign((size_t)C * K * T * S2, 0.0);
+  hm->CP.assign((size_t)C * nn * S2, 0.0);
+  for (int c = 0; c < C; ++c)
+    for (int b = 0; b < B; ++b) {
+      const double* P = &hm->P[((size_t)c * B + b) * S2];
+      double* cp = &hm->CP[((size_t)c * nn + b) * S2];
+      for (int x = 0; x < S; ++x) {
+        double cum = 0.0;
+        for (int y = 0; y < S; ++y) { cum += P[(size_t)x * S + y]; cp[(size_t)x * S + y] = cum; }
+      }
+      if (hm->taxon_of[b] >= 0) {
+        const int tx = hm->taxon_of[b];
+        double* lpt = &hm->LPT[((size_t)c * T + tx) * S2];
+        for (int x = 0; x < S; ++x)
+          for (int z = 0; z < S; ++z) lpt[(size_t)z * S + x] = P[(size_t)x * S + z];
+        for (int k = 0; k < K; ++k) {
+          const double* PNk = &hm->PN[(((size_t)c * B + b) * K + k) * S2];
+          double* ljt = &hm->LJT[(((size_t)c * K + k) * T + tx) * S2];
+          for (int x = 0; x < S; ++x)
+            for (int z = 0; z < S; ++z) ljt[(size_t)z * S + x] = PNk[(size_t)x * S + z];
+        }
+      } else {
+        const int sl = hm->slot[b];
+        pack_blocks(S, P, &hm->PP[((size_t)c * NI + sl) * S2]);
+        for (int k = 0; k < K; ++k)
+          pack_blocks(S, &hm->PN[(((size_t)c * B + b) * K + k) * S2], &hm->JP[(((size_t)c * NI + sl) * K + k) * S2]);
+      }
+    }
+  hm->cum_pi.resize(S);
+  hm->cum_probs.resize(C);
+  double cum = 0.0;
+  for (int x = 0; x < S; ++x) { cum += hm->pi[x]; hm->cum_pi[x] = cum; }
+  cum = 0.0;
+  for (int c = 0; c < C; ++c) { cum += hm->probs[c]; hm->cum_probs[c] = cum; }
+  *code = CMX_OK;
+  return std::string();
+}
+
+}  // namespace cmx

@@ -1,0 +1,31 @@
+// Host-side model preparation for the engine (internal).  Everything here runs once per context:
+// eigen-decomposition of the reversible generator, per (branch, class) transition matrices P = exp(Q r_c t_b),
+// joint count matrices P o N^k (SubstitutionCountInterface::getAllNumbersOfSubstitutions, called per branch and
+// class inside computeSubstitutionVectors in the reference -- here cached for all replicates), packing into the
+// device layouts, and the tree program.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/comap_mi355x.h"
+
+namespace cmx {
+
+struct HostModel {
+  int S = 0, C = 0, K = 0, nn = 0, B = 0, T = 0, NI = 0, root = 0;
+  std::vector<int> parent, first_child, next_sib, taxon_of, slot, int_post;
+  std::vector<double> blen, pi, rates, probs, cum_pi, cum_probs;
+  std::vector<double> P;    // [C][B][S*S] row-major (x -> y)
+  std::vector<double> PN;   // [C][B][K][S*S] P o N^k
+  std::vector<double> PP;   // [C][NI][S*S]     4x4-block packed P of internal nodes
+  std::vector<double> JP;   // [C][NI][K][S*S]  4x4-block packed PN of internal nodes
+  std::vector<double> LPT;  // [C][T][S][S]     transposed P of leaf branches
+  std::vector<double> LJT;  // [C][K][T][S][S]  transposed PN of leaf branches
+  std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
+};
+
+// returns empty string on success, otherwise the error message (status in *code)
+std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostModel* out, int* code);
+
+}  // namespace cmx

@@ -1,0 +1,814 @@
+// Hand-written gfx950 (CDNA4) kernels of the engine.  fp64 throughout (the reference computes in double and its
+// DR likelihood has no per-node rescaling, CoMap/CoETools.cpp:244).
+//
+// map_kernel<S, MODE>
+//   one wavefront = 64 sites (lane == site) x all rate classes in turn; four independent waves per workgroup.
+//   Replaces, per site: DRHomogeneousTreeLikelihood::initialize (post-order "inside" pass), the pre-order
+//   "outside" pass, LegacySubstitutionMappingTools::computeSubstitutionVectors and computeNormForSite
+//   (call sites CoMap/CoETools.cpp:397, CoMap/AnalysisTools.cpp:592-612; algorithm SURVEY.md A.2/A.3/A.6).
+//   The SxS operators of an edge are the same for all 64 lanes, so they are streamed through the SCALAR path
+//   (s_load_dwordx16 ping-pong into SGPRs, v_fma_f64 with an SGPR operand): no LDS or VGPR traffic for the
+//   matrix, 400 fp64 FMAs per 20x20 product.  Matrices are packed host-side in 4x4 blocks so that one copy serves
+//   both P.d (inside) and P^T.u (outside) with four independent accumulation chains per 16-value tile.
+//   Inside vectors of internal nodes are spilled to a per-wave HBM workspace in [state][lane] order, i.e. every
+//   access is one 512-byte fully coalesced row.
+//   MODE == kModeNull fuses simulate -> map (x2 batches) -> per-pair statistic of
+//   AnalysisTools::getNullDistributionIntraDR (CoMap/AnalysisTools.cpp:587-653).
+// pair_gram_kernel: all-pairs statistic as X.X^T on v_mfma_f64_16x16x4_f64 with per-statistic epilogues
+//   (CoMap/Statistics.h:164-329; loops CoMap/CoETools.cpp:672-692, 786-810).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "cmx_device.h"
+
+namespace cmx {
+
+// ------------------------------------------------------------------------------------------------ scalar-path matvec
+typedef int s16i __attribute__((ext_vector_type(16)));
+typedef double d8 __attribute__((ext_vector_type(8)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// two s_load_dwordx16 = one 16-double tile.  Early-clobber outputs: the address pair must survive both issues.
+#define CMX_SLOAD_TILE(p, off, r0, r1)                                                   \
+  asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"                \
+               : "=&s"(r0), "=&s"(r1)                                                    \
+               : "s"(p), "i"(off), "i"((off) + 64))
+// scalar loads return out of order: lgkmcnt(0) is the only valid wait.  "+s" ties the uses to the wait.
+#define CMX_SWAIT_TILE(r0, r1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0), "+s"(r1))
+
+__device__ __forceinline__ const double* uniform_ptr(const double* p) {
+  uint64_t v = reinterpret_cast<uint64_t>(p);
+  uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return reinterpret_cast<const double*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// tile T holds block (bi, bj) = (T / NB, T % NB) of the row-major matrix, element k -> (4bi + k/4, 4bj + k%4)
+template <int S, bool TR, int T>
+__device__ __forceinline__ void mv_tile(const s16i& r0, const s16i& r1, const double (&x)[S], double (&y)[S]) {
+  constexpr int NB = S / 4;
+  constexpr int bi = T / NB, bj = T % NB;
+  const d8 lo = __builtin_bit_cast(d8, r0), hi = __builtin_bit_cast(d8, r1);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = k / 4, j = k % 4;
+    const double a = k < 8 ? lo[k] : hi[k - 8];
+    if (!TR) y[4 * bi + i] = __builtin_fma(a, x[4 * bj + j], y[4 * bi + i]);
+    else y[4 * bj + j] = __builtin_fma(a, x[4 * bi + i], y[4 * bj + j]);
+  }
+}
+
+template <int S, bool TR, int T>
+__device__ __forceinline__ void mv_steps(const double* A, s16i& a0, s16i& a1, s16i& b0, s16i& b1,
+                                         const double (&x)[S], double (&y)[S]) {
+  constexpr int NT = (S / 4) * (S / 4);
+  if constexpr (T < NT) {
+    if constexpr (T + 1 < NT) {
+      CMX_SLOAD_TILE(A, (T + 1) * 128, b0, b1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's FMAs
+    }
+    mv_tile<S, TR, T>(a0, a1, x, y);
+    if constexpr (T + 1 < NT) {
+      CMX_SWAIT_TILE(b0, b1);
+      mv_steps<S, TR, T + 1>(A, b0, b1, a0, a1, x, y);
+    }
+  }
+}
+
+// y = A x (TR = false) or y = A^T x (TR = true); A: wave-uniform pointer to a 4x4-block-packed SxS matrix
+template <int S, bool TR>
+__device__ __forceinline__ void matvec_s(const double* A, const double (&x)[S], double (&y)[S]) {
+  static_assert(S % 4 == 0, "state count must be a multiple of 4");
+  s16i a0, a1, b0, b1;
+#pragma unroll
+  for (int i = 0; i < S; ++i) y[i] = 0.0;
+  A = uniform_ptr(A);
+  CMX_SLOAD_TILE(A, 0, a0, a1);
+  CMX_SWAIT_TILE(a0, a1);
+  mv_steps<S, TR, 0>(A, a0, a1, b0, b1, x, y);
+}
+
+// ------------------------------------------------------------------------------------------------ small helpers
+template <int S>
+__device__ __forceinline__ void load_vec(const double* p /* + lane */, double (&v)[S]) {
+#pragma unroll
+  for (int x = 0; x < S; ++x) v[x] = p[(size_t)x * kWave];
+}
+template <int S>
+__device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
+#pragma unroll
+  for (int x = 0; x < S; ++x) p[(size_t)x * kWave] = v[x];
+}
+
+// message of a leaf edge: m[x] = sum_{z compatible with the observed symbol} M[x][z], M given transposed ([z][x])
+template <int S>
+__device__ __forceinline__ void leaf_vec(const double* __restrict__ LT, unsigned code, const uint32_t* __restrict__ masks,
+                                         double (&m)[S]) {
+  if (code < (unsigned)S) {
+    const d2* r = reinterpret_cast<const d2*>(LT + (size_t)code * S);
+#pragma unroll
+    for (int x = 0; x < S / 2; ++x) {
+      d2 v = r[x];
+      m[2 * x] = v[0];
+      m[2 * x + 1] = v[1];
+    }
+  } else {
+    const uint32_t mk = masks ? masks[code] : ((1u << S) - 1u);
+#pragma unroll
+    for (int x = 0; x < S; ++x) m[x] = 0.0;
+    for (int z = 0; z < S; ++z)
+      if ((mk >> z) & 1u) {
+#pragma unroll
+        for (int x = 0; x < S; ++x) m[x] += LT[(size_t)z * S + x];
+      }
+  }
+}
+
+// Philox4x32-10, counter (g_lo, g_hi, draw, 'CMX1'), key = seed.  Same scheme as oracle/oracle.c (DESIGN.md "RNG").
+__device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
+  uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32), c2 = draw, c3 = 0x434d5831u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const uint64_t bits = (((uint64_t)c0 << 32) | c1) >> 11;
+  return (double)bits * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ int draw_index(double u, const double* __restrict__ cum, int n) {
+  int idx = 0;
+  for (int j = 0; j < n - 1; ++j) idx += (u >= cum[j]) ? 1 : 0;
+  return idx;
+}
+
+// ------------------------------------------------------------------------------------------------ mapping core
+// Maps the 64 sites of this wave (codes at aln_base[taxon * stride], per lane) for all rate classes.
+// On return cnt[(b*K+k)*64 + lane] holds the final counts n(b, site, k) and the scalars are per lane.
+template <int S>
+__device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
+                                               double* __restrict__ cnt, const uint8_t* __restrict__ aln_base,
+                                               size_t stride, int lane, double& L_out, double& pr_out, int& rc_out,
+                                               double& norm_out) {
+  const DevModel& m = a.m;
+  const int C = m.C, K = m.K, NI = m.NI, root = m.root;
+  double Lsum = 0.0, prsum = 0.0, best = -1.0;
+  int bestc = 0;
+  for (int c = 0; c < C; ++c) {
+    const double pc = m.probs[c];
+    // ---------------- inside (post-order) pass
+    double Lc = 0.0;
+    for (int idx = 0; idx < NI; ++idx) {
+      const int n = m.int_post[idx];
+      double acc[S];
+#pragma unroll
+      for (int x = 0; x < S; ++x) acc[x] = 1.0;
+      for (int e = m.first_child[n]; e >= 0; e = m.next_sib[e]) {
+        double msg[S];
+        const int tx = m.taxon_of[e];
+        if (tx >= 0) {
+          const unsigned code = aln_base[(size_t)tx * stride];
+          leaf_vec<S>(m.LPT + ((size_t)c * m.T + tx) * S * S, code, a.masks, msg);
+        } else {
+          const int sl = m.slot[e];
+          double d[S];
+          load_vec<S>(wsD + (size_t)sl * S * kWave + lane, d);
+          matvec_s<S, false>(m.PP + ((size_t)c * NI + sl) * S * S, d, msg);
+        }
+#pragma unroll
+        for (int x = 0; x < S; ++x) acc[x] *= msg[x];
+      }
+      if (n != root) {
+        store_vec<S>(wsD + (size_t)m.slot[n] * S * kWave + lane, acc);
+      } else {
+#pragma unroll
+        for (int x = 0; x < S; ++x) Lc = __builtin_fma(m.pi[x], acc[x], Lc);
+      }
+    }
+    Lsum += pc * Lc;
+    prsum += m.rates[c] * pc * Lc;
+    if (pc * Lc > best) { best = pc * Lc; bestc = c; }  // first maximum wins (getRateClassWithMaxPostProbPerSite)
+    // ---------------- outside (pre-order) pass + joint counts
+    for (int idx = NI - 1; idx >= 0; --idx) {
+      const int f = m.int_post[idx];
+      double upf[S];
+      if (f == root) {
+#pragma unroll
+        for (int x = 0; x < S; ++x) upf[x] = m.pi[x];
+      } else {
+        load_vec<S>(wsU + (size_t)m.slot[f] * S * kWave + lane, upf);
+      }
+      for (int n = m.first_child[f]; n >= 0; n = m.next_sib[n]) {
+        double u[S];
+#pragma unroll
+        for (int x = 0; x < S; ++x) u[x] = upf[x];
+        for (int sb = m.first_child[f]; sb >= 0; sb = m.next_sib[sb]) {
+          if (sb == n) continue;
+          double msg[S];
+          const int tx = m.taxon_of[sb];
+          if (tx >= 0) {
+            const unsigned code = aln_base[(size_t)tx * stride];
+            leaf_vec<S>(m.LPT + ((size_t)c * m.T + tx) * S * S, code, a.masks, msg);
+          } else {
+            const int sl = m.slot[sb];
+            double d[S];
+            load_vec<S>(wsD + (size_t)sl * S * kWave + lane, d);
+            matvec_s<S, false>(m.PP + ((size_t)c * NI + sl) * S * S, d, msg);
+          }
+#pragma unroll
+          for (int x = 0; x < S; ++x) u[x] *= msg[x];
+        }
+        const int tn = m.taxon_of[n];
+        if (tn >= 0) {
+          const unsigned code = aln_base[(size_t)tn * stride];
+          for (int k = 0; k < K; ++k) {
+            double jd[S];
+            leaf_vec<S>(m.LJT + (((size_t)c * K + k) * m.T + tn) * S * S, code, a.masks, jd);
+            double tot = 0.0;
+#pragma unroll
+            for (int x = 0; x < S; ++x) tot = __builtin_fma(u[x], jd[x], tot);
+            double* dst = cnt + ((size_t)n * K + k) * kWave + lane;
+            *dst = (c == 0) ? pc * tot : *dst + pc * tot;
+          }
+        } else {
+          const int sl = m.slot[n];
+          double d[S];
+          load_vec<S>(wsD + (size_t)sl * S * kWave + lane, d);
+          for (int k = 0; k < K; ++k) {
+            double jd[S];
+            matvec_s<S, false>(m.JP + (((size_t)c * NI + sl) * K + k) * S * S, d, jd);
+            double tot = 0.0;
+#pragma unroll
+            for (int x = 0; x < S; ++x) tot = __builtin_fma(u[x], jd[x], tot);
+            double* dst = cnt + ((size_t)n * K + k) * kWave + lane;
+            *dst = (c == 0) ? pc * tot : *dst + pc * tot;
+          }
+          double upn[S];
+          matvec_s<S, true>(m.PP + ((size_t)c * NI + sl) * S * S, u, upn);
+          store_vec<S>(wsU + (size_t)sl * S * kWave + lane, upn);
+        }
+      }
+    }
+  }
+  // ---------------- divide by the site likelihood, norm (computeNormForSite)
+  double nrm = 0.0;
+  for (int b = 0; b < m.B; ++b) {
+    double tot = 0.0;
+    for (int k = 0; k < K; ++k) {
+      double* p = cnt + ((size_t)b * K + k) * kWave + lane;
+      const double v = *p / Lsum;
+      *p = v;
+      tot += v;
+    }
+    nrm = __builtin_fma(tot, tot, nrm);
+  }
+  L_out = Lsum;
+  pr_out = prsum / Lsum;
+  rc_out = bestc;
+  norm_out = sqrt(nrm);
+}
+
+// per-lane statistic between two count columns (stride 64), CoMap/Statistics.h
+__device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, int K, const double* __restrict__ c1,
+                                                 const double* __restrict__ c2) {
+  switch (kind) {
+    case 0: case 4: {  // Correlation / Covariance: VectorTools::cor, two-pass on type 0
+      double m1 = 0, m2 = 0;
+      for (int b = 0; b < B; ++b) { m1 += c1[(size_t)b * K * kWave]; m2 += c2[(size_t)b * K * kWave]; }
+      m1 /= B; m2 /= B;
+      double sxy = 0, sxx = 0, syy = 0;
+      for (int b = 0; b < B; ++b) {
+        const double dx = c1[(size_t)b * K * kWave] - m1, dy = c2[(size_t)b * K * kWave] - m2;
+        sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
+      }
+      const double cov = sxy / (B - 1);
+      if (kind == 4) return cov;
+      return cov / (sqrt(sxx / (B - 1)) * sqrt(syy / (B - 1)));
+    }
+    case 3: {  // Cosinus
+      double sxy = 0, sxx = 0, syy = 0;
+      for (int b = 0; b < B; ++b) {
+        const double x = c1[(size_t)b * K * kWave], y = c2[(size_t)b * K * kWave];
+        sxy += x * y; sxx += x * x; syy += y * y;
+      }
+      return sxy / (sqrt(sxx) * sqrt(syy));
+    }
+    case 1: case 2: case 5: {
+      double s1 = 0, s2 = 0, s3 = 0, cc = 0, n11 = 0, r1 = 0, r2 = 0;
+      bool bad = false;
+      for (int b = 0; b < B; ++b) {
+        double t1 = 0, t2 = 0;
+        for (int k = 0; k < K; ++k) { t1 += c1[((size_t)b * K + k) * kWave]; t2 += c2[((size_t)b * K + k) * kWave]; }
+        s1 += t1 * t1; s2 += t2 * t2; s3 += (t1 + t2) * (t1 + t2);
+        if (t1 >= 1.0 && t2 >= 1.0) cc += 1.0;
+        if (!(t1 >= 0.0 && t1 < 10000.0) || !(t2 >= 0.0 && t2 < 10000.0)) bad = true;
+        const double i1 = t1 >= param ? 1.0 : 0.0, i2 = t2 >= param ? 1.0 : 0.0;
+        n11 += i1 * i2; r1 += i1; r2 += i2;
+      }
+      if (kind == 1) return 1.0 - sqrt(s3) / (sqrt(s1) + sqrt(s2));
+      if (kind == 2) return cc;
+      if (bad) return __builtin_nan("");
+      const double np = B;
+      const double cell[4] = {n11, r1 - n11, r2 - n11, np - r1 - r2 + n11};
+      const double ma[4] = {r1, r1, np - r1, np - r1}, mb[4] = {r2, np - r2, r2, np - r2};
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (cell[q] > 0) s += (cell[q] / np) * log(cell[q] * np / (ma[q] * mb[q]));
+      return s / log(2.7182818);
+    }
+  }
+  return __builtin_nan("");
+}
+
+template <int S, int MODE>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const MapArgs a) {
+  const DevModel& m = a.m;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  double* wsD = a.ws.D + (size_t)wave * m.NI * S * kWave;
+  double* wsU = a.ws.U + (size_t)wave * m.NI * S * kWave;
+  double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kWave;
+  double* cnt1 = cnt0 + (size_t)m.B * m.K * kWave;
+  const size_t nblocks = (a.nsites + kWave - 1) / kWave;
+  for (size_t sb = wave; sb < nblocks; sb += nwaves) {
+    const size_t site = sb * kWave + lane;
+    const bool active = site < a.nsites;
+    const size_t s = active ? site : a.nsites - 1;
+    if (MODE == kModeObserved) {
+      double L, pr, nrm;
+      int rc;
+      map_sites_wave<S>(a, wsD, wsU, cnt0, a.aln + s, a.ld, lane, L, pr, rc, nrm);
+      if (active) {
+        if (a.logL) a.logL[s] = log(L);
+        if (a.post_rate) a.post_rate[s] = pr;
+        if (a.rate_class) a.rate_class[s] = rc;
+        if (a.norm) a.norm[s] = nrm;
+        if (a.counts)
+          for (int r = 0; r < m.B * m.K; ++r) a.counts[(size_t)r * a.ldc + s] = cnt0[(size_t)r * kWave + lane];
+      }
+    } else {
+      // null pair q = s: replicate rep, column j; simulated-site index g_h = ((rep*2 + h)*rep_ram + j)
+      const size_t rep_local = s / a.rep_ram, j = s % a.rep_ram;
+      const size_t rep = a.rep_begin + rep_local;
+      double L[2], pr[2], nrm[2];
+      int rc[2];
+      for (int h = 0; h < 2; ++h) {
+        const uint8_t* base;
+        size_t stride;
+        if (a.supplied) {
+          base = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
+          stride = a.rep_ram;
+        } else {
+          uint8_t* st = a.ws.st + (size_t)wave * m.nn * kWave + lane;
+          uint8_t* al = a.ws.aln + (size_t)wave * m.T * kWave + lane;
+          const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
+          const int c = draw_index(philox_uniform(a.seed, g, 0), m.cum_probs, m.C);
+          st[(size_t)m.root * kWave] = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), m.cum_pi, S);
+          for (int node = m.nn - 2; node >= 0; --node) {
+            const int x = st[(size_t)m.parent[node] * kWave];
+            const double u = philox_uniform(a.seed, g, 2u + (uint32_t)node);
+            const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S + x) * S, S);
+            st[(size_t)node * kWave] = (uint8_t)y;
+            const int tx = m.taxon_of[node];
+            if (tx >= 0) al[(size_t)tx * kWave] = (uint8_t)y;
+          }
+          base = al;
+          stride = kWave;
+        }
+        map_sites_wave<S>(a, wsD, wsU, h ? cnt1 : cnt0, base, stride, lane, L[h], pr[h], rc[h], nrm[h]);
+      }
+      const double stat = pair_stat_lane(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + lane, cnt1 + lane);
+      if (active) {
+        a.null_stat[s] = stat;
+        if (a.null_rcmin) a.null_rcmin[s] = rc[0] < rc[1] ? rc[0] : rc[1];
+        if (a.null_prmin) a.null_prmin[s] = pr[0] < pr[1] ? pr[0] : pr[1];
+        if (a.null_nmin) a.null_nmin[s] = nrm[0] < nrm[1] ? nrm[0] : nrm[1];
+      }
+    }
+  }
+}
+
+hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream) {
+  dim3 grid(grid_blocks), block(kWave * kWavesPerBlock);
+  if (a.m.S == 20) {
+    if (mode == kModeObserved) hipLaunchKernelGGL((map_kernel<20, kModeObserved>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((map_kernel<20, kModeNull>), grid, block, 0, stream, a);
+  } else if (a.m.S == 4) {
+    if (mode == kModeObserved) hipLaunchKernelGGL((map_kernel<4, kModeObserved>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((map_kernel<4, kModeNull>), grid, block, 0, stream, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ stand-alone simulator
+__global__ void simulate_kernel(const DevModel m, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln, size_t ld,
+                                int32_t* classes, uint8_t* states) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint64_t g = g0 + j;
+  const int S = m.S;
+  const int c = draw_index(philox_uniform(seed, g, 0), m.cum_probs, m.C);
+  if (classes) classes[j] = c;
+  states[(size_t)m.root * ld + j] = (uint8_t)draw_index(philox_uniform(seed, g, 1), m.cum_pi, S);
+  for (int node = m.nn - 2; node >= 0; --node) {
+    const int x = states[(size_t)m.parent[node] * ld + j];
+    const int y = draw_index(philox_uniform(seed, g, 2u + (uint32_t)node), m.CP + (((size_t)c * m.nn + node) * S + x) * S, S);
+    states[(size_t)node * ld + j] = (uint8_t)y;
+    const int tx = m.taxon_of[node];
+    if (tx >= 0) aln[(size_t)tx * ld + j] = (uint8_t)y;
+  }
+}
+
+hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
+                           int32_t* d_classes, uint8_t* d_states, hipStream_t stream) {
+  const int block = 256;
+  const int grid = (int)((n + block - 1) / block);
+  hipLaunchKernelGGL(simulate_kernel, dim3(grid), dim3(block), 0, stream, m, seed, g0, n, d_aln, ld, d_classes, d_states);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ pair statistics
+// prep: X[b][i] (Bp rows, zero padded) and per-site scalars s (sum of squares) and r (row sum of indicators)
+//   kind 0/4: X = type-0 count - mean;  3: X = type-0 count;  1: X = per-branch total;
+//   2: X = [total >= 1];  5: X = [total >= threshold], r = sum X, s = NaN flag when a total leaves [0, 10000)
+__global__ void pair_prep_kernel(int kind, double param, const double* __restrict__ counts, size_t n, size_t ldc, int B,
+                                 int K, double* __restrict__ X, size_t ldx, int Bp, double* __restrict__ sv,
+                                 double* __restrict__ rv) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double mean = 0.0;
+  if (kind == 0 || kind == 4) {
+    for (int b = 0; b < B; ++b) mean += counts[(size_t)b * K * ldc + i];
+    mean /= B;
+  }
+  double s = 0.0, r = 0.0;
+  bool bad = false;
+  for (int b = 0; b < B; ++b) {
+    double v;
+    if (kind == 0 || kind == 4) v = counts[(size_t)b * K * ldc + i] - mean;
+    else if (kind == 3) v = counts[(size_t)b * K * ldc + i];
+    else {
+      double t = 0.0;
+      for (int k = 0; k < K; ++k) t += counts[((size_t)b * K + k) * ldc + i];
+      if (kind == 1) v = t;
+      else if (kind == 2) v = t >= 1.0 ? 1.0 : 0.0;
+      else {
+        v = t >= param ? 1.0 : 0.0;
+        if (!(t >= 0.0 && t < 10000.0)) bad = true;
+      }
+    }
+    X[(size_t)b * ldx + i] = v;
+    s += v * v;
+    r += v;
+  }
+  for (int b = B; b < Bp; ++b) X[(size_t)b * ldx + i] = 0.0;
+  sv[i] = bad ? __builtin_nan("") : s;
+  rv[i] = r;
+}
+
+hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,
+                            double* d_X, size_t ldx, int Bp, double* d_s, double* d_r, hipStream_t stream) {
+  const int block = 256;
+  hipLaunchKernelGGL(pair_prep_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, stream, kind, param,
+                     d_counts, n, ldc, B, K, d_X, ldx, Bp, d_s, d_r);
+  return hipGetLastError();
+}
+
+__device__ __forceinline__ double pair_epilogue(int kind, int B, double g, double si, double sj, double ri, double rj) {
+  switch (kind) {
+    case 0: {
+      const double cov = g / (B - 1);
+      return cov / (sqrt(si / (B - 1)) * sqrt(sj / (B - 1)));
+    }
+    case 4: return g / (B - 1);
+    case 3: return g / (sqrt(si) * sqrt(sj));
+    case 1: {
+      double s3 = si + sj + 2.0 * g;
+      if (s3 < 0.0) s3 = 0.0;
+      return 1.0 - sqrt(s3) / (sqrt(si) + sqrt(sj));
+    }
+    case 2: return g;
+    case 5: {
+      if (si != si || sj != sj) return __builtin_nan("");
+      const double np = B;
+      const double cell[4] = {g, ri - g, rj - g, np - ri - rj + g};
+      const double ma[4] = {ri, ri, np - ri, np - ri}, mb[4] = {rj, np - rj, rj, np - rj};
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (cell[q] > 0) s += (cell[q] / np) * log(cell[q] * np / (ma[q] * mb[q]));
+      return s / log(2.7182818);
+    }
+  }
+  return __builtin_nan("");
+}
+
+// One wave computes a 64x64 tile of G = X1^T-rows . X2-rows on v_mfma_f64_16x16x4_f64 (A[i][k]: lane = i + 16k,
+// C[row = (lane>>4) + 4r][col = lane & 15]); operands come straight from L2 (X is a few MB), prefetched one k-step
+// ahead; 16 MFMAs per 8 operand loads.
+__global__ __launch_bounds__(kWave) void pair_gram_kernel(int kind, int B, int Bp, const double* __restrict__ X1,
+                                                         const double* __restrict__ s1, const double* __restrict__ r1,
+                                                         size_t n1, size_t ldx1, const double* __restrict__ X2,
+                                                         const double* __restrict__ s2, const double* __restrict__ r2,
+                                                         size_t n2, size_t ldx2, int intra, double* __restrict__ out,
+                                                         size_t ldo) {
+  const int lane = threadIdx.x;
+  const size_t ti = blockIdx.y, tj = blockIdx.x;
+  const size_t i0 = ti * 64, j0 = tj * 64;
+  const double nanv = __builtin_nan("");
+  if (intra && tj < ti) {  // strictly below the diagonal: NaN fill (reference loop is j > i, CoETools.cpp:680)
+    for (int r = 0; r < 64; ++r) {
+      const size_t i = i0 + r, j = j0 + lane;
+      if (i < n1 && j < n2) out[i * ldo + j] = nanv;
+    }
+    return;
+  }
+  const int li = lane & 15, lk = lane >> 4;
+  size_t ia[4], jb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    size_t i = i0 + 16 * t + li, j = j0 + 16 * t + li;
+    ia[t] = i < n1 ? i : n1 - 1;
+    jb[t] = j < n2 ? j : n2 - 1;
+  }
+  d4 acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[p][q] = (d4){0.0, 0.0, 0.0, 0.0};
+  double a[4], b[4], an[4], bn[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    a[t] = X1[(size_t)lk * ldx1 + ia[t]];
+    b[t] = X2[(size_t)lk * ldx2 + jb[t]];
+  }
+  for (int k0 = 0; k0 < Bp; k0 += 4) {
+    const int kn = (k0 + 4 < Bp) ? k0 + 4 : k0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      an[t] = X1[(size_t)(kn + lk) * ldx1 + ia[t]];
+      bn[t] = X2[(size_t)(kn + lk) * ldx2 + jb[t]];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p], b[q], acc[p][q], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { a[t] = an[t]; b[t] = bn[t]; }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const size_t j = j0 + 16 * q + li;
+    const double sj = s2[j < n2 ? j : n2 - 1], rj = r2[j < n2 ? j : n2 - 1];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t i = i0 + 16 * p + lk + 4 * r;
+        if (i < n1 && j < n2) {
+          double v = pair_epilogue(kind, B, acc[p][q][r], s1[i], sj, r1[i], rj);
+          if (intra && j <= i) v = nanv;
+          out[i * ldo + j] = v;
+        }
+      }
+  }
+}
+
+hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const double* d_s1, const double* d_r1,
+                            size_t n1, size_t ldx1, const double* d_X2, const double* d_s2, const double* d_r2,
+                            size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream) {
+  dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 63) / 64));
+  hipLaunchKernelGGL(pair_gram_kernel, grid, dim3(kWave), 0, stream, kind, B, Bp, d_X1, d_s1, d_r1, n1, ldx1, d_X2,
+                     d_s2, d_r2, n2, ldx2, intra, d_out, ldo);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ p-values
+__global__ void max_reduce_kernel(const double* __restrict__ x, size_t n, double* out) {
+  __shared__ double sm[256];
+  double v = -__builtin_inf();
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) v = x[i] > v ? x[i] : v;
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = sm[threadIdx.x + s] > sm[threadIdx.x] ? sm[threadIdx.x + s] : sm[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
+}
+
+hipError_t launch_max_reduce(const double* d_x, size_t n, double* d_out, hipStream_t stream) {
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, d_x, n, d_out);
+  return hipGetLastError();
+}
+
+// Domain(0, maxnorm, n)::getIndex (CoMap/Domain.cpp:46-59, 113-122) with the reference's operation order and no
+// fused multiply-add, so that class indices are bit-exact.  -1 == OutOfRangeException.
+__device__ __forceinline__ int domain_index(double maxi, int n, double x) {
+  const double mini = 0.0;
+  const double w = __ddiv_rn(__dsub_rn(maxi, mini), (double)n);
+  if (x < mini || x >= __dadd_rn(mini, __dmul_rn((double)n, w))) return -1;
+  for (int i = 1; i < n + 1; ++i)
+    if (x < __dadd_rn(mini, __dmul_rn((double)i, w))) return i - 1;
+  return -1;
+}
+
+__global__ void null_classify_kernel(const double* __restrict__ stat, const double* __restrict__ nmin, size_t nnull,
+                                     const double* __restrict__ maxnorm, int nclasses, uint32_t* __restrict__ cls,
+                                     uint32_t* __restrict__ hist) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nnull) return;
+  int c = (stat[q] != stat[q]) ? -1 : domain_index(*maxnorm, nclasses, nmin[q]);
+  const uint32_t cc = c < 0 ? (uint32_t)nclasses : (uint32_t)c;
+  cls[q] = cc;
+  atomicAdd(&hist[cc], 1u);
+}
+
+hipError_t launch_null_classify(const double* d_stat, const double* d_nmin, size_t nnull, const double* d_maxnorm,
+                                int nclasses, uint32_t* d_cls, uint32_t* d_hist, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (nclasses + 1), stream);
+  if (e != hipSuccess) return e;
+  if (nnull == 0) return hipSuccess;
+  hipLaunchKernelGGL(null_classify_kernel, dim3((unsigned)((nnull + 255) / 256)), dim3(256), 0, stream, d_stat, d_nmin,
+                     nnull, d_maxnorm, nclasses, d_cls, d_hist);
+  return hipGetLastError();
+}
+
+// stable LSD: sort by statistic, then by class -> classes contiguous, each ascending (CoETools.cpp:650-652)
+hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in, double* d_stat_tmp, uint32_t* d_cls_in,
+                              uint32_t* d_cls_tmp, size_t n, hipStream_t stream) {
+  if (d_tmp == nullptr) {
+    size_t b1 = 0, b2 = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, b1, d_stat_in, d_stat_tmp, d_cls_in, d_cls_tmp, n, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(nullptr, b2, d_cls_tmp, d_cls_in, d_stat_tmp, d_stat_in, n, 0, 8, stream);
+    tmp_bytes = b1 > b2 ? b1 : b2;
+    return e;
+  }
+  hipError_t e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_stat_in, d_stat_tmp, d_cls_in, d_cls_tmp, n, 0, 64, stream);
+  if (e != hipSuccess) return e;
+  return rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_cls_tmp, d_cls_in, d_stat_tmp, d_stat_in, n, 0, 8, stream);
+}
+
+// p = (nsim - #{null < stat} + 1) / (nsim + 1), strict '<' (CoETools.cpp:712-717); the reference scans linearly,
+// the sorted class makes it a lower_bound.  hist[c] = class sizes; classes are laid out in order in `sorted`.
+__global__ void pvalue_kernel(const double* __restrict__ stat, size_t ldo, const double* __restrict__ norms, size_t n,
+                              const double* __restrict__ maxnorm, int nclasses, const double* __restrict__ sorted,
+                              const uint32_t* __restrict__ hist, double* __restrict__ pvalue, int32_t* __restrict__ nsim) {
+  __shared__ uint32_t off[66];
+  if (threadIdx.x == 0) {
+    uint32_t o = 0;
+    for (int c = 0; c <= nclasses && c < 65; ++c) { off[c] = o; o += hist[c]; }
+  }
+  __syncthreads();
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = blockIdx.y;
+  if (j >= n) return;
+  const size_t o = i * ldo + j;
+  if (j <= i) { pvalue[o] = __builtin_nan(""); nsim[o] = 0; return; }
+  const double ni = norms[i], nj = norms[j];
+  const double mn = ni < nj ? ni : nj;
+  const int cat = domain_index(*maxnorm, nclasses, mn);
+  if (cat < 0) { pvalue[o] = __builtin_nan(""); nsim[o] = 0; return; }
+  const uint32_t lo0 = off[cat], ns = hist[cat];
+  const double st = stat[o];
+  uint32_t lo = 0, hi = ns;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sorted[lo0 + mid] < st) lo = mid + 1; else hi = mid;
+  }
+  pvalue[o] = (double)(ns - lo + 1) / (double)(ns + 1);
+  nsim[o] = (int32_t)ns;
+}
+
+hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norms, size_t n, const double* d_maxnorm,
+                          int nclasses, const double* d_sorted, const uint32_t* d_hist, double* d_pvalue,
+                          int32_t* d_nsim, hipStream_t stream) {
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+  hipLaunchKernelGGL(pvalue_kernel, grid, dim3(256), 0, stream, d_stat, ldo, d_norms, n, d_maxnorm, nclasses, d_sorted,
+                     d_hist, d_pvalue, d_nsim);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ Mica column MI
+// SiteTools::mutualInformation / jointEntropy / entropy (resolveUnknowns = true), natural log (Mica.cpp:93-95).
+// v1: one wave per (i, 64 columns j): lane = column j; joint table in LDS as [a][b][lane] would be A*A*64*8 bytes
+// (205 KB for A = 20) -- too large, so the joint counts are accumulated per row a in registers over two passes of
+// the taxa is avoided by sorting... (kept simple and exact here: A*A fp32-exact fractional counts are NOT assumed;
+// counts are fp64 in a per-lane scratch table in global workspace-free form using LDS tiles of 16 lanes).
+template <int A>
+__global__ __launch_bounds__(64) void mi_columns_kernel(int T, const uint32_t* __restrict__ masks,
+                                                        const uint8_t* __restrict__ aln1, size_t n1, size_t ld1,
+                                                        const uint8_t* __restrict__ aln2, size_t n2, size_t ld2,
+                                                        int intra, double* __restrict__ mi, double* __restrict__ hj,
+                                                        size_t ldo) {
+  // LDS: joint table [A*A][16 lanes] fp64 per quarter-wave = A*A*16*8 B (51 KB for A = 20): 16 pairs per block pass
+  extern __shared__ double tab[];
+  const int lane = threadIdx.x;
+  const int sub = lane & 15;       // pair slot
+  const int part = lane >> 4;      // 4 lanes cooperate on one pair: taxa are split in 4 strides
+  const size_t i = blockIdx.y;
+  const size_t j = (size_t)blockIdx.x * 16 + sub;
+  const bool valid = j < n2 && (!intra || j > i);
+  const size_t jj = j < n2 ? j : n2 - 1;
+  for (int q = lane; q < A * A * 16; q += 64) tab[q] = 0.0;
+  __syncthreads();
+  for (int t = part; t < T; t += 4) {
+    const unsigned c1 = aln1[(size_t)t * ld1 + i], c2 = aln2[(size_t)t * ld2 + jj];
+    if (c1 < (unsigned)A && c2 < (unsigned)A) {
+      atomicAdd(&tab[(c1 * A + c2) * 16 + sub], 1.0);
+    } else {
+      const uint32_t m1 = c1 < (unsigned)A ? (1u << c1) : masks[c1], m2 = c2 < (unsigned)A ? (1u << c2) : masks[c2];
+      const double w = 1.0 / (double)(__popc(m1) * __popc(m2));
+      for (int a = 0; a < A; ++a)
+        if ((m1 >> a) & 1u)
+          for (int b = 0; b < A; ++b)
+            if ((m2 >> b) & 1u) atomicAdd(&tab[(a * A + b) * 16 + sub], w);
+    }
+  }
+  __syncthreads();
+  if (part == 0) {
+    double p1[A], p2[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) { p1[a] = 0.0; p2[a] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int b = 0; b < A; ++b) {
+        const double v = tab[(a * A + b) * 16 + sub];
+        p1[a] += v;
+        p2[b] += v;
+      }
+    double s = 0.0, h = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int b = 0; b < A; ++b) {
+        const double pab = tab[(a * A + b) * 16 + sub] / T;
+        if (pab > 0.0) {
+          s += pab * log(pab / ((p1[a] / T) * (p2[b] / T)));
+          h -= pab * log(pab);
+        }
+      }
+    if (j < n2) {
+      mi[i * ldo + j] = valid ? s : __builtin_nan("");
+      hj[i * ldo + j] = valid ? h : __builtin_nan("");
+    }
+  }
+}
+
+template <int A>
+__global__ void column_entropy_kernel(int T, const uint32_t* __restrict__ masks, const uint8_t* __restrict__ aln,
+                                      size_t n, size_t ld, double* __restrict__ h) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double p[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) p[a] = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const unsigned c = aln[(size_t)t * ld + i];
+    const uint32_t m = c < (unsigned)A ? (1u << c) : masks[c];
+    const double w = 1.0 / (double)__popc(m);
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+      if ((m >> a) & 1u) p[a] += w;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+    if (p[a] > 0.0) s -= (p[a] / T) * log(p[a] / T);
+  h[i] = s;
+}
+
+hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
+                             const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
+                             size_t ldo, double* d_h1, double* d_h2, hipStream_t stream) {
+  dim3 grid((unsigned)((n2 + 15) / 16), (unsigned)n1);
+  const size_t lds = sizeof(double) * A * A * 16;
+  if (A == 20) {
+    hipLaunchKernelGGL((mi_columns_kernel<20>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, n1, ld1, d_aln2, n2,
+                       ld2, intra, d_mi, d_hj, ldo);
+    if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
+    if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
+  } else if (A == 4) {
+    hipLaunchKernelGGL((mi_columns_kernel<4>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, n1, ld1, d_aln2, n2,
+                       ld2, intra, d_mi, d_hj, ldo);
+    if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
+    if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace cmx

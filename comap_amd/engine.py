@@ -1,0 +1,261 @@
+"""ctypes binding of libcomap_mi355x.so (include/comap_mi355x.h) -- plumbing only.
+
+All compute happens in the HIP kernels behind the C-ABI; this module never falls back to a CPU
+implementation: if the shared library is missing or no MI355X is visible, calls raise.
+numpy arrays go through the host-pointer entry points; torch CUDA tensors go through the `_dev`
+entry points (raw device pointers + the current torch stream).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcomap_mi355x.so")
+
+STAT_CORRELATION, STAT_COMPENSATION, STAT_COSUBSTITUTION, STAT_COSINUS, STAT_COVARIANCE, STAT_DISCRETE_MI = range(6)
+STAT_BY_NAME = {
+    # names of the reference's `statistic=` option (CoMap/CoETools.cpp:540-599)
+    "Correlation": STAT_CORRELATION, "Compensation": STAT_COMPENSATION, "Cosubstitution": STAT_COSUBSTITUTION,
+    "Cosinus": STAT_COSINUS, "Covariance": STAT_COVARIANCE, "MI": STAT_DISCRETE_MI,
+}
+COUNT_EXPECTED, COUNT_NAIVE = 0, 1
+
+EXPORTS = [
+    "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
+    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate",
+    "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_intra_pvalues",
+    "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev",
+]
+
+
+class CmxError(RuntimeError):
+    """Raised for any non-zero cmx_status (the reference throws bpp::Exception)."""
+
+    def __init__(self, status, message):
+        super().__init__(f"cmx status {status}: {message}")
+        self.status = status
+
+
+class _Model(ctypes.Structure):
+    _fields_ = [("nstates", ctypes.c_int32), ("nclasses", ctypes.c_int32), ("ntypes", ctypes.c_int32),
+                ("Q", ctypes.c_void_p), ("pi", ctypes.c_void_p), ("rates", ctypes.c_void_p),
+                ("probs", ctypes.c_void_p), ("Bk", ctypes.c_void_p), ("count_method", ctypes.c_int32),
+                ("clamp_negative", ctypes.c_int32), ("naive_weights", ctypes.c_void_p)]
+
+
+class _Tree(ctypes.Structure):
+    _fields_ = [("nnodes", ctypes.c_int32), ("parent", ctypes.c_void_p), ("blen", ctypes.c_void_p),
+                ("ntaxa", ctypes.c_int32), ("leaf_of_taxon", ctypes.c_void_p)]
+
+
+class _Info(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("nstates", "nclasses", "ntypes", "nnodes", "nbranches", "ntaxa",
+                                               "ninternal", "device", "cu_count", "waves")] + \
+               [("workspace_bytes", ctypes.c_size_t)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load the C-ABI library; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built; run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.cmx_version.restype = ctypes.c_char_p
+        lib.cmx_last_error.restype = ctypes.c_char_p
+        lib.cmx_last_error.argtypes = [ctypes.c_void_p]
+        lib.cmx_ctx_destroy.restype = None
+        lib.cmx_ctx_destroy.argtypes = [ctypes.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _vp(a):
+    if a is None:
+        return ctypes.c_void_p(None)
+    if isinstance(a, np.ndarray):
+        return ctypes.c_void_p(a.ctypes.data)
+    return ctypes.c_void_p(int(a.data_ptr()))  # torch tensor
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _sz(x):
+    return ctypes.c_size_t(int(x))
+
+
+class Engine:
+    """One context per GPU (cmx_ctx).  tree/model given as plain arrays (see include/comap_mi355x.h)."""
+
+    def __init__(self, parent=None, blen=None, leaf_of_taxon=None, Q=None, pi=None, rates=None, probs=None, Bk=None,
+                 count_method=COUNT_EXPECTED, clamp_negative=True, naive_weights=None, device=0):
+        self._lib = load_library()
+        self._ctx = ctypes.c_void_p(None)
+        self.device = device
+        if parent is None:
+            st = self._lib.cmx_ctx_create(None, None, int(device), ctypes.byref(self._ctx))
+            self.S = self.C = self.K = self.B = self.T = 0
+        else:
+            self._keep = [np.ascontiguousarray(parent, dtype=np.int32), _f64(blen),
+                          np.ascontiguousarray(leaf_of_taxon, dtype=np.int32), _f64(Q), _f64(pi), _f64(rates),
+                          _f64(probs), None if Bk is None else _f64(Bk),
+                          None if naive_weights is None else _f64(naive_weights)]
+            p, bl, lot, Qa, pia, ra, pr, Bka, nw = self._keep
+            S, C = len(pia), len(ra)
+            K = 1 if Bka is None else Bka.reshape(-1, S, S).shape[0]
+            model = _Model(S, C, K, _vp(Qa), _vp(pia), _vp(ra), _vp(pr), _vp(Bka), int(count_method),
+                           int(bool(clamp_negative)), _vp(nw))
+            tree = _Tree(len(p), _vp(p), _vp(bl), len(lot), _vp(lot))
+            st = self._lib.cmx_ctx_create(ctypes.byref(model), ctypes.byref(tree), int(device), ctypes.byref(self._ctx))
+            self.S, self.C, self.K, self.B, self.T = S, C, K, len(p) - 1, len(lot)
+        if st != 0:
+            raise CmxError(st, self._lib.cmx_last_error(None).decode())
+
+    # -- plumbing
+    def _check(self, st):
+        if st != 0:
+            raise CmxError(st, self._lib.cmx_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.cmx_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        i = _Info()
+        self._check(self._lib.cmx_get_info(self._ctx, ctypes.byref(i)))
+        return {n: getattr(i, n) for n, _ in _Info._fields_}
+
+    def transition_matrices(self):
+        P = np.zeros((self.C, self.B, self.S, self.S))
+        self._check(self._lib.cmx_get_transition_matrices(self._ctx, _vp(P)))
+        return P
+
+    def synchronize(self):
+        self._check(self._lib.cmx_synchronize(self._ctx))
+
+    @staticmethod
+    def _stream():
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # -- host-pointer entry points (numpy in, numpy out; reference layouts)
+    def map_sites(self, aln, masks=None, want_counts=True):
+        """aln: uint8 [T, N].  Returns dict(counts[N,B,K], logL, post_rate, rate_class, norm)."""
+        aln = np.ascontiguousarray(aln, dtype=np.uint8)
+        T, N = aln.shape
+        if T != self.T:
+            raise CmxError(-1, f"alignment has {T} rows, tree has {self.T} taxa")
+        counts = np.zeros((N, self.B, self.K)) if want_counts else None
+        logL, pr, norm = np.zeros(N), np.zeros(N), np.zeros(N)
+        rc = np.zeros(N, dtype=np.int32)
+        mk = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint32)
+        self._check(self._lib.cmx_map_sites(self._ctx, _vp(aln), _sz(N), _sz(N), _vp(mk),
+                                            _sz(0 if mk is None else len(mk)), _vp(counts), _vp(logL), _vp(pr),
+                                            _vp(rc), _vp(norm)))
+        return dict(counts=counts, logL=logL, post_rate=pr, rate_class=rc, norm=norm)
+
+    def simulate(self, seed, g0, n):
+        aln = np.zeros((self.T, n), dtype=np.uint8)
+        cls = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.cmx_simulate(self._ctx, ctypes.c_uint64(seed), ctypes.c_uint64(g0), _sz(n), _vp(aln),
+                                           _vp(cls)))
+        return aln, cls
+
+    def pair_stats(self, kind, counts1, counts2=None, threshold=0.99):
+        c1 = _f64(counts1).reshape(len(counts1), self.B, self.K)
+        n1 = c1.shape[0]
+        c2 = None if counts2 is None else _f64(counts2).reshape(len(counts2), self.B, self.K)
+        n2 = n1 if c2 is None else c2.shape[0]
+        out = np.zeros((n1, n2))
+        params = _f64([threshold])
+        self._check(self._lib.cmx_pair_stats(self._ctx, int(kind), _vp(params), _vp(c1), _sz(n1), _vp(c2), _sz(n2),
+                                             _vp(out)))
+        return out
+
+    def null_intra(self, kind, seed, rep_begin, rep_end, rep_ram, supplied=None, threshold=0.99):
+        n = (rep_end - rep_begin) * rep_ram
+        stat, prmin, nmin = np.zeros(n), np.zeros(n), np.zeros(n)
+        rcmin = np.zeros(n, dtype=np.int32)
+        sup = None
+        if supplied is not None:
+            sup = np.ascontiguousarray(supplied, dtype=np.uint8)
+            if sup.shape != (rep_end - rep_begin, 2, self.T, rep_ram):
+                raise CmxError(-1, "supplied alignments must be [nrep, 2, T, rep_ram]")
+        params = _f64([threshold])
+        self._check(self._lib.cmx_null_intra(self._ctx, int(kind), _vp(params), ctypes.c_uint64(seed), _sz(rep_begin),
+                                             _sz(rep_end), _sz(rep_ram), _vp(sup), _vp(stat), _vp(rcmin), _vp(prmin),
+                                             _vp(nmin)))
+        return dict(stat=stat, rcmin=rcmin, prmin=prmin, nmin=nmin)
+
+    def intra_pvalues(self, stat, norms, nclasses, null_stat, null_nmin):
+        stat, norms, ns, nm = _f64(stat), _f64(norms), _f64(null_stat), _f64(null_nmin)
+        n = len(norms)
+        pv = np.zeros((n, n))
+        nsim = np.zeros((n, n), dtype=np.int32)
+        self._check(self._lib.cmx_intra_pvalues(self._ctx, _vp(stat), _vp(norms), _sz(n), int(nclasses), _vp(ns),
+                                                _vp(nm), _sz(len(ns)), _vp(pv), _vp(nsim)))
+        return pv, nsim
+
+    def mi_columns(self, aln1, aln2=None, nalpha=20, masks=None):
+        a1 = np.ascontiguousarray(aln1, dtype=np.uint8)
+        T, n1 = a1.shape
+        a2 = None if aln2 is None else np.ascontiguousarray(aln2, dtype=np.uint8)
+        n2 = n1 if a2 is None else a2.shape[1]
+        mi, hj = np.zeros((n1, n2)), np.zeros((n1, n2))
+        h1, h2 = np.zeros(n1), np.zeros(n2)
+        mk = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint32)
+        self._check(self._lib.cmx_mi_columns(self._ctx, int(nalpha), int(T), _vp(mk), _sz(0 if mk is None else len(mk)),
+                                             _vp(a1), _sz(n1), _vp(a2), _sz(n2), _vp(mi), _vp(hj), _vp(h1), _vp(h2)))
+        return dict(mi=mi, hjoint=hj, h1=h1, h2=h2)
+
+    # -- device-pointer entry points (torch CUDA tensors, engine-native layouts, asynchronous)
+    def map_sites_dev(self, d_aln, counts=None, logL=None, post_rate=None, rate_class=None, norm=None, masks=None):
+        """d_aln: uint8 [T, ld] CUDA tensor; counts: float64 [B*K, ldc]; per-site outputs: [N]."""
+        n = d_aln.shape[1]
+        self._check(self._lib.cmx_map_sites_dev(self._ctx, _vp(d_aln), _sz(n), _sz(d_aln.stride(0)), _vp(masks),
+                                                _vp(counts), _sz(0 if counts is None else counts.stride(0)), _vp(logL),
+                                                _vp(post_rate), _vp(rate_class), _vp(norm), self._stream()))
+
+    def pair_stats_dev(self, kind, counts1, out, counts2=None, threshold=0.99):
+        params = _f64([threshold])
+        n1 = counts1.shape[1]
+        n2 = n1 if counts2 is None else counts2.shape[1]
+        self._check(self._lib.cmx_pair_stats_dev(self._ctx, int(kind), _vp(params), _vp(counts1), _sz(n1),
+                                                 _sz(counts1.stride(0)), _vp(counts2), _sz(n2),
+                                                 _sz(0 if counts2 is None else counts2.stride(0)), _vp(out),
+                                                 _sz(out.stride(0)), self._stream()))
+
+    def null_intra_dev(self, kind, seed, rep_begin, rep_end, rep_ram, stat, rcmin=None, prmin=None, nmin=None,
+                       supplied=None, threshold=0.99):
+        params = _f64([threshold])
+        self._check(self._lib.cmx_null_intra_dev(self._ctx, int(kind), _vp(params), ctypes.c_uint64(seed),
+                                                 _sz(rep_begin), _sz(rep_end), _sz(rep_ram), _vp(supplied), _vp(stat),
+                                                 _vp(rcmin), _vp(prmin), _vp(nmin), self._stream()))
+
+    def intra_pvalues_dev(self, stat, norms, nclasses, null_stat, null_nmin, pvalue, nsim):
+        n = norms.shape[0]
+        nnull = 0 if null_stat is None else null_stat.shape[0]
+        self._check(self._lib.cmx_intra_pvalues_dev(self._ctx, _vp(stat), _sz(stat.stride(0)), _vp(norms), _sz(n),
+                                                    int(nclasses), _vp(null_stat), _vp(null_nmin), _sz(nnull),
+                                                    _vp(pvalue), _vp(nsim), self._stream()))
+
+    def mi_columns_dev(self, d_aln1, mi, hjoint, d_aln2=None, nalpha=20, masks=None, h1=None, h2=None):
+        T, n1 = d_aln1.shape
+        n2 = n1 if d_aln2 is None else d_aln2.shape[1]
+        self._check(self._lib.cmx_mi_columns_dev(self._ctx, int(nalpha), int(T), _vp(masks), _vp(d_aln1), _sz(n1),
+                                                 _sz(d_aln1.stride(0)), _vp(d_aln2), _sz(n2),
+                                                 _sz(0 if d_aln2 is None else d_aln2.stride(0)), _vp(mi), _vp(hjoint),
+                                                 _sz(mi.stride(0)), _vp(h1), _vp(h2), self._stream()))

@@ -116,12 +116,11 @@ def grantham_distance():
 
 
 def gtr(a, b, c, d, e, theta, theta1, theta2):
-    """Bio++ GTR parameterisation (states A C G T):
-    exchangeabilities a=C<->T... as in bpp-phyl GTR: S(A,C)=d, S(A,G)=1(kappa slot)...
-    Implemented as: r_AC=d, r_AG=1, r_AT=b, r_CG=c, r_CT=a, r_GT=e ;
+    """Bio++ GTR parameterisation (states A C G T; recalled from bpp-phyl GTR.h, unpinned):
+    exchangeabilities S(A,C)=d, S(A,G)=1, S(A,T)=b, S(C,G)=e, S(C,T)=a, S(G,T)=c;
     piA=theta1(1-theta), piC=(1-theta2)theta, piG=theta2 theta, piT=(1-theta1)(1-theta)."""
     pi = np.array([theta1 * (1 - theta), (1 - theta2) * theta, theta2 * theta, (1 - theta1) * (1 - theta)])
-    S = np.array([[0, d, 1.0, b], [d, 0, c, a], [1.0, c, 0, e], [b, a, e, 0]], dtype=np.float64)
+    S = np.array([[0, d, 1.0, b], [d, 0, e, a], [1.0, e, 0, c], [b, a, c, 0]], dtype=np.float64)
     return reversible_generator(S, pi)
 
 

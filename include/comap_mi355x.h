@@ -1,0 +1,157 @@
+/* comap_mi355x.h -- C-ABI of the MI355X-native substitution-mapping + pairwise-coevolution engine.
+ *
+ * Drop-in boundary for ONE hot path of jydu/comap (paths below are relative to the reference tree):
+ *   CoETools::getVectors                         CoMap/CoETools.h:317-322, CoMap/CoETools.cpp:366-416
+ *   AnalysisTools::computeNorms                  CoMap/AnalysisTools.h:198,   CoMap/AnalysisTools.cpp:343-350
+ *   AnalysisTools::getNullDistributionIntraDR    CoMap/AnalysisTools.h:248-260, CoMap/AnalysisTools.cpp:564-658
+ *   Statistic::getValueForPair (all-pairs form)  CoMap/Statistics.h:72, loops CoMap/CoETools.cpp:672-724, 786-828
+ *   Distance::getDistanceForPair                 CoMap/Distance.h:71-72, loops CoMap/CoMap.cpp:432-440
+ *   Mica all-pairs MI                            CoMap/Mica.cpp:93-118, 346-361, 646-689
+ * The reference has no FFI layer of its own (its seams are C++ static methods over Bio++ types), so this header
+ * is what a binding for that path would bind; INTEGRATION.md shows the C++ adapter a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no exceptions cross the boundary: every call returns a cmx_status and
+ *     cmx_last_error(ctx) holds the message (the reference throws bpp::Exception, caught in main).
+ *   - one ctx per GPU; calls on one ctx are serialised by the caller (the reference is single-threaded).
+ *   - tree: nodes in post-order, root last, parent[root] = -1.  Branch index b == id of the branch's lower node,
+ *     i.e. the row order of the reference's .vec files (LegacySubstitutionMappingTools::writeToStream).
+ *   - alignment: uint8 codes, taxon-major: code of (taxon t, site i) at aln[t * ld + i].  code < S is a state;
+ *     code >= S indexes `masks` (bit z set <=> state z is compatible; X and gaps = all ones).
+ *   - "host" entry points take host pointers in the reference's layouts (counts site-major [N][B][K] ==
+ *     mapping[i][b][k], CoMap/Statistics.h:154-160).  "_dev" entry points take device pointers in the engine's
+ *     native layouts (counts branch-major [B*K][ld], one row per (branch, type), sites contiguous) and a
+ *     hipStream_t passed as void*; they never synchronise the device.
+ */
+#ifndef COMAP_MI355X_H
+#define COMAP_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmx_ctx cmx_ctx;
+
+typedef enum {
+  CMX_OK = 0,
+  CMX_ERR_INVALID = -1,      /* bad argument (reference: bpp::Exception / DimensionException) */
+  CMX_ERR_UNSUPPORTED = -2,  /* e.g. nstates not in {4, 20} */
+  CMX_ERR_DEVICE = -3,       /* HIP error; no CPU fallback exists */
+  CMX_ERR_NOMEM = -4
+} cmx_status;
+
+/* statistic kinds: CoMap/Statistics.h:164-329, factory CoMap/CoETools.cpp:535-600 */
+typedef enum {
+  CMX_STAT_CORRELATION = 0,    /* Statistics.h:164-174 */
+  CMX_STAT_COMPENSATION = 1,   /* Statistics.h:247-265 */
+  CMX_STAT_COSUBSTITUTION = 2, /* Statistics.h:230-245 */
+  CMX_STAT_COSINUS = 3,        /* Statistics.h:218-228 */
+  CMX_STAT_COVARIANCE = 4,     /* Statistics.h:206-216 */
+  CMX_STAT_DISCRETE_MI = 5     /* Statistics.h:307-327 with bounds {0, threshold, 10000} (CoETools.cpp:590-593) */
+} cmx_stat_kind;
+
+/* substitution-count flavour (SubstitutionCountInterface::getAllNumbersOfSubstitutions, CoMap/CoMap.cpp:152) */
+typedef enum {
+  CMX_COUNT_EXPECTED = 0, /* Uniformization == Decomposition (exact conditional expectation) */
+  CMX_COUNT_NAIVE = 1     /* N(x,y) = W(x,y) [x != y] */
+} cmx_count_method;
+
+typedef struct {
+  int32_t nstates;             /* S: 4 or 20 */
+  int32_t nclasses;            /* C: discrete rate classes */
+  int32_t ntypes;              /* K: substitution types (1 for the total register) */
+  const double* Q;             /* [S*S] row-major generator, reversible w.r.t. pi */
+  const double* pi;            /* [S] */
+  const double* rates;         /* [C] */
+  const double* probs;         /* [C] */
+  const double* Bk;            /* [K*S*S] Q o register_k o weights, zero diagonal; NULL => K = 1, unweighted total */
+  int32_t count_method;        /* cmx_count_method */
+  int32_t clamp_negative;      /* 1: clamp negative conditional counts to 0 (Bio++ rule for unweighted counts) */
+  const double* naive_weights; /* [S*S] for CMX_COUNT_NAIVE, NULL => 1 */
+} cmx_model;
+
+typedef struct {
+  int32_t nnodes;
+  const int32_t* parent;        /* [nnodes], post-order, root last */
+  const double* blen;           /* [nnodes], blen[root] ignored */
+  int32_t ntaxa;
+  const int32_t* leaf_of_taxon; /* [ntaxa] node id of each alignment row */
+} cmx_tree;
+
+typedef struct {
+  int32_t nstates, nclasses, ntypes, nnodes, nbranches, ntaxa, ninternal;
+  int32_t device, cu_count, waves; /* waves = resident mapping waves (workspace is sized for them) */
+  size_t workspace_bytes;
+} cmx_info;
+
+const char* cmx_version(void);
+cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int device, cmx_ctx** out);
+void cmx_ctx_destroy(cmx_ctx* ctx);
+const char* cmx_last_error(const cmx_ctx* ctx); /* ctx may be NULL: last error of a failed cmx_ctx_create */
+cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info);
+/* transition probabilities the engine uses, for inspection/tests: P[C][B][S][S] (row x -> column y) */
+cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P);
+cmx_status cmx_synchronize(cmx_ctx* ctx);
+
+/* ---- substitution mapping: replaces DRHomogeneousTreeLikelihood::initialize + getLogLikelihoodPerSite /
+ * getPosteriorRatePerSite / getRateClassWithMaxPostProbPerSite + computeSubstitutionVectors + computeNormForSite
+ * as reached from CoETools::getVectors (CoETools.cpp:397) and AnalysisTools.cpp:592-612.  Any output may be NULL. */
+cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t ld, const uint32_t* masks,
+                         size_t nmasks, double* counts /*[N][B][K]*/, double* logL, double* post_rate,
+                         int32_t* rate_class, double* norm);
+cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
+                             double* d_counts /*[B*K][ldc]*/, size_t ldc, double* d_logL, double* d_post_rate,
+                             int32_t* d_rate_class, double* d_norm, void* stream);
+
+/* ---- sequence simulator (NonHomogeneousSequenceSimulator::simulate, AnalysisTools.cpp:591): counter-based RNG,
+ * global site indices g0 .. g0+n-1 (see DESIGN.md "RNG").  aln_out: [T][n]. */
+cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln_out, int32_t* classes_out);
+
+/* ---- all-pairs statistic.  counts2 == NULL: intra (CoETools.cpp:672-692), out[i*N1+j] filled for j > i, NaN
+ * elsewhere.  Otherwise inter (CoETools.cpp:786-810), out[i*N2+j].  params: for CMX_STAT_DISCRETE_MI params[0] is
+ * the threshold; ignored otherwise (may be NULL). */
+cmx_status cmx_pair_stats(cmx_ctx* ctx, int kind, const double* params, const double* counts1, size_t n1,
+                          const double* counts2, size_t n2, double* out);
+cmx_status cmx_pair_stats_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts1, size_t n1,
+                              size_t ld1, const double* d_counts2, size_t n2, size_t ld2, double* d_out, size_t ldo,
+                              void* stream);
+
+/* ---- parametric-bootstrap null, replicates [rep_begin, rep_end) of AnalysisTools::getNullDistributionIntraDR
+ * (AnalysisTools.cpp:587-653): per replicate two batches of rep_ram simulated sites are mapped and site j of
+ * batch 1 is scored against site j of batch 2.  Outputs have (rep_end-rep_begin)*rep_ram entries, the four
+ * columns of AnalysisTools.cpp:642.  supplied (optional): [rep_end-rep_begin][2][T][rep_ram] alignments to map
+ * instead of simulating (deterministic cross-implementation checks).  Sharding replicates over GPUs gives results
+ * independent of the number of shards. */
+cmx_status cmx_null_intra(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin,
+                          size_t rep_end, size_t rep_ram, const uint8_t* supplied, double* stat, int32_t* rcmin,
+                          double* prmin, double* nmin);
+cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin,
+                              size_t rep_end, size_t rep_ram, const uint8_t* d_supplied, double* d_stat,
+                              int32_t* d_rcmin, double* d_prmin, double* d_nmin, void* stream);
+
+/* ---- p-values of CoETools::computeIntraStats (CoETools.cpp:636-652, 695-721): null stats are binned by
+ * Domain(0, max(norms), nclasses) on nmin (out-of-range and NaN dropped), sorted per class;
+ * p = (nsim - #{null < stat} + 1)/(nsim + 1).  pvalue = NaN / nsim = 0 where the reference prints "NA\t0". */
+cmx_status cmx_intra_pvalues(cmx_ctx* ctx, const double* stat /*[N*N]*/, const double* norms, size_t n,
+                             int nclasses, const double* null_stat, const double* null_nmin, size_t nnull,
+                             double* pvalue, int32_t* nsim);
+cmx_status cmx_intra_pvalues_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, const double* d_norms, size_t n,
+                                 int nclasses, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
+                                 double* d_pvalue, int32_t* d_nsim, void* stream);
+
+/* ---- Mica: mutual information between alignment columns over taxa (Mica.cpp:93-95, 349-361, 646-660).
+ * aln2 == NULL: intra.  Outputs dense [n1][n2] (mi, hjoint) and per-column entropies; nalpha = alphabet size. */
+cmx_status cmx_mi_columns(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks,
+                          const uint8_t* aln1, size_t n1, const uint8_t* aln2, size_t n2, double* mi,
+                          double* hjoint, double* h1, double* h2);
+cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* d_masks, const uint8_t* d_aln1,
+                              size_t n1, size_t ld1, const uint8_t* d_aln2, size_t n2, size_t ld2, double* d_mi,
+                              double* d_hjoint, size_t ldo, double* d_h1, double* d_h2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMAP_MI355X_H */

@@ -1,0 +1,203 @@
+"""-m gpu: the HIP path behind the C-ABI against the oracle on the same seeded inputs.
+
+Tolerances: substitution vectors, likelihoods, norms, statistics 1e-6 relative (north_star); rate classes, norm
+classes, Nsim, simulated states bit-exact.  Statistics that are differences of nearly equal numbers (correlation
+near 0, compensation near 0) additionally get an absolute floor of 1e-12, stated where used."""
+import numpy as np
+import pytest
+
+import oracle
+from comap_amd import engine, protein_models as pm, synthetic
+from conftest import make_case, rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(case, **kw):
+    return engine.Engine(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"],
+                         **kw)
+
+
+def _omodel(case, **kw):
+    return oracle.Model(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"],
+                        **kw)
+
+
+def _check_map(r, o):
+    rel_close(r["counts"], o["counts"], 1e-6, 1e-300)
+    rel_close(r["logL"], o["logL"], 1e-9)
+    rel_close(r["post_rate"], o["post_rate"], 1e-9)
+    rel_close(r["norm"], o["norm"], 1e-6)
+    assert np.array_equal(r["rate_class"], o["rate_class"])
+
+
+def test_transition_matrices_match_oracle_eigensystem():
+    case = make_case(8, 4, 20, 11)
+    eng = _engine(case)
+    P = eng.transition_matrices()
+    assert np.allclose(P.sum(-1), 1.0, atol=1e-12)
+    import scipy.linalg
+    for c in (0, 3):
+        for b in (0, 5):
+            ref = scipy.linalg.expm(case["Q"] * case["blen"][b] * case["rates"][c])
+            assert np.max(np.abs(P[c, b] - ref)) < 1e-12
+
+
+@pytest.mark.parametrize("nsites", [1, 63, 64, 65, 200])
+def test_map_sites_protein_ragged_sizes(nsites):
+    case = make_case(12, nsites, 20, 100 + nsites)
+    r = _engine(case).map_sites(case["aln"])
+    _check_map(r, oracle.map_sites(_omodel(case), case["aln"]))
+
+
+def test_map_sites_dna_five_classes_multifurcating_root():
+    case = make_case(33, 300, 4, 7, alpha=0.8, ncat=5)
+    r = _engine(case).map_sites(case["aln"])
+    _check_map(r, oracle.map_sites(_omodel(case), case["aln"]))
+    assert (r["counts"] >= 0).all()
+
+
+def test_map_sites_myoglobin_golden_with_ambiguity(myo):
+    """100 taxa, X/B/Z symbols, 1e-6 branches: GPU vs oracle at 1e-6, and vs the reference's own fixture."""
+    Q, pi = pm.jtt92()
+    rates, probs = pm.gamma_rates(float(myo["alpha"]), 4)
+    eng = engine.Engine(myo["parent"], myo["blen"], myo["leaf_of_taxon"], Q, pi, rates, probs)
+    r = eng.map_sites(myo["aln"], masks=myo["masks"])
+    o = oracle.map_sites(oracle.Model(myo["parent"], myo["blen"], myo["leaf_of_taxon"], Q, pi, rates, probs), myo["aln"],
+                         myo["masks"])
+    _check_map(r, o)
+    v = myo["vec_unif"].T
+    rel = np.abs(r["counts"][:, :, 0] - v) / np.where(v > 0, v, 1)
+    assert rel.max() < 1e-4 and np.median(rel) < 5e-6
+    assert np.array_equal(r["rate_class"], myo["infos_rc"])
+    assert np.max(np.abs(r["logL"] - myo["infos_logl"]) / np.abs(myo["infos_logl"])) < 1e-5
+
+
+def test_map_sites_two_types_weighted_and_naive():
+    case = make_case(10, 70, 20, 21)
+    Q = case["Q"]
+    W = pm.grantham_distance()
+    B0 = synthetic.weighted_register(Q)
+    ts = np.triu(np.ones((20, 20)), 1)
+    ts = ts + ts.T
+    ts[:, ::2] = 0                      # an arbitrary two-type register: type 0 = into odd states, type 1 = the rest
+    Bk = np.stack([B0 * ts, B0 * (1 - ts)])
+    r = _engine(case, Bk=Bk).map_sites(case["aln"])
+    o = oracle.map_sites(_omodel(case, Bk=Bk), case["aln"])
+    _check_map(r, o)
+    tot = _engine(case).map_sites(case["aln"])
+    rel_close(r["counts"].sum(-1), tot["counts"][:, :, 0], 1e-9)       # linearity over types
+    Bw = synthetic.weighted_register(Q, W - W.mean())                    # signed weights: no clamping
+    rw = _engine(case, Bk=Bw[None], clamp_negative=False).map_sites(case["aln"])
+    ow = oracle.map_sites(_omodel(case, Bk=Bw[None], nonneg=False), case["aln"])
+    rel_close(rw["counts"], ow["counts"], 1e-6, 1e-9)
+    rn = _engine(case, count_method=engine.COUNT_NAIVE, naive_weights=W).map_sites(case["aln"])
+    on = oracle.map_sites(_omodel(case, method=oracle.METHOD_NAIVE, naive_W=W), case["aln"])
+    rel_close(rn["counts"], on["counts"], 1e-6, 1e-300)
+
+
+def test_simulator_bit_exact_and_distribution():
+    case = make_case(16, 4, 20, 5)
+    eng, om = _engine(case), _omodel(case)
+    a, c = eng.simulate(seed=987654321, g0=12345, n=3000)
+    ao, co = oracle.simulate(om, 987654321, 12345, 3000)
+    assert np.array_equal(c, co)
+    assert np.array_equal(a, ao)
+    freq = np.bincount(a.ravel(), minlength=20) / a.size
+    assert np.max(np.abs(freq - case["pi"])) < 0.02
+    a2, _ = eng.simulate(seed=987654321, g0=12345 + 1000, n=10)
+    assert np.array_equal(a2, a[:, 1000:1010])            # counter-based: any sub-range reproduces
+
+
+@pytest.mark.parametrize("kind", range(6))
+def test_pair_stats_all_kinds_intra_and_inter(kind):
+    case = make_case(14, 150, 20, 31)
+    eng = _engine(case)
+    counts = eng.map_sites(case["aln"])["counts"]
+    if kind in (2, 5):
+        counts = counts * 3.0          # make ">= 1" / ">= 0.99" events common
+    g = eng.pair_stats(kind, counts)
+    o = oracle.pair_stats_intra(kind, counts)
+    rel_close(g, o, 1e-6, 1e-12)
+    g2 = eng.pair_stats(kind, counts[:40], counts[40:150])
+    o2 = oracle.pair_stats_inter(kind, counts[:40], counts[40:150])
+    rel_close(g2, o2, 1e-6, 1e-12)
+    iu = np.triu_indices(150, 1)
+    if kind == 0:
+        assert np.nanmax(np.abs(g[iu])) <= 1 + 1e-12
+
+
+def test_pair_stats_on_reference_fixture_vectors(myo):
+    """Feed the reference's own Myo_unif.vec (197 x 129) through the Gram kernel: all 8256 correlations."""
+    case = dict(parent=myo["parent"], blen=myo["blen"], lot=myo["leaf_of_taxon"])
+    Q, pi = pm.jtt92()
+    rates, probs = pm.gamma_rates(float(myo["alpha"]), 4)
+    eng = engine.Engine(myo["parent"], myo["blen"], myo["leaf_of_taxon"], Q, pi, rates, probs)
+    counts = myo["vec_unif"].T[:, :, None].copy()
+    for kind in (0, 3, 4):
+        rel_close(eng.pair_stats(kind, counts), oracle.pair_stats_intra(kind, counts), 1e-6, 1e-12)
+
+
+def test_null_intra_supplied_and_simulated_match_oracle():
+    case = make_case(10, 8, 20, 41)
+    eng, om = _engine(case), _omodel(case)
+    nrep, rep_ram = 3, 50                                   # 150 null pairs; blocks straddle replicates (50 % 64 != 0)
+    o = oracle.null_intra(om, 0, 777, 0, nrep, rep_ram)
+    g = eng.null_intra(0, 777, 0, nrep, rep_ram)
+    rel_close(g["stat"], o["stat"], 1e-6, 1e-12)
+    rel_close(g["prmin"], o["prmin"], 1e-9)
+    rel_close(g["nmin"], o["nmin"], 1e-6)
+    assert np.array_equal(g["rcmin"], o["rcmin"])
+    # sharding invariance: replicates [1,3) alone reproduce the tail of the full run (bit for bit)
+    g2 = eng.null_intra(0, 777, 1, 3, rep_ram)
+    assert np.array_equal(g2["stat"], g["stat"][rep_ram:])
+    assert np.array_equal(g2["nmin"], g["nmin"][rep_ram:])
+    # externally supplied alignments (deterministic cross-implementation path)
+    sup = np.stack([np.stack([oracle.simulate(om, 5, (r * 2 + h) * rep_ram, rep_ram)[0] for h in range(2)])
+                    for r in range(nrep)])
+    for kind in (0, 1, 5):
+        os_ = oracle.null_intra(om, kind, 0, 0, nrep, rep_ram, supplied=sup)
+        gs = eng.null_intra(kind, 0, 0, nrep, rep_ram, supplied=sup)
+        rel_close(gs["stat"], os_["stat"], 1e-6, 1e-12)
+
+
+def test_pvalues_bit_exact_counts_and_na_rule():
+    case = make_case(10, 90, 20, 51)
+    eng, om = _engine(case), _omodel(case)
+    m = eng.map_sites(case["aln"])
+    stat = eng.pair_stats(0, m["counts"])
+    null = eng.null_intra(0, 99, 0, 40, 64)
+    pv, ns = eng.intra_pvalues(stat, m["norm"], 10, null["stat"], null["nmin"])
+    po, no = oracle.intra_pvalues(stat, m["norm"], 10, null["stat"], null["nmin"])
+    assert np.array_equal(ns, no)
+    assert np.array_equal(np.isnan(pv), np.isnan(po))
+    assert np.array_equal(pv[~np.isnan(pv)], po[~np.isnan(po)])          # same integers -> same doubles
+    imax = int(np.argmax(m["norm"]))                                      # Domain upper bound is exclusive:
+    others = [j for j in range(90) if j != imax and m["norm"][j] == m["norm"][imax]]
+    assert not others
+    iu = np.triu_indices(90, 1)
+    assert (ns[iu] > 0).all()                                             # min(norm_i, norm_j) < max norm always here
+    pv0, ns0 = eng.intra_pvalues(stat, m["norm"], 10, np.zeros(0), np.zeros(0))
+    assert (ns0 == 0).all() and np.all(pv0[iu] == 1.0)                   # (0 - 0 + 1)/(0 + 1)
+
+
+def test_mi_columns_matches_oracle_with_ambiguity():
+    rng = np.random.default_rng(3)
+    T, n1, n2 = 40, 37, 21
+    a1 = rng.integers(0, 20, size=(T, n1)).astype(np.uint8)
+    a2 = rng.integers(0, 6, size=(T, n2)).astype(np.uint8)
+    a1[rng.random(a1.shape) < 0.05] = 22                  # 'X'
+    a2[rng.random(a2.shape) < 0.05] = 20                  # 'B' = {D, N}
+    masks = oracle.default_masks(20)
+    masks[20] = (1 << 3) | (1 << 2)
+    eng = engine.Engine()
+    g = eng.mi_columns(a1, a2, 20, masks)
+    o = oracle.mi_columns(a1, a2, 20, masks)
+    rel_close(g["mi"], o["mi"], 1e-6, 1e-12)
+    rel_close(g["hjoint"], o["hjoint"], 1e-6, 1e-12)
+    rel_close(g["h1"], o["h1"], 1e-9, 1e-12)
+    rel_close(g["h2"], o["h2"], 1e-9, 1e-12)
+    gi = eng.mi_columns(a2, None, 20, masks)
+    oi = oracle.mi_columns(a2, a2, 20, masks)
+    iu = np.triu_indices(n2, 1)
+    rel_close(gi["mi"][iu], oi["mi"][iu], 1e-6, 1e-12)
