@@ -159,7 +159,9 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
 #define UP(field) if ((s = upload(ctx, h.field, &d.field)) != CMX_OK) return s
     UP(int_post); UP(first_child); UP(next_sib); UP(taxon_of); UP(slot); UP(parent);
     UP(PP); UP(JP); UP(LPT); UP(LJT); UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
+    UP(ldsched);
 #undef UP
+    d.nloads = (int)h.ldsched.size();
     // ambiguity masks default: code c >= S compatible with every state; fix the table for this S
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
@@ -173,10 +175,12 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.D, bD));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.U, bD));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.cnt, bC));
+    const size_t bP = w * h.C * h.B * h.K * kWave * sizeof(double);
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.part, bP));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.st, bS));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.aln, bA));
     ctx->ws.waves = ctx->waves;
-    ctx->ws_bytes = 2 * bD + bC + bS + bA;
+    ctx->ws_bytes = 2 * bD + bC + bP + bS + bA;
     return CMX_OK;
   };
   cmx_status s = dev_init();
@@ -192,6 +196,7 @@ void cmx_ctx_destroy(cmx_ctx* ctx) {
   if (ctx->ws.D) (void)hipFree(ctx->ws.D);
   if (ctx->ws.U) (void)hipFree(ctx->ws.U);
   if (ctx->ws.cnt) (void)hipFree(ctx->ws.cnt);
+  if (ctx->ws.part) (void)hipFree(ctx->ws.part);
   if (ctx->ws.st) (void)hipFree(ctx->ws.st);
   if (ctx->ws.aln) (void)hipFree(ctx->ws.aln);
   delete ctx;

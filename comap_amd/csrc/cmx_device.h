@@ -32,13 +32,17 @@ struct DevModel {
   const double* probs;     // [C]
   const double* cum_pi;    // [S]
   const double* cum_probs; // [C]
+  // workspace-load schedule of one rate-class pass (see CMX_POP in cmx_kernels.hip)
+  const int* ldsched;      // [nloads] bit31 prefetchable, bit30 array (0 D, 1 U), low 24 bits slot
+  int nloads;
 };
 
 // Per-wave workspace strides (in elements); every wave owns one slice of each array.
 struct Workspace {
   double* D;        // [waves][NI][S][64]   inside (post-order) conditional likelihoods of internal nodes
   double* U;        // [waves][NI][S][64]   outside messages arriving at internal nodes
-  double* cnt;      // [waves][2][B*K][64]  per-class accumulated joint counts (two batches for the null)
+  double* cnt;      // [waves][2][B*K][64]  final counts of the wave's sites (two batches for the null)
+  double* part;     // [waves][C][B*K][64]  per-class joint counts, summed in class order at the end
   uint8_t* st;      // [waves][nn][64]      simulated states
   uint8_t* aln;     // [waves][T][64]       simulated leaf states
   int waves;

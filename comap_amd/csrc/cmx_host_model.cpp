@@ -68,6 +68,54 @@ void pack_blocks(int S, const double* M, double* out) {
 
 }  // namespace
 
+void build_load_schedule(HostModel* hm) {
+  const int NI = hm->NI, root = hm->root;
+  struct Ev { int arr, slot; long t, src_store; };
+  std::vector<Ev> pops;
+  std::vector<long> storeD(NI, -1), storeU(NI, -1);
+  long t = 0;
+  hm->stores_D = hm->stores_U = 0;
+  auto pop = [&](int arr, int slot) { pops.push_back({arr, slot, t++, arr ? storeU[slot] : storeD[slot]}); };
+  auto internal = [&](int n) { return hm->taxon_of[n] < 0; };
+  // inside pass
+  int carry_node = -1;
+  for (int idx = 0; idx < NI; ++idx) {
+    const int n = hm->int_post[idx];
+    const bool use_carry = carry_node >= 0 && hm->parent[carry_node] == n;
+    for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e])
+      if (internal(e) && !(use_carry && e == carry_node)) pop(0, hm->slot[e]);
+    if (n != root) { storeD[hm->slot[n]] = t++; hm->stores_D++; carry_node = n; }
+  }
+  // outside pass
+  int upc_node = -1;
+  for (int idx = NI - 1; idx >= 0; --idx) {
+    const int f = hm->int_post[idx];
+    if (f != root && f != upc_node) pop(1, hm->slot[f]);
+    const int ca = hm->first_child[f], cb = hm->next_sib[ca];
+    if (hm->next_sib[cb] < 0) {
+      if (internal(cb)) pop(0, hm->slot[cb]);
+      if (internal(ca)) { pop(0, hm->slot[ca]); storeU[hm->slot[ca]] = t++; hm->stores_U++; }
+      if (internal(cb)) { pop(0, hm->slot[cb]); upc_node = cb; }
+    } else {
+      for (int n = ca; n >= 0; n = hm->next_sib[n]) {
+        for (int sb = ca; sb >= 0; sb = hm->next_sib[sb])
+          if (sb != n && internal(sb)) pop(0, hm->slot[sb]);
+        if (internal(n)) { pop(0, hm->slot[n]); storeU[hm->slot[n]] = t++; hm->stores_U++; }
+      }
+    }
+  }
+  hm->ldsched.clear();
+  hm->loads_D = hm->loads_U = 0;
+  for (size_t j = 0; j < pops.size(); ++j) {
+    const Ev& e = pops[j];
+    unsigned v = (unsigned)e.slot | (e.arr ? 0x40000000u : 0u);
+    // prefetchable: its producer store is issued before the previous pop (where the prefetch is issued)
+    if (j > 0 && e.src_store >= 0 && e.src_store < pops[j - 1].t) v |= 0x80000000u;
+    hm->ldsched.push_back((int)v);
+    if (e.arr) hm->loads_U++; else hm->loads_D++;
+  }
+}
+
 std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostModel* hm, int* code) {
   *code = CMX_ERR_INVALID;
   if (!model || !tree) return "model and tree are required";
@@ -121,6 +169,7 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   }
   if (nchild[nn - 1] < 2) return "the root needs at least two children";
   hm->NI = (int)hm->int_post.size();
+  build_load_schedule(hm);
   // ---- model checks
   hm->pi.assign(model->pi, model->pi + S);
   hm->rates.assign(model->rates, model->rates + C);

@@ -23,7 +23,12 @@ struct HostModel {
   std::vector<double> LPT;  // [C][T][S][S]     transposed P of leaf branches
   std::vector<double> LJT;  // [C][K][T][S][S]  transposed PN of leaf branches
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
+  std::vector<int> ldsched; // workspace-load schedule of one class pass (DevModel::ldsched)
+  size_t loads_D = 0, loads_U = 0, stores_D = 0, stores_U = 0;  // per class pass, for traffic accounting
 };
+
+// Mirrors the loop nest of map_sites_wave (cmx_kernels.hip) and lists its workspace loads in program order.
+void build_load_schedule(HostModel* hm);
 
 // returns empty string on success, otherwise the error message (status in *code)
 std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostModel* out, int* code);

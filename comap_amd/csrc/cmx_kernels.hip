@@ -149,43 +149,93 @@ __device__ __forceinline__ int draw_index(double u, const double* __restrict__ c
 }
 
 // ------------------------------------------------------------------------------------------------ mapping core
+// Workspace vector loads go through a one-deep prefetch FIFO driven by a host-built schedule (m.ldsched): the
+// sequence of [slot] loads is a pure function of the tree, so the host lists it in program order and marks an
+// entry prefetchable when the store that produces it is issued before the previous pop.  pop() hands out the
+// vector fetched during the previous matrix product and immediately issues the next fetch, which then overlaps
+// the ~1600 cycles of FMAs that follow.  Bit 31 = prefetchable, bit 30 = array (0: inside D, 1: outside U).
+#define CMX_SCHED_ADDR(e) (((e) & 0x40000000) ? wsU : wsD) + (size_t)((e) & 0x00ffffff) * S * kWave + lane
+#define CMX_POP(dst)                                                        \
+  do {                                                                      \
+    if (pend) {                                                             \
+      _Pragma("unroll") for (int x_ = 0; x_ < S; ++x_) dst[x_] = pf[x_];    \
+    } else {                                                                \
+      const int e_ = m.ldsched[fi];                                         \
+      load_vec<S>(CMX_SCHED_ADDR(e_), dst);                                 \
+    }                                                                       \
+    ++fi;                                                                   \
+    pend = false;                                                           \
+    if (fi < m.nloads) {                                                    \
+      const int e2_ = m.ldsched[fi];                                        \
+      if (e2_ < 0) {                                                        \
+        load_vec<S>(CMX_SCHED_ADDR(e2_), pf);                               \
+        pend = true;                                                        \
+      }                                                                     \
+    }                                                                       \
+  } while (0)
+
 // Maps the 64 sites of this wave (codes at aln_base[taxon * stride], per lane) for all rate classes.
 // On return cnt[(b*K+k)*64 + lane] holds the final counts n(b, site, k) and the scalars are per lane.
+// part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
+// Register budget: five S-vectors live at most (acc/upf, u, d, t, pf) so that two waves fit per SIMD.
+// The loop nest below is mirrored statement for statement by build_load_schedule() in cmx_host_model.cpp.
 template <int S>
 __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
-                                               double* __restrict__ cnt, const uint8_t* __restrict__ aln_base,
-                                               size_t stride, int lane, double& L_out, double& pr_out, int& rc_out,
-                                               double& norm_out) {
+                                               double* __restrict__ part, double* __restrict__ cnt,
+                                               const uint8_t* __restrict__ aln_base, size_t stride, int lane,
+                                               double& L_out, double& pr_out, int& rc_out, double& norm_out) {
   const DevModel& m = a.m;
   const int C = m.C, K = m.K, NI = m.NI, root = m.root;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
+#define CMX_LEAF_P(tx, out) leaf_vec<S>(m.LPT + ((size_t)c * m.T + (tx)) * S * S, aln_base[(size_t)(tx) * stride], a.masks, out)
+#define CMX_LEAF_J(tx, k, out) \
+  leaf_vec<S>(m.LJT + (((size_t)c * K + (k)) * m.T + (tx)) * S * S, aln_base[(size_t)(tx) * stride], a.masks, out)
+#define CMX_PMAT(sl) (m.PP + ((size_t)c * NI + (sl)) * S * S)
+#define CMX_JMAT(sl, k) (m.JP + (((size_t)c * NI + (sl)) * K + (k)) * S * S)
+#define CMX_DOT(x_, y_, out)                                                          \
+  do {                                                                                \
+    out = 0.0;                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < S; ++i_) out = __builtin_fma(x_[i_], y_[i_], out); \
+  } while (0)
   for (int c = 0; c < C; ++c) {
     const double pc = m.probs[c];
-    // ---------------- inside (post-order) pass
+    double* pcnt = part + (size_t)c * m.B * K * kWave + lane;
+    double pf[S];       // prefetched workspace vector
+    double d[S], t[S];  // popped vector / matvec result
+    int fi = 0;         // next schedule entry
+    bool pend = false;  // pf holds entry fi
+    // ---------------- inside (post-order) pass.  acc leaves each iteration holding D of the node just finished; when
+    // that node is a child of the next one (it then is its last child) it is consumed from registers.
+    double acc[S];
+    int carry_node = -1;
     double Lc = 0.0;
     for (int idx = 0; idx < NI; ++idx) {
       const int n = m.int_post[idx];
-      double acc[S];
+      const bool use_carry = carry_node >= 0 && m.parent[carry_node] == n;
+      if (use_carry) {
+        matvec_s<S, false>(CMX_PMAT(m.slot[carry_node]), acc, t);
 #pragma unroll
-      for (int x = 0; x < S; ++x) acc[x] = 1.0;
+        for (int x = 0; x < S; ++x) acc[x] = t[x];
+      } else {
+#pragma unroll
+        for (int x = 0; x < S; ++x) acc[x] = 1.0;
+      }
       for (int e = m.first_child[n]; e >= 0; e = m.next_sib[e]) {
-        double msg[S];
         const int tx = m.taxon_of[e];
         if (tx >= 0) {
-          const unsigned code = aln_base[(size_t)tx * stride];
-          leaf_vec<S>(m.LPT + ((size_t)c * m.T + tx) * S * S, code, a.masks, msg);
+          CMX_LEAF_P(tx, t);
         } else {
-          const int sl = m.slot[e];
-          double d[S];
-          load_vec<S>(wsD + (size_t)sl * S * kWave + lane, d);
-          matvec_s<S, false>(m.PP + ((size_t)c * NI + sl) * S * S, d, msg);
+          if (use_carry && e == carry_node) continue;
+          CMX_POP(d);
+          matvec_s<S, false>(CMX_PMAT(m.slot[e]), d, t);
         }
 #pragma unroll
-        for (int x = 0; x < S; ++x) acc[x] *= msg[x];
+        for (int x = 0; x < S; ++x) acc[x] *= t[x];
       }
       if (n != root) {
         store_vec<S>(wsD + (size_t)m.slot[n] * S * kWave + lane, acc);
+        carry_node = n;
       } else {
 #pragma unroll
         for (int x = 0; x < S; ++x) Lc = __builtin_fma(m.pi[x], acc[x], Lc);
@@ -194,76 +244,131 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     Lsum += pc * Lc;
     prsum += m.rates[c] * pc * Lc;
     if (pc * Lc > best) { best = pc * Lc; bestc = c; }  // first maximum wins (getRateClassWithMaxPostProbPerSite)
-    // ---------------- outside (pre-order) pass + joint counts
+    // ---------------- outside (pre-order) pass + joint counts.  acc now carries the outside message Up_f; a binary
+    // node leaves Up of its last child in acc (that child is visited next in reverse post-order).
+    double u[S];
+    int up_node = -1;  // node whose Up is in acc
     for (int idx = NI - 1; idx >= 0; --idx) {
       const int f = m.int_post[idx];
-      double upf[S];
       if (f == root) {
 #pragma unroll
-        for (int x = 0; x < S; ++x) upf[x] = m.pi[x];
-      } else {
-        load_vec<S>(wsU + (size_t)m.slot[f] * S * kWave + lane, upf);
+        for (int x = 0; x < S; ++x) acc[x] = m.pi[x];
+      } else if (f != up_node) {
+        CMX_POP(acc);
       }
-      for (int n = m.first_child[f]; n >= 0; n = m.next_sib[n]) {
-        double u[S];
-#pragma unroll
-        for (int x = 0; x < S; ++x) u[x] = upf[x];
-        for (int sb = m.first_child[f]; sb >= 0; sb = m.next_sib[sb]) {
-          if (sb == n) continue;
-          double msg[S];
-          const int tx = m.taxon_of[sb];
-          if (tx >= 0) {
-            const unsigned code = aln_base[(size_t)tx * stride];
-            leaf_vec<S>(m.LPT + ((size_t)c * m.T + tx) * S * S, code, a.masks, msg);
-          } else {
-            const int sl = m.slot[sb];
-            double d[S];
-            load_vec<S>(wsD + (size_t)sl * S * kWave + lane, d);
-            matvec_s<S, false>(m.PP + ((size_t)c * NI + sl) * S * S, d, msg);
-          }
-#pragma unroll
-          for (int x = 0; x < S; ++x) u[x] *= msg[x];
+      const int ca = m.first_child[f];
+      const int cb = m.next_sib[ca];
+      if (m.next_sib[cb] < 0) {
+        // ---- binary node (children ca < cb): at most three workspace loads
+        const int ta = m.taxon_of[ca], tb = m.taxon_of[cb];
+        if (tb >= 0) {
+          CMX_LEAF_P(tb, t);
+        } else {
+          CMX_POP(d);
+          matvec_s<S, false>(CMX_PMAT(m.slot[cb]), d, t);
         }
-        const int tn = m.taxon_of[n];
-        if (tn >= 0) {
-          const unsigned code = aln_base[(size_t)tn * stride];
-          for (int k = 0; k < K; ++k) {
-            double jd[S];
-            leaf_vec<S>(m.LJT + (((size_t)c * K + k) * m.T + tn) * S * S, code, a.masks, jd);
-            double tot = 0.0;
 #pragma unroll
-            for (int x = 0; x < S; ++x) tot = __builtin_fma(u[x], jd[x], tot);
-            double* dst = cnt + ((size_t)n * K + k) * kWave + lane;
-            *dst = (c == 0) ? pc * tot : *dst + pc * tot;
+        for (int x = 0; x < S; ++x) u[x] = acc[x] * t[x];  // U_a = Up_f o M_b
+        if (ta >= 0) {
+          for (int k = 0; k < K; ++k) {
+            CMX_LEAF_J(ta, k, t);
+            double tot;
+            CMX_DOT(u, t, tot);
+            pcnt[((size_t)ca * K + k) * kWave] = pc * tot;
+          }
+          CMX_LEAF_P(ta, t);
+#pragma unroll
+          for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_b = Up_f o M_a
+        } else {
+          const int sl = m.slot[ca];
+          CMX_POP(d);
+          for (int k = 0; k < K; ++k) {
+            matvec_s<S, false>(CMX_JMAT(sl, k), d, t);
+            double tot;
+            CMX_DOT(u, t, tot);
+            pcnt[((size_t)ca * K + k) * kWave] = pc * tot;
+          }
+          matvec_s<S, false>(CMX_PMAT(sl), d, t);
+#pragma unroll
+          for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_b
+          matvec_s<S, true>(CMX_PMAT(sl), u, d);       // Up_a
+          store_vec<S>(wsU + (size_t)sl * S * kWave + lane, d);
+        }
+        if (tb >= 0) {
+          for (int k = 0; k < K; ++k) {
+            CMX_LEAF_J(tb, k, u);
+            double tot;
+            CMX_DOT(t, u, tot);
+            pcnt[((size_t)cb * K + k) * kWave] = pc * tot;
           }
         } else {
-          const int sl = m.slot[n];
-          double d[S];
-          load_vec<S>(wsD + (size_t)sl * S * kWave + lane, d);
+          const int sl = m.slot[cb];
+          CMX_POP(d);
           for (int k = 0; k < K; ++k) {
-            double jd[S];
-            matvec_s<S, false>(m.JP + (((size_t)c * NI + sl) * K + k) * S * S, d, jd);
-            double tot = 0.0;
-#pragma unroll
-            for (int x = 0; x < S; ++x) tot = __builtin_fma(u[x], jd[x], tot);
-            double* dst = cnt + ((size_t)n * K + k) * kWave + lane;
-            *dst = (c == 0) ? pc * tot : *dst + pc * tot;
+            matvec_s<S, false>(CMX_JMAT(sl, k), d, u);
+            double tot;
+            CMX_DOT(t, u, tot);
+            pcnt[((size_t)cb * K + k) * kWave] = pc * tot;
           }
-          double upn[S];
-          matvec_s<S, true>(m.PP + ((size_t)c * NI + sl) * S * S, u, upn);
-          store_vec<S>(wsU + (size_t)sl * S * kWave + lane, upn);
+          matvec_s<S, true>(CMX_PMAT(sl), t, acc);  // Up_b stays in registers for the next node
+          up_node = cb;
+        }
+      } else {
+        // ---- general node (root trifurcation, multifurcations): every sibling message recomputed per child
+        for (int n = ca; n >= 0; n = m.next_sib[n]) {
+#pragma unroll
+          for (int x = 0; x < S; ++x) u[x] = acc[x];
+          for (int sb = ca; sb >= 0; sb = m.next_sib[sb]) {
+            if (sb == n) continue;
+            const int tx = m.taxon_of[sb];
+            if (tx >= 0) {
+              CMX_LEAF_P(tx, t);
+            } else {
+              CMX_POP(d);
+              matvec_s<S, false>(CMX_PMAT(m.slot[sb]), d, t);
+            }
+#pragma unroll
+            for (int x = 0; x < S; ++x) u[x] *= t[x];
+          }
+          const int tn = m.taxon_of[n];
+          if (tn >= 0) {
+            for (int k = 0; k < K; ++k) {
+              CMX_LEAF_J(tn, k, t);
+              double tot;
+              CMX_DOT(u, t, tot);
+              pcnt[((size_t)n * K + k) * kWave] = pc * tot;
+            }
+          } else {
+            const int sl = m.slot[n];
+            CMX_POP(d);
+            for (int k = 0; k < K; ++k) {
+              matvec_s<S, false>(CMX_JMAT(sl, k), d, t);
+              double tot;
+              CMX_DOT(u, t, tot);
+              pcnt[((size_t)n * K + k) * kWave] = pc * tot;
+            }
+            matvec_s<S, true>(CMX_PMAT(sl), u, t);
+            store_vec<S>(wsU + (size_t)sl * S * kWave + lane, t);
+          }
         }
       }
     }
   }
-  // ---------------- divide by the site likelihood, norm (computeNormForSite)
+#undef CMX_LEAF_P
+#undef CMX_LEAF_J
+#undef CMX_PMAT
+#undef CMX_JMAT
+#undef CMX_DOT
+  // ---------------- sum the classes in class order, divide by the site likelihood, norm (computeNormForSite)
   double nrm = 0.0;
   for (int b = 0; b < m.B; ++b) {
     double tot = 0.0;
     for (int k = 0; k < K; ++k) {
-      double* p = cnt + ((size_t)b * K + k) * kWave + lane;
-      const double v = *p / Lsum;
-      *p = v;
+      const double* pp = part + ((size_t)b * K + k) * kWave + lane;
+      double v = 0.0;
+      for (int c = 0; c < C; ++c) v += pp[(size_t)c * m.B * K * kWave];
+      v /= Lsum;
+      cnt[((size_t)b * K + k) * kWave + lane] = v;
       tot += v;
     }
     nrm = __builtin_fma(tot, tot, nrm);
@@ -337,6 +442,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const Ma
   double* wsU = a.ws.U + (size_t)wave * m.NI * S * kWave;
   double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kWave;
   double* cnt1 = cnt0 + (size_t)m.B * m.K * kWave;
+  double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kWave;
   const size_t nblocks = (a.nsites + kWave - 1) / kWave;
   for (size_t sb = wave; sb < nblocks; sb += nwaves) {
     const size_t site = sb * kWave + lane;
@@ -345,7 +451,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const Ma
     if (MODE == kModeObserved) {
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S>(a, wsD, wsU, cnt0, a.aln + s, a.ld, lane, L, pr, rc, nrm);
+      map_sites_wave<S>(a, wsD, wsU, part, cnt0, a.aln + s, a.ld, lane, L, pr, rc, nrm);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
@@ -383,7 +489,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const Ma
           base = al;
           stride = kWave;
         }
-        map_sites_wave<S>(a, wsD, wsU, h ? cnt1 : cnt0, base, stride, lane, L[h], pr[h], rc[h], nrm[h]);
+        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, base, stride, lane, L[h], pr[h], rc[h], nrm[h]);
       }
       const double stat = pair_stat_lane(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + lane, cnt1 + lane);
       if (active) {
