@@ -158,7 +158,15 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     d.S = h.S; d.C = h.C; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.root = h.root;
 #define UP(field) if ((s = upload(ctx, h.field, &d.field)) != CMX_OK) return s
     UP(int_post); UP(first_child); UP(next_sib); UP(taxon_of); UP(slot); UP(parent);
-    UP(PP); UP(JP); UP(LPT); UP(LJT); UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
+    {  // P and (P o N^k) packed matrices in one allocation (one base pointer for the ring fetches)
+      std::vector<double> mat(h.PP);
+      mat.insert(mat.end(), h.JP.begin(), h.JP.end());
+      if ((s = upload(ctx, mat, &d.MAT)) != CMX_OK) return s;
+      d.joff = h.PP.size();
+    }
+    UP(msched);
+    d.nmv = (int)h.msched.size();
+    UP(LPT); UP(LJT); UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
     UP(ldsched);
 #undef UP
     d.nloads = (int)h.ldsched.size();
@@ -237,6 +245,7 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.aln = d_aln; a.ld = ld; a.nsites = nsites; a.masks = d_masks ? d_masks : ctx->d_default_masks;
+  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 80 * 1024;
   a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.norm = d_norm;
   const size_t blocks_needed = ((nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -399,6 +408,7 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.masks = ctx->d_default_masks;
+  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 80 * 1024;
   a.nsites = (rep_end - rep_begin) * rep_ram;
   a.stat_kind = kind;
   a.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;

@@ -20,8 +20,11 @@ struct DevModel {
   const int* slot;         // [nn]  internal nodes: 0..NI-1 (root = NI-1); leaves: -1
   const int* parent;       // [nn]
   // per (class, internal node): 4x4-block-packed matrices for the scalar-operand matvec
-  const double* PP;        // [C][NI][S*S]      P_node
-  const double* JP;        // [C][NI][K][S*S]   P_node o N^k_node
+  const double* MAT;       // packed matrices: P_node [C][NI][S*S] at 0, (P_node o N^k_node) [C][NI][K][S*S] at joff
+  size_t joff;
+  // matrix products of one class pass in program order: bit 31 set = (P o N^k) with index slot*K + k, else P[slot]
+  const int* msched;
+  int nmv;
   // per (class, taxon): transposed matrices for the per-lane leaf gather, [z][x] = M[x][z]
   const double* LPT;       // [C][T][S][S]
   const double* LJT;       // [C][K][T][S][S]
@@ -58,6 +61,7 @@ struct MapArgs {
   size_t ld;
   size_t nsites;           // observed: sites; null: (rep_end-rep_begin)*rep_ram null pairs
   const uint32_t* masks;   // ambiguity masks (may be null when all codes < S)
+  int codes_in_lds;        // leaf symbols of a wave's sites staged in LDS (fits when map_lds_bytes <= 80 KiB)
   double* counts;          // [B*K][ldc] or null
   size_t ldc;
   double* logL;            // [nsites] or null
@@ -77,6 +81,7 @@ struct MapArgs {
 };
 
 // launchers (cmx_kernels.hip)
+size_t map_lds_bytes(int S, int T, bool codes_in_lds);
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream);
 hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
                            int32_t* d_classes, uint8_t* d_states /*[nn][ld]*/, hipStream_t stream);

@@ -77,13 +77,18 @@ void build_load_schedule(HostModel* hm) {
   hm->stores_D = hm->stores_U = 0;
   auto pop = [&](int arr, int slot) { pops.push_back({arr, slot, t++, arr ? storeU[slot] : storeD[slot]}); };
   auto internal = [&](int n) { return hm->taxon_of[n] < 0; };
+  const int K = hm->K;
+  hm->msched.clear();
+  auto mvP = [&](int slot) { hm->msched.push_back(slot); };
+  auto mvJ = [&](int slot) { for (int k = 0; k < K; ++k) hm->msched.push_back((int)(0x80000000u | (unsigned)(slot * K + k))); };
   // inside pass
   int carry_node = -1;
   for (int idx = 0; idx < NI; ++idx) {
     const int n = hm->int_post[idx];
     const bool use_carry = carry_node >= 0 && hm->parent[carry_node] == n;
+    if (use_carry) mvP(hm->slot[carry_node]);
     for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e])
-      if (internal(e) && !(use_carry && e == carry_node)) pop(0, hm->slot[e]);
+      if (internal(e) && !(use_carry && e == carry_node)) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
     if (n != root) { storeD[hm->slot[n]] = t++; hm->stores_D++; carry_node = n; }
   }
   // outside pass
@@ -93,14 +98,18 @@ void build_load_schedule(HostModel* hm) {
     if (f != root && f != upc_node) pop(1, hm->slot[f]);
     const int ca = hm->first_child[f], cb = hm->next_sib[ca];
     if (hm->next_sib[cb] < 0) {
-      if (internal(cb)) pop(0, hm->slot[cb]);
-      if (internal(ca)) { pop(0, hm->slot[ca]); storeU[hm->slot[ca]] = t++; hm->stores_U++; }
-      if (internal(cb)) { pop(0, hm->slot[cb]); upc_node = cb; }
+      if (internal(cb)) { pop(0, hm->slot[cb]); mvP(hm->slot[cb]); }
+      if (internal(ca)) {
+        pop(0, hm->slot[ca]);
+        mvJ(hm->slot[ca]); mvP(hm->slot[ca]); mvP(hm->slot[ca]);   // J.D, P.D, P^T.U
+        storeU[hm->slot[ca]] = t++; hm->stores_U++;
+      }
+      if (internal(cb)) { pop(0, hm->slot[cb]); mvJ(hm->slot[cb]); mvP(hm->slot[cb]); upc_node = cb; }
     } else {
       for (int n = ca; n >= 0; n = hm->next_sib[n]) {
         for (int sb = ca; sb >= 0; sb = hm->next_sib[sb])
-          if (sb != n && internal(sb)) pop(0, hm->slot[sb]);
-        if (internal(n)) { pop(0, hm->slot[n]); storeU[hm->slot[n]] = t++; hm->stores_U++; }
+          if (sb != n && internal(sb)) { pop(0, hm->slot[sb]); mvP(hm->slot[sb]); }
+        if (internal(n)) { pop(0, hm->slot[n]); mvJ(hm->slot[n]); mvP(hm->slot[n]); storeU[hm->slot[n]] = t++; hm->stores_U++; }
       }
     }
   }

@@ -24,88 +24,117 @@
 
 namespace cmx {
 
-// ------------------------------------------------------------------------------------------------ scalar-path matvec
-typedef int s16i __attribute__((ext_vector_type(16)));
+// ------------------------------------------------------------------------------------------------ ring matvec
 typedef double d8 __attribute__((ext_vector_type(8)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-// two s_load_dwordx16 = one 16-double tile.  Early-clobber outputs: the address pair must survive both issues.
-#define CMX_SLOAD_TILE(p, off, r0, r1)                                                   \
-  asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"                \
-               : "=&s"(r0), "=&s"(r1)                                                    \
-               : "s"(p), "i"(off), "i"((off) + 64))
-// scalar loads return out of order: lgkmcnt(0) is the only valid wait.  "+s" ties the uses to the wait.
-#define CMX_SWAIT_TILE(r0, r1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0), "+s"(r1))
+#ifndef CMX_ABLATE
+#define CMX_ABLATE 0  // diagnostic builds: 1 = no leaf gathers, 2 = no workspace traffic, 3 = no matrix products
+#endif
 
-__device__ __forceinline__ const double* uniform_ptr(const double* p) {
-  uint64_t v = reinterpret_cast<uint64_t>(p);
-  uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
-  uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
-  return reinterpret_cast<const double*>((static_cast<uint64_t>(hi) << 32) | lo);
-}
-
-// tile T holds block (bi, bj) = (T / NB, T % NB) of the row-major matrix, element k -> (4bi + k/4, 4bj + k%4)
-template <int S, bool TR, int T>
-__device__ __forceinline__ void mv_tile(const s16i& r0, const s16i& r1, const double (&x)[S], double (&y)[S]) {
-  constexpr int NB = S / 4;
-  constexpr int bi = T / NB, bj = T % NB;
-  const d8 lo = __builtin_bit_cast(d8, r0), hi = __builtin_bit_cast(d8, r1);
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int i = k / 4, j = k % 4;
-    const double a = k < 8 ? lo[k] : hi[k - 8];
-    if (!TR) y[4 * bi + i] = __builtin_fma(a, x[4 * bj + j], y[4 * bi + i]);
-    else y[4 * bj + j] = __builtin_fma(a, x[4 * bi + i], y[4 * bj + j]);
-  }
-}
+// The SxS operator of an edge is the same for all 64 lanes.  It is kept in a ring of fixed VGPRs (v[206:255]: 25
+// tiles of the 4x4-block-packed matrix, one f64 per lane and tile, i.e. the 16 values of a tile in every DPP row)
+// and applied with v_fmac_f64_dpp row_newbcast -- 400 fp64 FMAs per 20x20 product, no LDS, SGPR or extra VGPR
+// traffic.  While tile T's FMAs run, its slot is refilled with tile T of the NEXT product's matrix (the sequence of
+// products is known: m.msched), so every matrix is fetched one full product (~1600 cycles) ahead of its use.
+// Measured (scripts/dppmv.hip): 53 TFLOP/s at 2 waves/SIMD vs 39 for s_load-fed v_fma_f64.
+#include "cmx_ring_tiles.inc"
 
 template <int S, bool TR, int T>
-__device__ __forceinline__ void mv_steps(const double* A, s16i& a0, s16i& a1, s16i& b0, s16i& b1,
-                                         const double (&x)[S], double (&y)[S]) {
-  constexpr int NT = (S / 4) * (S / 4);
+__device__ __forceinline__ void ring_steps(const double* nxt, const double (&x)[S], double (&y)[S]) {
+  constexpr int NB = S / 4, NT = NB * NB;
   if constexpr (T < NT) {
-    if constexpr (T + 1 < NT) {
-      CMX_SLOAD_TILE(A, (T + 1) * 128, b0, b1);
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's FMAs
-    }
-    mv_tile<S, TR, T>(a0, a1, x, y);
-    if constexpr (T + 1 < NT) {
-      CMX_SWAIT_TILE(b0, b1);
-      mv_steps<S, TR, T + 1>(A, b0, b1, a0, a1, x, y);
-    }
+    constexpr int bi = T / NB, bj = T % NB;
+    // tile T was requested NT loads ago; every vector-memory operation issued since only makes the wait stricter
+    constexpr int WAIT = NT - 1;
+    if constexpr (!TR)
+      ring_tile_f<T, WAIT>(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], x[4 * bj], x[4 * bj + 1],
+                           x[4 * bj + 2], x[4 * bj + 3], nxt);
+    else
+      ring_tile_t<T, WAIT>(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], x[4 * bi], x[4 * bi + 1],
+                           x[4 * bi + 2], x[4 * bi + 3], nxt);
+    ring_steps<S, TR, T + 1>(nxt, x, y);
   }
 }
 
-// y = A x (TR = false) or y = A^T x (TR = true); A: wave-uniform pointer to a 4x4-block-packed SxS matrix
+// y = M x (TR = false) or y = M^T x (TR = true) with M = the matrix currently in the ring; nxt = per-lane pointer
+// (matrix base + (lane & 15)) of the matrix of the next product in program order.
 template <int S, bool TR>
-__device__ __forceinline__ void matvec_s(const double* A, const double (&x)[S], double (&y)[S]) {
+__device__ __forceinline__ void matvec_ring(const double* nxt, const double (&x)[S], double (&y)[S]) {
   static_assert(S % 4 == 0, "state count must be a multiple of 4");
-  s16i a0, a1, b0, b1;
+  if (CMX_ABLATE == 3) {
+#pragma unroll
+    for (int i = 0; i < S; ++i) y[i] = x[i] * 0.5;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < S; ++i) y[i] = 0.0;
-  A = uniform_ptr(A);
-  CMX_SLOAD_TILE(A, 0, a0, a1);
-  CMX_SWAIT_TILE(a0, a1);
-  mv_steps<S, TR, 0>(A, a0, a1, b0, b1, x, y);
+  ring_steps<S, TR, 0>(nxt, x, y);
 }
 
 // ------------------------------------------------------------------------------------------------ small helpers
+// Workspace vectors are stored as [S/2][64 lanes][2 doubles]: one 16-byte access per lane and row, 1 KiB per
+// wave-instruction, the same image in HBM and (for prefetched vectors) in LDS.
 template <int S>
-__device__ __forceinline__ void load_vec(const double* p /* + lane */, double (&v)[S]) {
+__device__ __forceinline__ void load_vec(const double* p /* slice base + 2*lane */, double (&v)[S]) {
+  if (CMX_ABLATE == 2 || CMX_ABLATE == 4) {
 #pragma unroll
-  for (int x = 0; x < S; ++x) v[x] = p[(size_t)x * kWave];
+    for (int i = 0; i < S; ++i) v[i] = 0.9;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < S / 2; ++i) {
+    const d2 t = *reinterpret_cast<const d2*>(p + (size_t)i * 2 * kWave);
+    v[2 * i] = t[0];
+    v[2 * i + 1] = t[1];
+  }
 }
 template <int S>
 __device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
+  if (CMX_ABLATE == 2 || CMX_ABLATE == 4) {
+    asm volatile("" ::"v"(v[0]), "v"(v[S - 1]));
+    return;
+  }
 #pragma unroll
-  for (int x = 0; x < S; ++x) p[(size_t)x * kWave] = v[x];
+  for (int i = 0; i < S / 2; ++i) {
+    d2 t;
+    t[0] = v[2 * i];
+    t[1] = v[2 * i + 1];
+    *reinterpret_cast<d2*>(p + (size_t)i * 2 * kWave) = t;
+  }
+}
+
+typedef __attribute__((address_space(1))) const void* cmx_gptr;
+typedef __attribute__((address_space(3))) void* cmx_lptr;
+
+// asynchronous HBM -> LDS copy of one workspace vector (S/2 LDS-DMA instructions, no VGPR destination)
+template <int S>
+__device__ __forceinline__ void prefetch_vec_lds(const double* p /* slice base + 2*lane */, uint8_t* lds /* wave-uniform */) {
+  if (CMX_ABLATE == 2 || CMX_ABLATE == 4) return;
+#pragma unroll
+  for (int i = 0; i < S / 2; ++i)
+    __builtin_amdgcn_global_load_lds((cmx_gptr)(p + (size_t)i * 2 * kWave), (cmx_lptr)(lds + i * 16 * kWave), 16, 0, 0);
+}
+template <int S>
+__device__ __forceinline__ void read_vec_lds(const uint8_t* lds /* wave-uniform */, int lane, double (&v)[S]) {
+#pragma unroll
+  for (int i = 0; i < S / 2; ++i) {
+    const d2 t = *reinterpret_cast<const d2*>(lds + (size_t)(i * kWave + lane) * 16);
+    v[2 * i] = t[0];
+    v[2 * i + 1] = t[1];
+  }
 }
 
 // message of a leaf edge: m[x] = sum_{z compatible with the observed symbol} M[x][z], M given transposed ([z][x])
 template <int S>
 __device__ __forceinline__ void leaf_vec(const double* __restrict__ LT, unsigned code, const uint32_t* __restrict__ masks,
                                          double (&m)[S]) {
+  if (CMX_ABLATE == 1 || CMX_ABLATE == 4) {
+#pragma unroll
+    for (int x = 0; x < S; ++x) m[x] = 0.05 + 0.001 * code;
+    return;
+  }
   if (code < (unsigned)S) {
     const d2* r = reinterpret_cast<const d2*>(LT + (size_t)code * S);
 #pragma unroll
@@ -149,16 +178,20 @@ __device__ __forceinline__ int draw_index(double u, const double* __restrict__ c
 }
 
 // ------------------------------------------------------------------------------------------------ mapping core
-// Workspace vector loads go through a one-deep prefetch FIFO driven by a host-built schedule (m.ldsched): the
-// sequence of [slot] loads is a pure function of the tree, so the host lists it in program order and marks an
-// entry prefetchable when the store that produces it is issued before the previous pop.  pop() hands out the
-// vector fetched during the previous matrix product and immediately issues the next fetch, which then overlaps
-// the ~1600 cycles of FMAs that follow.  Bit 31 = prefetchable, bit 30 = array (0: inside D, 1: outside U).
-#define CMX_SCHED_ADDR(e) (((e) & 0x40000000) ? wsU : wsD) + (size_t)((e) & 0x00ffffff) * S * kWave + lane
+extern __shared__ __attribute__((aligned(16))) uint8_t cmx_smem[];
+// Workspace vector loads follow a host-built schedule (m.ldsched, one entry per load in program order):
+// bit 30 = array (0: inside D, 1: outside U), low 24 bits = slot.
+#define CMX_SCHED_ADDR(e) (((e) & 0x40000000) ? wsU : wsD) + (size_t)((e) & 0x00ffffff) * S * kWave + 2 * lane
+// pop: take the vector prefetched into LDS (or load it now), then start the LDS-DMA of the next schedule entry if
+// the host marked it prefetchable (bit 31: its producing store precedes this point).  The DMA needs no VGPRs and
+// overlaps the matrix product that follows; vmcnt(0) orders the LDS read behind it, lgkmcnt(0) orders the next DMA
+// behind the LDS read.
 #define CMX_POP(dst)                                                        \
   do {                                                                      \
     if (pend) {                                                             \
-      _Pragma("unroll") for (int x_ = 0; x_ < S; ++x_) dst[x_] = pf[x_];    \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+      read_vec_lds<S>(pfl, lane, dst);                                      \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
     } else {                                                                \
       const int e_ = m.ldsched[fi];                                         \
       load_vec<S>(CMX_SCHED_ADDR(e_), dst);                                 \
@@ -168,7 +201,7 @@ __device__ __forceinline__ int draw_index(double u, const double* __restrict__ c
     if (fi < m.nloads) {                                                    \
       const int e2_ = m.ldsched[fi];                                        \
       if (e2_ < 0) {                                                        \
-        load_vec<S>(CMX_SCHED_ADDR(e2_), pf);                               \
+        prefetch_vec_lds<S>(CMX_SCHED_ADDR(e2_), pfl);                      \
         pend = true;                                                        \
       }                                                                     \
     }                                                                       \
@@ -177,22 +210,37 @@ __device__ __forceinline__ int draw_index(double u, const double* __restrict__ c
 // Maps the 64 sites of this wave (codes at aln_base[taxon * stride], per lane) for all rate classes.
 // On return cnt[(b*K+k)*64 + lane] holds the final counts n(b, site, k) and the scalars are per lane.
 // part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
-// Register budget: five S-vectors live at most (acc/upf, u, d, t, pf) so that two waves fit per SIMD.
+// Register budget: four S-vectors live at most (acc, u, d, t) so that two waves fit per SIMD without scratch.
 // The loop nest below is mirrored statement for statement by build_load_schedule() in cmx_host_model.cpp.
 template <int S>
 __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
-                                               double* __restrict__ part, double* __restrict__ cnt,
-                                               const uint8_t* __restrict__ aln_base, size_t stride, int lane,
+                                               double* __restrict__ part, double* __restrict__ cnt, int lds_off,
+                                               const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
                                                double& L_out, double& pr_out, int& rc_out, double& norm_out) {
   const DevModel& m = a.m;
+  const double* matl = m.MAT + (lane & 15);  // per-lane base of the packed matrices (16 values per DPP row)
+  uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, S*64*8 bytes
+  // leaf symbols of this wave's sites: [taxon][64] in LDS when they fit (a.codes_in_lds), else read from HBM
+  const uint8_t* codes = cmx_smem + lds_off + S * kWave * 8 + lane;
+  const bool clds = a.codes_in_lds != 0;
+#define CMX_CODE(tx) (clds ? (unsigned)codes[(size_t)(tx) * kWave] : (unsigned)gcodes[(size_t)(tx) * gstride])
   const int C = m.C, K = m.K, NI = m.NI, root = m.root;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
-#define CMX_LEAF_P(tx, out) leaf_vec<S>(m.LPT + ((size_t)c * m.T + (tx)) * S * S, aln_base[(size_t)(tx) * stride], a.masks, out)
+#define CMX_LEAF_P(tx, out) leaf_vec<S>(m.LPT + ((size_t)c * m.T + (tx)) * S * S, CMX_CODE(tx), a.masks, out)
 #define CMX_LEAF_J(tx, k, out) \
-  leaf_vec<S>(m.LJT + (((size_t)c * K + (k)) * m.T + (tx)) * S * S, aln_base[(size_t)(tx) * stride], a.masks, out)
-#define CMX_PMAT(sl) (m.PP + ((size_t)c * NI + (sl)) * S * S)
-#define CMX_JMAT(sl, k) (m.JP + (((size_t)c * NI + (sl)) * K + (k)) * S * S)
+  leaf_vec<S>(m.LJT + (((size_t)c * K + (k)) * m.T + (tx)) * S * S, CMX_CODE(tx), a.masks, out)
+// matrix product number mi of this class pass (the matrix is already in the ring); streams in the matrix of the next
+// product: entry mi + 1 of m.msched, or entry 0 of the next class / next site block.
+#define CMX_MV(TR, in, out)                                                                            \
+  do {                                                                                                 \
+    ++mi;                                                                                              \
+    const int cn_ = (mi < m.nmv) ? c : ((c + 1 < C) ? c + 1 : 0);                                      \
+    const int en_ = m.msched[(mi < m.nmv) ? mi : 0];                                                   \
+    const size_t off_ = (en_ < 0) ? m.joff + ((size_t)cn_ * NI * K + (size_t)(en_ & 0x7fffffff)) * S * S \
+                                  : ((size_t)cn_ * NI + (size_t)en_) * S * S;                          \
+    matvec_ring<S, TR>(matl + off_, in, out);                                                          \
+  } while (0)
 #define CMX_DOT(x_, y_, out)                                                          \
   do {                                                                                \
     out = 0.0;                                                                        \
@@ -201,10 +249,10 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   for (int c = 0; c < C; ++c) {
     const double pc = m.probs[c];
     double* pcnt = part + (size_t)c * m.B * K * kWave + lane;
-    double pf[S];       // prefetched workspace vector
     double d[S], t[S];  // popped vector / matvec result
     int fi = 0;         // next schedule entry
-    bool pend = false;  // pf holds entry fi
+    int mi = 0;         // matrix products done in this class pass
+    bool pend = false;  // the LDS prefetch buffer holds entry fi
     // ---------------- inside (post-order) pass.  acc leaves each iteration holding D of the node just finished; when
     // that node is a child of the next one (it then is its last child) it is consumed from registers.
     double acc[S];
@@ -214,7 +262,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       const int n = m.int_post[idx];
       const bool use_carry = carry_node >= 0 && m.parent[carry_node] == n;
       if (use_carry) {
-        matvec_s<S, false>(CMX_PMAT(m.slot[carry_node]), acc, t);
+        CMX_MV(false, acc, t);
 #pragma unroll
         for (int x = 0; x < S; ++x) acc[x] = t[x];
       } else {
@@ -228,13 +276,13 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         } else {
           if (use_carry && e == carry_node) continue;
           CMX_POP(d);
-          matvec_s<S, false>(CMX_PMAT(m.slot[e]), d, t);
+          CMX_MV(false, d, t);
         }
 #pragma unroll
         for (int x = 0; x < S; ++x) acc[x] *= t[x];
       }
       if (n != root) {
-        store_vec<S>(wsD + (size_t)m.slot[n] * S * kWave + lane, acc);
+        store_vec<S>(wsD + (size_t)m.slot[n] * S * kWave + 2 * lane, acc);
         carry_node = n;
       } else {
 #pragma unroll
@@ -265,7 +313,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           CMX_LEAF_P(tb, t);
         } else {
           CMX_POP(d);
-          matvec_s<S, false>(CMX_PMAT(m.slot[cb]), d, t);
+          CMX_MV(false, d, t);
         }
 #pragma unroll
         for (int x = 0; x < S; ++x) u[x] = acc[x] * t[x];  // U_a = Up_f o M_b
@@ -283,16 +331,16 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           const int sl = m.slot[ca];
           CMX_POP(d);
           for (int k = 0; k < K; ++k) {
-            matvec_s<S, false>(CMX_JMAT(sl, k), d, t);
+            CMX_MV(false, d, t);
             double tot;
             CMX_DOT(u, t, tot);
             pcnt[((size_t)ca * K + k) * kWave] = pc * tot;
           }
-          matvec_s<S, false>(CMX_PMAT(sl), d, t);
+          CMX_MV(false, d, t);
 #pragma unroll
           for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_b
-          matvec_s<S, true>(CMX_PMAT(sl), u, d);       // Up_a
-          store_vec<S>(wsU + (size_t)sl * S * kWave + lane, d);
+          CMX_MV(true, u, d);       // Up_a
+          store_vec<S>(wsU + (size_t)sl * S * kWave + 2 * lane, d);
         }
         if (tb >= 0) {
           for (int k = 0; k < K; ++k) {
@@ -305,12 +353,12 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           const int sl = m.slot[cb];
           CMX_POP(d);
           for (int k = 0; k < K; ++k) {
-            matvec_s<S, false>(CMX_JMAT(sl, k), d, u);
+            CMX_MV(false, d, u);
             double tot;
             CMX_DOT(t, u, tot);
             pcnt[((size_t)cb * K + k) * kWave] = pc * tot;
           }
-          matvec_s<S, true>(CMX_PMAT(sl), t, acc);  // Up_b stays in registers for the next node
+          CMX_MV(true, t, acc);  // Up_b stays in registers for the next node
           up_node = cb;
         }
       } else {
@@ -325,7 +373,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
               CMX_LEAF_P(tx, t);
             } else {
               CMX_POP(d);
-              matvec_s<S, false>(CMX_PMAT(m.slot[sb]), d, t);
+              CMX_MV(false, d, t);
             }
 #pragma unroll
             for (int x = 0; x < S; ++x) u[x] *= t[x];
@@ -342,22 +390,22 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
             const int sl = m.slot[n];
             CMX_POP(d);
             for (int k = 0; k < K; ++k) {
-              matvec_s<S, false>(CMX_JMAT(sl, k), d, t);
+              CMX_MV(false, d, t);
               double tot;
               CMX_DOT(u, t, tot);
               pcnt[((size_t)n * K + k) * kWave] = pc * tot;
             }
-            matvec_s<S, true>(CMX_PMAT(sl), u, t);
-            store_vec<S>(wsU + (size_t)sl * S * kWave + lane, t);
+            CMX_MV(true, u, t);
+            store_vec<S>(wsU + (size_t)sl * S * kWave + 2 * lane, t);
           }
         }
       }
     }
   }
 #undef CMX_LEAF_P
+#undef CMX_CODE
 #undef CMX_LEAF_J
-#undef CMX_PMAT
-#undef CMX_JMAT
+#undef CMX_MV
 #undef CMX_DOT
   // ---------------- sum the classes in class order, divide by the site likelihood, norm (computeNormForSite)
   double nrm = 0.0;
@@ -433,7 +481,8 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
 }
 
 template <int S, int MODE>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const MapArgs a) {
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_num_vgpr(206))) void map_kernel(
+    const MapArgs a) {
   const DevModel& m = a.m;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -443,7 +492,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const Ma
   double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kWave;
   double* cnt1 = cnt0 + (size_t)m.B * m.K * kWave;
   double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kWave;
+  // LDS per wave: prefetch landing buffer (S*64*8 B) followed by the [T][64] leaf symbols of the wave's sites
+  const int lds_off = (int)(threadIdx.x >> 6) * (S * kWave * 8 + (a.codes_in_lds ? ((m.T * kWave + 15) & ~15) : 0));
+  uint8_t* codes = cmx_smem + lds_off + S * kWave * 8 + lane;
   const size_t nblocks = (a.nsites + kWave - 1) / kWave;
+  // prime the matrix ring with the first product's matrix (class 0, entry 0); every product refills it for the next
+  if ((size_t)wave < nblocks) {
+    const int e0 = m.msched[0];
+    const size_t off0 = (e0 < 0) ? m.joff + (size_t)(e0 & 0x7fffffff) * S * S : (size_t)e0 * S * S;
+    ring_prime<(S / 4) * (S / 4)>(m.MAT + (lane & 15) + off0);
+  }
   for (size_t sb = wave; sb < nblocks; sb += nwaves) {
     const size_t site = sb * kWave + lane;
     const bool active = site < a.nsites;
@@ -451,7 +509,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const Ma
     if (MODE == kModeObserved) {
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S>(a, wsD, wsU, part, cnt0, a.aln + s, a.ld, lane, L, pr, rc, nrm);
+      if (a.codes_in_lds)
+        for (int t = 0; t < m.T; ++t) codes[(size_t)t * kWave] = a.aln[(size_t)t * a.ld + s];
+      map_sites_wave<S>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, L, pr, rc, nrm);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
@@ -467,14 +527,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const Ma
       double L[2], pr[2], nrm[2];
       int rc[2];
       for (int h = 0; h < 2; ++h) {
-        const uint8_t* base;
-        size_t stride;
+        const uint8_t* gbase;
+        size_t gstride;
         if (a.supplied) {
-          base = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
-          stride = a.rep_ram;
+          gbase = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
+          gstride = a.rep_ram;
+          if (a.codes_in_lds)
+            for (int t = 0; t < m.T; ++t) codes[(size_t)t * kWave] = gbase[(size_t)t * gstride];
         } else {
           uint8_t* st = a.ws.st + (size_t)wave * m.nn * kWave + lane;
           uint8_t* al = a.ws.aln + (size_t)wave * m.T * kWave + lane;
+          gbase = al;
+          gstride = kWave;
           const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
           const int c = draw_index(philox_uniform(a.seed, g, 0), m.cum_probs, m.C);
           st[(size_t)m.root * kWave] = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), m.cum_pi, S);
@@ -484,12 +548,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const Ma
             const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S + x) * S, S);
             st[(size_t)node * kWave] = (uint8_t)y;
             const int tx = m.taxon_of[node];
-            if (tx >= 0) al[(size_t)tx * kWave] = (uint8_t)y;
+            if (tx >= 0) {
+              if (a.codes_in_lds) codes[(size_t)tx * kWave] = (uint8_t)y;
+              else al[(size_t)tx * kWave] = (uint8_t)y;
+            }
           }
-          base = al;
-          stride = kWave;
         }
-        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, base, stride, lane, L[h], pr[h], rc[h], nrm[h]);
+        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, L[h], pr[h], rc[h], nrm[h]);
       }
       const double stat = pair_stat_lane(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + lane, cnt1 + lane);
       if (active) {
@@ -500,16 +565,31 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void map_kernel(const Ma
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last product left a matrix fetch in flight
+}
+
+size_t map_lds_bytes(int S, int T, bool codes_in_lds) {
+  return (size_t)kWavesPerBlock * ((size_t)S * kWave * 8 + (codes_in_lds ? (((size_t)T * kWave + 15) & ~(size_t)15) : 0));
 }
 
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream) {
   dim3 grid(grid_blocks), block(kWave * kWavesPerBlock);
+  const size_t lds = map_lds_bytes(a.m.S, a.m.T, a.codes_in_lds != 0);
+  static bool attr_set = false;
+  if (!attr_set) {  // allow up to 80 KiB of dynamic LDS per workgroup (two workgroups per CU)
+    const int lim = 80 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<20, kModeObserved>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<20, kModeNull>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<4, kModeObserved>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<4, kModeNull>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    attr_set = true;
+  }
   if (a.m.S == 20) {
-    if (mode == kModeObserved) hipLaunchKernelGGL((map_kernel<20, kModeObserved>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((map_kernel<20, kModeNull>), grid, block, 0, stream, a);
+    if (mode == kModeObserved) hipLaunchKernelGGL((map_kernel<20, kModeObserved>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((map_kernel<20, kModeNull>), grid, block, lds, stream, a);
   } else if (a.m.S == 4) {
-    if (mode == kModeObserved) hipLaunchKernelGGL((map_kernel<4, kModeObserved>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((map_kernel<4, kModeNull>), grid, block, 0, stream, a);
+    if (mode == kModeObserved) hipLaunchKernelGGL((map_kernel<4, kModeObserved>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((map_kernel<4, kModeNull>), grid, block, lds, stream, a);
   } else {
     return hipErrorInvalidValue;
   }

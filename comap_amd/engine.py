@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcomap_mi355x.so")
+LIB_PATH = os.environ.get("COMAP_MI355X_LIB", os.path.join(_HERE, "libcomap_mi355x.so"))  # override: diagnostic builds
 
 STAT_CORRELATION, STAT_COMPENSATION, STAT_COSUBSTITUTION, STAT_COSINUS, STAT_COVARIANCE, STAT_DISCRETE_MI = range(6)
 STAT_BY_NAME = {
