@@ -31,7 +31,9 @@ struct cmx_ctx {
   bool has_model = false;
   HostModel hm;
   DevModel dm{};
-  Workspace ws{};
+  Workspace ws{};       // null-distribution launches (persistent grid: 2 waves per SIMD on every CU)
+  Workspace ws_obs{};   // observed-alignment launches: own slices, so both kinds can overlap on two streams
+  int obs_blocks = 0;
   int cu_count = 0, waves = 0, grid_blocks = 0;
   size_t ws_bytes = 0;
   std::vector<void*> model_allocs;
@@ -173,22 +175,28 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     // ambiguity masks default: code c >= S compatible with every state; fix the table for this S
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
-    // per-wave workspace: 2 waves per SIMD on every CU
+    // per-wave workspaces: 2 waves per SIMD on every CU for the null; a quarter of that for observed alignments
     ctx->grid_blocks = ctx->cu_count * 2;
     ctx->waves = ctx->grid_blocks * kWavesPerBlock;
-    const size_t w = (size_t)ctx->waves;
-    const size_t bD = w * h.NI * h.S * kWave * sizeof(double);
-    const size_t bC = w * 2 * h.B * h.K * kWave * sizeof(double);
-    const size_t bS = w * h.nn * kWave, bA = w * h.T * kWave;
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.D, bD));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.U, bD));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.cnt, bC));
-    const size_t bP = w * h.C * h.B * h.K * kWave * sizeof(double);
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.part, bP));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.st, bS));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ws.aln, bA));
-    ctx->ws.waves = ctx->waves;
-    ctx->ws_bytes = 2 * bD + bC + bP + bS + bA;
+    ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
+    auto alloc_ws = [&](Workspace* ws, size_t w, size_t* bytes) -> cmx_status {
+      const size_t bD = w * h.NI * h.S * kWave * sizeof(double);
+      const size_t bC = w * 2 * h.B * h.K * kWave * sizeof(double);
+      const size_t bP = w * h.C * h.B * h.K * kWave * sizeof(double);
+      const size_t bS = w * h.nn * kWave, bA = w * h.T * kWave;
+      HIP_TRY(ctx, hipMalloc((void**)&ws->D, bD));
+      HIP_TRY(ctx, hipMalloc((void**)&ws->U, bD));
+      HIP_TRY(ctx, hipMalloc((void**)&ws->cnt, bC));
+      HIP_TRY(ctx, hipMalloc((void**)&ws->part, bP));
+      HIP_TRY(ctx, hipMalloc((void**)&ws->st, bS));
+      HIP_TRY(ctx, hipMalloc((void**)&ws->aln, bA));
+      ws->waves = (int)w;
+      *bytes += 2 * bD + bC + bP + bS + bA;
+      return CMX_OK;
+    };
+    ctx->ws_bytes = 0;
+    if ((s = alloc_ws(&ctx->ws, (size_t)ctx->waves, &ctx->ws_bytes)) != CMX_OK) return s;
+    if ((s = alloc_ws(&ctx->ws_obs, (size_t)ctx->obs_blocks * kWavesPerBlock, &ctx->ws_bytes)) != CMX_OK) return s;
     return CMX_OK;
   };
   cmx_status s = dev_init();
@@ -201,12 +209,14 @@ void cmx_ctx_destroy(cmx_ctx* ctx) {
   if (!ctx) return;
   for (void* p : ctx->model_allocs) (void)hipFree(p);
   for (auto& kv : ctx->scratch) if (kv.second.p) (void)hipFree(kv.second.p);
-  if (ctx->ws.D) (void)hipFree(ctx->ws.D);
-  if (ctx->ws.U) (void)hipFree(ctx->ws.U);
-  if (ctx->ws.cnt) (void)hipFree(ctx->ws.cnt);
-  if (ctx->ws.part) (void)hipFree(ctx->ws.part);
-  if (ctx->ws.st) (void)hipFree(ctx->ws.st);
-  if (ctx->ws.aln) (void)hipFree(ctx->ws.aln);
+  for (Workspace* ws : {&ctx->ws, &ctx->ws_obs}) {
+    if (ws->D) (void)hipFree(ws->D);
+    if (ws->U) (void)hipFree(ws->U);
+    if (ws->cnt) (void)hipFree(ws->cnt);
+    if (ws->part) (void)hipFree(ws->part);
+    if (ws->st) (void)hipFree(ws->st);
+    if (ws->aln) (void)hipFree(ws->aln);
+  }
   delete ctx;
 }
 
@@ -243,13 +253,13 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   if (d_counts && ldc < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: ldc < nsites");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MapArgs a{};
-  a.m = ctx->dm; a.ws = ctx->ws;
+  a.m = ctx->dm; a.ws = ctx->ws_obs;
   a.aln = d_aln; a.ld = ld; a.nsites = nsites; a.masks = d_masks ? d_masks : ctx->d_default_masks;
   a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 80 * 1024;
   a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.norm = d_norm;
   const size_t blocks_needed = ((nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int grid = (int)std::min<size_t>(blocks_needed, (size_t)ctx->grid_blocks);
+  const int grid = (int)std::min<size_t>(blocks_needed, (size_t)ctx->obs_blocks);
   HIP_TRY(ctx, launch_map(a, kModeObserved, grid, (hipStream_t)stream));
   return CMX_OK;
 }

@@ -16,6 +16,7 @@
 //   AnalysisTools::getNullDistributionIntraDR (CoMap/AnalysisTools.cpp:587-653).
 // pair_gram_kernel: all-pairs statistic as X.X^T on v_mfma_f64_16x16x4_f64 with per-statistic epilogues
 //   (CoMap/Statistics.h:164-329; loops CoMap/CoETools.cpp:672-692, 786-810).
+#include <algorithm>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -812,12 +813,18 @@ __device__ __forceinline__ int domain_index(double maxi, int n, double x) {
 __global__ void null_classify_kernel(const double* __restrict__ stat, const double* __restrict__ nmin, size_t nnull,
                                      const double* __restrict__ maxnorm, int nclasses, uint32_t* __restrict__ cls,
                                      uint32_t* __restrict__ hist) {
-  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nnull) return;
-  int c = (stat[q] != stat[q]) ? -1 : domain_index(*maxnorm, nclasses, nmin[q]);
-  const uint32_t cc = c < 0 ? (uint32_t)nclasses : (uint32_t)c;
-  cls[q] = cc;
-  atomicAdd(&hist[cc], 1u);
+  __shared__ uint32_t lh[65];
+  for (int i = threadIdx.x; i <= nclasses; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnull; q += (size_t)gridDim.x * blockDim.x) {
+    const int c = (stat[q] != stat[q]) ? -1 : domain_index(*maxnorm, nclasses, nmin[q]);
+    const uint32_t cc = c < 0 ? (uint32_t)nclasses : (uint32_t)c;
+    cls[q] = cc;
+    atomicAdd(&lh[cc], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= nclasses; i += blockDim.x)
+    if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
 hipError_t launch_null_classify(const double* d_stat, const double* d_nmin, size_t nnull, const double* d_maxnorm,
@@ -825,8 +832,9 @@ hipError_t launch_null_classify(const double* d_stat, const double* d_nmin, size
   hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (nclasses + 1), stream);
   if (e != hipSuccess) return e;
   if (nnull == 0) return hipSuccess;
-  hipLaunchKernelGGL(null_classify_kernel, dim3((unsigned)((nnull + 255) / 256)), dim3(256), 0, stream, d_stat, d_nmin,
-                     nnull, d_maxnorm, nclasses, d_cls, d_hist);
+  const unsigned blocks = (unsigned)std::min<size_t>((nnull + 255) / 256, 1024);
+  hipLaunchKernelGGL(null_classify_kernel, dim3(blocks), dim3(256), 0, stream, d_stat, d_nmin, nnull, d_maxnorm,
+                     nclasses, d_cls, d_hist);
   return hipGetLastError();
 }
 

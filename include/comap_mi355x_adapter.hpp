@@ -1,0 +1,367 @@
+// comap_mi355x_adapter.hpp -- C++ host-side mirror of the reference's interface for the pairwise path, on top of
+// the C-ABI (comap_mi355x.h).  Header-only, no Bio++: it uses the same class and method names and the same
+// argument meaning / error behaviour as the reference so that call sites read alike:
+//
+//   reference (jydu/comap)                                   here (namespace cmx)
+//   ------------------------------------------------------   -------------------------------------------------
+//   Domain(a, b, n), getIndex, OutOfRangeException           cmx::Domain, cmx::OutOfRangeException
+//     CoMap/Domain.h:59-152, CoMap/Domain.cpp:46-122
+//   Statistic / CorrelationStatistic / CompensationStatistic cmx::Statistic hierarchy: kind() + getValuesForAllPairs()
+//     ... getValueForPair(v1, v2)  CoMap/Statistics.h:57-329    (the all-pairs loop of CoETools.cpp:672-692 in one call)
+//   Distance / StatisticBasedDistance / CompensationDistance cmx::StatisticBasedDistance etc. (CoMap/Distance.h:316-424)
+//   CoETools::getVectors             CoMap/CoETools.cpp:366   cmx::CoETools::getVectors -> ProbabilisticSubstitutionMapping
+//   AnalysisTools::computeNorms      AnalysisTools.cpp:343    cmx::AnalysisTools::computeNorms
+//   AnalysisTools::getNullDistributionIntraDR  :564-658        cmx::AnalysisTools::getNullDistributionIntraDR
+//   CoETools::computeIntraStats      CoETools.cpp:604-728     cmx::CoETools::computeIntraStats (rows instead of a TSV stream)
+//
+// The Bio++-typed originals take DRTreeLikelihoodInterface / SubstitutionCountInterface / SequenceSimulatorInterface
+// objects; their roles (tree + model + rates, count registers/weights, simulator) are all carried by cmx::Engine,
+// built from plain arrays.  INTEGRATION.md shows the glue a CoMap maintainer would write to fill those arrays from
+// the Bio++ objects.  Errors: every failing C-ABI status becomes a cmx::Exception (the reference throws
+// bpp::Exception and catches it in main, CoMap/CoMap.cpp:730-734).
+#ifndef COMAP_MI355X_ADAPTER_HPP
+#define COMAP_MI355X_ADAPTER_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "comap_mi355x.h"
+
+namespace cmx {
+
+typedef std::vector<double> Vdouble;
+typedef std::vector<Vdouble> VVdouble;
+
+class Exception : public std::runtime_error {
+ public:
+  explicit Exception(const std::string& what) : std::runtime_error(what) {}
+};
+class DimensionException : public Exception {
+ public:
+  DimensionException(const std::string& where, size_t got, size_t expected)
+      : Exception(where + " dimension " + std::to_string(got) + " != " + std::to_string(expected)) {}
+};
+class OutOfRangeException : public Exception {
+ public:
+  OutOfRangeException(const std::string& where, double x, double lo, double hi)
+      : Exception(where + ": " + std::to_string(x) + " out of [" + std::to_string(lo) + ", " + std::to_string(hi) + "[") {}
+};
+
+// ------------------------------------------------------------------------------------------------ Domain
+// CoMap/Domain.cpp:46-59 (equal-width bounds), :113-122 (half-open getIndex).
+class Domain {
+ public:
+  Domain(double a, double b, size_t n) : bounds_(n + 1) {
+    if (n == 0) throw Exception("Domain::constructor1. Number of classes should be > 0.");
+    const double mini = std::min(a, b), maxi = std::max(a, b);
+    const double w = (maxi - mini) / static_cast<double>(n);
+    bounds_[0] = mini;
+    for (size_t i = 1; i < n + 1; i++) bounds_[i] = mini + static_cast<double>(i) * w;
+  }
+  explicit Domain(const Vdouble& bounds) : bounds_(bounds) {
+    for (size_t i = 0; i + 1 < bounds_.size(); i++)
+      if (bounds_[i + 1] < bounds_[i]) throw Exception("Domain: bounds must be increasing.");
+  }
+  size_t getSize() const { return bounds_.size() - 1; }
+  double getLowerBound() const { return bounds_.front(); }
+  double getUpperBound() const { return bounds_.back(); }
+  size_t getIndex(double x) const {
+    if (x < getLowerBound() || x >= getUpperBound())
+      throw OutOfRangeException("Domain::getIndex", x, getLowerBound(), getUpperBound());
+    for (size_t i = 1; i < bounds_.size(); i++)
+      if (x < bounds_[i]) return i - 1;
+    throw Exception("Unexpected error!");
+  }
+
+ private:
+  Vdouble bounds_;
+};
+
+// ------------------------------------------------------------------------------------------------ Engine
+struct TreeArrays {  // nodes in post-order, root last (== row order of the reference's .vec files)
+  std::vector<int32_t> parent;
+  std::vector<double> branchLengths;
+  std::vector<int32_t> leafOfTaxon;
+};
+struct ModelArrays {
+  int nbStates = 0;
+  std::vector<double> generator;    // Q, row-major
+  std::vector<double> frequencies;  // pi
+  std::vector<double> rates, rateProbabilities;
+  std::vector<double> registers;    // K * S * S: Q o register_k o weights; empty => unweighted total count
+  int nbTypes = 1;
+  bool naive = false;               // nijt = Naive
+  std::vector<double> naiveWeights;
+  bool clampNegative = true;        // unweighted counts (Bio++ clamps negative round-off)
+};
+
+// Owns one cmx_ctx (one per GPU).  Stands in for the (drtl, substitutionCount, seqSim) triple of the reference.
+class Engine {
+ public:
+  Engine(const TreeArrays& t, const ModelArrays& m, int device = 0) : S_(m.nbStates) {
+    cmx_model cm;
+    cm.nstates = m.nbStates;
+    cm.nclasses = static_cast<int32_t>(m.rates.size());
+    cm.ntypes = m.registers.empty() ? 1 : m.nbTypes;
+    cm.Q = m.generator.data();
+    cm.pi = m.frequencies.data();
+    cm.rates = m.rates.data();
+    cm.probs = m.rateProbabilities.data();
+    cm.Bk = m.registers.empty() ? nullptr : m.registers.data();
+    cm.count_method = m.naive ? CMX_COUNT_NAIVE : CMX_COUNT_EXPECTED;
+    cm.clamp_negative = m.clampNegative ? 1 : 0;
+    cm.naive_weights = m.naiveWeights.empty() ? nullptr : m.naiveWeights.data();
+    cmx_tree ct;
+    ct.nnodes = static_cast<int32_t>(t.parent.size());
+    ct.parent = t.parent.data();
+    ct.blen = t.branchLengths.data();
+    ct.ntaxa = static_cast<int32_t>(t.leafOfTaxon.size());
+    ct.leaf_of_taxon = t.leafOfTaxon.data();
+    if (cmx_ctx_create(&cm, &ct, device, &ctx_) != CMX_OK) throw Exception(cmx_last_error(nullptr));
+    nbBranches_ = static_cast<size_t>(ct.nnodes) - 1;
+    nbTypes_ = static_cast<size_t>(cm.ntypes);
+    nbTaxa_ = static_cast<size_t>(ct.ntaxa);
+  }
+  ~Engine() { cmx_ctx_destroy(ctx_); }
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  cmx_ctx* ctx() const { return ctx_; }
+  size_t getNumberOfBranches() const { return nbBranches_; }
+  size_t getNumberOfSubstitutionTypes() const { return nbTypes_; }
+  size_t getNumberOfTaxa() const { return nbTaxa_; }
+  void check(cmx_status s) const {
+    if (s != CMX_OK) throw Exception(cmx_last_error(ctx_));
+  }
+
+ private:
+  cmx_ctx* ctx_ = nullptr;
+  int S_;
+  size_t nbBranches_ = 0, nbTypes_ = 0, nbTaxa_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------ mapping
+// LegacyProbabilisticSubstitutionMapping stand-in: mapping[i] is the VVdouble v[branch][type] of site i
+// (CoMap/Statistics.h:154-160), operator()(branch, site, type) the scalar accessor (CoMap/ClusterTools.cpp:237).
+class ProbabilisticSubstitutionMapping {
+ public:
+  ProbabilisticSubstitutionMapping(size_t nbSites, size_t nbBranches, size_t nbTypes)
+      : n_(nbSites), b_(nbBranches), k_(nbTypes), counts_(nbSites * nbBranches * nbTypes) {}
+  size_t getNumberOfSites() const { return n_; }
+  size_t getNumberOfBranches() const { return b_; }
+  size_t getNumberOfSubstitutionTypes() const { return k_; }
+  double operator()(size_t branch, size_t site, size_t type) const { return counts_[(site * b_ + branch) * k_ + type]; }
+  VVdouble operator[](size_t site) const {
+    VVdouble v(b_, Vdouble(k_));
+    for (size_t b = 0; b < b_; ++b)
+      for (size_t k = 0; k < k_; ++k) v[b][k] = (*this)(b, site, k);
+    return v;
+  }
+  double* data() { return counts_.data(); }
+  const double* data() const { return counts_.data(); }
+  // filled by getVectors alongside the counts (the reference reads them back from the likelihood object,
+  // CoMap/CoETools.cpp:507-510, 669-670)
+  Vdouble logLikelihoods, posteriorRates, norms;
+  std::vector<int32_t> rateClasses;
+
+ private:
+  size_t n_, b_, k_;
+  Vdouble counts_;
+};
+
+// ------------------------------------------------------------------------------------------------ statistics
+class Statistic {
+ public:
+  virtual ~Statistic() {}
+  virtual int kind() const = 0;                       // cmx_stat_kind
+  virtual const double* params() const { return nullptr; }
+  // all-pairs form of getValueForPair: out[i * n + j] for j > i (NaN elsewhere), CoMap/CoETools.cpp:672-692
+  Vdouble getValuesForAllPairs(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping) const {
+    const size_t n = mapping.getNumberOfSites();
+    Vdouble out(n * n);
+    eng.check(cmx_pair_stats(eng.ctx(), kind(), params(), mapping.data(), n, nullptr, 0, out.data()));
+    return out;
+  }
+  // rectangular form, CoMap/CoETools.cpp:786-810
+  Vdouble getValuesForAllPairs(const Engine& eng, const ProbabilisticSubstitutionMapping& m1,
+                               const ProbabilisticSubstitutionMapping& m2) const {
+    if (m1.getNumberOfBranches() != m2.getNumberOfBranches())
+      throw DimensionException("Statistic::getValuesForAllPairs.", m2.getNumberOfBranches(), m1.getNumberOfBranches());
+    Vdouble out(m1.getNumberOfSites() * m2.getNumberOfSites());
+    eng.check(cmx_pair_stats(eng.ctx(), kind(), params(), m1.data(), m1.getNumberOfSites(), m2.data(),
+                             m2.getNumberOfSites(), out.data()));
+    return out;
+  }
+};
+class CorrelationStatistic : public Statistic { public: int kind() const override { return CMX_STAT_CORRELATION; } };
+class CovarianceStatistic : public Statistic { public: int kind() const override { return CMX_STAT_COVARIANCE; } };
+class CosinusStatistic : public Statistic { public: int kind() const override { return CMX_STAT_COSINUS; } };
+class CosubstitutionNumberStatistic : public Statistic { public: int kind() const override { return CMX_STAT_COSUBSTITUTION; } };
+class CompensationStatistic : public Statistic { public: int kind() const override { return CMX_STAT_COMPENSATION; } };
+class DiscreteMutualInformationStatistic : public Statistic {  // bounds {0, threshold, 10000}, CoETools.cpp:590-593
+ public:
+  explicit DiscreteMutualInformationStatistic(double threshold = 0.99) : threshold_(threshold) {}
+  int kind() const override { return CMX_STAT_DISCRETE_MI; }
+  const double* params() const override { return &threshold_; }
+
+ private:
+  double threshold_;
+};
+
+// CoMap/Distance.h:316-370 (comp - stat) and :372-424 (1 - stat); matrix fill loops CoMap/CoMap.cpp:432-440
+class StatisticBasedDistance {
+ public:
+  StatisticBasedDistance(std::shared_ptr<Statistic> stat, double comp) : stat_(stat), comp_(comp) {}
+  Vdouble getDistancesForAllPairs(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping) const {
+    Vdouble d = stat_->getValuesForAllPairs(eng, mapping);
+    for (double& v : d) v = comp_ - v;
+    return d;
+  }
+
+ private:
+  std::shared_ptr<Statistic> stat_;
+  double comp_;
+};
+class CompensationDistance : public StatisticBasedDistance {
+ public:
+  CompensationDistance() : StatisticBasedDistance(std::make_shared<CompensationStatistic>(), 1.) {}
+};
+
+// ------------------------------------------------------------------------------------------------ AnalysisTools
+struct NullDistributionRow { double stat; int32_t rcMin; double prMin, nMin; };  // columns of AnalysisTools.cpp:642
+
+class AnalysisTools {
+ public:
+  // AnalysisTools.cpp:343-350 (the norms come out of the mapping kernel; recomputed here from the counts on request)
+  static Vdouble computeNorms(const ProbabilisticSubstitutionMapping& mapping) {
+    if (!mapping.norms.empty()) return mapping.norms;
+    Vdouble v(mapping.getNumberOfSites());
+    for (size_t i = 0; i < v.size(); ++i) {
+      double s = 0;
+      for (size_t b = 0; b < mapping.getNumberOfBranches(); ++b) {
+        double t = 0;
+        for (size_t k = 0; k < mapping.getNumberOfSubstitutionTypes(); ++k) t += mapping(b, i, k);
+        s += t * t;
+      }
+      v[i] = std::sqrt(s);
+    }
+    return v;
+  }
+  // AnalysisTools.cpp:564-658.  simstats (optional, one vector per class of rateDomain) receives the statistics as
+  // in the reference (pairs whose min norm is out of the domain are dropped, :645-648); rows receives all of them.
+  static void getNullDistributionIntraDR(const Engine& eng, const Statistic& statistic, uint64_t seed, size_t repCPU,
+                                         size_t repRAM, std::vector<NullDistributionRow>* rows,
+                                         std::vector<std::vector<double>>* simstats, const Domain* rateDomain,
+                                         size_t repBegin = 0) {
+    if (simstats && rateDomain && rateDomain->getSize() != simstats->size())
+      throw Exception("AnalysisTools::getNullDistributionIntraDR. Input vector should be of same size as rate domain.");
+    if (simstats && !rateDomain && simstats->size() != 1)
+      throw Exception("AnalysisTools::getNullDistributionIntraDR. Input vector should be of same size 1 as no rate domain was specified.");
+    const size_t n = repCPU * repRAM;
+    Vdouble stat(n), pr(n), nm(n);
+    std::vector<int32_t> rc(n);
+    eng.check(cmx_null_intra(eng.ctx(), statistic.kind(), statistic.params(), seed, repBegin, repBegin + repCPU, repRAM,
+                             nullptr, stat.data(), rc.data(), pr.data(), nm.data()));
+    for (size_t q = 0; q < n; ++q) {
+      if (rows) rows->push_back({stat[q], rc[q], pr[q], nm[q]});
+      if (simstats) {
+        if (rateDomain) {
+          try {
+            (*simstats)[rateDomain->getIndex(nm[q])].push_back(stat[q]);
+          } catch (OutOfRangeException&) {
+          }
+        } else {
+          (*simstats)[0].push_back(stat[q]);
+        }
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ CoETools
+struct IntraStatRow {  // one line of statistics.txt, CoETools.cpp:662-722
+  size_t i, j;
+  double stat;
+  int32_t rcMin;
+  double prMin, nMin, pValue;  // pValue NaN == "NA"
+  int32_t nSim;
+};
+struct PairFilters {  // CoETools.cpp:420-481
+  int minRateClass = 0, maxRateClassDiff = -1;
+  double minRate = 0., maxRateDiff = -1., minStatistic = 0.;
+};
+
+class CoETools {
+ public:
+  // CoETools.cpp:366-416: aln[t * nbSites + i] are state codes (>= nbStates: index into masks)
+  static std::unique_ptr<ProbabilisticSubstitutionMapping> getVectors(const Engine& eng, const uint8_t* aln,
+                                                                      size_t nbSites, const uint32_t* masks = nullptr,
+                                                                      size_t nbMasks = 0) {
+    std::unique_ptr<ProbabilisticSubstitutionMapping> m(new ProbabilisticSubstitutionMapping(
+        nbSites, eng.getNumberOfBranches(), eng.getNumberOfSubstitutionTypes()));
+    m->logLikelihoods.resize(nbSites);
+    m->posteriorRates.resize(nbSites);
+    m->norms.resize(nbSites);
+    m->rateClasses.resize(nbSites);
+    eng.check(cmx_map_sites(eng.ctx(), aln, nbSites, nbSites, masks, nbMasks, m->data(), m->logLikelihoods.data(),
+                            m->posteriorRates.data(), m->rateClasses.data(), m->norms.data()));
+    return m;
+  }
+
+  // CoETools.cpp:604-728 with the null of :836-872; returns the rows the reference would write, in its (i, j) order.
+  static std::vector<IntraStatRow> computeIntraStats(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping,
+                                                     const Statistic& statistic, bool computeNull, uint64_t seed,
+                                                     size_t nbRepCPU = 100, size_t nbRepRAM = 1000,
+                                                     size_t nbRateClasses = 10, const PairFilters& f = PairFilters()) {
+    const size_t n = mapping.getNumberOfSites();
+    const Vdouble norms = AnalysisTools::computeNorms(mapping);
+    Vdouble stat = statistic.getValuesForAllPairs(eng, mapping);
+    Vdouble pv;
+    std::vector<int32_t> nsim;
+    if (computeNull) {
+      const size_t nn = nbRepCPU * nbRepRAM;
+      Vdouble ns(nn), nm(nn);
+      eng.check(cmx_null_intra(eng.ctx(), statistic.kind(), statistic.params(), seed, 0, nbRepCPU, nbRepRAM, nullptr,
+                               ns.data(), nullptr, nullptr, nm.data()));
+      pv.resize(n * n);
+      nsim.resize(n * n);
+      eng.check(cmx_intra_pvalues(eng.ctx(), stat.data(), norms.data(), n, static_cast<int>(nbRateClasses), ns.data(),
+                                  nm.data(), nn, pv.data(), nsim.data()));
+    }
+    std::vector<IntraStatRow> rows;
+    for (size_t i = 0; i < n; i++) {
+      const int iClass = mapping.rateClasses[i];
+      const double iRate = mapping.posteriorRates[i];
+      if (iClass < f.minRateClass) continue;
+      if (iRate < f.minRate) continue;
+      for (size_t j = i + 1; j < n; j++) {
+        const int jClass = mapping.rateClasses[j];
+        const double jRate = mapping.posteriorRates[j];
+        if (jClass < f.minRateClass) continue;
+        if (jRate < f.minRate) continue;
+        if (f.maxRateClassDiff >= 0 && std::abs(jClass - iClass) > f.maxRateClassDiff) continue;
+        if (f.maxRateDiff >= 0. && std::fabs(jRate - iRate) > f.maxRateDiff) continue;
+        const double s = stat[i * n + j];
+        if (std::fabs(s) < f.minStatistic) continue;
+        IntraStatRow r;
+        r.i = i; r.j = j; r.stat = s;
+        r.rcMin = std::min(iClass, jClass);
+        r.prMin = std::min(iRate, jRate);
+        r.nMin = std::min(norms[i], norms[j]);
+        r.pValue = computeNull ? pv[i * n + j] : std::numeric_limits<double>::quiet_NaN();
+        r.nSim = computeNull ? nsim[i * n + j] : 0;
+        rows.push_back(r);
+      }
+    }
+    return rows;
+  }
+};
+
+}  // namespace cmx
+#endif  // COMAP_MI355X_ADAPTER_HPP

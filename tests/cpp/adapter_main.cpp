@@ -1,0 +1,75 @@
+// Test driver for include/comap_mi355x_adapter.hpp (the C++ mirror of the reference's interface).
+//   adapter_main domain <lo> <hi> <n> <x>...         -> prints getIndex(x) or -1 per x (host logic only, no GPU)
+//   adapter_main run <input.bin> <output.bin>        -> getVectors + computeIntraStats with null on the GPU
+// input.bin (little endian): int32 nn, T, S, C, N, repCPU, repRAM, nclasses; uint64 seed;
+//   int32 parent[nn]; f64 blen[nn]; int32 lot[T]; f64 Q[S*S], pi[S], rates[C], probs[C]; uint8 aln[T*N]
+// output.bin: int64 nrows; per row: int64 i, j; f64 stat, prMin, nMin, pValue; int32 rcMin, nSim;
+//   then f64 counts[N*B], f64 norms[N]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "comap_mi355x_adapter.hpp"
+
+template <class T>
+static void rd(std::ifstream& f, T* p, size_t n) { f.read(reinterpret_cast<char*>(p), sizeof(T) * n); }
+template <class T>
+static void wr(std::ofstream& f, const T* p, size_t n) { f.write(reinterpret_cast<const char*>(p), sizeof(T) * n); }
+
+int main(int argc, char** argv) {
+  try {
+    if (argc >= 6 && std::strcmp(argv[1], "domain") == 0) {
+      cmx::Domain d(std::atof(argv[2]), std::atof(argv[3]), static_cast<size_t>(std::atoi(argv[4])));
+      for (int a = 5; a < argc; ++a) {
+        try {
+          std::cout << d.getIndex(std::strtod(argv[a], nullptr)) << "\n";
+        } catch (cmx::OutOfRangeException&) {
+          std::cout << -1 << "\n";
+        }
+      }
+      return 0;
+    }
+    if (argc == 4 && std::strcmp(argv[1], "run") == 0) {
+      std::ifstream in(argv[2], std::ios::binary);
+      int32_t h[8];
+      uint64_t seed;
+      rd(in, h, 8);
+      rd(in, &seed, 1);
+      const int nn = h[0], T = h[1], S = h[2], C = h[3], N = h[4];
+      cmx::TreeArrays t;
+      cmx::ModelArrays m;
+      t.parent.resize(nn); t.branchLengths.resize(nn); t.leafOfTaxon.resize(T);
+      rd(in, t.parent.data(), nn); rd(in, t.branchLengths.data(), nn); rd(in, t.leafOfTaxon.data(), T);
+      m.nbStates = S;
+      m.generator.resize(S * S); m.frequencies.resize(S); m.rates.resize(C); m.rateProbabilities.resize(C);
+      rd(in, m.generator.data(), S * S); rd(in, m.frequencies.data(), S); rd(in, m.rates.data(), C);
+      rd(in, m.rateProbabilities.data(), C);
+      std::vector<uint8_t> aln(static_cast<size_t>(T) * N);
+      rd(in, aln.data(), aln.size());
+      cmx::Engine eng(t, m, 0);
+      auto mapping = cmx::CoETools::getVectors(eng, aln.data(), N);
+      cmx::CorrelationStatistic stat;
+      auto rows = cmx::CoETools::computeIntraStats(eng, *mapping, stat, true, seed, h[5], h[6], h[7]);
+      std::ofstream out(argv[3], std::ios::binary);
+      int64_t nr = static_cast<int64_t>(rows.size());
+      wr(out, &nr, 1);
+      for (const auto& r : rows) {
+        int64_t ij[2] = {static_cast<int64_t>(r.i), static_cast<int64_t>(r.j)};
+        double v[4] = {r.stat, r.prMin, r.nMin, r.pValue};
+        int32_t k[2] = {r.rcMin, r.nSim};
+        wr(out, ij, 2); wr(out, v, 4); wr(out, k, 2);
+      }
+      wr(out, mapping->data(), static_cast<size_t>(N) * eng.getNumberOfBranches());
+      cmx::Vdouble norms = cmx::AnalysisTools::computeNorms(*mapping);
+      wr(out, norms.data(), norms.size());
+      return 0;
+    }
+    std::cerr << "usage: adapter_main domain lo hi n x... | run in.bin out.bin\n";
+    return 2;
+  } catch (cmx::Exception& e) {   // the reference's main catches bpp::Exception and exits (CoMap.cpp:730-734)
+    std::cerr << "cmx::Exception: " << e.what() << "\n";
+    return 1;
+  }
+}

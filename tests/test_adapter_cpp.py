@@ -1,0 +1,87 @@
+"""The C++ mirror of the reference interface (include/comap_mi355x_adapter.hpp): compiles with g++ against the C-ABI
+library; Domain matches the oracle on CPU; the full getVectors -> computeIntraStats call sequence matches the oracle
+on the GPU."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from comap_amd import engine
+from conftest import make_case, rel_close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "adapter_main")
+
+
+@pytest.fixture(scope="module")
+def adapter_exe():
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(engine.LIB_PATH)):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+                               "-L", os.path.dirname(engine.LIB_PATH), "-lcomap_mi355x",
+                               "-Wl,-rpath," + os.path.dirname(engine.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    return EXE
+
+
+def test_domain_matches_oracle(adapter_exe):
+    rng = np.random.default_rng(0)
+    hi = 4.98613
+    xs = np.concatenate([rng.uniform(-0.1, hi * 1.05, 200), [0.0, hi, hi / 10 * 3, np.nextafter(hi, 0)]])
+    out = subprocess.check_output([adapter_exe, "domain", "0", repr(hi), "10"] + [repr(float(x)) for x in xs]).split()
+    got = np.array([int(v) for v in out])
+    exp = np.array([oracle.domain_index(0, hi, 10, float(x)) for x in xs])
+    assert np.array_equal(got, exp)
+    assert got[-3] == -1 and got[-4] == 0          # upper bound exclusive, lower inclusive (Domain.cpp:115)
+
+
+def test_errors_surface_as_exceptions(adapter_exe, tmp_path):
+    bad = tmp_path / "bad.bin"
+    # S = 5 is rejected by the engine -> cmx::Exception -> exit code 1 (reference: bpp::Exception caught in main)
+    nn, T, S, C, N = 4, 3, 5, 1, 1
+    with open(bad, "wb") as f:
+        f.write(struct.pack("<8i", nn, T, S, C, N, 1, 1, 1) + struct.pack("<Q", 1))
+        f.write(np.array([3, 3, 3, -1], dtype=np.int32).tobytes() + np.ones(4).tobytes())
+        f.write(np.array([0, 1, 2], dtype=np.int32).tobytes())
+        f.write(np.zeros(S * S).tobytes() + np.full(S, 0.2).tobytes() + np.ones(1).tobytes() + np.ones(1).tobytes())
+        f.write(bytes(T * N))
+    r = subprocess.run([adapter_exe, "run", str(bad), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "nstates" in r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_call_sequence_matches_oracle(adapter_exe, tmp_path):
+    case = make_case(9, 70, 20, 61)
+    nn, T, S, C, N = len(case["parent"]), len(case["lot"]), 20, 4, 70
+    rep_cpu, rep_ram, ncls, seed = 3, 64, 5, 4242
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<8i", nn, T, S, C, N, rep_cpu, rep_ram, ncls) + struct.pack("<Q", seed))
+        f.write(case["parent"].astype(np.int32).tobytes() + case["blen"].tobytes() + case["lot"].astype(np.int32).tobytes())
+        f.write(case["Q"].tobytes() + case["pi"].tobytes() + case["rates"].tobytes() + case["probs"].tobytes())
+        f.write(np.ascontiguousarray(case["aln"]).tobytes())
+    subprocess.check_call([adapter_exe, "run", str(inp), str(outp)])
+    raw = open(outp, "rb").read()
+    nrows = struct.unpack_from("<q", raw, 0)[0]
+    assert nrows == N * (N - 1) // 2
+    rec = np.dtype([("i", "<i8"), ("j", "<i8"), ("stat", "<f8"), ("pr", "<f8"), ("nm", "<f8"), ("pv", "<f8"),
+                    ("rc", "<i4"), ("ns", "<i4")])
+    rows = np.frombuffer(raw, dtype=rec, count=nrows, offset=8)
+    B = nn - 1
+    counts = np.frombuffer(raw, dtype="<f8", count=N * B, offset=8 + nrows * rec.itemsize).reshape(N, B, 1)
+    om = oracle.Model(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    o = oracle.map_sites(om, case["aln"])
+    rel_close(counts, o["counts"], 1e-6, 1e-300)
+    st = oracle.pair_stats_intra(0, o["counts"])
+    nl = oracle.null_intra(om, 0, seed, 0, rep_cpu, rep_ram)
+    pv, ns = oracle.intra_pvalues(st, o["norm"], ncls, nl["stat"], nl["nmin"])
+    iu = np.triu_indices(N, 1)
+    assert np.array_equal(rows["i"], iu[0]) and np.array_equal(rows["j"], iu[1])      # the reference's row order
+    rel_close(rows["stat"], st[iu], 1e-6, 1e-12)
+    assert np.array_equal(rows["ns"], ns[iu])
+    assert np.array_equal(rows["rc"], np.minimum(o["rate_class"][iu[0]], o["rate_class"][iu[1]]))
+    rel_close(rows["nm"], np.minimum(o["norm"][iu[0]], o["norm"][iu[1]]), 1e-6)
+    # p-values: same sorted null to 1e-6 => counts may differ only where a null value ties the statistic to 1e-6
+    assert np.mean(rows["pv"] == pv[iu]) > 0.99
