@@ -130,13 +130,13 @@ def main():
     aln_h, _ = eng.simulate(w["seed"] + 1, 0, w["nsites"])
     d_aln = torch.from_numpy(aln_h).to(dev)
     ana = IntraAnalysis(eng, d_aln, w["statistic"], w["nclasses"])
-    nrep, ram = w["rep_per_gpu"], w["rep_ram"]
-    n_local = nrep * ram
-    gathered = torch.empty((world, 2, n_local), dtype=torch.float64, device=dev) if world > 1 else None
-    local2 = torch.empty((2, n_local), dtype=torch.float64, device=dev)
+    from comap_amd.distributed import gather_null, replicate_shard
+    ram = w["rep_ram"]
+    nrep_total = w["rep_per_gpu"] * world                  # weak scaling: fixed replicates per GPU
+    rep_begin, rep_end = replicate_shard(rank, world, nrep_total)
+    n_local = (rep_end - rep_begin) * ram
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
-
     side = torch.cuda.Stream(device=dev)   # observed-alignment mapping overlaps the null kernel (independent work)
     main = torch.cuda.current_stream()
 
@@ -146,17 +146,12 @@ def main():
             ana.get_vectors()
         if timed:
             ev[i][0].record()
-        nb = ana.null_distribution(w["seed"] + 7, rank * nrep, (rank + 1) * nrep, ram)
+        nb = ana.null_distribution(w["seed"] + 7, rep_begin, rep_end, ram)
         if timed:
             ev[i][1].record()
         main.wait_stream(side)
-        if world > 1:   # the path's one exchange: every rank needs the merged null before p-values
-            local2[0].copy_(nb["stat"])
-            local2[1].copy_(nb["nmin"])
-            dist.all_gather_into_tensor(gathered.view(-1), local2.view(-1))
-            ns, nm = gathered[:, 0, :].reshape(-1), gathered[:, 1, :].reshape(-1)
-        else:
-            ns, nm = nb["stat"], nb["nmin"]
+        # the path's one exchange: every rank needs the merged null before p-values (one RCCL all-gather)
+        ns, nm = gather_null(nb["stat"], nb["nmin"], nrep_total, ram)
         ana.compute_intra_stats(ns, nm)
 
     for i in range(args.warmup):
@@ -179,7 +174,7 @@ def main():
         elapsed = float(tt.item())
 
     pairs_obs = w["nsites"] * (w["nsites"] - 1) // 2
-    units_per_step = pairs_obs + world * n_local
+    units_per_step = pairs_obs + nrep_total * ram
     ms_per_step = 1e3 * elapsed / args.steps
     value = units_per_step * args.steps / elapsed
 

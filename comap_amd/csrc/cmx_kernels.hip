@@ -39,7 +39,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // and applied with v_fmac_f64_dpp row_newbcast -- 400 fp64 FMAs per 20x20 product, no LDS, SGPR or extra VGPR
 // traffic.  While tile T's FMAs run, its slot is refilled with tile T of the NEXT product's matrix (the sequence of
 // products is known: m.msched), so every matrix is fetched one full product (~1600 cycles) ahead of its use.
-// Measured (scripts/dppmv.hip): 53 TFLOP/s at 2 waves/SIMD vs 39 for s_load-fed v_fma_f64.
+// Measured (scripts/ubench_dpp_matvec.hip): 53 TFLOP/s at 2 waves/SIMD vs 39 for s_load-fed v_fma_f64.
 #include "cmx_ring_tiles.inc"
 
 template <int S, bool TR, int T>

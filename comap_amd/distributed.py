@@ -1,0 +1,34 @@
+"""Multi-GPU sharding of the parametric-bootstrap null: replicates are independent
+(CoMap/AnalysisTools.cpp:587 loop body carries no state besides appending results), so rank r maps the contiguous
+replicate range replicate_shard(r, world, nrep) with the counter-based RNG keyed by the GLOBAL replicate index, and
+ONE all-gather reassembles the reference's replicate order.  The result is bit-identical for any number of shards.
+torch.distributed only (backend "nccl" == RCCL over xGMI on MI355X; "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def replicate_shard(rank, world, nrep):
+    """Contiguous, balanced split of [0, nrep): the first nrep % world ranks get one extra replicate."""
+    q, r = divmod(nrep, world)
+    begin = rank * q + min(rank, r)
+    return begin, begin + q + (1 if rank < r else 0)
+
+
+def gather_null(local_stat, local_nmin, nrep, rep_ram, group=None):
+    """All-gather the (stat, nmin) columns of every rank's shard into replicate order.
+
+    local_*: 1-D float64 tensors of (end - begin) * rep_ram entries on the rank's device.  Shards may differ by one
+    replicate; they are padded to the largest shard for the collective and trimmed afterwards."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_stat, local_nmin
+    world = dist.get_world_size(group)
+    sizes = [(e - b) * rep_ram for b, e in (replicate_shard(r, world, nrep) for r in range(world))]
+    mx = max(sizes)
+    send = torch.full((2, mx), float("nan"), dtype=torch.float64, device=local_stat.device)
+    send[0, : local_stat.numel()] = local_stat
+    send[1, : local_nmin.numel()] = local_nmin
+    recv = torch.empty((world, 2, mx), dtype=torch.float64, device=local_stat.device)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    stat = torch.cat([recv[r, 0, : sizes[r]] for r in range(world)])
+    nmin = torch.cat([recv[r, 1, : sizes[r]] for r in range(world)])
+    return stat, nmin

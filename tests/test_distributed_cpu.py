@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: two gloo ranks each produce their replicate shard of the null (through the oracle, since there
+is no GPU here), all-gather it with comap_amd.distributed, and must reproduce the single-process null bit for bit in
+the reference's replicate order (sharding invariance comes from the counter-based RNG keyed by global indices)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, nrep, rep_ram, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from comap_amd.distributed import gather_null, replicate_shard
+    from conftest import make_case
+    case = make_case(8, 4, 4, 77)
+    om = oracle.Model(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    b, e = replicate_shard(rank, world, nrep)
+    loc = oracle.null_intra(om, 0, 99, b, e, rep_ram)
+    stat, nmin = gather_null(torch.from_numpy(loc["stat"]), torch.from_numpy(loc["nmin"]), nrep, rep_ram)
+    if rank == 0:
+        full = oracle.null_intra(om, 0, 99, 0, nrep, rep_ram)
+        q.put((np.array_equal(stat.numpy(), full["stat"], equal_nan=True),
+               np.array_equal(nmin.numpy(), full["nmin"]), int(stat.numel())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicate_shard_is_a_balanced_partition():
+    from comap_amd.distributed import replicate_shard
+    for nrep in (1, 7, 125, 1000):
+        for world in (1, 2, 3, 8):
+            parts = [replicate_shard(r, world, nrep) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == nrep
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("nrep", [4, 5])       # even and uneven shards
+def test_two_rank_gloo_null_matches_single_process(nrep):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + nrep) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nrep, 10, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok_stat, ok_nmin, n = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok_stat and ok_nmin and n == nrep * 10
