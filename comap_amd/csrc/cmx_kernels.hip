@@ -172,7 +172,8 @@ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t g, uint
   return (double)bits * (1.0 / 9007199254740992.0);
 }
 
-__device__ __forceinline__ int draw_index(double u, const double* __restrict__ cum, int n) {
+template <class CumPtr>
+__device__ __forceinline__ int draw_index(double u, CumPtr cum, int n) {
   int idx = 0;
   for (int j = 0; j < n - 1; ++j) idx += (u >= cum[j]) ? 1 : 0;
   return idx;
@@ -180,6 +181,29 @@ __device__ __forceinline__ int draw_index(double u, const double* __restrict__ c
 
 // ------------------------------------------------------------------------------------------------ mapping core
 extern __shared__ __attribute__((aligned(16))) uint8_t cmx_smem[];
+
+// Read-only, wave-uniform metadata (tree program, schedules, pi, class rates) is read through the CONSTANT address
+// space so that hipcc emits s_load (scalar cache, lgkmcnt) instead of global_load + v_readfirstlane: the latter would
+// queue every dependent tree-walk step behind the HBM prefetches outstanding on vmcnt.
+typedef const int __attribute__((address_space(4)))* cmx_cint;
+typedef const double __attribute__((address_space(4)))* cmx_cdbl;
+// schedule words feed vector address arithmetic, where hipcc would pick a VECTOR load for them (and then wait
+// vmcnt(0), draining the prefetches in flight): force the scalar path.
+__device__ __forceinline__ int sload_i32(cmx_cint p) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+struct ConstModel {
+  cmx_cint int_post, first_child, next_sib, taxon_of, slot, parent, ldsched, msched;
+  cmx_cdbl pi, rates, probs, cum_pi, cum_probs;
+  __device__ __forceinline__ explicit ConstModel(const DevModel& m)
+      : int_post((cmx_cint)m.int_post), first_child((cmx_cint)m.first_child), next_sib((cmx_cint)m.next_sib),
+        taxon_of((cmx_cint)m.taxon_of), slot((cmx_cint)m.slot), parent((cmx_cint)m.parent),
+        ldsched((cmx_cint)m.ldsched), msched((cmx_cint)m.msched), pi((cmx_cdbl)m.pi), rates((cmx_cdbl)m.rates),
+        probs((cmx_cdbl)m.probs), cum_pi((cmx_cdbl)m.cum_pi), cum_probs((cmx_cdbl)m.cum_probs) {}
+};
 // Workspace vector loads follow a host-built schedule (m.ldsched, one entry per load in program order):
 // bit 30 = array (0: inside D, 1: outside U), low 24 bits = slot.
 #define CMX_SCHED_ADDR(e) (((e) & 0x40000000) ? wsU : wsD) + (size_t)((e) & 0x00ffffff) * S * kWave + 2 * lane
@@ -219,6 +243,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
                                                double& L_out, double& pr_out, int& rc_out, double& norm_out) {
   const DevModel& m = a.m;
+  const ConstModel cm(m);
   const double* matl = m.MAT + (lane & 15);  // per-lane base of the packed matrices (16 values per DPP row)
   uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, S*64*8 bytes
   // leaf symbols of this wave's sites: [taxon][64] in LDS when they fit (a.codes_in_lds), else read from HBM
@@ -232,12 +257,12 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #define CMX_LEAF_J(tx, k, out) \
   leaf_vec<S>(m.LJT + (((size_t)c * K + (k)) * m.T + (tx)) * S * S, CMX_CODE(tx), a.masks, out)
 // matrix product number mi of this class pass (the matrix is already in the ring); streams in the matrix of the next
-// product: entry mi + 1 of m.msched, or entry 0 of the next class / next site block.
+// product: entry mi + 1 of cm.msched, or entry 0 of the next class / next site block.
 #define CMX_MV(TR, in, out)                                                                            \
   do {                                                                                                 \
     ++mi;                                                                                              \
     const int cn_ = (mi < m.nmv) ? c : ((c + 1 < C) ? c + 1 : 0);                                      \
-    const int en_ = m.msched[(mi < m.nmv) ? mi : 0];                                                   \
+    const int en_ = sload_i32(cm.msched + ((mi < m.nmv) ? mi : 0));                                                   \
     const size_t off_ = (en_ < 0) ? m.joff + ((size_t)cn_ * NI * K + (size_t)(en_ & 0x7fffffff)) * S * S \
                                   : ((size_t)cn_ * NI + (size_t)en_) * S * S;                          \
     matvec_ring<S, TR>(matl + off_, in, out);                                                          \
@@ -248,7 +273,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     _Pragma("unroll") for (int i_ = 0; i_ < S; ++i_) out = __builtin_fma(x_[i_], y_[i_], out); \
   } while (0)
   for (int c = 0; c < C; ++c) {
-    const double pc = m.probs[c];
+    const double pc = cm.probs[c];
     double* pcnt = part + (size_t)c * m.B * K * kWave + lane;
     double d[S], t[S];  // popped vector / matvec result
     int fi = 0;         // next schedule entry
@@ -260,8 +285,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     int carry_node = -1;
     double Lc = 0.0;
     for (int idx = 0; idx < NI; ++idx) {
-      const int n = m.int_post[idx];
-      const bool use_carry = carry_node >= 0 && m.parent[carry_node] == n;
+      const int n = cm.int_post[idx];
+      const bool use_carry = carry_node >= 0 && cm.parent[carry_node] == n;
       if (use_carry) {
         CMX_MV(false, acc, t);
 #pragma unroll
@@ -270,8 +295,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #pragma unroll
         for (int x = 0; x < S; ++x) acc[x] = 1.0;
       }
-      for (int e = m.first_child[n]; e >= 0; e = m.next_sib[e]) {
-        const int tx = m.taxon_of[e];
+      for (int e = cm.first_child[n]; e >= 0; e = cm.next_sib[e]) {
+        const int tx = cm.taxon_of[e];
         if (tx >= 0) {
           CMX_LEAF_P(tx, t);
         } else {
@@ -283,33 +308,33 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         for (int x = 0; x < S; ++x) acc[x] *= t[x];
       }
       if (n != root) {
-        store_vec<S>(wsD + (size_t)m.slot[n] * S * kWave + 2 * lane, acc);
+        store_vec<S>(wsD + (size_t)cm.slot[n] * S * kWave + 2 * lane, acc);
         carry_node = n;
       } else {
 #pragma unroll
-        for (int x = 0; x < S; ++x) Lc = __builtin_fma(m.pi[x], acc[x], Lc);
+        for (int x = 0; x < S; ++x) Lc = __builtin_fma(cm.pi[x], acc[x], Lc);
       }
     }
     Lsum += pc * Lc;
-    prsum += m.rates[c] * pc * Lc;
+    prsum += cm.rates[c] * pc * Lc;
     if (pc * Lc > best) { best = pc * Lc; bestc = c; }  // first maximum wins (getRateClassWithMaxPostProbPerSite)
     // ---------------- outside (pre-order) pass + joint counts.  acc now carries the outside message Up_f; a binary
     // node leaves Up of its last child in acc (that child is visited next in reverse post-order).
     double u[S];
     int up_node = -1;  // node whose Up is in acc
     for (int idx = NI - 1; idx >= 0; --idx) {
-      const int f = m.int_post[idx];
+      const int f = cm.int_post[idx];
       if (f == root) {
 #pragma unroll
-        for (int x = 0; x < S; ++x) acc[x] = m.pi[x];
+        for (int x = 0; x < S; ++x) acc[x] = cm.pi[x];
       } else if (f != up_node) {
         CMX_POP(acc);
       }
-      const int ca = m.first_child[f];
-      const int cb = m.next_sib[ca];
-      if (m.next_sib[cb] < 0) {
+      const int ca = cm.first_child[f];
+      const int cb = cm.next_sib[ca];
+      if (cm.next_sib[cb] < 0) {
         // ---- binary node (children ca < cb): at most three workspace loads
-        const int ta = m.taxon_of[ca], tb = m.taxon_of[cb];
+        const int ta = cm.taxon_of[ca], tb = cm.taxon_of[cb];
         if (tb >= 0) {
           CMX_LEAF_P(tb, t);
         } else {
@@ -329,7 +354,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #pragma unroll
           for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_b = Up_f o M_a
         } else {
-          const int sl = m.slot[ca];
+          const int sl = cm.slot[ca];
           CMX_POP(d);
           for (int k = 0; k < K; ++k) {
             CMX_MV(false, d, t);
@@ -351,7 +376,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
             pcnt[((size_t)cb * K + k) * kWave] = pc * tot;
           }
         } else {
-          const int sl = m.slot[cb];
+          const int sl = cm.slot[cb];
           CMX_POP(d);
           for (int k = 0; k < K; ++k) {
             CMX_MV(false, d, u);
@@ -364,12 +389,12 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         }
       } else {
         // ---- general node (root trifurcation, multifurcations): every sibling message recomputed per child
-        for (int n = ca; n >= 0; n = m.next_sib[n]) {
+        for (int n = ca; n >= 0; n = cm.next_sib[n]) {
 #pragma unroll
           for (int x = 0; x < S; ++x) u[x] = acc[x];
-          for (int sb = ca; sb >= 0; sb = m.next_sib[sb]) {
+          for (int sb = ca; sb >= 0; sb = cm.next_sib[sb]) {
             if (sb == n) continue;
-            const int tx = m.taxon_of[sb];
+            const int tx = cm.taxon_of[sb];
             if (tx >= 0) {
               CMX_LEAF_P(tx, t);
             } else {
@@ -379,7 +404,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #pragma unroll
             for (int x = 0; x < S; ++x) u[x] *= t[x];
           }
-          const int tn = m.taxon_of[n];
+          const int tn = cm.taxon_of[n];
           if (tn >= 0) {
             for (int k = 0; k < K; ++k) {
               CMX_LEAF_J(tn, k, t);
@@ -388,7 +413,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
               pcnt[((size_t)n * K + k) * kWave] = pc * tot;
             }
           } else {
-            const int sl = m.slot[n];
+            const int sl = cm.slot[n];
             CMX_POP(d);
             for (int k = 0; k < K; ++k) {
               CMX_MV(false, d, t);
@@ -485,6 +510,7 @@ template <int S, int MODE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_num_vgpr(206))) void map_kernel(
     const MapArgs a) {
   const DevModel& m = a.m;
+  const ConstModel cm(m);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * kWavesPerBlock;
@@ -499,7 +525,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_nu
   const size_t nblocks = (a.nsites + kWave - 1) / kWave;
   // prime the matrix ring with the first product's matrix (class 0, entry 0); every product refills it for the next
   if ((size_t)wave < nblocks) {
-    const int e0 = m.msched[0];
+    const int e0 = sload_i32(cm.msched);
     const size_t off0 = (e0 < 0) ? m.joff + (size_t)(e0 & 0x7fffffff) * S * S : (size_t)e0 * S * S;
     ring_prime<(S / 4) * (S / 4)>(m.MAT + (lane & 15) + off0);
   }
@@ -541,14 +567,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_nu
           gbase = al;
           gstride = kWave;
           const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
-          const int c = draw_index(philox_uniform(a.seed, g, 0), m.cum_probs, m.C);
-          st[(size_t)m.root * kWave] = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), m.cum_pi, S);
+          const int c = draw_index(philox_uniform(a.seed, g, 0), cm.cum_probs, m.C);
+          st[(size_t)m.root * kWave] = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S);
           for (int node = m.nn - 2; node >= 0; --node) {
-            const int x = st[(size_t)m.parent[node] * kWave];
+            const int x = st[(size_t)cm.parent[node] * kWave];
             const double u = philox_uniform(a.seed, g, 2u + (uint32_t)node);
             const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S + x) * S, S);
             st[(size_t)node * kWave] = (uint8_t)y;
-            const int tx = m.taxon_of[node];
+            const int tx = cm.taxon_of[node];
             if (tx >= 0) {
               if (a.codes_in_lds) codes[(size_t)tx * kWave] = (uint8_t)y;
               else al[(size_t)tx * kWave] = (uint8_t)y;
