@@ -167,6 +167,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       d.joff = h.PP.size();
     }
     UP(msched);
+    UP(nrec);
     d.nmv = (int)h.msched.size();
     UP(LPT); UP(LJT); UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
     UP(ldsched);

@@ -25,6 +25,7 @@ struct DevModel {
   // matrix products of one class pass in program order: bit 31 set = (P o N^k) with index slot*K + k, else P[slot]
   const int* msched;
   int nmv;
+  const int* nrec;         // [NI][16] per-internal-node records (enum REC_* in cmx_kernels.hip)
   // per (class, taxon): transposed matrices for the per-lane leaf gather, [z][x] = M[x][z]
   const double* LPT;       // [C][T][S][S]
   const double* LJT;       // [C][K][T][S][S]

@@ -81,11 +81,22 @@ void build_load_schedule(HostModel* hm) {
   hm->msched.clear();
   auto mvP = [&](int slot) { hm->msched.push_back(slot); };
   auto mvJ = [&](int slot) { for (int k = 0; k < K; ++k) hm->msched.push_back((int)(0x80000000u | (unsigned)(slot * K + k))); };
+  hm->nrec.assign((size_t)NI * 16, -1);
+  for (int idx = 0; idx < NI; ++idx) {
+    const int n = hm->int_post[idx];
+    int* r = &hm->nrec[(size_t)idx * 16];
+    int nch = 0, ch[2] = {-1, -1};
+    for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e]) { if (nch < 2) ch[nch] = e; ++nch; }
+    r[0] = n; r[1] = hm->slot[n]; r[2] = nch; r[3] = ch[0]; r[4] = ch[1];
+    r[5] = hm->taxon_of[ch[0]]; r[6] = hm->taxon_of[ch[1]]; r[7] = hm->slot[ch[0]]; r[8] = hm->slot[ch[1]];
+    r[9] = -1; r[10] = -1; r[11] = 0;
+  }
   // inside pass
   int carry_node = -1;
   for (int idx = 0; idx < NI; ++idx) {
     const int n = hm->int_post[idx];
     const bool use_carry = carry_node >= 0 && hm->parent[carry_node] == n;
+    if (use_carry) { hm->nrec[(size_t)idx * 16 + 9] = carry_node; hm->nrec[(size_t)idx * 16 + 10] = hm->slot[carry_node]; }
     if (use_carry) mvP(hm->slot[carry_node]);
     for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e])
       if (internal(e) && !(use_carry && e == carry_node)) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
@@ -96,6 +107,7 @@ void build_load_schedule(HostModel* hm) {
   for (int idx = NI - 1; idx >= 0; --idx) {
     const int f = hm->int_post[idx];
     if (f != root && f != upc_node) pop(1, hm->slot[f]);
+    if (f != root && f == upc_node) hm->nrec[(size_t)idx * 16 + 11] = 1;
     const int ca = hm->first_child[f], cb = hm->next_sib[ca];
     if (hm->next_sib[cb] < 0) {
       if (internal(cb)) { pop(0, hm->slot[cb]); mvP(hm->slot[cb]); }

@@ -25,6 +25,7 @@ struct HostModel {
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
   std::vector<int> ldsched; // workspace-load schedule of one class pass (DevModel::ldsched)
   std::vector<int> msched;  // matrix products of one class pass in program order (DevModel::msched)
+  std::vector<int> nrec;    // [NI][16] per-internal-node records (DevModel::nrec)
   size_t loads_D = 0, loads_U = 0, stores_D = 0, stores_U = 0;  // per class pass, for traffic accounting
 };
 

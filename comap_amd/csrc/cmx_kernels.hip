@@ -42,26 +42,29 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // Measured (scripts/ubench_dpp_matvec.hip): 53 TFLOP/s at 2 waves/SIMD vs 39 for s_load-fed v_fma_f64.
 #include "cmx_ring_tiles.inc"
 
-template <int S, bool TR, int T>
+template <int S, bool TR, int EXTRA, int T>
 __device__ __forceinline__ void ring_steps(const double* nxt, const double (&x)[S], double (&y)[S]) {
   constexpr int NB = S / 4, NT = NB * NB;
   if constexpr (T < NT) {
     constexpr int bi = T / NB, bj = T % NB;
-    // tile T was requested NT loads ago; every vector-memory operation issued since only makes the wait stricter
-    constexpr int WAIT = NT - 1;
+    // tile T was requested NT loads ago: NT - 1 younger ring loads may stay in flight.  EXTRA = number of
+    // vector-memory operations KNOWN to have been issued since the previous product (the S/2 LDS-DMA rows of a fresh
+    // workspace prefetch): they are younger than every tile of this matrix and may stay in flight too.  Any other
+    // operation issued in between only makes the wait stricter, never unsafe.
+    constexpr int WAIT = NT - 1 + EXTRA;
     if constexpr (!TR)
       ring_tile_f<T, WAIT>(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], x[4 * bj], x[4 * bj + 1],
                            x[4 * bj + 2], x[4 * bj + 3], nxt);
     else
       ring_tile_t<T, WAIT>(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], x[4 * bi], x[4 * bi + 1],
                            x[4 * bi + 2], x[4 * bi + 3], nxt);
-    ring_steps<S, TR, T + 1>(nxt, x, y);
+    ring_steps<S, TR, EXTRA, T + 1>(nxt, x, y);
   }
 }
 
 // y = M x (TR = false) or y = M^T x (TR = true) with M = the matrix currently in the ring; nxt = per-lane pointer
 // (matrix base + (lane & 15)) of the matrix of the next product in program order.
-template <int S, bool TR>
+template <int S, bool TR, int EXTRA>
 __device__ __forceinline__ void matvec_ring(const double* nxt, const double (&x)[S], double (&y)[S]) {
   static_assert(S % 4 == 0, "state count must be a multiple of 4");
   if (CMX_ABLATE == 3) {
@@ -71,7 +74,7 @@ __device__ __forceinline__ void matvec_ring(const double* nxt, const double (&x)
   }
 #pragma unroll
   for (int i = 0; i < S; ++i) y[i] = 0.0;
-  ring_steps<S, TR, 0>(nxt, x, y);
+  ring_steps<S, TR, EXTRA, 0>(nxt, x, y);
 }
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -195,13 +198,22 @@ __device__ __forceinline__ int sload_i32(cmx_cint p) {
   return v;
 }
 
+// per-internal-node record (host-built, cmx_host_model.cpp): one scalar load instead of a chain of dependent ones
+typedef int cmx_i16 __attribute__((ext_vector_type(16)));
+enum { REC_N = 0, REC_SLOT, REC_NCH, REC_CA, REC_CB, REC_TA, REC_TB, REC_SA, REC_SB, REC_CARRY, REC_CARRY_SLOT, REC_UPREG };
+__device__ __forceinline__ cmx_i16 sload_rec(cmx_cint p) {
+  cmx_i16 v;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
 struct ConstModel {
-  cmx_cint int_post, first_child, next_sib, taxon_of, slot, parent, ldsched, msched;
+  cmx_cint int_post, first_child, next_sib, taxon_of, slot, parent, ldsched, msched, nrec;
   cmx_cdbl pi, rates, probs, cum_pi, cum_probs;
   __device__ __forceinline__ explicit ConstModel(const DevModel& m)
       : int_post((cmx_cint)m.int_post), first_child((cmx_cint)m.first_child), next_sib((cmx_cint)m.next_sib),
         taxon_of((cmx_cint)m.taxon_of), slot((cmx_cint)m.slot), parent((cmx_cint)m.parent),
-        ldsched((cmx_cint)m.ldsched), msched((cmx_cint)m.msched), pi((cmx_cdbl)m.pi), rates((cmx_cdbl)m.rates),
+        ldsched((cmx_cint)m.ldsched), msched((cmx_cint)m.msched), nrec((cmx_cint)m.nrec), pi((cmx_cdbl)m.pi), rates((cmx_cdbl)m.rates),
         probs((cmx_cdbl)m.probs), cum_pi((cmx_cdbl)m.cum_pi), cum_probs((cmx_cdbl)m.cum_probs) {}
 };
 // Workspace vector loads follow a host-built schedule (m.ldsched, one entry per load in program order):
@@ -214,20 +226,24 @@ struct ConstModel {
 #define CMX_POP(dst)                                                        \
   do {                                                                      \
     if (pend) {                                                             \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+      /* the DMA rows are older than the ring loads of every product run since: those may stay in flight */ \
+      if (mv_since_pf) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((S / 4) * (S / 4)) : "memory"); \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
       read_vec_lds<S>(pfl, lane, dst);                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
     } else {                                                                \
-      const int e_ = m.ldsched[fi];                                         \
+      const int e_ = sload_i32(cm.ldsched + fi);                            \
       load_vec<S>(CMX_SCHED_ADDR(e_), dst);                                 \
     }                                                                       \
     ++fi;                                                                   \
     pend = false;                                                           \
     if (fi < m.nloads) {                                                    \
-      const int e2_ = m.ldsched[fi];                                        \
+      const int e2_ = sload_i32(cm.ldsched + fi);                           \
       if (e2_ < 0) {                                                        \
         prefetch_vec_lds<S>(CMX_SCHED_ADDR(e2_), pfl);                      \
         pend = true;                                                        \
+        pf_fresh = true;                                                    \
+        mv_since_pf = false;                                                \
       }                                                                     \
     }                                                                       \
   } while (0)
@@ -265,7 +281,10 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     const int en_ = sload_i32(cm.msched + ((mi < m.nmv) ? mi : 0));                                                   \
     const size_t off_ = (en_ < 0) ? m.joff + ((size_t)cn_ * NI * K + (size_t)(en_ & 0x7fffffff)) * S * S \
                                   : ((size_t)cn_ * NI + (size_t)en_) * S * S;                          \
-    matvec_ring<S, TR>(matl + off_, in, out);                                                          \
+    if (pf_fresh) matvec_ring<S, TR, S / 2>(matl + off_, in, out);                                     \
+    else matvec_ring<S, TR, 0>(matl + off_, in, out);                                                  \
+    pf_fresh = false;                                                                                  \
+    mv_since_pf = true;                                                                                \
   } while (0)
 #define CMX_DOT(x_, y_, out)                                                          \
   do {                                                                                \
@@ -279,15 +298,15 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     int fi = 0;         // next schedule entry
     int mi = 0;         // matrix products done in this class pass
     bool pend = false;  // the LDS prefetch buffer holds entry fi
+    bool pf_fresh = false, mv_since_pf = false;  // no product / at least one product since the prefetch was issued
     // ---------------- inside (post-order) pass.  acc leaves each iteration holding D of the node just finished; when
     // that node is a child of the next one (it then is its last child) it is consumed from registers.
     double acc[S];
-    int carry_node = -1;
     double Lc = 0.0;
     for (int idx = 0; idx < NI; ++idx) {
-      const int n = cm.int_post[idx];
-      const bool use_carry = carry_node >= 0 && cm.parent[carry_node] == n;
-      if (use_carry) {
+      const cmx_i16 r = sload_rec(cm.nrec + idx * 16);
+      const int n = r[REC_N];
+      if (r[REC_CARRY] >= 0) {  // the node finished last is a child of n: its vector is still in acc
         CMX_MV(false, acc, t);
 #pragma unroll
         for (int x = 0; x < S; ++x) acc[x] = t[x];
@@ -295,21 +314,43 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #pragma unroll
         for (int x = 0; x < S; ++x) acc[x] = 1.0;
       }
-      for (int e = cm.first_child[n]; e >= 0; e = cm.next_sib[e]) {
-        const int tx = cm.taxon_of[e];
-        if (tx >= 0) {
-          CMX_LEAF_P(tx, t);
-        } else {
-          if (use_carry && e == carry_node) continue;
+      if (r[REC_NCH] == 2) {
+        if (r[REC_TA] >= 0) {
+          CMX_LEAF_P(r[REC_TA], t);
+#pragma unroll
+          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+        } else if (r[REC_CARRY] != r[REC_CA]) {
           CMX_POP(d);
           CMX_MV(false, d, t);
-        }
 #pragma unroll
-        for (int x = 0; x < S; ++x) acc[x] *= t[x];
+          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+        }
+        if (r[REC_TB] >= 0) {
+          CMX_LEAF_P(r[REC_TB], t);
+#pragma unroll
+          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+        } else if (r[REC_CARRY] != r[REC_CB]) {
+          CMX_POP(d);
+          CMX_MV(false, d, t);
+#pragma unroll
+          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+        }
+      } else {
+        for (int e = cm.first_child[n]; e >= 0; e = cm.next_sib[e]) {
+          const int tx = cm.taxon_of[e];
+          if (tx >= 0) {
+            CMX_LEAF_P(tx, t);
+          } else {
+            if (e == r[REC_CARRY]) continue;
+            CMX_POP(d);
+            CMX_MV(false, d, t);
+          }
+#pragma unroll
+          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+        }
       }
       if (n != root) {
-        store_vec<S>(wsD + (size_t)cm.slot[n] * S * kWave + 2 * lane, acc);
-        carry_node = n;
+        store_vec<S>(wsD + (size_t)r[REC_SLOT] * S * kWave + 2 * lane, acc);
       } else {
 #pragma unroll
         for (int x = 0; x < S; ++x) Lc = __builtin_fma(cm.pi[x], acc[x], Lc);
@@ -321,20 +362,20 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     // ---------------- outside (pre-order) pass + joint counts.  acc now carries the outside message Up_f; a binary
     // node leaves Up of its last child in acc (that child is visited next in reverse post-order).
     double u[S];
-    int up_node = -1;  // node whose Up is in acc
     for (int idx = NI - 1; idx >= 0; --idx) {
-      const int f = cm.int_post[idx];
+      const cmx_i16 r = sload_rec(cm.nrec + idx * 16);
+      const int f = r[REC_N];
       if (f == root) {
 #pragma unroll
         for (int x = 0; x < S; ++x) acc[x] = cm.pi[x];
-      } else if (f != up_node) {
+      } else if (!r[REC_UPREG]) {  // otherwise Up_f was left in acc by the parent (f is its last child)
         CMX_POP(acc);
       }
-      const int ca = cm.first_child[f];
-      const int cb = cm.next_sib[ca];
-      if (cm.next_sib[cb] < 0) {
+      const int ca = r[REC_CA];
+      const int cb = r[REC_CB];
+      if (r[REC_NCH] == 2) {
         // ---- binary node (children ca < cb): at most three workspace loads
-        const int ta = cm.taxon_of[ca], tb = cm.taxon_of[cb];
+        const int ta = r[REC_TA], tb = r[REC_TB];
         if (tb >= 0) {
           CMX_LEAF_P(tb, t);
         } else {
@@ -354,7 +395,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #pragma unroll
           for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_b = Up_f o M_a
         } else {
-          const int sl = cm.slot[ca];
+          const int sl = r[REC_SA];
           CMX_POP(d);
           for (int k = 0; k < K; ++k) {
             CMX_MV(false, d, t);
@@ -376,7 +417,6 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
             pcnt[((size_t)cb * K + k) * kWave] = pc * tot;
           }
         } else {
-          const int sl = cm.slot[cb];
           CMX_POP(d);
           for (int k = 0; k < K; ++k) {
             CMX_MV(false, d, u);
@@ -385,7 +425,6 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
             pcnt[((size_t)cb * K + k) * kWave] = pc * tot;
           }
           CMX_MV(true, t, acc);  // Up_b stays in registers for the next node
-          up_node = cb;
         }
       } else {
         // ---- general node (root trifurcation, multifurcations): every sibling message recomputed per child
