@@ -31,7 +31,7 @@ struct cmx_ctx {
   bool has_model = false;
   HostModel hm;
   DevModel dm{};
-  Workspace ws{};       // null-distribution launches (persistent grid: 2 waves per SIMD on every CU)
+  Workspace ws{};       // null-distribution launches (persistent grid: 1 wave per SIMD on every CU)
   Workspace ws_obs{};   // observed-alignment launches: own slices, so both kinds can overlap on two streams
   int obs_blocks = 0;
   int cu_count = 0, waves = 0, grid_blocks = 0;
@@ -157,7 +157,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     if (!ctx->has_model) return CMX_OK;
     const HostModel& h = ctx->hm;
     DevModel& d = ctx->dm;
-    d.S = h.S; d.C = h.C; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.root = h.root;
+    d.S = h.S; d.C = h.C; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.NV = h.NV; d.root = h.root;
 #define UP(field) if ((s = upload(ctx, h.field, &d.field)) != CMX_OK) return s
     UP(int_post); UP(first_child); UP(next_sib); UP(taxon_of); UP(slot); UP(parent);
     {  // P and (P o N^k) packed matrices in one allocation (one base pointer for the ring fetches)
@@ -176,8 +176,8 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     // ambiguity masks default: code c >= S compatible with every state; fix the table for this S
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
-    // per-wave workspaces: 2 waves per SIMD on every CU for the null; a quarter of that for observed alignments
-    ctx->grid_blocks = ctx->cu_count * 2;
+    // per-wave workspaces: 1 wave per SIMD on every CU for the null; a quarter of that for observed alignments
+    ctx->grid_blocks = ctx->cu_count;   // one 4-wave workgroup per CU: one wave per SIMD with the full 512-VGPR budget
     ctx->waves = ctx->grid_blocks * kWavesPerBlock;
     ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
     auto alloc_ws = [&](Workspace* ws, size_t w, size_t* bytes) -> cmx_status {
@@ -237,6 +237,28 @@ cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P) {
   return CMX_OK;
 }
 
+cmx_status cmx_debug_traversal(const cmx_model* model, const cmx_tree* tree, int32_t* nrec, size_t nrec_cap,
+                               size_t* nrec_n, int32_t* ldsched, size_t ld_cap, size_t* ld_n, int32_t* msched,
+                               size_t m_cap, size_t* m_n, int32_t* slot_of_node) {
+  HostModel hm;
+  int code = CMX_OK;
+  const std::string msg = build_host_model(model, tree, &hm, &code);
+  if (!msg.empty()) {
+    g_create_error = msg;
+    return (cmx_status)code;
+  }
+  if (hm.nrec.size() > nrec_cap || hm.ldsched.size() > ld_cap || hm.msched.size() > m_cap) {
+    g_create_error = "cmx_debug_traversal: buffers too small";
+    return CMX_ERR_INVALID;
+  }
+  std::memcpy(nrec, hm.nrec.data(), hm.nrec.size() * sizeof(int32_t));
+  std::memcpy(ldsched, hm.ldsched.data(), hm.ldsched.size() * sizeof(int32_t));
+  std::memcpy(msched, hm.msched.data(), hm.msched.size() * sizeof(int32_t));
+  *nrec_n = hm.nrec.size(); *ld_n = hm.ldsched.size(); *m_n = hm.msched.size();
+  if (slot_of_node) std::memcpy(slot_of_node, hm.slot.data(), hm.slot.size() * sizeof(int32_t));
+  return CMX_OK;
+}
+
 cmx_status cmx_synchronize(cmx_ctx* ctx) {
   if (!ctx) return CMX_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -256,7 +278,7 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws_obs;
   a.aln = d_aln; a.ld = ld; a.nsites = nsites; a.masks = d_masks ? d_masks : ctx->d_default_masks;
-  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 80 * 1024;
+  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 160 * 1024;
   a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.norm = d_norm;
   const size_t blocks_needed = ((nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -419,7 +441,7 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.masks = ctx->d_default_masks;
-  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 80 * 1024;
+  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 160 * 1024;
   a.nsites = (rep_end - rep_begin) * rep_ram;
   a.stat_kind = kind;
   a.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;

@@ -11,7 +11,7 @@ constexpr int kWavesPerBlock = 4;   // mapping kernels: 4 independent waves per 
 
 // Device-resident model + tree program.  All pointers are device pointers.
 struct DevModel {
-  int S, C, K, nn, B, T, NI, root;
+  int S, C, K, nn, B, T, NI, NV, root;  // NI internal nodes (slots), NV of them visited by the traversal
   // tree program (wave-uniform, read through the scalar cache)
   const int* int_post;     // [NI]  internal nodes in post-order, root last
   const int* first_child;  // [nn]
@@ -25,7 +25,7 @@ struct DevModel {
   // matrix products of one class pass in program order: bit 31 set = (P o N^k) with index slot*K + k, else P[slot]
   const int* msched;
   int nmv;
-  const int* nrec;         // [NI][16] per-internal-node records (enum REC_* in cmx_kernels.hip)
+  const int* nrec;         // [NV][32] per-visited-node records (enum REC_* in cmx_kernels.hip)
   // per (class, taxon): transposed matrices for the per-lane leaf gather, [z][x] = M[x][z]
   const double* LPT;       // [C][T][S][S]
   const double* LJT;       // [C][K][T][S][S]

@@ -68,58 +68,112 @@ void pack_blocks(int S, const double* M, double* out) {
 
 }  // namespace
 
+// Builds the traversal of one rate-class pass: the per-node records the kernel walks, and -- by simulating exactly
+// the kernel's control flow (map_sites_wave in cmx_kernels.hip) -- the order of its workspace loads (ldsched, with
+// prefetchability) and of its matrix products (msched).
+//
+// Bytes are ~10x dearer than flops in this kernel (a 10 KiB workspace vector costs a wave ~5 us of its HBM share, a
+// 20x20 product ~1 us), so the traversal avoids workspace traffic wherever a vector can stay in registers or be
+// rebuilt from leaves:
+//   * "inlined cherries": an internal node whose two children are leaves (and whose parent is binary) is never
+//     visited on its own.  Its inside vector is rebuilt from two leaf gathers where needed, and the counts of its
+//     two leaf branches are taken right where its outside message is produced -- no store, no load for either.
+//   * a binary node's child Y = its largest-id child that is a visited node: Y is visited right before (inside
+//     pass) / right after (outside pass) its parent, so its vectors are handed over in registers both ways.
 void build_load_schedule(HostModel* hm) {
-  const int NI = hm->NI, root = hm->root;
+  const int NI = hm->NI, root = hm->root, K = hm->K, nn = hm->nn;
+  auto internal = [&](int n) { return hm->taxon_of[n] < 0; };
+  auto kids = [&](int n) { std::vector<int> v; for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e]) v.push_back(e); return v; };
+  std::vector<char> inlined(nn, 0);
+  for (int n = 0; n < nn; ++n) {
+    if (!internal(n) || n == root) continue;
+    const std::vector<int> c = kids(n);
+    if (c.size() == 2 && !internal(c[0]) && !internal(c[1]) && kids(hm->parent[n]).size() == 2) inlined[n] = 1;
+  }
+  auto kind = [&](int e) { return !internal(e) ? 0 : (inlined[e] ? 2 : 1); };
+  std::vector<int> visited;
+  for (int idx = 0; idx < NI; ++idx) if (!inlined[hm->int_post[idx]]) visited.push_back(hm->int_post[idx]);
+  const int NV = (int)visited.size();
+  hm->NV = NV;
+  hm->nrec.assign((size_t)NV * 32, -1);
+  auto fill_child = [&](int* r, int e) {
+    r[0] = kind(e); r[1] = e;
+    r[2] = internal(e) ? hm->slot[e] : hm->taxon_of[e];
+    if (kind(e) == 2) {
+      const std::vector<int> c = kids(e);
+      r[3] = hm->taxon_of[c[0]]; r[4] = hm->taxon_of[c[1]]; r[5] = c[0]; r[6] = c[1];
+    }
+  };
+  std::vector<int> Xof(nn, -1), Yof(nn, -1);
+  for (int v = 0; v < NV; ++v) {
+    const int n = visited[v];
+    int* r = &hm->nrec[(size_t)v * 32];
+    const std::vector<int> c = kids(n);
+    r[0] = n; r[1] = hm->slot[n]; r[2] = (int)c.size(); r[3] = 0; r[30] = -1;
+    if (c.size() == 2) {
+      int y = (kind(c[1]) == 1) ? c[1] : ((kind(c[0]) == 1) ? c[0] : c[1]);
+      int x = (y == c[1]) ? c[0] : c[1];
+      Xof[n] = x; Yof[n] = y;
+      fill_child(r + 4, x);
+      fill_child(r + 16, y);
+      if (kind(y) == 1) r[3] |= 2;   // Y's vectors are handed over in registers
+    } else {
+      const int last = c.back();
+      if (kind(last) == 1) r[30] = last;   // general node: its last child is the node finished right before it
+    }
+  }
+  // ---- simulate the kernel
   struct Ev { int arr, slot; long t, src_store; };
   std::vector<Ev> pops;
   std::vector<long> storeD(NI, -1), storeU(NI, -1);
   long t = 0;
   hm->stores_D = hm->stores_U = 0;
   auto pop = [&](int arr, int slot) { pops.push_back({arr, slot, t++, arr ? storeU[slot] : storeD[slot]}); };
-  auto internal = [&](int n) { return hm->taxon_of[n] < 0; };
-  const int K = hm->K;
   hm->msched.clear();
   auto mvP = [&](int slot) { hm->msched.push_back(slot); };
   auto mvJ = [&](int slot) { for (int k = 0; k < K; ++k) hm->msched.push_back((int)(0x80000000u | (unsigned)(slot * K + k))); };
-  hm->nrec.assign((size_t)NI * 16, -1);
-  for (int idx = 0; idx < NI; ++idx) {
-    const int n = hm->int_post[idx];
-    int* r = &hm->nrec[(size_t)idx * 16];
-    int nch = 0, ch[2] = {-1, -1};
-    for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e]) { if (nch < 2) ch[nch] = e; ++nch; }
-    r[0] = n; r[1] = hm->slot[n]; r[2] = nch; r[3] = ch[0]; r[4] = ch[1];
-    r[5] = hm->taxon_of[ch[0]]; r[6] = hm->taxon_of[ch[1]]; r[7] = hm->slot[ch[0]]; r[8] = hm->slot[ch[1]];
-    r[9] = -1; r[10] = -1; r[11] = 0;
-  }
   // inside pass
-  int carry_node = -1;
-  for (int idx = 0; idx < NI; ++idx) {
-    const int n = hm->int_post[idx];
-    const bool use_carry = carry_node >= 0 && hm->parent[carry_node] == n;
-    if (use_carry) { hm->nrec[(size_t)idx * 16 + 9] = carry_node; hm->nrec[(size_t)idx * 16 + 10] = hm->slot[carry_node]; }
-    if (use_carry) mvP(hm->slot[carry_node]);
-    for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e])
-      if (internal(e) && !(use_carry && e == carry_node)) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
-    if (n != root) { storeD[hm->slot[n]] = t++; hm->stores_D++; carry_node = n; }
+  for (int v = 0; v < NV; ++v) {
+    const int n = visited[v];
+    const std::vector<int> c = kids(n);
+    if (c.size() == 2) {
+      const int x = Xof[n], y = Yof[n];
+      if (kind(y) == 1) mvP(hm->slot[y]);                       // carried
+      auto edge = [&](int e) {
+        if (kind(e) == 1) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
+        else if (kind(e) == 2) mvP(hm->slot[e]);
+      };
+      edge(x);
+      if (kind(y) != 1) edge(y);
+    } else {
+      const int carry = hm->nrec[(size_t)v * 32 + 30];
+      if (carry >= 0) mvP(hm->slot[carry]);
+      for (int e : c)
+        if (internal(e) && e != carry) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
+    }
+    if (n != root) { storeD[hm->slot[n]] = t++; hm->stores_D++; }
   }
   // outside pass
-  int upc_node = -1;
-  for (int idx = NI - 1; idx >= 0; --idx) {
-    const int f = hm->int_post[idx];
-    if (f != root && f != upc_node) pop(1, hm->slot[f]);
-    if (f != root && f == upc_node) hm->nrec[(size_t)idx * 16 + 11] = 1;
-    const int ca = hm->first_child[f], cb = hm->next_sib[ca];
-    if (hm->next_sib[cb] < 0) {
-      if (internal(cb)) { pop(0, hm->slot[cb]); mvP(hm->slot[cb]); }
-      if (internal(ca)) {
-        pop(0, hm->slot[ca]);
-        mvJ(hm->slot[ca]); mvP(hm->slot[ca]); mvP(hm->slot[ca]);   // J.D, P.D, P^T.U
-        storeU[hm->slot[ca]] = t++; hm->stores_U++;
-      }
-      if (internal(cb)) { pop(0, hm->slot[cb]); mvJ(hm->slot[cb]); mvP(hm->slot[cb]); upc_node = cb; }
+  std::vector<char> up_in_acc(nn, 0);
+  for (int v = NV - 1; v >= 0; --v) {
+    const int f = visited[v];
+    if (f != root) {
+      if (up_in_acc[f]) hm->nrec[(size_t)v * 32 + 3] |= 4;
+      else pop(1, hm->slot[f]);
+    }
+    const std::vector<int> c = kids(f);
+    if (c.size() == 2) {
+      const int x = Xof[f], y = Yof[f];
+      if (kind(y) == 1) { pop(0, hm->slot[y]); mvP(hm->slot[y]); } else if (kind(y) == 2) mvP(hm->slot[y]);
+      if (kind(x) == 1) {
+        pop(0, hm->slot[x]); mvJ(hm->slot[x]); mvP(hm->slot[x]); mvP(hm->slot[x]);
+        storeU[hm->slot[x]] = t++; hm->stores_U++;
+      } else if (kind(x) == 2) { mvJ(hm->slot[x]); mvP(hm->slot[x]); mvP(hm->slot[x]); }
+      if (kind(y) == 1) { pop(0, hm->slot[y]); mvJ(hm->slot[y]); mvP(hm->slot[y]); up_in_acc[y] = 1; }
+      else if (kind(y) == 2) { mvJ(hm->slot[y]); mvP(hm->slot[y]); }
     } else {
-      for (int n = ca; n >= 0; n = hm->next_sib[n]) {
-        for (int sb = ca; sb >= 0; sb = hm->next_sib[sb])
+      for (int n : c) {
+        for (int sb : c)
           if (sb != n && internal(sb)) { pop(0, hm->slot[sb]); mvP(hm->slot[sb]); }
         if (internal(n)) { pop(0, hm->slot[n]); mvJ(hm->slot[n]); mvP(hm->slot[n]); storeU[hm->slot[n]] = t++; hm->stores_U++; }
       }
@@ -129,12 +183,128 @@ void build_load_schedule(HostModel* hm) {
   hm->loads_D = hm->loads_U = 0;
   for (size_t j = 0; j < pops.size(); ++j) {
     const Ev& e = pops[j];
-    unsigned v = (unsigned)e.slot | (e.arr ? 0x40000000u : 0u);
+    unsigned w = (unsigned)e.slot | (e.arr ? 0x40000000u : 0u);
     // prefetchable: its producer store is issued before the previous pop (where the prefetch is issued)
-    if (j > 0 && e.src_store >= 0 && e.src_store < pops[j - 1].t) v |= 0x80000000u;
-    hm->ldsched.push_back((int)v);
+    if (j > 0 && e.src_store >= 0 && e.src_store < pops[j - 1].t) w |= 0x80000000u;
+    hm->ldsched.push_back((int)w);
     if (e.arr) hm->loads_U++; else hm->loads_D++;
   }
+}
+
+// Host-side dry run of map_sites_wave's control flow, driven by the SAME records and schedules the kernel reads:
+// every index is bounds-checked, every workspace load must name the vector the code needs and must have been stored
+// before, every matrix product must find its matrix next in msched.  A mismatch here would be an out-of-bounds or
+// stale access on the GPU, so a context is refused instead (cmx_ctx_create).
+std::string verify_traversal(const HostModel& hm) {
+  const int NI = hm.NI, NV = hm.NV, K = hm.K, T = hm.T, nn = hm.nn, root = hm.root;
+  if ((int)hm.nrec.size() != NV * 32) return "nrec size";
+  size_t fi = 0, mi = 0;
+  std::vector<char> haveD(NI, 0), haveU(NI, 0), counted((size_t)hm.B * K, 0);
+  std::string err;
+  auto fail = [&](const std::string& m) { if (err.empty()) err = "traversal self-check failed: " + m; };
+  auto pop = [&](int arr, int slot) {
+    if (fi >= hm.ldsched.size()) return fail("more workspace loads than scheduled");
+    const int e = hm.ldsched[fi++];
+    if ((((unsigned)e >> 30) & 1) != (unsigned)arr || (e & 0xffffff) != slot) return fail("load " + std::to_string(fi - 1) + " names the wrong vector");
+    if (slot < 0 || slot >= NI) return fail("slot out of range");
+    if (!(arr ? haveU[slot] : haveD[slot])) return fail("load of a vector that was never stored");
+  };
+  auto mv = [&](bool isJ, int idx) {
+    if (mi >= hm.msched.size()) return fail("more matrix products than scheduled");
+    const int e = hm.msched[mi++];
+    const int want = isJ ? (int)(0x80000000u | (unsigned)idx) : idx;
+    if (e != want) return fail("product " + std::to_string(mi - 1) + " finds the wrong matrix in the ring");
+    if (isJ ? (idx < 0 || idx >= NI * K) : (idx < 0 || idx >= NI)) return fail("matrix index out of range");
+  };
+  auto leaf = [&](int tx) { if (tx < 0 || tx >= T) fail("taxon out of range"); };
+  auto count = [&](int node) {
+    if (node < 0 || node >= nn - 1) return fail("branch out of range");
+    for (int k = 0; k < K; ++k) { if (counted[(size_t)node * K + k]) fail("branch counted twice"); counted[(size_t)node * K + k] = 1; }
+  };
+  auto getD = [&](const int* ch) {
+    if (ch[0] == 1) pop(0, ch[2]);
+    else if (ch[0] == 2) { leaf(ch[3]); leaf(ch[4]); }
+    else fail("bad child kind");
+  };
+  auto cherry_counts = [&](const int* ch) { leaf(ch[3]); leaf(ch[4]); count(ch[5]); count(ch[6]); };
+  auto kids = [&](int n) { std::vector<int> v; for (int e = hm.first_child[n]; e >= 0; e = hm.next_sib[e]) v.push_back(e); return v; };
+  bool acc_is_D_of_prev = false;
+  int prev_node = -1;
+  // inside pass
+  for (int idx = 0; idx < NV && err.empty(); ++idx) {
+    const int* r = &hm.nrec[(size_t)idx * 32];
+    const int n = r[0];
+    if (n < 0 || n >= nn || r[1] != hm.slot[n]) return "traversal self-check failed: bad node record";
+    if (r[2] == 2) {
+      const int* X = r + 4; const int* Y = r + 16;
+      if (r[3] & 2) {
+        if (!acc_is_D_of_prev || prev_node != Y[1] || Y[0] != 1) fail("Y is not the node finished last");
+        mv(false, Y[2]);
+      }
+      if (X[0] == 0) leaf(X[2]); else { getD(X); mv(false, X[2]); }
+      if (!(r[3] & 2)) { if (Y[0] == 0) leaf(Y[2]); else { if (Y[0] != 2) fail("stored Y not handed over"); getD(Y); mv(false, Y[2]); } }
+    } else {
+      const int carry = r[30];
+      if (carry >= 0) { if (!acc_is_D_of_prev || prev_node != carry) fail("general carry"); mv(false, hm.slot[carry]); }
+      for (int e : kids(n)) {
+        if (hm.taxon_of[e] >= 0) leaf(hm.taxon_of[e]);
+        else if (e != carry) { pop(0, hm.slot[e]); mv(false, hm.slot[e]); }
+      }
+    }
+    if (n != root) haveD[r[1]] = 1;
+    acc_is_D_of_prev = true;
+    prev_node = n;
+  }
+  // outside pass
+  int up_node_in_acc = -1;
+  for (int idx = NV - 1; idx >= 0 && err.empty(); --idx) {
+    const int* r = &hm.nrec[(size_t)idx * 32];
+    const int f = r[0];
+    if (f != root) {
+      if (r[3] & 4) { if (up_node_in_acc != f) fail("outside message not in registers"); }
+      else pop(1, r[1]);
+    }
+    up_node_in_acc = -1;
+    if (r[2] == 2) {
+      const int* X = r + 4; const int* Y = r + 16;
+      if (Y[0] == 0) leaf(Y[2]); else { getD(Y); mv(false, Y[2]); }
+      if (X[0] == 0) { leaf(X[2]); count(X[1]); }
+      else {
+        getD(X);
+        for (int k = 0; k < K; ++k) mv(true, X[2] * K + k);
+        count(X[1]);
+        mv(false, X[2]); mv(false, X[2]);
+        if (X[0] == 1) haveU[X[2]] = 1; else cherry_counts(X);
+      }
+      if (Y[0] == 0) { leaf(Y[2]); count(Y[1]); }
+      else {
+        getD(Y);
+        for (int k = 0; k < K; ++k) mv(true, Y[2] * K + k);
+        count(Y[1]);
+        mv(false, Y[2]);
+        if (Y[0] == 1) up_node_in_acc = Y[1]; else cherry_counts(Y);
+      }
+    } else {
+      const std::vector<int> c = kids(f);
+      for (int n : c) {
+        for (int sb : c)
+          if (sb != n) { if (hm.taxon_of[sb] >= 0) leaf(hm.taxon_of[sb]); else { pop(0, hm.slot[sb]); mv(false, hm.slot[sb]); } }
+        if (hm.taxon_of[n] >= 0) { leaf(hm.taxon_of[n]); count(n); }
+        else {
+          pop(0, hm.slot[n]);
+          for (int k = 0; k < K; ++k) mv(true, hm.slot[n] * K + k);
+          count(n);
+          mv(false, hm.slot[n]);
+          haveU[hm.slot[n]] = 1;
+        }
+      }
+    }
+  }
+  if (!err.empty()) return err;
+  if (fi != hm.ldsched.size()) return "traversal self-check failed: unused workspace loads in the schedule";
+  if (mi != hm.msched.size()) return "traversal self-check failed: unused matrix products in the schedule";
+  for (char c : counted) if (!c) return "traversal self-check failed: a branch is never counted";
+  return std::string();
 }
 
 std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostModel* hm, int* code) {
@@ -191,6 +361,10 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   if (nchild[nn - 1] < 2) return "the root needs at least two children";
   hm->NI = (int)hm->int_post.size();
   build_load_schedule(hm);
+  {
+    const std::string bad = verify_traversal(*hm);
+    if (!bad.empty()) return bad;
+  }
   // ---- model checks
   hm->pi.assign(model->pi, model->pi + S);
   hm->rates.assign(model->rates, model->rates + C);

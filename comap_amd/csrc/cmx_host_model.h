@@ -13,7 +13,7 @@
 namespace cmx {
 
 struct HostModel {
-  int S = 0, C = 0, K = 0, nn = 0, B = 0, T = 0, NI = 0, root = 0;
+  int S = 0, C = 0, K = 0, nn = 0, B = 0, T = 0, NI = 0, NV = 0, root = 0;  // NV = visited (non-inlined) internal nodes
   std::vector<int> parent, first_child, next_sib, taxon_of, slot, int_post;
   std::vector<double> blen, pi, rates, probs, cum_pi, cum_probs;
   std::vector<double> P;    // [C][B][S*S] row-major (x -> y)
@@ -25,12 +25,14 @@ struct HostModel {
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
   std::vector<int> ldsched; // workspace-load schedule of one class pass (DevModel::ldsched)
   std::vector<int> msched;  // matrix products of one class pass in program order (DevModel::msched)
-  std::vector<int> nrec;    // [NI][16] per-internal-node records (DevModel::nrec)
+  std::vector<int> nrec;    // [NV][32] per-visited-node records (DevModel::nrec)
   size_t loads_D = 0, loads_U = 0, stores_D = 0, stores_U = 0;  // per class pass, for traffic accounting
 };
 
 // Mirrors the loop nest of map_sites_wave (cmx_kernels.hip) and lists its workspace loads in program order.
 void build_load_schedule(HostModel* hm);
+
+std::string verify_traversal(const HostModel& hm);
 
 // returns empty string on success, otherwise the error message (status in *code)
 std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostModel* out, int* code);

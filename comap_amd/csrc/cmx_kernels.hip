@@ -34,38 +34,38 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define CMX_ABLATE 0  // diagnostic builds: 1 = no leaf gathers, 2 = no workspace traffic, 3 = no matrix products
 #endif
 
-// The SxS operator of an edge is the same for all 64 lanes.  It is kept in a ring of fixed VGPRs (v[206:255]: 25
-// tiles of the 4x4-block-packed matrix, one f64 per lane and tile, i.e. the 16 values of a tile in every DPP row)
-// and applied with v_fmac_f64_dpp row_newbcast -- 400 fp64 FMAs per 20x20 product, no LDS, SGPR or extra VGPR
-// traffic.  While tile T's FMAs run, its slot is refilled with tile T of the NEXT product's matrix (the sequence of
-// products is known: m.msched), so every matrix is fetched one full product (~1600 cycles) ahead of its use.
-// Measured (scripts/ubench_dpp_matvec.hip): 53 TFLOP/s at 2 waves/SIMD vs 39 for s_load-fed v_fma_f64.
+// The SxS operator of an edge is the same for all 64 lanes.  It is held one 4x4 block ("tile", 16 values) per
+// VGPR pair -- ring[t], the 16 values of tile t replicated in every DPP row -- and applied with v_fmac_f64_dpp
+// row_newbcast: 400 fp64 FMAs per 20x20 product, no LDS or SGPR traffic.  Right after tile t's FMAs ring[t] is
+// reloaded with tile t of the NEXT product's matrix (the sequence of products is known: m.msched), so every matrix
+// is requested one full product (~1600 cycles) before its use.  The ring is an ordinary register array: hipcc owns
+// its allocation and its vmcnt waits (a first version pinned it to v[206:255] behind amdgpu_num_vgpr, which turned
+// out NOT to be a hard limit under pressure -- the compiler reused those registers).
+// Measured (scripts/ubench_dpp_matvec.hip): 46 / 53 TFLOP/s at 1 / 2 waves per SIMD vs 24 / 39 for s_load-fed v_fma_f64.
 #include "cmx_ring_tiles.inc"
 
-template <int S, bool TR, int EXTRA, int T>
-__device__ __forceinline__ void ring_steps(const double* nxt, const double (&x)[S], double (&y)[S]) {
+template <int S, bool TR, int T>
+__device__ __forceinline__ void ring_steps(double (&ring)[(S / 4) * (S / 4)], const double* __restrict__ nxt,
+                                           const double (&x)[S], double (&y)[S]) {
   constexpr int NB = S / 4, NT = NB * NB;
   if constexpr (T < NT) {
     constexpr int bi = T / NB, bj = T % NB;
-    // tile T was requested NT loads ago: NT - 1 younger ring loads may stay in flight.  EXTRA = number of
-    // vector-memory operations KNOWN to have been issued since the previous product (the S/2 LDS-DMA rows of a fresh
-    // workspace prefetch): they are younger than every tile of this matrix and may stay in flight too.  Any other
-    // operation issued in between only makes the wait stricter, never unsafe.
-    constexpr int WAIT = NT - 1 + EXTRA;
     if constexpr (!TR)
-      ring_tile_f<T, WAIT>(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], x[4 * bj], x[4 * bj + 1],
-                           x[4 * bj + 2], x[4 * bj + 3], nxt);
+      dpp_tile_f(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], ring[T], x[4 * bj], x[4 * bj + 1], x[4 * bj + 2],
+                 x[4 * bj + 3]);
     else
-      ring_tile_t<T, WAIT>(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], x[4 * bi], x[4 * bi + 1],
-                           x[4 * bi + 2], x[4 * bi + 3], nxt);
-    ring_steps<S, TR, EXTRA, T + 1>(nxt, x, y);
+      dpp_tile_t(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], ring[T], x[4 * bi], x[4 * bi + 1], x[4 * bi + 2],
+                 x[4 * bi + 3]);
+    ring[T] = nxt[T * 16];
+    ring_steps<S, TR, T + 1>(ring, nxt, x, y);
   }
 }
 
 // y = M x (TR = false) or y = M^T x (TR = true) with M = the matrix currently in the ring; nxt = per-lane pointer
 // (matrix base + (lane & 15)) of the matrix of the next product in program order.
-template <int S, bool TR, int EXTRA>
-__device__ __forceinline__ void matvec_ring(const double* nxt, const double (&x)[S], double (&y)[S]) {
+template <int S, bool TR>
+__device__ __forceinline__ void matvec_ring(double (&ring)[(S / 4) * (S / 4)], const double* __restrict__ nxt,
+                                            const double (&x)[S], double (&y)[S]) {
   static_assert(S % 4 == 0, "state count must be a multiple of 4");
   if (CMX_ABLATE == 3) {
 #pragma unroll
@@ -74,7 +74,7 @@ __device__ __forceinline__ void matvec_ring(const double* nxt, const double (&x)
   }
 #pragma unroll
   for (int i = 0; i < S; ++i) y[i] = 0.0;
-  ring_steps<S, TR, EXTRA, 0>(nxt, x, y);
+  ring_steps<S, TR, 0>(ring, nxt, x, y);
 }
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -198,13 +198,17 @@ __device__ __forceinline__ int sload_i32(cmx_cint p) {
   return v;
 }
 
-// per-internal-node record (host-built, cmx_host_model.cpp): one scalar load instead of a chain of dependent ones
+// per-visited-node record (host-built, cmx_host_model.cpp build_load_schedule): 32 ints, two scalar loads
 typedef int cmx_i16 __attribute__((ext_vector_type(16)));
-enum { REC_N = 0, REC_SLOT, REC_NCH, REC_CA, REC_CB, REC_TA, REC_TB, REC_SA, REC_SB, REC_CARRY, REC_CARRY_SLOT, REC_UPREG };
-__device__ __forceinline__ cmx_i16 sload_rec(cmx_cint p) {
-  cmx_i16 v;
-  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-  return v;
+enum { REC_N = 0, REC_SLOT = 1, REC_NCH = 2, REC_FLAGS = 3, REC_X = 4 /* ints 4..10 */, REC_Y = 0 /* of the 2nd half: ints 16..22 */,
+       REC_GCARRY = 14 /* of the 2nd half: int 30 */ };
+enum { CH_KIND = 0, CH_NODE = 1, CH_ID = 2, CH_T1 = 3, CH_T2 = 4, CH_L1 = 5, CH_L2 = 6 };  // child descriptor
+enum { FLAG_Y_IN_REGS = 2, FLAG_UP_IN_ACC = 4 };
+__device__ __forceinline__ void sload_rec(cmx_cint p, cmx_i16& lo, cmx_i16& hi) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(lo), "=&s"(hi)
+               : "s"(p)
+               : "memory");
 }
 
 struct ConstModel {
@@ -226,9 +230,7 @@ struct ConstModel {
 #define CMX_POP(dst)                                                        \
   do {                                                                      \
     if (pend) {                                                             \
-      /* the DMA rows are older than the ring loads of every product run since: those may stay in flight */ \
-      if (mv_since_pf) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((S / 4) * (S / 4)) : "memory"); \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
       read_vec_lds<S>(pfl, lane, dst);                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
     } else {                                                                \
@@ -242,8 +244,6 @@ struct ConstModel {
       if (e2_ < 0) {                                                        \
         prefetch_vec_lds<S>(CMX_SCHED_ADDR(e2_), pfl);                      \
         pend = true;                                                        \
-        pf_fresh = true;                                                    \
-        mv_since_pf = false;                                                \
       }                                                                     \
     }                                                                       \
   } while (0)
@@ -257,7 +257,8 @@ template <int S>
 __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
                                                double* __restrict__ part, double* __restrict__ cnt, int lds_off,
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
-                                               double& L_out, double& pr_out, int& rc_out, double& norm_out) {
+                                               double (&ring)[(S / 4) * (S / 4)], double& L_out, double& pr_out,
+                                               int& rc_out, double& norm_out) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
   const double* matl = m.MAT + (lane & 15);  // per-lane base of the packed matrices (16 values per DPP row)
@@ -281,10 +282,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     const int en_ = sload_i32(cm.msched + ((mi < m.nmv) ? mi : 0));                                                   \
     const size_t off_ = (en_ < 0) ? m.joff + ((size_t)cn_ * NI * K + (size_t)(en_ & 0x7fffffff)) * S * S \
                                   : ((size_t)cn_ * NI + (size_t)en_) * S * S;                          \
-    if (pf_fresh) matvec_ring<S, TR, S / 2>(matl + off_, in, out);                                     \
-    else matvec_ring<S, TR, 0>(matl + off_, in, out);                                                  \
-    pf_fresh = false;                                                                                  \
-    mv_since_pf = true;                                                                                \
+    matvec_ring<S, TR>(ring, matl + off_, in, out);                                                    \
   } while (0)
 #define CMX_DOT(x_, y_, out)                                                          \
   do {                                                                                \
@@ -298,50 +296,89 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     int fi = 0;         // next schedule entry
     int mi = 0;         // matrix products done in this class pass
     bool pend = false;  // the LDS prefetch buffer holds entry fi
-    bool pf_fresh = false, mv_since_pf = false;  // no product / at least one product since the prefetch was issued
-    // ---------------- inside (post-order) pass.  acc leaves each iteration holding D of the node just finished; when
-    // that node is a child of the next one (it then is its last child) it is consumed from registers.
-    double acc[S];
+    double acc[S], u[S];
     double Lc = 0.0;
-    for (int idx = 0; idx < NI; ++idx) {
-      const cmx_i16 r = sload_rec(cm.nrec + idx * 16);
+// inside vector of a child edge into `d`: kind 1 = stored (pop), kind 2 = inlined cherry (two leaf gathers)
+#define CMX_GET_D(r_, off_)                                    \
+  do {                                                         \
+    if ((r_)[(off_) + CH_KIND] == 1) {                         \
+      CMX_POP(d);                                              \
+    } else {                                                   \
+      CMX_LEAF_P((r_)[(off_) + CH_T1], d);                     \
+      CMX_LEAF_P((r_)[(off_) + CH_T2], t);                     \
+      _Pragma("unroll") for (int x = 0; x < S; ++x) d[x] *= t[x]; \
+    }                                                          \
+  } while (0)
+// counts of the two leaf branches of an inlined cherry whose outside message is `up`; t1_/t2_ are scratch vectors
+#define CMX_CHERRY_COUNTS(r_, off_, up, t1_, t2_)                                        \
+  do {                                                                                   \
+    CMX_LEAF_P((r_)[(off_) + CH_T2], t1_);                                               \
+    _Pragma("unroll") for (int x = 0; x < S; ++x) t1_[x] *= up[x];                       \
+    for (int k = 0; k < K; ++k) {                                                        \
+      CMX_LEAF_J((r_)[(off_) + CH_T1], k, t2_);                                          \
+      double tot_;                                                                       \
+      CMX_DOT(t1_, t2_, tot_);                                                           \
+      pcnt[((size_t)(r_)[(off_) + CH_L1] * K + k) * kWave] = pc * tot_;                  \
+    }                                                                                    \
+    CMX_LEAF_P((r_)[(off_) + CH_T1], t1_);                                               \
+    _Pragma("unroll") for (int x = 0; x < S; ++x) t1_[x] *= up[x];                       \
+    for (int k = 0; k < K; ++k) {                                                        \
+      CMX_LEAF_J((r_)[(off_) + CH_T2], k, t2_);                                          \
+      double tot_;                                                                       \
+      CMX_DOT(t1_, t2_, tot_);                                                           \
+      pcnt[((size_t)(r_)[(off_) + CH_L2] * K + k) * kWave] = pc * tot_;                  \
+    }                                                                                    \
+  } while (0)
+    // ---------------- inside (post-order) pass over the visited nodes.  acc leaves each iteration holding D of the
+    // node just finished; it is the Y child of the next node whenever FLAG_Y_IN_REGS is set there.
+    for (int idx = 0; idx < m.NV; ++idx) {
+      cmx_i16 r, r2;
+      sload_rec(cm.nrec + idx * 32, r, r2);
       const int n = r[REC_N];
-      if (r[REC_CARRY] >= 0) {  // the node finished last is a child of n: its vector is still in acc
-        CMX_MV(false, acc, t);
-#pragma unroll
-        for (int x = 0; x < S; ++x) acc[x] = t[x];
-      } else {
-#pragma unroll
-        for (int x = 0; x < S; ++x) acc[x] = 1.0;
-      }
       if (r[REC_NCH] == 2) {
-        if (r[REC_TA] >= 0) {
-          CMX_LEAF_P(r[REC_TA], t);
+        if (r[REC_FLAGS] & FLAG_Y_IN_REGS) {
+          CMX_MV(false, acc, t);
 #pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] *= t[x];
-        } else if (r[REC_CARRY] != r[REC_CA]) {
-          CMX_POP(d);
-          CMX_MV(false, d, t);
+          for (int x = 0; x < S; ++x) acc[x] = t[x];
+        } else {
 #pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+          for (int x = 0; x < S; ++x) acc[x] = 1.0;
         }
-        if (r[REC_TB] >= 0) {
-          CMX_LEAF_P(r[REC_TB], t);
-#pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] *= t[x];
-        } else if (r[REC_CARRY] != r[REC_CB]) {
-          CMX_POP(d);
+        // child X (never handed over in registers), then child Y unless it was
+        if (r[REC_X + CH_KIND] == 0) {
+          CMX_LEAF_P(r[REC_X + CH_ID], t);
+        } else {
+          CMX_GET_D(r, REC_X);
           CMX_MV(false, d, t);
+        }
+#pragma unroll
+        for (int x = 0; x < S; ++x) acc[x] *= t[x];
+        if (!(r[REC_FLAGS] & FLAG_Y_IN_REGS)) {
+          if (r2[REC_Y + CH_KIND] == 0) {
+            CMX_LEAF_P(r2[REC_Y + CH_ID], t);
+          } else {  // inlined cherry (a stored Y is always handed over)
+            CMX_GET_D(r2, REC_Y);
+            CMX_MV(false, d, t);
+          }
 #pragma unroll
           for (int x = 0; x < S; ++x) acc[x] *= t[x];
         }
       } else {
+        const int carry = r2[REC_GCARRY];
+        if (carry >= 0) {
+          CMX_MV(false, acc, t);
+#pragma unroll
+          for (int x = 0; x < S; ++x) acc[x] = t[x];
+        } else {
+#pragma unroll
+          for (int x = 0; x < S; ++x) acc[x] = 1.0;
+        }
         for (int e = cm.first_child[n]; e >= 0; e = cm.next_sib[e]) {
           const int tx = cm.taxon_of[e];
           if (tx >= 0) {
             CMX_LEAF_P(tx, t);
           } else {
-            if (e == r[REC_CARRY]) continue;
+            if (e == carry) continue;
             CMX_POP(d);
             CMX_MV(false, d, t);
           }
@@ -359,75 +396,87 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     Lsum += pc * Lc;
     prsum += cm.rates[c] * pc * Lc;
     if (pc * Lc > best) { best = pc * Lc; bestc = c; }  // first maximum wins (getRateClassWithMaxPostProbPerSite)
-    // ---------------- outside (pre-order) pass + joint counts.  acc now carries the outside message Up_f; a binary
-    // node leaves Up of its last child in acc (that child is visited next in reverse post-order).
-    double u[S];
-    for (int idx = NI - 1; idx >= 0; --idx) {
-      const cmx_i16 r = sload_rec(cm.nrec + idx * 16);
+    // ---------------- outside (pre-order) pass + joint counts.  acc carries the outside message Up_f.
+    for (int idx = m.NV - 1; idx >= 0; --idx) {
+      cmx_i16 r, r2;
+      sload_rec(cm.nrec + idx * 32, r, r2);
       const int f = r[REC_N];
       if (f == root) {
 #pragma unroll
         for (int x = 0; x < S; ++x) acc[x] = cm.pi[x];
-      } else if (!r[REC_UPREG]) {  // otherwise Up_f was left in acc by the parent (f is its last child)
+      } else if (!(r[REC_FLAGS] & FLAG_UP_IN_ACC)) {  // otherwise Up_f was left in acc by the parent
         CMX_POP(acc);
       }
-      const int ca = r[REC_CA];
-      const int cb = r[REC_CB];
       if (r[REC_NCH] == 2) {
-        // ---- binary node (children ca < cb): at most three workspace loads
-        const int ta = r[REC_TA], tb = r[REC_TB];
-        if (tb >= 0) {
-          CMX_LEAF_P(tb, t);
+        const int kx = r[REC_X + CH_KIND], ky = r2[REC_Y + CH_KIND];
+        // ---- message of Y -> U_X = Up_f o M_Y
+        if (ky == 0) {
+          CMX_LEAF_P(r2[REC_Y + CH_ID], t);
         } else {
-          CMX_POP(d);
+          CMX_GET_D(r2, REC_Y);
           CMX_MV(false, d, t);
         }
 #pragma unroll
-        for (int x = 0; x < S; ++x) u[x] = acc[x] * t[x];  // U_a = Up_f o M_b
-        if (ta >= 0) {
+        for (int x = 0; x < S; ++x) u[x] = acc[x] * t[x];
+        // ---- X: counts of its branch, its message -> U_Y, its outside message
+        if (kx == 0) {
           for (int k = 0; k < K; ++k) {
-            CMX_LEAF_J(ta, k, t);
+            CMX_LEAF_J(r[REC_X + CH_ID], k, t);
             double tot;
             CMX_DOT(u, t, tot);
-            pcnt[((size_t)ca * K + k) * kWave] = pc * tot;
+            pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kWave] = pc * tot;
           }
-          CMX_LEAF_P(ta, t);
+          CMX_LEAF_P(r[REC_X + CH_ID], t);
 #pragma unroll
-          for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_b = Up_f o M_a
+          for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_Y = Up_f o M_X
         } else {
-          const int sl = r[REC_SA];
-          CMX_POP(d);
+          CMX_GET_D(r, REC_X);
           for (int k = 0; k < K; ++k) {
             CMX_MV(false, d, t);
             double tot;
             CMX_DOT(u, t, tot);
-            pcnt[((size_t)ca * K + k) * kWave] = pc * tot;
+            pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kWave] = pc * tot;
           }
           CMX_MV(false, d, t);
 #pragma unroll
-          for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_b
-          CMX_MV(true, u, d);       // Up_a
-          store_vec<S>(wsU + (size_t)sl * S * kWave + 2 * lane, d);
+          for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_Y
+          CMX_MV(true, u, d);                          // Up_X
+          if (kx == 1) {
+            store_vec<S>(wsU + (size_t)r[REC_X + CH_ID] * S * kWave + 2 * lane, d);
+          } else {
+            CMX_CHERRY_COUNTS(r, REC_X, d, acc, u);    // Up_f and U_X are dead here
+          }
         }
-        if (tb >= 0) {
+        // ---- Y: counts of its branch, its outside message (t = U_Y)
+        if (ky == 0) {
           for (int k = 0; k < K; ++k) {
-            CMX_LEAF_J(tb, k, u);
+            CMX_LEAF_J(r2[REC_Y + CH_ID], k, u);
             double tot;
             CMX_DOT(t, u, tot);
-            pcnt[((size_t)cb * K + k) * kWave] = pc * tot;
+            pcnt[((size_t)r2[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
           }
         } else {
-          CMX_POP(d);
+          // d <- D_Y needs t as scratch for a cherry: park U_Y in acc first
+#pragma unroll
+          for (int x = 0; x < S; ++x) acc[x] = t[x];
+          CMX_GET_D(r2, REC_Y);
           for (int k = 0; k < K; ++k) {
             CMX_MV(false, d, u);
             double tot;
-            CMX_DOT(t, u, tot);
-            pcnt[((size_t)cb * K + k) * kWave] = pc * tot;
+            CMX_DOT(acc, u, tot);
+            pcnt[((size_t)r2[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
           }
-          CMX_MV(true, t, acc);  // Up_b stays in registers for the next node
+          CMX_MV(true, acc, t);                        // Up_Y
+          if (ky == 1) {
+#pragma unroll
+            for (int x = 0; x < S; ++x) acc[x] = t[x];  // handed to the next visited node (Y)
+          } else {
+            CMX_CHERRY_COUNTS(r2, REC_Y, t, acc, u);
+          }
         }
       } else {
         // ---- general node (root trifurcation, multifurcations): every sibling message recomputed per child
+        const int ca = cm.first_child[f];
         for (int n = ca; n >= 0; n = cm.next_sib[n]) {
 #pragma unroll
           for (int x = 0; x < S; ++x) u[x] = acc[x];
@@ -467,6 +516,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       }
     }
   }
+#undef CMX_GET_D
+#undef CMX_CHERRY_COUNTS
 #undef CMX_LEAF_P
 #undef CMX_CODE
 #undef CMX_LEAF_J
@@ -546,8 +597,7 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
 }
 
 template <int S, int MODE>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_num_vgpr(206))) void map_kernel(
-    const MapArgs a) {
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 1) void map_kernel(const MapArgs a) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
   const int lane = threadIdx.x & (kWave - 1);
@@ -563,10 +613,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_nu
   uint8_t* codes = cmx_smem + lds_off + S * kWave * 8 + lane;
   const size_t nblocks = (a.nsites + kWave - 1) / kWave;
   // prime the matrix ring with the first product's matrix (class 0, entry 0); every product refills it for the next
-  if ((size_t)wave < nblocks) {
+  double ring[(S / 4) * (S / 4)];
+  {
     const int e0 = sload_i32(cm.msched);
     const size_t off0 = (e0 < 0) ? m.joff + (size_t)(e0 & 0x7fffffff) * S * S : (size_t)e0 * S * S;
-    ring_prime<(S / 4) * (S / 4)>(m.MAT + (lane & 15) + off0);
+    const double* m0 = m.MAT + (lane & 15) + off0;
+#pragma unroll
+    for (int t = 0; t < (S / 4) * (S / 4); ++t) ring[t] = m0[t * 16];
   }
   for (size_t sb = wave; sb < nblocks; sb += nwaves) {
     const size_t site = sb * kWave + lane;
@@ -577,7 +630,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_nu
       int rc;
       if (a.codes_in_lds)
         for (int t = 0; t < m.T; ++t) codes[(size_t)t * kWave] = a.aln[(size_t)t * a.ld + s];
-      map_sites_wave<S>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, L, pr, rc, nrm);
+      map_sites_wave<S>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, ring, L, pr, rc, nrm);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
@@ -620,7 +673,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_nu
             }
           }
         }
-        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, L[h], pr[h], rc[h], nrm[h]);
+        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, ring, L[h], pr[h], rc[h], nrm[h]);
       }
       const double stat = pair_stat_lane(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + lane, cnt1 + lane);
       if (active) {
@@ -631,7 +684,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) __attribute__((amdgpu_nu
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last product left a matrix fetch in flight
 }
 
 size_t map_lds_bytes(int S, int T, bool codes_in_lds) {
@@ -642,8 +694,8 @@ hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t s
   dim3 grid(grid_blocks), block(kWave * kWavesPerBlock);
   const size_t lds = map_lds_bytes(a.m.S, a.m.T, a.codes_in_lds != 0);
   static bool attr_set = false;
-  if (!attr_set) {  // allow up to 80 KiB of dynamic LDS per workgroup (two workgroups per CU)
-    const int lim = 80 * 1024;
+  if (!attr_set) {  // one workgroup (4 waves, one per SIMD) per CU may use all 160 KiB of LDS
+    const int lim = 160 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<20, kModeObserved>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<20, kModeNull>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<4, kModeObserved>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
