@@ -163,6 +163,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     {  // P and (P o N^k) packed matrices in one allocation (one base pointer for the ring fetches)
       std::vector<double> mat(h.PP);
       mat.insert(mat.end(), h.JP.begin(), h.JP.end());
+      mat.resize(mat.size() + 256, 0.0);   // the last DMA row of the last matrix reads up to 1 KiB past its end
       if ((s = upload(ctx, mat, &d.MAT)) != CMX_OK) return s;
       d.joff = h.PP.size();
     }
@@ -177,7 +178,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
     // per-wave workspaces: 1 wave per SIMD on every CU for the null; a quarter of that for observed alignments
-    ctx->grid_blocks = ctx->cu_count;   // one 4-wave workgroup per CU: one wave per SIMD with the full 512-VGPR budget
+    ctx->grid_blocks = ctx->cu_count * CMX_WAVES_PER_SIMD;   // 4-wave workgroups, CMX_WAVES_PER_SIMD per CU
     ctx->waves = ctx->grid_blocks * kWavesPerBlock;
     ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
     auto alloc_ws = [&](Workspace* ws, size_t w, size_t* bytes) -> cmx_status {
@@ -278,7 +279,7 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws_obs;
   a.aln = d_aln; a.ld = ld; a.nsites = nsites; a.masks = d_masks ? d_masks : ctx->d_default_masks;
-  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 160 * 1024;
+  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 160 * 1024 / CMX_WAVES_PER_SIMD;
   a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.norm = d_norm;
   const size_t blocks_needed = ((nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -441,7 +442,7 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.masks = ctx->d_default_masks;
-  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 160 * 1024;
+  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 160 * 1024 / CMX_WAVES_PER_SIMD;
   a.nsites = (rep_end - rep_begin) * rep_ram;
   a.stat_kind = kind;
   a.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;

@@ -8,6 +8,9 @@ namespace cmx {
 
 constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kWavesPerBlock = 4;   // mapping kernels: 4 independent waves per 256-thread workgroup
+#ifndef CMX_WAVES_PER_SIMD
+#define CMX_WAVES_PER_SIMD 2       // resident mapping waves per SIMD (1: 512-register budget, 2: 256)
+#endif
 
 // Device-resident model + tree program.  All pointers are device pointers.
 struct DevModel {

@@ -34,47 +34,73 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define CMX_ABLATE 0  // diagnostic builds: 1 = no leaf gathers, 2 = no workspace traffic, 3 = no matrix products
 #endif
 
-// The SxS operator of an edge is the same for all 64 lanes.  It is held one 4x4 block ("tile", 16 values) per
-// VGPR pair -- ring[t], the 16 values of tile t replicated in every DPP row -- and applied with v_fmac_f64_dpp
-// row_newbcast: 400 fp64 FMAs per 20x20 product, no LDS or SGPR traffic.  Right after tile t's FMAs ring[t] is
-// reloaded with tile t of the NEXT product's matrix (the sequence of products is known: m.msched), so every matrix
-// is requested one full product (~1600 cycles) before its use.  The ring is an ordinary register array: hipcc owns
-// its allocation and its vmcnt waits (a first version pinned it to v[206:255] behind amdgpu_num_vgpr, which turned
-// out NOT to be a hard limit under pressure -- the compiler reused those registers).
-// Measured (scripts/ubench_dpp_matvec.hip): 46 / 53 TFLOP/s at 1 / 2 waves per SIMD vs 24 / 39 for s_load-fed v_fma_f64.
+// The SxS operator of an edge is the same for all 64 lanes.  It is staged in LDS (one 4 KiB buffer per wave, filled
+// by LDS-DMA one product ahead: the sequence of products is known, m.msched) and applied one 4x4 block ("tile", 16
+// values) at a time: a ds_read_b64 puts the 16 values of tile t in every DPP row of a VGPR pair, and
+// v_fmac_f64_dpp row_newbcast:k multiplies by element k -- 400 fp64 FMAs per 20x20 product, no SGPR traffic, two
+// transient VGPRs.  The buffer is refilled row by row (1 KiB = 8 tiles per DMA instruction) behind the tiles that
+// have been consumed, so the next matrix is requested ~1600 cycles before its first use.
+// History: an s_load-fed v_fma_f64 version ran at 39 TFLOP/s; keeping the tiles in a VGPR ring (53
+// TFLOP/s in isolation) needed either fixed registers -- amdgpu_num_vgpr turned out not to be a hard limit, the
+// compiler reused them under pressure -- or 50 more loop-carried registers than two waves per SIMD can afford.
 #include "cmx_ring_tiles.inc"
 
+typedef __attribute__((address_space(1))) const void* cmx_gptr;
+typedef __attribute__((address_space(3))) void* cmx_lptr;
+
+template <int S>
+struct MatStage {
+  static constexpr int NT = (S / 4) * (S / 4);             // tiles
+  static constexpr int ROWS = (NT * 128 + 1023) / 1024;    // 1 KiB DMA rows
+  static constexpr int BYTES = ROWS * 1024;
+};
+
+// DMA row r of the matrix at `src` (global, wave-uniform) into the wave's stage buffer
+template <int S>
+__device__ __forceinline__ void mat_dma_row(const double* src, uint8_t* mbuf, int lane, int r) {
+  __builtin_amdgcn_global_load_lds((cmx_gptr)(src + (size_t)r * 128 + 2 * lane), (cmx_lptr)(mbuf + r * 1024), 16, 0, 0);
+}
+
 template <int S, bool TR, int T>
-__device__ __forceinline__ void ring_steps(double (&ring)[(S / 4) * (S / 4)], const double* __restrict__ nxt,
-                                           const double (&x)[S], double (&y)[S]) {
+__device__ __forceinline__ void stage_steps(const uint8_t* mbuf, int lane16, const double* nxt, int lane,
+                                            const double (&x)[S], double (&y)[S]) {
   constexpr int NB = S / 4, NT = NB * NB;
   if constexpr (T < NT) {
     constexpr int bi = T / NB, bj = T % NB;
+    const double mt = *reinterpret_cast<const double*>(mbuf + T * 128 + lane16);
     if constexpr (!TR)
-      dpp_tile_f(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], ring[T], x[4 * bj], x[4 * bj + 1], x[4 * bj + 2],
+      dpp_tile_f(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], mt, x[4 * bj], x[4 * bj + 1], x[4 * bj + 2],
                  x[4 * bj + 3]);
     else
-      dpp_tile_t(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], ring[T], x[4 * bi], x[4 * bi + 1], x[4 * bi + 2],
+      dpp_tile_t(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], mt, x[4 * bi], x[4 * bi + 1], x[4 * bi + 2],
                  x[4 * bi + 3]);
-    ring[T] = nxt[T * 16];
-    ring_steps<S, TR, T + 1>(ring, nxt, x, y);
+    // a 1 KiB row (8 tiles) has been consumed: refill it with the same row of the next product's matrix.  The
+    // compiler barrier keeps the refill behind the LDS reads of this row.
+    if constexpr (T % 8 == 7 || T == NT - 1) {
+      asm volatile("" ::: "memory");
+      mat_dma_row<S>(nxt, const_cast<uint8_t*>(mbuf), lane, T / 8);
+    }
+    stage_steps<S, TR, T + 1>(mbuf, lane16, nxt, lane, x, y);
   }
 }
 
-// y = M x (TR = false) or y = M^T x (TR = true) with M = the matrix currently in the ring; nxt = per-lane pointer
-// (matrix base + (lane & 15)) of the matrix of the next product in program order.
+// y = M x (TR = false) or y = M^T x (TR = true) with M = the matrix staged in mbuf; nxt = base of the matrix of the
+// next product in program order.  pf_young = a workspace prefetch (S/2 DMA rows) was issued after the stage buffer's
+// own DMA rows: those S/2 youngest operations may stay in flight, everything older (the matrix) must have landed.
 template <int S, bool TR>
-__device__ __forceinline__ void matvec_ring(double (&ring)[(S / 4) * (S / 4)], const double* __restrict__ nxt,
-                                            const double (&x)[S], double (&y)[S]) {
+__device__ __forceinline__ void matvec_stage(uint8_t* mbuf, int lane, const double* nxt, bool pf_young,
+                                             const double (&x)[S], double (&y)[S]) {
   static_assert(S % 4 == 0, "state count must be a multiple of 4");
   if (CMX_ABLATE == 3) {
 #pragma unroll
     for (int i = 0; i < S; ++i) y[i] = x[i] * 0.5;
     return;
   }
+  if (pf_young) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S / 2) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int i = 0; i < S; ++i) y[i] = 0.0;
-  ring_steps<S, TR, 0>(ring, nxt, x, y);
+  stage_steps<S, TR, 0>(mbuf, (lane & 15) * 8, nxt, lane, x, y);
 }
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -108,9 +134,6 @@ __device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
     *reinterpret_cast<d2*>(p + (size_t)i * 2 * kWave) = t;
   }
 }
-
-typedef __attribute__((address_space(1))) const void* cmx_gptr;
-typedef __attribute__((address_space(3))) void* cmx_lptr;
 
 // asynchronous HBM -> LDS copy of one workspace vector (S/2 LDS-DMA instructions, no VGPR destination)
 template <int S>
@@ -244,6 +267,7 @@ struct ConstModel {
       if (e2_ < 0) {                                                        \
         prefetch_vec_lds<S>(CMX_SCHED_ADDR(e2_), pfl);                      \
         pend = true;                                                        \
+        pf_young = true;                                                    \
       }                                                                     \
     }                                                                       \
   } while (0)
@@ -253,20 +277,25 @@ struct ConstModel {
 // part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
 // Register budget: four S-vectors live at most (acc, u, d, t) so that two waves fit per SIMD without scratch.
 // The loop nest below is mirrored statement for statement by build_load_schedule() in cmx_host_model.cpp.
-template <int S>
+template <bool CLDS>
+__device__ __forceinline__ unsigned leaf_code(int codes_off, const uint8_t* __restrict__ gcodes, size_t gstride, int tx) {
+  if constexpr (CLDS) return cmx_smem[codes_off + tx * kWave];  // ds_read_u8
+  else return gcodes[(size_t)tx * gstride];                     // global_load_ubyte
+}
+
+template <int S, bool CLDS>
 __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
                                                double* __restrict__ part, double* __restrict__ cnt, int lds_off,
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
-                                               double (&ring)[(S / 4) * (S / 4)], double& L_out, double& pr_out,
+                                               uint8_t* mbuf, bool& pf_young, double& L_out, double& pr_out,
                                                int& rc_out, double& norm_out) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
-  const double* matl = m.MAT + (lane & 15);  // per-lane base of the packed matrices (16 values per DPP row)
   uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, S*64*8 bytes
   // leaf symbols of this wave's sites: [taxon][64] in LDS when they fit (a.codes_in_lds), else read from HBM
-  const uint8_t* codes = cmx_smem + lds_off + S * kWave * 8 + lane;
-  const bool clds = a.codes_in_lds != 0;
-#define CMX_CODE(tx) (clds ? (unsigned)codes[(size_t)(tx) * kWave] : (unsigned)gcodes[(size_t)(tx) * gstride])
+  const int codes_off = lds_off + S * kWave * 8 + MatStage<S>::BYTES + lane;
+// (a pointer select between LDS and HBM would make a generic pointer: flat_load + a full vmcnt/lgkmcnt drain per leaf)
+#define CMX_CODE(tx) leaf_code<CLDS>(codes_off, gcodes, gstride, (tx))
   const int C = m.C, K = m.K, NI = m.NI, root = m.root;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
@@ -282,7 +311,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     const int en_ = sload_i32(cm.msched + ((mi < m.nmv) ? mi : 0));                                                   \
     const size_t off_ = (en_ < 0) ? m.joff + ((size_t)cn_ * NI * K + (size_t)(en_ & 0x7fffffff)) * S * S \
                                   : ((size_t)cn_ * NI + (size_t)en_) * S * S;                          \
-    matvec_ring<S, TR>(ring, matl + off_, in, out);                                                    \
+    matvec_stage<S, TR>(mbuf, lane, m.MAT + off_, pf_young, in, out);                                  \
+    pf_young = false;                                                                                  \
   } while (0)
 #define CMX_DOT(x_, y_, out)                                                          \
   do {                                                                                \
@@ -596,8 +626,11 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
   return __builtin_nan("");
 }
 
-template <int S, int MODE>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, 1) void map_kernel(const MapArgs a) {
+#ifndef CMX_WAVES_PER_SIMD
+#define CMX_WAVES_PER_SIMD 2
+#endif
+template <int S, int MODE, bool CLDS>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void map_kernel(const MapArgs a) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
   const int lane = threadIdx.x & (kWave - 1);
@@ -608,18 +641,19 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 1) void map_kernel(const Ma
   double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kWave;
   double* cnt1 = cnt0 + (size_t)m.B * m.K * kWave;
   double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kWave;
-  // LDS per wave: prefetch landing buffer (S*64*8 B) followed by the [T][64] leaf symbols of the wave's sites
-  const int lds_off = (int)(threadIdx.x >> 6) * (S * kWave * 8 + (a.codes_in_lds ? ((m.T * kWave + 15) & ~15) : 0));
-  uint8_t* codes = cmx_smem + lds_off + S * kWave * 8 + lane;
+  // LDS per wave: workspace prefetch buffer (S*64*8 B), matrix stage (4 KiB), then the [T][64] leaf symbols
+  const int lds_off = (int)(threadIdx.x >> 6) *
+                      (S * kWave * 8 + MatStage<S>::BYTES + (CLDS ? ((m.T * kWave + 15) & ~15) : 0));
+  uint8_t* mbuf = cmx_smem + lds_off + S * kWave * 8;
+  uint8_t* codes = cmx_smem + lds_off + S * kWave * 8 + MatStage<S>::BYTES + lane;
   const size_t nblocks = (a.nsites + kWave - 1) / kWave;
-  // prime the matrix ring with the first product's matrix (class 0, entry 0); every product refills it for the next
-  double ring[(S / 4) * (S / 4)];
+  // stage the first product's matrix (class 0, entry 0); every product then requests the next one
+  bool pf_young = false;
   {
     const int e0 = sload_i32(cm.msched);
     const size_t off0 = (e0 < 0) ? m.joff + (size_t)(e0 & 0x7fffffff) * S * S : (size_t)e0 * S * S;
-    const double* m0 = m.MAT + (lane & 15) + off0;
 #pragma unroll
-    for (int t = 0; t < (S / 4) * (S / 4); ++t) ring[t] = m0[t * 16];
+    for (int r = 0; r < MatStage<S>::ROWS; ++r) mat_dma_row<S>(m.MAT + off0, mbuf, lane, r);
   }
   for (size_t sb = wave; sb < nblocks; sb += nwaves) {
     const size_t site = sb * kWave + lane;
@@ -628,9 +662,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 1) void map_kernel(const Ma
     if (MODE == kModeObserved) {
       double L, pr, nrm;
       int rc;
-      if (a.codes_in_lds)
+      if (CLDS)
         for (int t = 0; t < m.T; ++t) codes[(size_t)t * kWave] = a.aln[(size_t)t * a.ld + s];
-      map_sites_wave<S>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, ring, L, pr, rc, nrm);
+      map_sites_wave<S, CLDS>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, mbuf, pf_young, L, pr, rc, nrm);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
@@ -651,7 +685,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 1) void map_kernel(const Ma
         if (a.supplied) {
           gbase = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
           gstride = a.rep_ram;
-          if (a.codes_in_lds)
+          if (CLDS)
             for (int t = 0; t < m.T; ++t) codes[(size_t)t * kWave] = gbase[(size_t)t * gstride];
         } else {
           uint8_t* st = a.ws.st + (size_t)wave * m.nn * kWave + lane;
@@ -668,12 +702,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 1) void map_kernel(const Ma
             st[(size_t)node * kWave] = (uint8_t)y;
             const int tx = cm.taxon_of[node];
             if (tx >= 0) {
-              if (a.codes_in_lds) codes[(size_t)tx * kWave] = (uint8_t)y;
+              if (CLDS) codes[(size_t)tx * kWave] = (uint8_t)y;
               else al[(size_t)tx * kWave] = (uint8_t)y;
             }
           }
         }
-        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, ring, L[h], pr[h], rc[h], nrm[h]);
+        map_sites_wave<S, CLDS>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, mbuf, pf_young, L[h], pr[h], rc[h], nrm[h]);
       }
       const double stat = pair_stat_lane(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + lane, cnt1 + lane);
       if (active) {
@@ -684,30 +718,36 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 1) void map_kernel(const Ma
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last product left a matrix DMA in flight
 }
 
 size_t map_lds_bytes(int S, int T, bool codes_in_lds) {
-  return (size_t)kWavesPerBlock * ((size_t)S * kWave * 8 + (codes_in_lds ? (((size_t)T * kWave + 15) & ~(size_t)15) : 0));
+  const size_t stage = (size_t)(((S / 4) * (S / 4) * 128 + 1023) / 1024) * 1024;
+  return (size_t)kWavesPerBlock * ((size_t)S * kWave * 8 + stage + (codes_in_lds ? (((size_t)T * kWave + 15) & ~(size_t)15) : 0));
 }
 
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream) {
   dim3 grid(grid_blocks), block(kWave * kWavesPerBlock);
   const size_t lds = map_lds_bytes(a.m.S, a.m.T, a.codes_in_lds != 0);
-  static bool attr_set = false;
-  if (!attr_set) {  // one workgroup (4 waves, one per SIMD) per CU may use all 160 KiB of LDS
-    const int lim = 160 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<20, kModeObserved>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<20, kModeNull>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<4, kModeObserved>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<4, kModeNull>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    attr_set = true;
-  }
+  const int lim = 160 * 1024 / CMX_WAVES_PER_SIMD;  // dynamic LDS a workgroup may use (CMX_WAVES_PER_SIMD workgroups per CU)
+#define CMX_LAUNCH(S_, MODE_, CLDS_)                                                                          \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<S_, MODE_, CLDS_>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lim);                             \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((map_kernel<S_, MODE_, CLDS_>), grid, block, lds, stream, a);                          \
+  } while (0)
+  const bool cl = a.codes_in_lds != 0;
   if (a.m.S == 20) {
-    if (mode == kModeObserved) hipLaunchKernelGGL((map_kernel<20, kModeObserved>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((map_kernel<20, kModeNull>), grid, block, lds, stream, a);
+    if (mode == kModeObserved) { if (cl) CMX_LAUNCH(20, kModeObserved, true); else CMX_LAUNCH(20, kModeObserved, false); }
+    else { if (cl) CMX_LAUNCH(20, kModeNull, true); else CMX_LAUNCH(20, kModeNull, false); }
   } else if (a.m.S == 4) {
-    if (mode == kModeObserved) hipLaunchKernelGGL((map_kernel<4, kModeObserved>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((map_kernel<4, kModeNull>), grid, block, lds, stream, a);
+    if (mode == kModeObserved) { if (cl) CMX_LAUNCH(4, kModeObserved, true); else CMX_LAUNCH(4, kModeObserved, false); }
+    else { if (cl) CMX_LAUNCH(4, kModeNull, true); else CMX_LAUNCH(4, kModeNull, false); }
+#undef CMX_LAUNCH
   } else {
     return hipErrorInvalidValue;
   }
