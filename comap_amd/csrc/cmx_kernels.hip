@@ -253,7 +253,9 @@ struct ConstModel {
 #define CMX_POP(dst)                                                        \
   do {                                                                      \
     if (pend) {                                                             \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+      /* the prefetch rows are older than the matrix rows of any product run since: those may stay in flight */ \
+      if (mv_since_pf) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MatStage<S>::ROWS) : "memory"); \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
       read_vec_lds<S>(pfl, lane, dst);                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
     } else {                                                                \
@@ -268,6 +270,7 @@ struct ConstModel {
         prefetch_vec_lds<S>(CMX_SCHED_ADDR(e2_), pfl);                      \
         pend = true;                                                        \
         pf_young = true;                                                    \
+        mv_since_pf = false;                                                \
       }                                                                     \
     }                                                                       \
   } while (0)
@@ -313,6 +316,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
                                   : ((size_t)cn_ * NI + (size_t)en_) * S * S;                          \
     matvec_stage<S, TR>(mbuf, lane, m.MAT + off_, pf_young, in, out);                                  \
     pf_young = false;                                                                                  \
+    mv_since_pf = true;                                                                                \
   } while (0)
 #define CMX_DOT(x_, y_, out)                                                          \
   do {                                                                                \
@@ -326,6 +330,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     int fi = 0;         // next schedule entry
     int mi = 0;         // matrix products done in this class pass
     bool pend = false;  // the LDS prefetch buffer holds entry fi
+    bool mv_since_pf = false;  // a product (hence >= ROWS matrix DMA rows) was issued after the pending prefetch
     double acc[S], u[S];
     double Lc = 0.0;
 // inside vector of a child edge into `d`: kind 1 = stored (pop), kind 2 = inlined cherry (two leaf gathers)
