@@ -39,6 +39,7 @@ struct cmx_ctx {
   std::vector<void*> model_allocs;
   std::map<std::string, DevBuf> scratch;
   uint32_t* d_default_masks = nullptr;
+  bool leaf_rows_custom = false;   // the leaf operators' ambiguity rows were built from a caller's mask table
   mutable std::string err;
 };
 
@@ -160,20 +161,23 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     d.S = h.S; d.C = h.C; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.NV = h.NV; d.root = h.root;
 #define UP(field) if ((s = upload(ctx, h.field, &d.field)) != CMX_OK) return s
     UP(int_post); UP(first_child); UP(next_sib); UP(taxon_of); UP(slot); UP(parent);
-    {  // P and (P o N^k) packed matrices in one allocation (one base pointer for the ring fetches)
-      std::vector<double> mat(h.PP);
-      mat.insert(mat.end(), h.JP.begin(), h.JP.end());
-      mat.resize(mat.size() + 256, 0.0);   // the last DMA row of the last matrix reads up to 1 KiB past its end
-      if ((s = upload(ctx, mat, &d.MAT)) != CMX_OK) return s;
-      d.joff = h.PP.size();
+    {
+      const double* mat = nullptr;
+      if ((s = upload(ctx, h.MAT, &mat)) != CMX_OK) return s;
+      d.MAT = const_cast<double*>(mat);
     }
+    d.MC = h.MC;
     UP(msched);
     UP(nrec);
-    d.nmv = (int)h.msched.size();
-    UP(LPT); UP(LJT); UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
+    d.nmv = (int)(h.msched.size() / 2);
+    UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
     UP(ldsched);
 #undef UP
     d.nloads = (int)h.ldsched.size();
+    // ambiguity rows of the leaf operators: default "every state compatible" until a call brings a mask table
+    HIP_TRY(ctx, launch_extend_leaf_rows(d, nullptr, nullptr));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->leaf_rows_custom = false;
     // ambiguity masks default: code c >= S compatible with every state; fix the table for this S
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
@@ -278,8 +282,12 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws_obs;
-  a.aln = d_aln; a.ld = ld; a.nsites = nsites; a.masks = d_masks ? d_masks : ctx->d_default_masks;
-  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 160 * 1024 / CMX_WAVES_PER_SIMD;
+  a.aln = d_aln; a.ld = ld; a.nsites = nsites;
+  // ambiguity ids S .. S+max_ambig(S)-1: rebuild the extra rows of the leaf operators when the table changes
+  if (d_masks || ctx->leaf_rows_custom) {
+    HIP_TRY(ctx, launch_extend_leaf_rows(ctx->dm, d_masks, (hipStream_t)stream));
+    ctx->leaf_rows_custom = d_masks != nullptr;
+  }
   a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.norm = d_norm;
   const size_t blocks_needed = ((nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -295,6 +303,9 @@ cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t
   if (s != CMX_OK) return s;
   if (!aln || nsites == 0 || ld < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: bad alignment arguments");
   const HostModel& h = ctx->hm;
+  if (masks && nmasks > (size_t)(h.S + max_ambig(h.S)))
+    return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_map_sites: at most " + std::to_string(max_ambig(h.S)) +
+                                              " ambiguity ids (codes >= nstates) are supported for this alphabet");
   // every code must be a state or a known mask (the reference throws BadCharException at alignment parsing)
   for (int t = 0; t < h.T; ++t)
     for (size_t i = 0; i < nsites; ++i) {
@@ -441,8 +452,6 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
-  a.masks = ctx->d_default_masks;
-  a.codes_in_lds = map_lds_bytes(ctx->hm.S, ctx->hm.T, true) <= 160 * 1024 / CMX_WAVES_PER_SIMD;
   a.nsites = (rep_end - rep_begin) * rep_ram;
   a.stat_kind = kind;
   a.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;

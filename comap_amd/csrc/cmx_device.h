@@ -8,6 +8,11 @@ namespace cmx {
 
 constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kWavesPerBlock = 4;   // mapping kernels: 4 independent waves per 256-thread workgroup
+// Ambiguous symbols (alignment codes >= S) are served from extra rows S .. S+A-1 appended to every transposed leaf
+// operator: row S+a = sum of the rows of the states compatible with ambiguity id a (filled per call from the caller's
+// mask table, default "every state").  A = 12 for nucleotides (IUPAC + gap), 4 for proteins (B, Z, J, X/gap).
+constexpr int max_ambig(int S) { return S == 4 ? 12 : 4; }
+constexpr int mat_unit(int S) { return (S + max_ambig(S)) * S; }   // doubles per device matrix
 #ifndef CMX_WAVES_PER_SIMD
 #define CMX_WAVES_PER_SIMD 2       // resident mapping waves per SIMD (1: 512-register budget, 2: 256)
 #endif
@@ -22,16 +27,14 @@ struct DevModel {
   const int* taxon_of;     // [nn]  alignment row of a leaf, -1 for internal nodes
   const int* slot;         // [nn]  internal nodes: 0..NI-1 (root = NI-1); leaves: -1
   const int* parent;       // [nn]
-  // per (class, internal node): 4x4-block-packed matrices for the scalar-operand matvec
-  const double* MAT;       // packed matrices: P_node [C][NI][S*S] at 0, (P_node o N^k_node) [C][NI][K][S*S] at joff
-  size_t joff;
-  // matrix products of one class pass in program order: bit 31 set = (P o N^k) with index slot*K + k, else P[slot]
+  // matrices, [C][MC][mat_unit(S)]: per class a block of packed P | packed (P o N^k) | leaf P^T | leaf (P o N^k)^T
+  // (cmx_host_model.cpp); a matrix use DMAs mat_unit(S)*8 bytes from MAT + (class*MC + index)*mat_unit(S) into LDS
+  double* MAT;
+  int MC;
+  // matrix uses of one class pass in program order: pairs (matrix index in the class block, taxon or -1)
   const int* msched;
-  int nmv;
+  int nmv;                 // number of pairs
   const int* nrec;         // [NV][32] per-visited-node records (enum REC_* in cmx_kernels.hip)
-  // per (class, taxon): transposed matrices for the per-lane leaf gather, [z][x] = M[x][z]
-  const double* LPT;       // [C][T][S][S]
-  const double* LJT;       // [C][K][T][S][S]
   // simulator: running sums of the rows of P, [C][nn][S(x)][S]
   const double* CP;
   const double* pi;        // [S]
@@ -64,8 +67,6 @@ struct MapArgs {
   const uint8_t* aln;      // [T][ld]
   size_t ld;
   size_t nsites;           // observed: sites; null: (rep_end-rep_begin)*rep_ram null pairs
-  const uint32_t* masks;   // ambiguity masks (may be null when all codes < S)
-  int codes_in_lds;        // leaf symbols of a wave's sites staged in LDS (fits when map_lds_bytes <= 80 KiB)
   double* counts;          // [B*K][ldc] or null
   size_t ldc;
   double* logL;            // [nsites] or null
@@ -85,8 +86,10 @@ struct MapArgs {
 };
 
 // launchers (cmx_kernels.hip)
-size_t map_lds_bytes(int S, int T, bool codes_in_lds);
+size_t map_lds_bytes(int S);
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream);
+// fills rows S.. of every leaf operator from d_masks[S .. S+max_ambig(S)) (null: every state compatible)
+hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, hipStream_t stream);
 hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
                            int32_t* d_classes, uint8_t* d_states /*[nn][ld]*/, hipStream_t stream);
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,

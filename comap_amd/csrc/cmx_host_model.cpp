@@ -1,5 +1,6 @@
 // Host-side model preparation (see cmx_host_model.h).  Plain C++17, no device code.
 #include "cmx_host_model.h"
+#include "cmx_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -130,8 +131,22 @@ void build_load_schedule(HostModel* hm) {
   hm->stores_D = hm->stores_U = 0;
   auto pop = [&](int arr, int slot) { pops.push_back({arr, slot, t++, arr ? storeU[slot] : storeD[slot]}); };
   hm->msched.clear();
-  auto mvP = [&](int slot) { hm->msched.push_back(slot); };
-  auto mvJ = [&](int slot) { for (int k = 0; k < K; ++k) hm->msched.push_back((int)(0x80000000u | (unsigned)(slot * K + k))); };
+  // op stream: one (matrix index within a class block, taxon or -1) pair per matrix use, in kernel program order.
+  // Class block layout (HostModel::MAT): P[slot] | J[slot*K+k] | leaf P^T[taxon] | leaf J^T[k*T+taxon]
+  const int T = hm->T;
+  auto op = [&](int mat, int tx) { hm->msched.push_back(mat); hm->msched.push_back(tx); };
+  auto mvP = [&](int slot) { op(slot, -1); };
+  auto mvJ = [&](int slot) { for (int k = 0; k < K; ++k) op(NI + slot * K + k, -1); };
+  auto leafP = [&](int tx) { op(NI + NI * K + tx, tx); };
+  auto leafJ = [&](int tx) { for (int k = 0; k < K; ++k) op(NI + NI * K + T + k * T + tx, tx); };
+  auto txof = [&](int e) { return hm->taxon_of[e]; };
+  auto cherry_leaves = [&](int e) { const std::vector<int> c = kids(e); leafP(txof(c[0])); leafP(txof(c[1])); };
+  auto cherry_counts = [&](int e) {
+    const std::vector<int> c = kids(e);
+    leafP(txof(c[1])); leafJ(txof(c[0])); leafP(txof(c[0])); leafJ(txof(c[1]));
+  };
+  // inside vector of child edge e into registers (CMX_GET_D)
+  auto getD = [&](int e) { if (kind(e) == 1) pop(0, hm->slot[e]); else cherry_leaves(e); };
   // inside pass
   for (int v = 0; v < NV; ++v) {
     const int n = visited[v];
@@ -140,16 +155,18 @@ void build_load_schedule(HostModel* hm) {
       const int x = Xof[n], y = Yof[n];
       if (kind(y) == 1) mvP(hm->slot[y]);                       // carried
       auto edge = [&](int e) {
-        if (kind(e) == 1) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
-        else if (kind(e) == 2) mvP(hm->slot[e]);
+        if (kind(e) == 0) leafP(txof(e));
+        else { getD(e); mvP(hm->slot[e]); }
       };
       edge(x);
       if (kind(y) != 1) edge(y);
     } else {
       const int carry = hm->nrec[(size_t)v * 32 + 30];
       if (carry >= 0) mvP(hm->slot[carry]);
-      for (int e : c)
-        if (internal(e) && e != carry) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
+      for (int e : c) {
+        if (!internal(e)) leafP(txof(e));
+        else if (e != carry) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
+      }
     }
     if (n != root) { storeD[hm->slot[n]] = t++; hm->stores_D++; }
   }
@@ -164,18 +181,25 @@ void build_load_schedule(HostModel* hm) {
     const std::vector<int> c = kids(f);
     if (c.size() == 2) {
       const int x = Xof[f], y = Yof[f];
-      if (kind(y) == 1) { pop(0, hm->slot[y]); mvP(hm->slot[y]); } else if (kind(y) == 2) mvP(hm->slot[y]);
-      if (kind(x) == 1) {
-        pop(0, hm->slot[x]); mvJ(hm->slot[x]); mvP(hm->slot[x]); mvP(hm->slot[x]);
-        storeU[hm->slot[x]] = t++; hm->stores_U++;
-      } else if (kind(x) == 2) { mvJ(hm->slot[x]); mvP(hm->slot[x]); mvP(hm->slot[x]); }
-      if (kind(y) == 1) { pop(0, hm->slot[y]); mvJ(hm->slot[y]); mvP(hm->slot[y]); up_in_acc[y] = 1; }
-      else if (kind(y) == 2) { mvJ(hm->slot[y]); mvP(hm->slot[y]); }
+      if (kind(y) == 0) leafP(txof(y)); else { getD(y); mvP(hm->slot[y]); }
+      if (kind(x) == 0) { leafJ(txof(x)); leafP(txof(x)); }
+      else {
+        getD(x); mvJ(hm->slot[x]); mvP(hm->slot[x]); mvP(hm->slot[x]);
+        if (kind(x) == 1) { storeU[hm->slot[x]] = t++; hm->stores_U++; } else cherry_counts(x);
+      }
+      if (kind(y) == 0) leafJ(txof(y));
+      else {
+        getD(y); mvJ(hm->slot[y]); mvP(hm->slot[y]);
+        if (kind(y) == 1) up_in_acc[y] = 1; else cherry_counts(y);
+      }
     } else {
       for (int n : c) {
-        for (int sb : c)
-          if (sb != n && internal(sb)) { pop(0, hm->slot[sb]); mvP(hm->slot[sb]); }
-        if (internal(n)) { pop(0, hm->slot[n]); mvJ(hm->slot[n]); mvP(hm->slot[n]); storeU[hm->slot[n]] = t++; hm->stores_U++; }
+        for (int sb : c) {
+          if (sb == n) continue;
+          if (!internal(sb)) leafP(txof(sb)); else { pop(0, hm->slot[sb]); mvP(hm->slot[sb]); }
+        }
+        if (!internal(n)) leafJ(txof(n));
+        else { pop(0, hm->slot[n]); mvJ(hm->slot[n]); mvP(hm->slot[n]); storeU[hm->slot[n]] = t++; hm->stores_U++; }
       }
     }
   }
@@ -209,14 +233,26 @@ std::string verify_traversal(const HostModel& hm) {
     if (slot < 0 || slot >= NI) return fail("slot out of range");
     if (!(arr ? haveU[slot] : haveD[slot])) return fail("load of a vector that was never stored");
   };
-  auto mv = [&](bool isJ, int idx) {
-    if (mi >= hm.msched.size()) return fail("more matrix products than scheduled");
-    const int e = hm.msched[mi++];
-    const int want = isJ ? (int)(0x80000000u | (unsigned)idx) : idx;
-    if (e != want) return fail("product " + std::to_string(mi - 1) + " finds the wrong matrix in the ring");
-    if (isJ ? (idx < 0 || idx >= NI * K) : (idx < 0 || idx >= NI)) return fail("matrix index out of range");
+  const int MC = NI + NI * K + T + K * T;  // matrices per class block
+  auto opchk = [&](int want_mat, int want_tx, const char* what) {
+    if (2 * mi + 1 >= hm.msched.size()) return fail(std::string("more matrix uses than scheduled (") + what + ")");
+    const int mat = hm.msched[2 * mi], tx = hm.msched[2 * mi + 1];
+    ++mi;
+    if (mat < 0 || mat >= MC) return fail("matrix index out of range");
+    if (mat != want_mat || tx != want_tx) return fail("op " + std::to_string(mi - 1) + " (" + what + ") finds the wrong matrix staged");
   };
-  auto leaf = [&](int tx) { if (tx < 0 || tx >= T) fail("taxon out of range"); };
+  auto mv = [&](bool isJ, int idx) {
+    if (isJ ? (idx < 0 || idx >= NI * K) : (idx < 0 || idx >= NI)) return fail("matrix index out of range");
+    opchk(isJ ? NI + idx : idx, -1, isJ ? "count product" : "product");
+  };
+  auto leaf = [&](int tx) {  // leaf edge, transition matrix
+    if (tx < 0 || tx >= T) return fail("taxon out of range");
+    opchk(NI + NI * K + tx, tx, "leaf P");
+  };
+  auto leafJ = [&](int tx) {
+    if (tx < 0 || tx >= T) return fail("taxon out of range");
+    for (int k = 0; k < K; ++k) opchk(NI + NI * K + T + k * T + tx, tx, "leaf J");
+  };
   auto count = [&](int node) {
     if (node < 0 || node >= nn - 1) return fail("branch out of range");
     for (int k = 0; k < K; ++k) { if (counted[(size_t)node * K + k]) fail("branch counted twice"); counted[(size_t)node * K + k] = 1; }
@@ -226,7 +262,7 @@ std::string verify_traversal(const HostModel& hm) {
     else if (ch[0] == 2) { leaf(ch[3]); leaf(ch[4]); }
     else fail("bad child kind");
   };
-  auto cherry_counts = [&](const int* ch) { leaf(ch[3]); leaf(ch[4]); count(ch[5]); count(ch[6]); };
+  auto cherry_counts = [&](const int* ch) { leaf(ch[4]); leafJ(ch[3]); count(ch[5]); leaf(ch[3]); leafJ(ch[4]); count(ch[6]); };
   auto kids = [&](int n) { std::vector<int> v; for (int e = hm.first_child[n]; e >= 0; e = hm.next_sib[e]) v.push_back(e); return v; };
   bool acc_is_D_of_prev = false;
   int prev_node = -1;
@@ -268,7 +304,7 @@ std::string verify_traversal(const HostModel& hm) {
     if (r[2] == 2) {
       const int* X = r + 4; const int* Y = r + 16;
       if (Y[0] == 0) leaf(Y[2]); else { getD(Y); mv(false, Y[2]); }
-      if (X[0] == 0) { leaf(X[2]); count(X[1]); }
+      if (X[0] == 0) { leafJ(X[2]); count(X[1]); leaf(X[2]); }
       else {
         getD(X);
         for (int k = 0; k < K; ++k) mv(true, X[2] * K + k);
@@ -276,7 +312,7 @@ std::string verify_traversal(const HostModel& hm) {
         mv(false, X[2]); mv(false, X[2]);
         if (X[0] == 1) haveU[X[2]] = 1; else cherry_counts(X);
       }
-      if (Y[0] == 0) { leaf(Y[2]); count(Y[1]); }
+      if (Y[0] == 0) { leafJ(Y[2]); count(Y[1]); }
       else {
         getD(Y);
         for (int k = 0; k < K; ++k) mv(true, Y[2] * K + k);
@@ -289,7 +325,7 @@ std::string verify_traversal(const HostModel& hm) {
       for (int n : c) {
         for (int sb : c)
           if (sb != n) { if (hm.taxon_of[sb] >= 0) leaf(hm.taxon_of[sb]); else { pop(0, hm.slot[sb]); mv(false, hm.slot[sb]); } }
-        if (hm.taxon_of[n] >= 0) { leaf(hm.taxon_of[n]); count(n); }
+        if (hm.taxon_of[n] >= 0) { leafJ(hm.taxon_of[n]); count(n); }
         else {
           pop(0, hm.slot[n]);
           for (int k = 0; k < K; ++k) mv(true, hm.slot[n] * K + k);
@@ -302,7 +338,7 @@ std::string verify_traversal(const HostModel& hm) {
   }
   if (!err.empty()) return err;
   if (fi != hm.ldsched.size()) return "traversal self-check failed: unused workspace loads in the schedule";
-  if (mi != hm.msched.size()) return "traversal self-check failed: unused matrix products in the schedule";
+  if (2 * mi != hm.msched.size()) return "traversal self-check failed: unused matrix uses in the schedule";
   for (char c : counted) if (!c) return "traversal self-check failed: a branch is never counted";
   return std::string();
 }
@@ -444,13 +480,19 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
       }
     }
   // ---- device layouts
+  // One allocation, per class a block of MC matrices of S*S doubles (the unit the kernel DMAs into LDS):
+  //   [0, NI)                    P of internal edges, 4x4-block packed (matrix-vector products)
+  //   [NI, NI + NI*K)            P o N^k of internal edges, packed, index slot*K + k
+  //   [.., + T)                  P of leaf edges transposed, [z][x] = P[x][z] (per-lane row gather by observed symbol)
+  //   [.., + K*T)                P o N^k of leaf edges transposed, index k*T + taxon
   const int NI = hm->NI;
-  hm->PP.assign((size_t)C * NI * S2, 0.0);
-  hm->JP.assign((size_t)C * NI * K * S2, 0.0);
-  hm->LPT.assign((size_t)C * T * S2, 0.0);
-  hm->LJT.assign((size_t)C * K * T * S2, 0.0);
+  const int MC = NI + NI * K + T + K * T;
+  hm->MC = MC;
+  const size_t MU = (size_t)mat_unit(S);   // doubles per device matrix: S*S plus max_ambig(S) extra leaf rows
+  hm->MAT.assign((size_t)C * MC * MU, 0.0);
   hm->CP.assign((size_t)C * nn * S2, 0.0);
-  for (int c = 0; c < C; ++c)
+  for (int c = 0; c < C; ++c) {
+    double* blk = &hm->MAT[(size_t)c * MC * MU];
     for (int b = 0; b < B; ++b) {
       const double* P = &hm->P[((size_t)c * B + b) * S2];
       double* cp = &hm->CP[((size_t)c * nn + b) * S2];
@@ -460,22 +502,23 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
       }
       if (hm->taxon_of[b] >= 0) {
         const int tx = hm->taxon_of[b];
-        double* lpt = &hm->LPT[((size_t)c * T + tx) * S2];
+        double* lpt = blk + (size_t)(NI + NI * K + tx) * MU;
         for (int x = 0; x < S; ++x)
           for (int z = 0; z < S; ++z) lpt[(size_t)z * S + x] = P[(size_t)x * S + z];
         for (int k = 0; k < K; ++k) {
           const double* PNk = &hm->PN[(((size_t)c * B + b) * K + k) * S2];
-          double* ljt = &hm->LJT[(((size_t)c * K + k) * T + tx) * S2];
+          double* ljt = blk + (size_t)(NI + NI * K + T + k * T + tx) * MU;
           for (int x = 0; x < S; ++x)
             for (int z = 0; z < S; ++z) ljt[(size_t)z * S + x] = PNk[(size_t)x * S + z];
         }
       } else {
         const int sl = hm->slot[b];
-        pack_blocks(S, P, &hm->PP[((size_t)c * NI + sl) * S2]);
+        pack_blocks(S, P, blk + (size_t)sl * MU);
         for (int k = 0; k < K; ++k)
-          pack_blocks(S, &hm->PN[(((size_t)c * B + b) * K + k) * S2], &hm->JP[(((size_t)c * NI + sl) * K + k) * S2]);
+          pack_blocks(S, &hm->PN[(((size_t)c * B + b) * K + k) * S2], blk + (size_t)(NI + sl * K + k) * MU);
       }
     }
+  }
   hm->cum_pi.resize(S);
   hm->cum_probs.resize(C);
   double cum = 0.0;

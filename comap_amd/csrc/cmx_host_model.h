@@ -18,13 +18,11 @@ struct HostModel {
   std::vector<double> blen, pi, rates, probs, cum_pi, cum_probs;
   std::vector<double> P;    // [C][B][S*S] row-major (x -> y)
   std::vector<double> PN;   // [C][B][K][S*S] P o N^k
-  std::vector<double> PP;   // [C][NI][S*S]     4x4-block packed P of internal nodes
-  std::vector<double> JP;   // [C][NI][K][S*S]  4x4-block packed PN of internal nodes
-  std::vector<double> LPT;  // [C][T][S][S]     transposed P of leaf branches
-  std::vector<double> LJT;  // [C][K][T][S][S]  transposed PN of leaf branches
+  std::vector<double> MAT;  // [C][MC][S*S]     device matrices: packed P | packed PN | leaf P^T | leaf PN^T (cmx_host_model.cpp)
+  int MC = 0;               // matrices per class block = NI + NI*K + T + K*T
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
   std::vector<int> ldsched; // workspace-load schedule of one class pass (DevModel::ldsched)
-  std::vector<int> msched;  // matrix products of one class pass in program order (DevModel::msched)
+  std::vector<int> msched;  // matrix uses of one class pass in program order: (matrix index, taxon or -1) pairs
   std::vector<int> nrec;    // [NV][32] per-visited-node records (DevModel::nrec)
   size_t loads_D = 0, loads_U = 0, stores_D = 0, stores_U = 0;  // per class pass, for traffic accounting
 };

@@ -31,18 +31,22 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #ifndef CMX_ABLATE
-#define CMX_ABLATE 0  // diagnostic builds: 1 = no leaf gathers, 2 = no workspace traffic, 3 = no matrix products
+#define CMX_ABLATE 0  // diagnostic builds (wrong results, timing only): 1 no leaf gathers, 2 no workspace vectors,
+                      // 3 no matrix products, 4 = 1 + 2, 5 no vector stores, 6 no vector loads, 8 no wait for the staged operator, 9 = 1 + 2 + 3, 10 = 8 + 9
 #endif
 
-// The SxS operator of an edge is the same for all 64 lanes.  It is staged in LDS (one 4 KiB buffer per wave, filled
-// by LDS-DMA one product ahead: the sequence of products is known, m.msched) and applied one 4x4 block ("tile", 16
-// values) at a time: a ds_read_b64 puts the 16 values of tile t in every DPP row of a VGPR pair, and
-// v_fmac_f64_dpp row_newbcast:k multiplies by element k -- 400 fp64 FMAs per 20x20 product, no SGPR traffic, two
-// transient VGPRs.  The buffer is refilled row by row (1 KiB = 8 tiles per DMA instruction) behind the tiles that
-// have been consumed, so the next matrix is requested ~1600 cycles before its first use.
+// Every edge of the tree applies one SxS operator that is the same for all 64 lanes: a matrix-vector product on
+// internal edges, a row gather by observed symbol on leaf edges.  The sequence of operators of a class pass is known
+// (host-built op stream, m.msched), so each operator is DMAed into LDS one op ahead: two S*S*8-byte stage buffers per
+// wave, op i reads buffer i&1 while the DMA of op i+1 fills the other (global_load_lds_dwordx4, 1 KiB per
+// instruction, no VGPRs).  A product reads one 4x4 block ("tile", 16 values) per ds_read_b64 into every DPP row of a
+// VGPR pair and v_fmac_f64_dpp row_newbcast:k multiplies by element k -- 400 fp64 FMAs per 20x20 product, no SGPR
+// operand traffic, two transient VGPRs.  A leaf op reads row `symbol` of the transposed matrix (S/2 ds_read_b128).
+// The symbols of the next leaf op are DMAed the same way (global_load_lds_ubyte into a 256-byte slot).
 // History: an s_load-fed v_fma_f64 version ran at 39 TFLOP/s; keeping the tiles in a VGPR ring (53
 // TFLOP/s in isolation) needed either fixed registers -- amdgpu_num_vgpr turned out not to be a hard limit, the
-// compiler reused them under pressure -- or 50 more loop-carried registers than two waves per SIMD can afford.
+// compiler reused them under pressure -- or 50 more loop-carried registers than two waves per SIMD can afford;
+// gathering leaf rows straight from L2 (lane-divergent 160-byte rows, latency exposed at every leaf) cost 5 of 21 ms.
 #include "cmx_ring_tiles.inc"
 
 typedef __attribute__((address_space(1))) const void* cmx_gptr;
@@ -50,57 +54,140 @@ typedef __attribute__((address_space(3))) void* cmx_lptr;
 
 template <int S>
 struct MatStage {
-  static constexpr int NT = (S / 4) * (S / 4);             // tiles
-  static constexpr int ROWS = (NT * 128 + 1023) / 1024;    // 1 KiB DMA rows
-  static constexpr int BYTES = ROWS * 1024;
+  static constexpr int NROW = S + max_ambig(S);              // rows of a transposed leaf operator (states + ambiguity ids)
+  static constexpr int UNIT = mat_unit(S);                   // doubles per device matrix
+  static constexpr int BYTES = UNIT * 8;                     // one operator
+  static constexpr int FULL = BYTES / 1024;                  // full 1 KiB DMA rows
+  static constexpr int TAIL = (BYTES % 1024) / 16;           // lanes of the last, partial row
+  static constexpr int ROWS = FULL + (TAIL ? 1 : 0);         // VMEM instructions per operator
+  static_assert(BYTES % 16 == 0, "operator size must be a multiple of 16 bytes");
 };
+constexpr int kCodeSlotBytes = 4 * kWave;  // one dword per lane
 
-// DMA row r of the matrix at `src` (global, wave-uniform) into the wave's stage buffer
+// LDS-DMA is issued through inline asm on purpose.  hipcc models __builtin_amdgcn_global_load_lds as a write to
+// LDS that any later ds_read may alias, and puts s_waitcnt vmcnt(0) in front of the next LDS read: with one dynamic LDS
+// array every operator, workspace vector and symbol would then be waited for right after the NEXT one was requested,
+// i.e. the whole L2/HBM latency exposed once per op.  An asm DMA is invisible to that bookkeeping; the ordering
+// between a DMA and the LDS reads of its data is kept by the counted waits below (wait_vm), and compiler-issued
+// vmcnt waits for its own loads only become stricter (it undercounts what is in flight).
+// One instruction moves 64 lanes x 16 B = 1 KiB; the instruction offset advances the global and the LDS address alike,
+// so consecutive 1 KiB rows need one M0 value and one address register.
+__device__ __forceinline__ uint32_t lds_addr(const uint8_t* p) {
+  // wave-uniform by construction; readfirstlane tells the compiler so (M0 is written from an SGPR)
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)p);
+}
+template <int NROWS>
+__device__ __forceinline__ void dma_rows16(const void* g /* per lane: row 0 address of this lane */, uint32_t lds) {
+  static_assert(NROWS >= 1 && NROWS <= 4, "instruction offset range");
+  if constexpr (NROWS == 1)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(g) : "memory");
+  else if constexpr (NROWS == 2)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024" ::"s"(lds), "v"(g) : "memory");
+  else if constexpr (NROWS == 3)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048" ::"s"(lds), "v"(g) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072" ::"s"(lds), "v"(g) : "memory");
+}
+
+// DMA the operator at `src` (global, wave-uniform) into the stage buffer `buf` (LDS, wave-uniform)
 template <int S>
-__device__ __forceinline__ void mat_dma_row(const double* src, uint8_t* mbuf, int lane, int r) {
-  __builtin_amdgcn_global_load_lds((cmx_gptr)(src + (size_t)r * 128 + 2 * lane), (cmx_lptr)(mbuf + r * 1024), 16, 0, 0);
+__device__ __forceinline__ void mat_dma(const double* src, uint8_t* buf, int lane) {
+  const double* g = src + 2 * lane;
+  const uint32_t l = lds_addr(buf);
+  if constexpr (MatStage<S>::FULL > 0) dma_rows16<MatStage<S>::FULL>(g, l);
+  if constexpr (MatStage<S>::TAIL > 0) {
+    if (lane < MatStage<S>::TAIL) dma_rows16<1>(g + MatStage<S>::FULL * 128, l + MatStage<S>::FULL * 1024);
+  }
+}
+// DMA one symbol per lane (address p is per lane) into dword `lane` of the code slot.  The symbols of the null are
+// written by this very wave (simulation) through the same address, hence the L1-bypassing cache policy (sc0 sc1).
+__device__ __forceinline__ void code_dma(const uint8_t* p, uint8_t* slot) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off sc0 sc1" ::"s"(lds_addr(slot)), "v"(p) : "memory");
+}
+
+// s_waitcnt vmcnt(n) needs an immediate: pick the largest supported threshold <= allowed (waiting for more is safe)
+template <int S>
+__device__ __forceinline__ void wait_vm(int allowed) {
+  if constexpr (S >= 16) {
+    if (allowed >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (allowed >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (allowed >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (allowed >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (allowed >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (allowed >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    if (allowed >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (allowed >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (allowed >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (allowed >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (allowed >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
 }
 
 template <int S, bool TR, int T>
-__device__ __forceinline__ void stage_steps(const uint8_t* mbuf, int lane16, const double* nxt, int lane,
-                                            const double (&x)[S], double (&y)[S]) {
+__device__ __forceinline__ void stage_steps(const uint8_t* tile0 /* buffer + (lane & 15) * 8 */, const double (&x)[S],
+                                            double (&y)[S]) {
   constexpr int NB = S / 4, NT = NB * NB;
   if constexpr (T < NT) {
     constexpr int bi = T / NB, bj = T % NB;
-    const double mt = *reinterpret_cast<const double*>(mbuf + T * 128 + lane16);
+    const double mt = *reinterpret_cast<const double*>(tile0 + T * 128);
     if constexpr (!TR)
       dpp_tile_f(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], mt, x[4 * bj], x[4 * bj + 1], x[4 * bj + 2],
                  x[4 * bj + 3]);
     else
       dpp_tile_t(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], mt, x[4 * bi], x[4 * bi + 1], x[4 * bi + 2],
                  x[4 * bi + 3]);
-    // a 1 KiB row (8 tiles) has been consumed: refill it with the same row of the next product's matrix.  The
-    // compiler barrier keeps the refill behind the LDS reads of this row.
-    if constexpr (T % 8 == 7 || T == NT - 1) {
-      asm volatile("" ::: "memory");
-      mat_dma_row<S>(nxt, const_cast<uint8_t*>(mbuf), lane, T / 8);
-    }
-    stage_steps<S, TR, T + 1>(mbuf, lane16, nxt, lane, x, y);
+    stage_steps<S, TR, T + 1>(tile0, x, y);
   }
 }
 
-// y = M x (TR = false) or y = M^T x (TR = true) with M = the matrix staged in mbuf; nxt = base of the matrix of the
-// next product in program order.  pf_young = a workspace prefetch (S/2 DMA rows) was issued after the stage buffer's
-// own DMA rows: those S/2 youngest operations may stay in flight, everything older (the matrix) must have landed.
+// y = M x (TR = false) or y = M^T x (TR = true) with M = the packed matrix staged in buf (already landed)
 template <int S, bool TR>
-__device__ __forceinline__ void matvec_stage(uint8_t* mbuf, int lane, const double* nxt, bool pf_young,
-                                             const double (&x)[S], double (&y)[S]) {
+__device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const double (&x)[S], double (&y)[S]) {
   static_assert(S % 4 == 0, "state count must be a multiple of 4");
-  if (CMX_ABLATE == 3) {
+  if (CMX_ABLATE == 3 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
 #pragma unroll
     for (int i = 0; i < S; ++i) y[i] = x[i] * 0.5;
     return;
   }
-  if (pf_young) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S / 2) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int i = 0; i < S; ++i) y[i] = 0.0;
-  stage_steps<S, TR, 0>(mbuf, (lane & 15) * 8, nxt, lane, x, y);
+  stage_steps<S, TR, 0>(buf + (lane & 15) * 8, x, y);
+}
+
+// Message of a leaf edge from the transposed operator staged in buf ([z][x] = M[x][z], rows >= S: ambiguity ids):
+// row `symbol`, consumed 16 bytes at a time as it arrives from LDS so that no S-vector of temporaries is live.
+// SET out = row, MUL out = row o in (in may be out), DOT returns sum_x in[x] * row[x] (x ascending, one FMA chain).
+enum { LEAF_SET = 0, LEAF_MUL = 1, LEAF_DOT = 2 };
+template <int S, int MODE>
+__device__ __forceinline__ double leaf_apply(const uint8_t* buf, unsigned code, const double (&in)[S], double (&out)[S]) {
+  double dot = 0.0;
+  if (CMX_ABLATE == 1 || CMX_ABLATE == 4 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
+#pragma unroll
+    for (int x = 0; x < S; ++x) {
+      const double v = 0.05 + 0.001 * code;
+      if (MODE == LEAF_SET) out[x] = v;
+      else if (MODE == LEAF_MUL) out[x] = v * in[x];
+      else dot = __builtin_fma(in[x], v, dot);
+    }
+    return dot;
+  }
+  const unsigned row = code < (unsigned)MatStage<S>::NROW ? code : (unsigned)(MatStage<S>::NROW - 1);
+  const d2* r = reinterpret_cast<const d2*>(buf + row * (S * 8));
+#pragma unroll
+  for (int q = 0; q < S / 2; ++q) {
+    const d2 v = r[q];
+    if (MODE == LEAF_SET) { out[2 * q] = v[0]; out[2 * q + 1] = v[1]; }
+    else if (MODE == LEAF_MUL) { out[2 * q] = v[0] * in[2 * q]; out[2 * q + 1] = v[1] * in[2 * q + 1]; }
+    else { dot = __builtin_fma(in[2 * q], v[0], dot); dot = __builtin_fma(in[2 * q + 1], v[1], dot); }
+  }
+  return dot;
 }
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -108,7 +195,7 @@ __device__ __forceinline__ void matvec_stage(uint8_t* mbuf, int lane, const doub
 // wave-instruction, the same image in HBM and (for prefetched vectors) in LDS.
 template <int S>
 __device__ __forceinline__ void load_vec(const double* p /* slice base + 2*lane */, double (&v)[S]) {
-  if (CMX_ABLATE == 2 || CMX_ABLATE == 4) {
+  if (CMX_ABLATE == 2 || CMX_ABLATE == 4 || CMX_ABLATE == 6 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
 #pragma unroll
     for (int i = 0; i < S; ++i) v[i] = 0.9;
     return;
@@ -122,7 +209,7 @@ __device__ __forceinline__ void load_vec(const double* p /* slice base + 2*lane 
 }
 template <int S>
 __device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
-  if (CMX_ABLATE == 2 || CMX_ABLATE == 4) {
+  if (CMX_ABLATE == 2 || CMX_ABLATE == 4 || CMX_ABLATE == 5 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
     asm volatile("" ::"v"(v[0]), "v"(v[S - 1]));
     return;
   }
@@ -138,10 +225,12 @@ __device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
 // asynchronous HBM -> LDS copy of one workspace vector (S/2 LDS-DMA instructions, no VGPR destination)
 template <int S>
 __device__ __forceinline__ void prefetch_vec_lds(const double* p /* slice base + 2*lane */, uint8_t* lds /* wave-uniform */) {
-  if (CMX_ABLATE == 2 || CMX_ABLATE == 4) return;
+  if (CMX_ABLATE == 2 || CMX_ABLATE == 4 || CMX_ABLATE == 6 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) return;
+  constexpr int R = S / 2;
+  const uint32_t l = lds_addr(lds);
 #pragma unroll
-  for (int i = 0; i < S / 2; ++i)
-    __builtin_amdgcn_global_load_lds((cmx_gptr)(p + (size_t)i * 2 * kWave), (cmx_lptr)(lds + i * 16 * kWave), 16, 0, 0);
+  for (int i = 0; i + 4 <= R; i += 4) dma_rows16<4>(p + (size_t)i * 2 * kWave, l + i * 1024);
+  if constexpr (R % 4 != 0) dma_rows16<R % 4>(p + (size_t)(R / 4) * 4 * 2 * kWave, l + (R / 4) * 4 * 1024);
 }
 template <int S>
 __device__ __forceinline__ void read_vec_lds(const uint8_t* lds /* wave-uniform */, int lane, double (&v)[S]) {
@@ -150,35 +239,6 @@ __device__ __forceinline__ void read_vec_lds(const uint8_t* lds /* wave-uniform 
     const d2 t = *reinterpret_cast<const d2*>(lds + (size_t)(i * kWave + lane) * 16);
     v[2 * i] = t[0];
     v[2 * i + 1] = t[1];
-  }
-}
-
-// message of a leaf edge: m[x] = sum_{z compatible with the observed symbol} M[x][z], M given transposed ([z][x])
-template <int S>
-__device__ __forceinline__ void leaf_vec(const double* __restrict__ LT, unsigned code, const uint32_t* __restrict__ masks,
-                                         double (&m)[S]) {
-  if (CMX_ABLATE == 1 || CMX_ABLATE == 4) {
-#pragma unroll
-    for (int x = 0; x < S; ++x) m[x] = 0.05 + 0.001 * code;
-    return;
-  }
-  if (code < (unsigned)S) {
-    const d2* r = reinterpret_cast<const d2*>(LT + (size_t)code * S);
-#pragma unroll
-    for (int x = 0; x < S / 2; ++x) {
-      d2 v = r[x];
-      m[2 * x] = v[0];
-      m[2 * x + 1] = v[1];
-    }
-  } else {
-    const uint32_t mk = masks ? masks[code] : ((1u << S) - 1u);
-#pragma unroll
-    for (int x = 0; x < S; ++x) m[x] = 0.0;
-    for (int z = 0; z < S; ++z)
-      if ((mk >> z) & 1u) {
-#pragma unroll
-        for (int x = 0; x < S; ++x) m[x] += LT[(size_t)z * S + x];
-      }
   }
 }
 
@@ -221,6 +281,14 @@ __device__ __forceinline__ int sload_i32(cmx_cint p) {
   return v;
 }
 
+__device__ __forceinline__ void sload_i32x2(cmx_cint p, int& a, int& b) {
+  typedef int cmx_i2 __attribute__((ext_vector_type(2)));
+  cmx_i2 v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  a = v[0];
+  b = v[1];
+}
+
 // per-visited-node record (host-built, cmx_host_model.cpp build_load_schedule): 32 ints, two scalar loads
 typedef int cmx_i16 __attribute__((ext_vector_type(16)));
 enum { REC_N = 0, REC_SLOT = 1, REC_NCH = 2, REC_FLAGS = 3, REC_X = 4 /* ints 4..10 */, REC_Y = 0 /* of the 2nd half: ints 16..22 */,
@@ -243,19 +311,26 @@ struct ConstModel {
         ldsched((cmx_cint)m.ldsched), msched((cmx_cint)m.msched), nrec((cmx_cint)m.nrec), pi((cmx_cdbl)m.pi), rates((cmx_cdbl)m.rates),
         probs((cmx_cdbl)m.probs), cum_pi((cmx_cdbl)m.cum_pi), cum_probs((cmx_cdbl)m.cum_probs) {}
 };
+// Op-stream bookkeeping of a wave (wave-uniform, lives across site blocks).  vs counts the VMEM instructions this
+// code issued and knows about (DMA rows, vector stores); an asynchronous transfer remembers vs right after its issue,
+// and "wait for X" is s_waitcnt vmcnt(vs - X_seq): VMEM completes in order, so the instructions issued after X may stay
+// in flight.  Instructions that are not counted only make the wait stricter.
+struct OpState {
+  unsigned par;      // stage buffer / code slot of the current op
+  unsigned vs;       // counted VMEM instructions issued so far
+  unsigned cur_seq;  // vs right after the current op's operator (and symbols) were requested
+};
+
 // Workspace vector loads follow a host-built schedule (m.ldsched, one entry per load in program order):
 // bit 30 = array (0: inside D, 1: outside U), low 24 bits = slot.
 #define CMX_SCHED_ADDR(e) (((e) & 0x40000000) ? wsU : wsD) + (size_t)((e) & 0x00ffffff) * S * kWave + 2 * lane
 // pop: take the vector prefetched into LDS (or load it now), then start the LDS-DMA of the next schedule entry if
 // the host marked it prefetchable (bit 31: its producing store precedes this point).  The DMA needs no VGPRs and
-// overlaps the matrix product that follows; vmcnt(0) orders the LDS read behind it, lgkmcnt(0) orders the next DMA
-// behind the LDS read.
+// overlaps the ops that follow; lgkmcnt(0) orders the next DMA behind the LDS read.
 #define CMX_POP(dst)                                                        \
   do {                                                                      \
     if (pend) {                                                             \
-      /* the prefetch rows are older than the matrix rows of any product run since: those may stay in flight */ \
-      if (mv_since_pf) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MatStage<S>::ROWS) : "memory"); \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+      wait_vm<S>((int)(os.vs - pf_seq));                                    \
       read_vec_lds<S>(pfl, lane, dst);                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
     } else {                                                                \
@@ -269,55 +344,88 @@ struct ConstModel {
       if (e2_ < 0) {                                                        \
         prefetch_vec_lds<S>(CMX_SCHED_ADDR(e2_), pfl);                      \
         pend = true;                                                        \
-        pf_young = true;                                                    \
-        mv_since_pf = false;                                                \
+        os.vs += S / 2;                                                     \
+        pf_seq = os.vs;                                                     \
       }                                                                     \
     }                                                                       \
   } while (0)
+#define CMX_STORE(ptr, v)     \
+  do {                        \
+    store_vec<S>(ptr, v);     \
+    os.vs += S / 2;           \
+  } while (0)
 
-// Maps the 64 sites of this wave (codes at aln_base[taxon * stride], per lane) for all rate classes.
+// Maps the 64 sites of this wave (symbol of taxon t at gcodes[t * gstride], per lane) for all rate classes.
 // On return cnt[(b*K+k)*64 + lane] holds the final counts n(b, site, k) and the scalars are per lane.
 // part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
-// Register budget: four S-vectors live at most (acc, u, d, t) so that two waves fit per SIMD without scratch.
-// The loop nest below is mirrored statement for statement by build_load_schedule() in cmx_host_model.cpp.
-template <bool CLDS>
-__device__ __forceinline__ unsigned leaf_code(int codes_off, const uint8_t* __restrict__ gcodes, size_t gstride, int tx) {
-  if constexpr (CLDS) return cmx_smem[codes_off + tx * kWave];  // ds_read_u8
-  else return gcodes[(size_t)tx * gstride];                     // global_load_ubyte
-}
-
-template <int S, bool CLDS>
+// The loop nest below is mirrored statement for statement by build_load_schedule() / verify_traversal() in
+// cmx_host_model.cpp: the op stream decides WHICH operator every CMX_MV / CMX_LEAF applies.
+template <int S>
 __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
                                                double* __restrict__ part, double* __restrict__ cnt, int lds_off,
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
-                                               uint8_t* mbuf, bool& pf_young, double& L_out, double& pr_out,
-                                               int& rc_out, double& norm_out) {
+                                               OpState& os, double& L_out, double& pr_out, int& rc_out,
+                                               double& norm_out) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
   uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, S*64*8 bytes
-  // leaf symbols of this wave's sites: [taxon][64] in LDS when they fit (a.codes_in_lds), else read from HBM
-  const int codes_off = lds_off + S * kWave * 8 + MatStage<S>::BYTES + lane;
-// (a pointer select between LDS and HBM would make a generic pointer: flat_load + a full vmcnt/lgkmcnt drain per leaf)
-#define CMX_CODE(tx) leaf_code<CLDS>(codes_off, gcodes, gstride, (tx))
-  const int C = m.C, K = m.K, NI = m.NI, root = m.root;
+  uint8_t* stage = pfl + S * kWave * 8;                                // two operator buffers
+  uint8_t* cslot = stage + 2 * MatStage<S>::BYTES;                     // two symbol slots
+  const int C = m.C, K = m.K, root = m.root;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
-#define CMX_LEAF_P(tx, out) leaf_vec<S>(m.LPT + ((size_t)c * m.T + (tx)) * S * S, CMX_CODE(tx), a.masks, out)
-#define CMX_LEAF_J(tx, k, out) \
-  leaf_vec<S>(m.LJT + (((size_t)c * K + (k)) * m.T + (tx)) * S * S, CMX_CODE(tx), a.masks, out)
-// matrix product number mi of this class pass (the matrix is already in the ring); streams in the matrix of the next
-// product: entry mi + 1 of cm.msched, or entry 0 of the next class / next site block.
-#define CMX_MV(TR, in, out)                                                                            \
-  do {                                                                                                 \
-    ++mi;                                                                                              \
-    const int cn_ = (mi < m.nmv) ? c : ((c + 1 < C) ? c + 1 : 0);                                      \
-    const int en_ = sload_i32(cm.msched + ((mi < m.nmv) ? mi : 0));                                                   \
-    const size_t off_ = (en_ < 0) ? m.joff + ((size_t)cn_ * NI * K + (size_t)(en_ & 0x7fffffff)) * S * S \
-                                  : ((size_t)cn_ * NI + (size_t)en_) * S * S;                          \
-    matvec_stage<S, TR>(mbuf, lane, m.MAT + off_, pf_young, in, out);                                  \
-    pf_young = false;                                                                                  \
-    mv_since_pf = true;                                                                                \
+  {  // symbols of op 0 if it is a leaf op (the previous site block could not request them).  Everything this wave
+     // wrote before (simulated symbols) is in L2 first; the request is not counted, so drain it here.
+    int mat0, tx0;
+    sload_i32x2(cm.msched, mat0, tx0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tx0 >= 0) {
+      code_dma(gcodes + (size_t)tx0 * gstride, cslot + os.par * kCodeSlotBytes);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+// One op: request the operator (and symbols) of the NEXT op of the stream -- entry mi + 1, or entry 0 of the next
+// class / next site block -- into the other buffer, then wait for this op's operator.
+#define CMX_OP_BEGIN()                                                                                   \
+  const bool more_ = (mi + 1 < m.nmv);                                                                   \
+  const int cn_ = more_ ? c : ((c + 1 < C) ? c + 1 : 0);                                                 \
+  int emat_, etx_;                                                                                       \
+  sload_i32x2(cm.msched + 2 * (more_ ? mi + 1 : 0), emat_, etx_); /* lgkmcnt(0): the other buffer is read */ \
+  mat_dma<S>(m.MAT + ((size_t)cn_ * m.MC + (size_t)emat_) * MatStage<S>::UNIT, stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane); \
+  unsigned issued_ = MatStage<S>::ROWS;                                                                  \
+  if (etx_ >= 0 && (more_ || c + 1 < C)) {                                                               \
+    code_dma(gcodes + (size_t)etx_ * gstride, cslot + (os.par ^ 1u) * kCodeSlotBytes);                   \
+    issued_ += 1;                                                                                        \
+  }                                                                                                      \
+  if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S>((int)(os.vs - os.cur_seq + issued_));                                  \
+  os.vs += issued_;                                                                                      \
+  const unsigned nseq_ = os.vs;                                                                          \
+  const uint8_t* buf_ = stage + os.par * MatStage<S>::BYTES
+#define CMX_OP_END()   \
+  os.par ^= 1u;        \
+  os.cur_seq = nseq_;  \
+  ++mi
+#define CMX_MV(TR, in, out)                     \
+  do {                                          \
+    CMX_OP_BEGIN();                             \
+    matvec_stage<S, TR>(buf_, lane, in, out);   \
+    CMX_OP_END();                               \
   } while (0)
+// leaf edge the op stream names (P or P o N^k of a taxon, transposed): out = message, out = message o in, tot = <in, message>
+#define CMX_LEAF_OP(MODE_, in, out, tot)                                                     \
+  do {                                                                                       \
+    CMX_OP_BEGIN();                                                                          \
+    const unsigned code_ = *(cslot + os.par * kCodeSlotBytes + 4 * lane);                    \
+    tot = leaf_apply<S, MODE_>(buf_, code_, in, out);                               \
+    CMX_OP_END();                                                                            \
+  } while (0)
+#define CMX_LEAF(out)          do { double z_; CMX_LEAF_OP(LEAF_SET, out, out, z_); (void)z_; } while (0)
+#define CMX_LEAF_MUL(in, out)  do { double z_; CMX_LEAF_OP(LEAF_MUL, in, out, z_); (void)z_; } while (0)
+#define CMX_LEAF_DOT(in, tot)  CMX_LEAF_OP(LEAF_DOT, in, in, tot)
+// tells the compiler a vector is dead here (defines it without an instruction): the four S-vectors are loop-carried
+// variables and would otherwise count as live on paths whose successors never read them
+#define CMX_KILL(v) \
+  do { _Pragma("unroll") for (int i_ = 0; i_ < S; ++i_) asm volatile("" : "=v"(v[i_])); } while (0)
 #define CMX_DOT(x_, y_, out)                                                          \
   do {                                                                                \
     out = 0.0;                                                                        \
@@ -330,37 +438,32 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     int fi = 0;         // next schedule entry
     int mi = 0;         // matrix products done in this class pass
     bool pend = false;  // the LDS prefetch buffer holds entry fi
-    bool mv_since_pf = false;  // a product (hence >= ROWS matrix DMA rows) was issued after the pending prefetch
+    unsigned pf_seq = 0;  // os.vs right after that prefetch was issued
     double acc[S], u[S];
     double Lc = 0.0;
-// inside vector of a child edge into `d`: kind 1 = stored (pop), kind 2 = inlined cherry (two leaf gathers)
+// inside vector of a child edge into `d`: kind 1 = stored (pop), kind 2 = inlined cherry (two leaf ops)
 #define CMX_GET_D(r_, off_)                                    \
   do {                                                         \
     if ((r_)[(off_) + CH_KIND] == 1) {                         \
       CMX_POP(d);                                              \
     } else {                                                   \
-      CMX_LEAF_P((r_)[(off_) + CH_T1], d);                     \
-      CMX_LEAF_P((r_)[(off_) + CH_T2], t);                     \
-      _Pragma("unroll") for (int x = 0; x < S; ++x) d[x] *= t[x]; \
+      CMX_LEAF(d);                                             \
+      CMX_LEAF_MUL(d, d);                                      \
     }                                                          \
   } while (0)
-// counts of the two leaf branches of an inlined cherry whose outside message is `up`; t1_/t2_ are scratch vectors
-#define CMX_CHERRY_COUNTS(r_, off_, up, t1_, t2_)                                        \
+// counts of the two leaf branches of an inlined cherry whose outside message is `up`; t1_ is a scratch vector
+#define CMX_CHERRY_COUNTS(r_, off_, up, t1_)                                             \
   do {                                                                                   \
-    CMX_LEAF_P((r_)[(off_) + CH_T2], t1_);                                               \
-    _Pragma("unroll") for (int x = 0; x < S; ++x) t1_[x] *= up[x];                       \
+    CMX_LEAF_MUL(up, t1_);                       /* up o (P of leaf 2) */                \
     for (int k = 0; k < K; ++k) {                                                        \
-      CMX_LEAF_J((r_)[(off_) + CH_T1], k, t2_);                                          \
       double tot_;                                                                       \
-      CMX_DOT(t1_, t2_, tot_);                                                           \
+      CMX_LEAF_DOT(t1_, tot_);                   /* . (P o N^k of leaf 1) */             \
       pcnt[((size_t)(r_)[(off_) + CH_L1] * K + k) * kWave] = pc * tot_;                  \
     }                                                                                    \
-    CMX_LEAF_P((r_)[(off_) + CH_T1], t1_);                                               \
-    _Pragma("unroll") for (int x = 0; x < S; ++x) t1_[x] *= up[x];                       \
+    CMX_LEAF_MUL(up, t1_);                       /* up o (P of leaf 1) */                \
     for (int k = 0; k < K; ++k) {                                                        \
-      CMX_LEAF_J((r_)[(off_) + CH_T2], k, t2_);                                          \
       double tot_;                                                                       \
-      CMX_DOT(t1_, t2_, tot_);                                                           \
+      CMX_LEAF_DOT(t1_, tot_);                   /* . (P o N^k of leaf 2) */             \
       pcnt[((size_t)(r_)[(off_) + CH_L2] * K + k) * kWave] = pc * tot_;                  \
     }                                                                                    \
   } while (0)
@@ -381,22 +484,22 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         }
         // child X (never handed over in registers), then child Y unless it was
         if (r[REC_X + CH_KIND] == 0) {
-          CMX_LEAF_P(r[REC_X + CH_ID], t);
+          CMX_LEAF_MUL(acc, acc);
         } else {
           CMX_GET_D(r, REC_X);
           CMX_MV(false, d, t);
-        }
 #pragma unroll
-        for (int x = 0; x < S; ++x) acc[x] *= t[x];
+          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+        }
         if (!(r[REC_FLAGS] & FLAG_Y_IN_REGS)) {
           if (r2[REC_Y + CH_KIND] == 0) {
-            CMX_LEAF_P(r2[REC_Y + CH_ID], t);
+            CMX_LEAF_MUL(acc, acc);
           } else {  // inlined cherry (a stored Y is always handed over)
             CMX_GET_D(r2, REC_Y);
             CMX_MV(false, d, t);
-          }
 #pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+            for (int x = 0; x < S; ++x) acc[x] *= t[x];
+          }
         }
       } else {
         const int carry = r2[REC_GCARRY];
@@ -409,25 +512,27 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           for (int x = 0; x < S; ++x) acc[x] = 1.0;
         }
         for (int e = cm.first_child[n]; e >= 0; e = cm.next_sib[e]) {
-          const int tx = cm.taxon_of[e];
-          if (tx >= 0) {
-            CMX_LEAF_P(tx, t);
+          if (cm.taxon_of[e] >= 0) {
+            CMX_LEAF_MUL(acc, acc);
           } else {
             if (e == carry) continue;
             CMX_POP(d);
             CMX_MV(false, d, t);
-          }
 #pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+            for (int x = 0; x < S; ++x) acc[x] *= t[x];
+          }
         }
       }
       if (n != root) {
-        store_vec<S>(wsD + (size_t)r[REC_SLOT] * S * kWave + 2 * lane, acc);
+        CMX_STORE(wsD + (size_t)r[REC_SLOT] * S * kWave + 2 * lane, acc);
       } else {
 #pragma unroll
         for (int x = 0; x < S; ++x) Lc = __builtin_fma(cm.pi[x], acc[x], Lc);
       }
+      CMX_KILL(d);
+      CMX_KILL(t);
     }
+    CMX_KILL(acc);
     Lsum += pc * Lc;
     prsum += cm.rates[c] * pc * Lc;
     if (pc * Lc > best) { best = pc * Lc; bestc = c; }  // first maximum wins (getRateClassWithMaxPostProbPerSite)
@@ -446,24 +551,21 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         const int kx = r[REC_X + CH_KIND], ky = r2[REC_Y + CH_KIND];
         // ---- message of Y -> U_X = Up_f o M_Y
         if (ky == 0) {
-          CMX_LEAF_P(r2[REC_Y + CH_ID], t);
+          CMX_LEAF_MUL(acc, u);
         } else {
           CMX_GET_D(r2, REC_Y);
           CMX_MV(false, d, t);
-        }
 #pragma unroll
-        for (int x = 0; x < S; ++x) u[x] = acc[x] * t[x];
+          for (int x = 0; x < S; ++x) u[x] = acc[x] * t[x];
+        }
         // ---- X: counts of its branch, its message -> U_Y, its outside message
         if (kx == 0) {
           for (int k = 0; k < K; ++k) {
-            CMX_LEAF_J(r[REC_X + CH_ID], k, t);
             double tot;
-            CMX_DOT(u, t, tot);
+            CMX_LEAF_DOT(u, tot);
             pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kWave] = pc * tot;
           }
-          CMX_LEAF_P(r[REC_X + CH_ID], t);
-#pragma unroll
-          for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_Y = Up_f o M_X
+          CMX_LEAF_MUL(acc, t);                        // U_Y = Up_f o M_X
         } else {
           CMX_GET_D(r, REC_X);
           for (int k = 0; k < K; ++k) {
@@ -477,36 +579,31 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_Y
           CMX_MV(true, u, d);                          // Up_X
           if (kx == 1) {
-            store_vec<S>(wsU + (size_t)r[REC_X + CH_ID] * S * kWave + 2 * lane, d);
+            CMX_STORE(wsU + (size_t)r[REC_X + CH_ID] * S * kWave + 2 * lane, d);
           } else {
-            CMX_CHERRY_COUNTS(r, REC_X, d, acc, u);    // Up_f and U_X are dead here
+            CMX_CHERRY_COUNTS(r, REC_X, d, acc);       // Up_f is dead here
           }
         }
         // ---- Y: counts of its branch, its outside message (t = U_Y)
         if (ky == 0) {
           for (int k = 0; k < K; ++k) {
-            CMX_LEAF_J(r2[REC_Y + CH_ID], k, u);
             double tot;
-            CMX_DOT(t, u, tot);
+            CMX_LEAF_DOT(t, tot);
             pcnt[((size_t)r2[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
           }
+          CMX_KILL(acc);
         } else {
-          // d <- D_Y needs t as scratch for a cherry: park U_Y in acc first
-#pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] = t[x];
           CMX_GET_D(r2, REC_Y);
           for (int k = 0; k < K; ++k) {
             CMX_MV(false, d, u);
             double tot;
-            CMX_DOT(acc, u, tot);
+            CMX_DOT(t, u, tot);
             pcnt[((size_t)r2[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
           }
-          CMX_MV(true, acc, t);                        // Up_Y
-          if (ky == 1) {
-#pragma unroll
-            for (int x = 0; x < S; ++x) acc[x] = t[x];  // handed to the next visited node (Y)
-          } else {
-            CMX_CHERRY_COUNTS(r2, REC_Y, t, acc, u);
+          CMX_MV(true, t, acc);                        // Up_Y: handed to the next visited node when Y is stored
+          if (ky != 1) {
+            CMX_CHERRY_COUNTS(r2, REC_Y, acc, u);
+            CMX_KILL(acc);
           }
         }
       } else {
@@ -517,22 +614,19 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           for (int x = 0; x < S; ++x) u[x] = acc[x];
           for (int sb = ca; sb >= 0; sb = cm.next_sib[sb]) {
             if (sb == n) continue;
-            const int tx = cm.taxon_of[sb];
-            if (tx >= 0) {
-              CMX_LEAF_P(tx, t);
+            if (cm.taxon_of[sb] >= 0) {
+              CMX_LEAF_MUL(u, u);
             } else {
               CMX_POP(d);
               CMX_MV(false, d, t);
-            }
 #pragma unroll
-            for (int x = 0; x < S; ++x) u[x] *= t[x];
+              for (int x = 0; x < S; ++x) u[x] *= t[x];
+            }
           }
-          const int tn = cm.taxon_of[n];
-          if (tn >= 0) {
+          if (cm.taxon_of[n] >= 0) {
             for (int k = 0; k < K; ++k) {
-              CMX_LEAF_J(tn, k, t);
               double tot;
-              CMX_DOT(u, t, tot);
+              CMX_LEAF_DOT(u, tot);
               pcnt[((size_t)n * K + k) * kWave] = pc * tot;
             }
           } else {
@@ -545,19 +639,28 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
               pcnt[((size_t)n * K + k) * kWave] = pc * tot;
             }
             CMX_MV(true, u, t);
-            store_vec<S>(wsU + (size_t)sl * S * kWave + 2 * lane, t);
+            CMX_STORE(wsU + (size_t)sl * S * kWave + 2 * lane, t);
           }
         }
+        CMX_KILL(acc);
       }
+      CMX_KILL(d);
+      CMX_KILL(t);
+      CMX_KILL(u);
     }
   }
 #undef CMX_GET_D
 #undef CMX_CHERRY_COUNTS
-#undef CMX_LEAF_P
-#undef CMX_CODE
-#undef CMX_LEAF_J
+#undef CMX_LEAF
+#undef CMX_LEAF_MUL
+#undef CMX_LEAF_DOT
+#undef CMX_LEAF_OP
 #undef CMX_MV
+#undef CMX_OP_BEGIN
+#undef CMX_OP_END
+#undef CMX_STORE
 #undef CMX_DOT
+#undef CMX_KILL
   // ---------------- sum the classes in class order, divide by the site likelihood, norm (computeNormForSite)
   double nrm = 0.0;
   for (int b = 0; b < m.B; ++b) {
@@ -634,7 +737,10 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
 #ifndef CMX_WAVES_PER_SIMD
 #define CMX_WAVES_PER_SIMD 2
 #endif
-template <int S, int MODE, bool CLDS>
+template <int S>
+constexpr int map_lds_per_wave() { return S * kWave * 8 + 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }
+
+template <int S, int MODE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void map_kernel(const MapArgs a) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
@@ -646,20 +752,19 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void ma
   double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kWave;
   double* cnt1 = cnt0 + (size_t)m.B * m.K * kWave;
   double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kWave;
-  // LDS per wave: workspace prefetch buffer (S*64*8 B), matrix stage (4 KiB), then the [T][64] leaf symbols
-  const int lds_off = (int)(threadIdx.x >> 6) *
-                      (S * kWave * 8 + MatStage<S>::BYTES + (CLDS ? ((m.T * kWave + 15) & ~15) : 0));
-  uint8_t* mbuf = cmx_smem + lds_off + S * kWave * 8;
-  uint8_t* codes = cmx_smem + lds_off + S * kWave * 8 + MatStage<S>::BYTES + lane;
+  // LDS per wave: workspace prefetch buffer (S*64*8 B), two operator stage buffers, two symbol slots
+  const int lds_off = (int)(threadIdx.x >> 6) * map_lds_per_wave<S>();
   const size_t nblocks = (a.nsites + kWave - 1) / kWave;
-  // stage the first product's matrix (class 0, entry 0); every product then requests the next one
-  bool pf_young = false;
+  // request the first op's operator (class 0, entry 0); every op then requests the next one
+  OpState os;
+  os.par = 0;
   {
-    const int e0 = sload_i32(cm.msched);
-    const size_t off0 = (e0 < 0) ? m.joff + (size_t)(e0 & 0x7fffffff) * S * S : (size_t)e0 * S * S;
-#pragma unroll
-    for (int r = 0; r < MatStage<S>::ROWS; ++r) mat_dma_row<S>(m.MAT + off0, mbuf, lane, r);
+    int mat0, tx0;
+    sload_i32x2(cm.msched, mat0, tx0);
+    mat_dma<S>(m.MAT + (size_t)mat0 * MatStage<S>::UNIT, cmx_smem + lds_off + S * kWave * 8, lane);
   }
+  os.vs = MatStage<S>::ROWS;
+  os.cur_seq = os.vs;
   for (size_t sb = wave; sb < nblocks; sb += nwaves) {
     const size_t site = sb * kWave + lane;
     const bool active = site < a.nsites;
@@ -667,9 +772,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void ma
     if (MODE == kModeObserved) {
       double L, pr, nrm;
       int rc;
-      if (CLDS)
-        for (int t = 0; t < m.T; ++t) codes[(size_t)t * kWave] = a.aln[(size_t)t * a.ld + s];
-      map_sites_wave<S, CLDS>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, mbuf, pf_young, L, pr, rc, nrm);
+      map_sites_wave<S>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
@@ -679,20 +782,19 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void ma
           for (int r = 0; r < m.B * m.K; ++r) a.counts[(size_t)r * a.ldc + s] = cnt0[(size_t)r * kWave + lane];
       }
     } else {
-      // null pair q = s: replicate rep, column j; simulated-site index g_h = ((rep*2 + h)*rep_ram + j)
-      const size_t rep_local = s / a.rep_ram, j = s % a.rep_ram;
-      const size_t rep = a.rep_begin + rep_local;
-      double L[2], pr[2], nrm[2];
-      int rc[2];
+      // null pair q = s: replicate rep, column j; simulated-site index g_h = ((rep*2 + h)*rep_ram + j).
+      // Only the minima over the two batches leave the loop (AnalysisTools.cpp:643-652) -- fewer live registers.
+      double prmin = 0.0, nmin = 0.0;
+      int rcmin = 0;
       for (int h = 0; h < 2; ++h) {
+        const size_t rep_local = s / a.rep_ram, j = s % a.rep_ram;
         const uint8_t* gbase;
         size_t gstride;
         if (a.supplied) {
           gbase = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
           gstride = a.rep_ram;
-          if (CLDS)
-            for (int t = 0; t < m.T; ++t) codes[(size_t)t * kWave] = gbase[(size_t)t * gstride];
         } else {
+          const size_t rep = a.rep_begin + rep_local;
           uint8_t* st = a.ws.st + (size_t)wave * m.nn * kWave + lane;
           uint8_t* al = a.ws.aln + (size_t)wave * m.T * kWave + lane;
           gbase = al;
@@ -706,56 +808,81 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void ma
             const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S + x) * S, S);
             st[(size_t)node * kWave] = (uint8_t)y;
             const int tx = cm.taxon_of[node];
-            if (tx >= 0) {
-              if (CLDS) codes[(size_t)tx * kWave] = (uint8_t)y;
-              else al[(size_t)tx * kWave] = (uint8_t)y;
-            }
+            if (tx >= 0) al[(size_t)tx * kWave] = (uint8_t)y;
           }
         }
-        map_sites_wave<S, CLDS>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, mbuf, pf_young, L[h], pr[h], rc[h], nrm[h]);
+        double L, pr, nrm;
+        int rc;
+        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm);
+        if (h == 0) { prmin = pr; nmin = nrm; rcmin = rc; }
+        else { prmin = pr < prmin ? pr : prmin; nmin = nrm < nmin ? nrm : nmin; rcmin = rc < rcmin ? rc : rcmin; }
       }
       const double stat = pair_stat_lane(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + lane, cnt1 + lane);
       if (active) {
         a.null_stat[s] = stat;
-        if (a.null_rcmin) a.null_rcmin[s] = rc[0] < rc[1] ? rc[0] : rc[1];
-        if (a.null_prmin) a.null_prmin[s] = pr[0] < pr[1] ? pr[0] : pr[1];
-        if (a.null_nmin) a.null_nmin[s] = nrm[0] < nrm[1] ? nrm[0] : nrm[1];
+        if (a.null_rcmin) a.null_rcmin[s] = rcmin;
+        if (a.null_prmin) a.null_prmin[s] = prmin;
+        if (a.null_nmin) a.null_nmin[s] = nmin;
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last product left a matrix DMA in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last op left an operator DMA in flight
 }
 
-size_t map_lds_bytes(int S, int T, bool codes_in_lds) {
-  const size_t stage = (size_t)(((S / 4) * (S / 4) * 128 + 1023) / 1024) * 1024;
-  return (size_t)kWavesPerBlock * ((size_t)S * kWave * 8 + stage + (codes_in_lds ? (((size_t)T * kWave + 15) & ~(size_t)15) : 0));
+size_t map_lds_bytes(int S) {
+  return (size_t)kWavesPerBlock * (size_t)(S == 20 ? map_lds_per_wave<20>() : map_lds_per_wave<4>());
 }
 
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream) {
   dim3 grid(grid_blocks), block(kWave * kWavesPerBlock);
-  const size_t lds = map_lds_bytes(a.m.S, a.m.T, a.codes_in_lds != 0);
+  const size_t lds = map_lds_bytes(a.m.S);
   const int lim = 160 * 1024 / CMX_WAVES_PER_SIMD;  // dynamic LDS a workgroup may use (CMX_WAVES_PER_SIMD workgroups per CU)
-#define CMX_LAUNCH(S_, MODE_, CLDS_)                                                                          \
+  if ((int)lds > lim) return hipErrorInvalidValue;
+#define CMX_LAUNCH(S_, MODE_)                                                                                 \
   do {                                                                                                        \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<S_, MODE_, CLDS_>),                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<S_, MODE_>),                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim);                             \
       attr_set = true;                                                                                        \
     }                                                                                                         \
-    hipLaunchKernelGGL((map_kernel<S_, MODE_, CLDS_>), grid, block, lds, stream, a);                          \
+    hipLaunchKernelGGL((map_kernel<S_, MODE_>), grid, block, lds, stream, a);                                 \
   } while (0)
-  const bool cl = a.codes_in_lds != 0;
   if (a.m.S == 20) {
-    if (mode == kModeObserved) { if (cl) CMX_LAUNCH(20, kModeObserved, true); else CMX_LAUNCH(20, kModeObserved, false); }
-    else { if (cl) CMX_LAUNCH(20, kModeNull, true); else CMX_LAUNCH(20, kModeNull, false); }
+    if (mode == kModeObserved) CMX_LAUNCH(20, kModeObserved); else CMX_LAUNCH(20, kModeNull);
   } else if (a.m.S == 4) {
-    if (mode == kModeObserved) { if (cl) CMX_LAUNCH(4, kModeObserved, true); else CMX_LAUNCH(4, kModeObserved, false); }
-    else { if (cl) CMX_LAUNCH(4, kModeNull, true); else CMX_LAUNCH(4, kModeNull, false); }
+    if (mode == kModeObserved) CMX_LAUNCH(4, kModeObserved); else CMX_LAUNCH(4, kModeNull);
 #undef CMX_LAUNCH
   } else {
     return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// Rows S .. S+A-1 of every transposed leaf operator: sum of the rows of the states compatible with ambiguity id a
+// (what the DR likelihood's leaf initialisation does for B/Z/X/gap).  One thread per (class, leaf operator, a, x).
+__global__ void extend_leaf_rows_kernel(double* MAT, int C, int MC, int first_leaf, int nleaf, int S, int A, int unit,
+                                        const uint32_t* __restrict__ masks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)C * nleaf * A * S;
+  if (i >= total) return;
+  const int x = (int)(i % S);
+  const int a = (int)((i / S) % A);
+  const int l = (int)((i / ((size_t)S * A)) % nleaf);
+  const int c = (int)(i / ((size_t)S * A * nleaf));
+  double* M = MAT + ((size_t)c * MC + first_leaf + l) * unit;
+  const uint32_t mk = masks ? masks[S + a] : 0xffffffffu;
+  double v = 0.0;
+  for (int z = 0; z < S; ++z)
+    if ((mk >> z) & 1u) v += M[(size_t)z * S + x];
+  M[(size_t)(S + a) * S + x] = v;
+}
+
+hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, hipStream_t stream) {
+  const int A = max_ambig(m.S), nleaf = m.T + m.K * m.T;
+  const size_t total = (size_t)m.C * nleaf * A * m.S;
+  hipLaunchKernelGGL(extend_leaf_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, m.MAT, m.C, m.MC,
+                     m.NI + m.NI * m.K, nleaf, m.S, A, mat_unit(m.S), d_masks);
   return hipGetLastError();
 }
 

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Diagnostic builds of the library with parts of the mapping kernel removed (CMX_ABLATE, see cmx_kernels.hip):
+# timing only, results are wrong.  Usage: scripts/build_ablations.sh "1 2 3" -> build/abl/libcmx_abl<N>.so
+set -e
+cd "$(dirname "$0")/../comap_amd/csrc"
+mkdir -p ../../build/abl
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result"
+for n in ${1:-1 2 3 4 5 6}; do
+  /opt/rocm/bin/hipcc $FLAGS -DCMX_ABLATE=$n -shared cmx_kernels.hip -x hip cmx_api.cpp cmx_host_model.cpp -o ../../build/abl/libcmx_abl$n.so &
+done
+wait
+ls -la ../../build/abl
