@@ -130,20 +130,27 @@ __device__ __forceinline__ void wait_vm(int allowed) {
   }
 }
 
+// Tiles are read two ahead of their use: an LDS read takes ~100+ cycles, the 16 FMAs of a tile 64, and hipcc keeps
+// a ds_read right in front of the asm that consumes it unless the source orders them (the empty asm is a compiler
+// barrier for memory operations only; the s_waitcnt for a tile lands in front of its own FMAs, two tiles later).
 template <int S, bool TR, int T>
-__device__ __forceinline__ void stage_steps(const uint8_t* tile0 /* buffer + (lane & 15) * 8 */, const double (&x)[S],
-                                            double (&y)[S]) {
+__device__ __forceinline__ void stage_steps(const uint8_t* tile0 /* buffer + (lane & 15) * 8 */, double m0, double m1,
+                                            const double (&x)[S], double (&y)[S]) {
   constexpr int NB = S / 4, NT = NB * NB;
   if constexpr (T < NT) {
     constexpr int bi = T / NB, bj = T % NB;
-    const double mt = *reinterpret_cast<const double*>(tile0 + T * 128);
+    double m2 = 0.0;
+    if constexpr (T + 2 < NT) {
+      m2 = *reinterpret_cast<const double*>(tile0 + (T + 2) * 128);
+      asm volatile("" ::: "memory");
+    }
     if constexpr (!TR)
-      dpp_tile_f(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], mt, x[4 * bj], x[4 * bj + 1], x[4 * bj + 2],
+      dpp_tile_f(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], m0, x[4 * bj], x[4 * bj + 1], x[4 * bj + 2],
                  x[4 * bj + 3]);
     else
-      dpp_tile_t(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], mt, x[4 * bi], x[4 * bi + 1], x[4 * bi + 2],
+      dpp_tile_t(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], m0, x[4 * bi], x[4 * bi + 1], x[4 * bi + 2],
                  x[4 * bi + 3]);
-    stage_steps<S, TR, T + 1>(tile0, x, y);
+    stage_steps<S, TR, T + 1>(tile0, m1, m2, x, y);
   }
 }
 
@@ -156,9 +163,14 @@ __device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const
     for (int i = 0; i < S; ++i) y[i] = x[i] * 0.5;
     return;
   }
+  const uint8_t* tile0 = buf + (lane & 15) * 8;
+  const double m0 = *reinterpret_cast<const double*>(tile0);
+  double m1 = 0.0;
+  if constexpr ((S / 4) * (S / 4) > 1) m1 = *reinterpret_cast<const double*>(tile0 + 128);
+  asm volatile("" ::: "memory");
 #pragma unroll
   for (int i = 0; i < S; ++i) y[i] = 0.0;
-  stage_steps<S, TR, 0>(buf + (lane & 15) * 8, x, y);
+  stage_steps<S, TR, 0>(tile0, m0, m1, x, y);
 }
 
 // Message of a leaf edge from the transposed operator staged in buf ([z][x] = M[x][z], rows >= S: ambiguity ids):
@@ -474,24 +486,20 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       sload_rec(cm.nrec + idx * 32, r, r2);
       const int n = r[REC_N];
       if (r[REC_NCH] == 2) {
-        if (r[REC_FLAGS] & FLAG_Y_IN_REGS) {
-          CMX_MV(false, acc, t);
-#pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] = t[x];
-        } else {
-#pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] = 1.0;
-        }
-        // child X (never handed over in registers), then child Y unless it was
+        // child Y arrives in acc when it was the node finished last (its message goes to t), child X never does
+        const bool yreg = (r[REC_FLAGS] & FLAG_Y_IN_REGS) != 0;
+        if (yreg) CMX_MV(false, acc, t);
         if (r[REC_X + CH_KIND] == 0) {
-          CMX_LEAF_MUL(acc, acc);
+          if (yreg) CMX_LEAF_MUL(t, acc); else CMX_LEAF(acc);
         } else {
           CMX_GET_D(r, REC_X);
-          CMX_MV(false, d, t);
+          CMX_MV(false, d, acc);
+          if (yreg) {
 #pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] *= t[x];
+            for (int x = 0; x < S; ++x) acc[x] *= t[x];
+          }
         }
-        if (!(r[REC_FLAGS] & FLAG_Y_IN_REGS)) {
+        if (!yreg) {
           if (r2[REC_Y + CH_KIND] == 0) {
             CMX_LEAF_MUL(acc, acc);
           } else {  // inlined cherry (a stored Y is always handed over)
@@ -568,13 +576,14 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           CMX_LEAF_MUL(acc, t);                        // U_Y = Up_f o M_X
         } else {
           CMX_GET_D(r, REC_X);
-          for (int k = 0; k < K; ++k) {
+          for (int k = 0; k <= K; ++k) {               // K count operators, then P itself (one product site)
             CMX_MV(false, d, t);
-            double tot;
-            CMX_DOT(u, t, tot);
-            pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kWave] = pc * tot;
+            if (k < K) {
+              double tot;
+              CMX_DOT(u, t, tot);
+              pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kWave] = pc * tot;
+            }
           }
-          CMX_MV(false, d, t);
 #pragma unroll
           for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_Y
           CMX_MV(true, u, d);                          // Up_X
