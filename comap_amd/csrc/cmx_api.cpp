@@ -496,6 +496,79 @@ cmx_status cmx_null_intra(cmx_ctx* ctx, int kind, const double* params, uint64_t
   return CMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ inter-gene null
+// AnalysisTools::getNullDistributionInterDR (AnalysisTools.cpp:662-735): per replicate simulate + map rep_ram sites
+// under data set 1 and rep_ram sites under data set 2, then score site j of the one against site j of the other.
+// Not fused (a "next" row of SURVEY 8f): simulate -> map -> diagonal-pair kernel, everything resident in HBM.
+// Simulated-site indices follow the intra scheme: g = ((rep*2 + h)*rep_ram + j), h = 0 for ctx1 and 1 for ctx2.
+cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed,
+                              size_t rep_begin, size_t rep_end, size_t rep_ram, double* d_stat, int32_t* d_rcmin,
+                              double* d_prmin, double* d_nmin, void* stream) {
+  cmx_status s = need_model(ctx1);
+  if (s != CMX_OK) return s;
+  if (!ctx2 || !ctx2->has_model) return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: second context has no model");
+  if ((s = check_kind(ctx1, kind)) != CMX_OK) return s;
+  if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: bad arguments");
+  if (ctx1->device != ctx2->device) return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: contexts live on different devices");
+  if (ctx1->hm.B != ctx2->hm.B || ctx1->hm.K != ctx2->hm.K)
+    return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: the two data sets must have the same branches and substitution types "
+                                       "(Statistic::getValueForPair throws DimensionException otherwise)");
+  HIP_TRY(ctx1, hipSetDevice(ctx1->device));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nrep = rep_end - rep_begin, n = nrep * rep_ram;
+  const size_t BK = (size_t)ctx1->hm.B * ctx1->hm.K;
+  double *cnt[2], *pr[2], *nm[2];
+  int32_t* rc[2];
+  cmx_ctx* cx[2] = {ctx1, ctx2};
+  for (int h = 0; h < 2; ++h) {
+    cmx_ctx* c = cx[h];
+    const std::string tag = std::string("inter") + char('0' + h);
+    uint8_t *d_aln, *d_st;
+    int32_t* d_cls;
+    if ((s = scratch(ctx1, (tag + "_aln").c_str(), (size_t)c->hm.T * n, (void**)&d_aln)) != CMX_OK) return s;
+    if ((s = scratch(ctx1, (tag + "_st").c_str(), (size_t)c->hm.nn * rep_ram, (void**)&d_st)) != CMX_OK) return s;
+    if ((s = scratch(ctx1, (tag + "_cls").c_str(), sizeof(int32_t) * rep_ram, (void**)&d_cls)) != CMX_OK) return s;
+    if ((s = scratch(ctx1, (tag + "_cnt").c_str(), sizeof(double) * BK * n, (void**)&cnt[h])) != CMX_OK) return s;
+    if ((s = scratch(ctx1, (tag + "_pr").c_str(), sizeof(double) * n, (void**)&pr[h])) != CMX_OK) return s;
+    if ((s = scratch(ctx1, (tag + "_nm").c_str(), sizeof(double) * n, (void**)&nm[h])) != CMX_OK) return s;
+    if ((s = scratch(ctx1, (tag + "_rc").c_str(), sizeof(int32_t) * n, (void**)&rc[h])) != CMX_OK) return s;
+    for (size_t r = 0; r < nrep; ++r) {
+      const uint64_t g0 = ((uint64_t)(rep_begin + r) * 2 + h) * (uint64_t)rep_ram;
+      HIP_TRY(ctx1, launch_simulate(c->dm, seed, g0, rep_ram, d_aln + r * rep_ram, n, d_cls, d_st, st));
+    }
+    s = cmx_map_sites_dev(c, d_aln, n, n, nullptr, cnt[h], n, nullptr, pr[h], rc[h], nm[h], stream);
+    if (s != CMX_OK) { if (c != ctx1) ctx1->err = c->err; return s; }
+  }
+  const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  HIP_TRY(ctx1, launch_pair_diag(kind, param, ctx1->hm.B, ctx1->hm.K, cnt[0], n, cnt[1], n, n, rc[0], rc[1], pr[0], pr[1],
+                                 nm[0], nm[1], d_stat, d_rcmin, d_prmin, d_nmin, st));
+  return CMX_OK;
+}
+
+cmx_status cmx_null_inter(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed, size_t rep_begin,
+                          size_t rep_end, size_t rep_ram, double* stat, int32_t* rcmin, double* prmin, double* nmin) {
+  cmx_status s = need_model(ctx1);
+  if (s != CMX_OK) return s;
+  if (rep_end <= rep_begin || rep_ram == 0 || !stat) return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: bad arguments");
+  HIP_TRY(ctx1, hipSetDevice(ctx1->device));
+  const size_t n = (rep_end - rep_begin) * rep_ram;
+  TmpDev tmp;
+  double *d_stat, *d_pr, *d_nm;
+  int32_t* d_rc;
+  HIP_TRY(ctx1, tmp.alloc((void**)&d_stat, n * sizeof(double)));
+  HIP_TRY(ctx1, tmp.alloc((void**)&d_pr, n * sizeof(double)));
+  HIP_TRY(ctx1, tmp.alloc((void**)&d_nm, n * sizeof(double)));
+  HIP_TRY(ctx1, tmp.alloc((void**)&d_rc, n * sizeof(int32_t)));
+  s = cmx_null_inter_dev(ctx1, ctx2, kind, params, seed, rep_begin, rep_end, rep_ram, d_stat, d_rc, d_pr, d_nm, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx1, hipDeviceSynchronize());
+  HIP_TRY(ctx1, hipMemcpy(stat, d_stat, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (rcmin) HIP_TRY(ctx1, hipMemcpy(rcmin, d_rc, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (prmin) HIP_TRY(ctx1, hipMemcpy(prmin, d_pr, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (nmin) HIP_TRY(ctx1, hipMemcpy(nmin, d_nm, n * sizeof(double), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ p-values
 cmx_status cmx_intra_pvalues_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, const double* d_norms, size_t n,
                                  int nclasses, const double* d_null_stat, const double* d_null_nmin, size_t nnull,

@@ -90,6 +90,10 @@ size_t map_lds_bytes(int S);
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream);
 // fills rows S.. of every leaf operator from d_masks[S .. S+max_ambig(S)) (null: every state compatible)
 hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, hipStream_t stream);
+hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* c1, size_t ld1, const double* c2, size_t ld2,
+                            size_t n, const int32_t* rc1, const int32_t* rc2, const double* pr1, const double* pr2,
+                            const double* nm1, const double* nm2, double* stat, int32_t* rcmin, double* prmin, double* nmin,
+                            hipStream_t stream);
 hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
                            int32_t* d_classes, uint8_t* d_states /*[nn][ld]*/, hipStream_t stream);
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,

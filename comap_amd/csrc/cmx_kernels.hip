@@ -690,17 +690,17 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   norm_out = sqrt(nrm);
 }
 
-// per-lane statistic between two count columns (stride 64), CoMap/Statistics.h
-__device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, int K, const double* __restrict__ c1,
-                                                 const double* __restrict__ c2) {
+// per-lane statistic between two count columns (row strides ld1 / ld2), CoMap/Statistics.h
+__device__ __forceinline__ double pair_stat_strided(int kind, double param, int B, int K, const double* __restrict__ c1,
+                                                    size_t ld1, const double* __restrict__ c2, size_t ld2) {
   switch (kind) {
     case 0: case 4: {  // Correlation / Covariance: VectorTools::cor, two-pass on type 0
       double m1 = 0, m2 = 0;
-      for (int b = 0; b < B; ++b) { m1 += c1[(size_t)b * K * kWave]; m2 += c2[(size_t)b * K * kWave]; }
+      for (int b = 0; b < B; ++b) { m1 += c1[(size_t)b * K * ld1]; m2 += c2[(size_t)b * K * ld2]; }
       m1 /= B; m2 /= B;
       double sxy = 0, sxx = 0, syy = 0;
       for (int b = 0; b < B; ++b) {
-        const double dx = c1[(size_t)b * K * kWave] - m1, dy = c2[(size_t)b * K * kWave] - m2;
+        const double dx = c1[(size_t)b * K * ld1] - m1, dy = c2[(size_t)b * K * ld2] - m2;
         sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
       }
       const double cov = sxy / (B - 1);
@@ -710,7 +710,7 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
     case 3: {  // Cosinus
       double sxy = 0, sxx = 0, syy = 0;
       for (int b = 0; b < B; ++b) {
-        const double x = c1[(size_t)b * K * kWave], y = c2[(size_t)b * K * kWave];
+        const double x = c1[(size_t)b * K * ld1], y = c2[(size_t)b * K * ld2];
         sxy += x * y; sxx += x * x; syy += y * y;
       }
       return sxy / (sqrt(sxx) * sqrt(syy));
@@ -720,7 +720,7 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
       bool bad = false;
       for (int b = 0; b < B; ++b) {
         double t1 = 0, t2 = 0;
-        for (int k = 0; k < K; ++k) { t1 += c1[((size_t)b * K + k) * kWave]; t2 += c2[((size_t)b * K + k) * kWave]; }
+        for (int k = 0; k < K; ++k) { t1 += c1[((size_t)b * K + k) * ld1]; t2 += c2[((size_t)b * K + k) * ld2]; }
         s1 += t1 * t1; s2 += t2 * t2; s3 += (t1 + t2) * (t1 + t2);
         if (t1 >= 1.0 && t2 >= 1.0) cc += 1.0;
         if (!(t1 >= 0.0 && t1 < 10000.0) || !(t2 >= 0.0 && t2 < 10000.0)) bad = true;
@@ -741,6 +741,11 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
     }
   }
   return __builtin_nan("");
+}
+
+__device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, int K, const double* __restrict__ c1,
+                                                 const double* __restrict__ c2) {
+  return pair_stat_strided(kind, param, B, K, c1, (size_t)kWave, c2, (size_t)kWave);
 }
 
 #ifndef CMX_WAVES_PER_SIMD
@@ -892,6 +897,31 @@ hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, h
   const size_t total = (size_t)m.C * nleaf * A * m.S;
   hipLaunchKernelGGL(extend_leaf_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, m.MAT, m.C, m.MC,
                      m.NI + m.NI * m.K, nleaf, m.S, A, mat_unit(m.S), d_masks);
+  return hipGetLastError();
+}
+
+// statistic of the pairs (j of data set 1, j of data set 2), j < n, and the minima the null file carries
+// (AnalysisTools.cpp:728-732): counts are branch-major [B*K][ld]
+__global__ void pair_diag_kernel(int kind, double param, int B, int K, const double* __restrict__ c1, size_t ld1,
+                                 const double* __restrict__ c2, size_t ld2, size_t n, const int32_t* __restrict__ rc1,
+                                 const int32_t* __restrict__ rc2, const double* __restrict__ pr1,
+                                 const double* __restrict__ pr2, const double* __restrict__ nm1,
+                                 const double* __restrict__ nm2, double* __restrict__ stat, int32_t* __restrict__ rcmin,
+                                 double* __restrict__ prmin, double* __restrict__ nmin) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  stat[j] = pair_stat_strided(kind, param, B, K, c1 + j, ld1, c2 + j, ld2);
+  if (rcmin) rcmin[j] = rc1[j] < rc2[j] ? rc1[j] : rc2[j];
+  if (prmin) prmin[j] = pr1[j] < pr2[j] ? pr1[j] : pr2[j];
+  if (nmin) nmin[j] = nm1[j] < nm2[j] ? nm1[j] : nm2[j];
+}
+
+hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* c1, size_t ld1, const double* c2, size_t ld2,
+                            size_t n, const int32_t* rc1, const int32_t* rc2, const double* pr1, const double* pr2,
+                            const double* nm1, const double* nm2, double* stat, int32_t* rcmin, double* prmin, double* nmin,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(pair_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, param, B, K, c1, ld1,
+                     c2, ld2, n, rc1, rc2, pr1, pr2, nm1, nm2, stat, rcmin, prmin, nmin);
   return hipGetLastError();
 }
 

@@ -24,7 +24,8 @@ COUNT_EXPECTED, COUNT_NAIVE = 0, 1
 EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
     "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_traversal", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate",
-    "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_intra_pvalues",
+    "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
+    "cmx_null_inter_dev", "cmx_intra_pvalues",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev",
 ]
 
@@ -223,6 +224,17 @@ class Engine:
                                              _vp(nmin)))
         return dict(stat=stat, rcmin=rcmin, prmin=prmin, nmin=nmin)
 
+    def null_inter(self, other, kind, seed, rep_begin, rep_end, rep_ram, threshold=0.99):
+        """AnalysisTools::getNullDistributionInterDR: self = data set 1, other = data set 2 (same branches)."""
+        n = (rep_end - rep_begin) * rep_ram
+        stat, prmin, nmin = np.zeros(n), np.zeros(n), np.zeros(n)
+        rcmin = np.zeros(n, dtype=np.int32)
+        params = _f64([threshold])
+        self._check(self._lib.cmx_null_inter(self._ctx, other._ctx, int(kind), _vp(params), ctypes.c_uint64(seed),
+                                             _sz(rep_begin), _sz(rep_end), _sz(rep_ram), _vp(stat), _vp(rcmin),
+                                             _vp(prmin), _vp(nmin)))
+        return dict(stat=stat, rcmin=rcmin, prmin=prmin, nmin=nmin)
+
     def intra_pvalues(self, stat, norms, nclasses, null_stat, null_nmin):
         stat, norms, ns, nm = _f64(stat), _f64(norms), _f64(null_stat), _f64(null_nmin)
         n = len(norms)
@@ -267,6 +279,13 @@ class Engine:
         self._check(self._lib.cmx_null_intra_dev(self._ctx, int(kind), _vp(params), ctypes.c_uint64(seed),
                                                  _sz(rep_begin), _sz(rep_end), _sz(rep_ram), _vp(supplied), _vp(stat),
                                                  _vp(rcmin), _vp(prmin), _vp(nmin), self._stream()))
+
+    def null_inter_dev(self, other, kind, seed, rep_begin, rep_end, rep_ram, stat, rcmin=None, prmin=None, nmin=None,
+                       threshold=0.99):
+        params = _f64([threshold])
+        self._check(self._lib.cmx_null_inter_dev(self._ctx, other._ctx, int(kind), _vp(params), ctypes.c_uint64(seed),
+                                                 _sz(rep_begin), _sz(rep_end), _sz(rep_ram), _vp(stat), _vp(rcmin),
+                                                 _vp(prmin), _vp(nmin), self._stream()))
 
     def intra_pvalues_dev(self, stat, norms, nclasses, null_stat, null_nmin, pvalue, nsim):
         n = norms.shape[0]

@@ -138,6 +138,17 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
                               size_t rep_end, size_t rep_ram, const uint8_t* d_supplied, double* d_stat,
                               int32_t* d_rcmin, double* d_prmin, double* d_nmin, void* stream);
 
+/* Inter-gene null: AnalysisTools::getNullDistributionInterDR (CoMap/AnalysisTools.cpp:662-735, driver
+ * CoETools::computeInterNullDistribution CoETools.cpp:873-897).  Per replicate rep_ram sites are simulated and mapped
+ * under ctx1 (data set 1) and under ctx2 (data set 2, its own model / branch lengths, same branches) and site j of
+ * the one is scored against site j of the other; outputs are the four columns of the null file
+ * (Stat, RCmin, PRmin, Nmin), [(rep_end - rep_begin) * rep_ram].  Both contexts must live on the same device. */
+cmx_status cmx_null_inter(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed, size_t rep_begin,
+                          size_t rep_end, size_t rep_ram, double* stat, int32_t* rcmin, double* prmin, double* nmin);
+cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed,
+                              size_t rep_begin, size_t rep_end, size_t rep_ram, double* d_stat, int32_t* d_rcmin,
+                              double* d_prmin, double* d_nmin, void* stream);
+
 /* ---- p-values of CoETools::computeIntraStats (CoETools.cpp:636-652, 695-721): null stats are binned by
  * Domain(0, max(norms), nclasses) on nmin (out-of-range and NaN dropped), sorted per class;
  * p = (nsim - #{null < stat} + 1)/(nsim + 1).  pvalue = NaN / nsim = 0 where the reference prints "NA\t0". */

@@ -29,6 +29,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <ostream>
 #include <vector>
 
 #include "comap_mi355x.h"
@@ -282,6 +283,19 @@ class AnalysisTools {
       }
     }
   }
+  // AnalysisTools.cpp:662-735: eng1 / eng2 hold the two data sets (own model and branch lengths, same branches);
+  // rows = the lines of statistics.null.txt (Stat, RCmin, PRmin, Nmin).
+  static void getNullDistributionInterDR(const Engine& eng1, const Engine& eng2, const Statistic& statistic,
+                                         uint64_t seed, size_t repCPU, size_t repRAM,
+                                         std::vector<NullDistributionRow>* rows, size_t repBegin = 0) {
+    const size_t n = repCPU * repRAM;
+    Vdouble stat(n), pr(n), nm(n);
+    std::vector<int32_t> rc(n);
+    eng1.check(cmx_null_inter(eng1.ctx(), eng2.ctx(), statistic.kind(), statistic.params(), seed, repBegin,
+                              repBegin + repCPU, repRAM, stat.data(), rc.data(), pr.data(), nm.data()));
+    if (rows)
+      for (size_t q = 0; q < n; ++q) rows->push_back({stat[q], rc[q], pr[q], nm[q]});
+  }
 };
 
 // ------------------------------------------------------------------------------------------------ CoETools
@@ -361,7 +375,89 @@ class CoETools {
     }
     return rows;
   }
+
+  // CoETools.cpp:732-832 (no p-values there: the reference leaves them to computePValues.R).  Nmin is
+  // min(norm1[i], norm2[j]); the reference reads norms2[i] at :803, which is not reproduced.
+  static std::vector<IntraStatRow> computeInterStats(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping1,
+                                                     const ProbabilisticSubstitutionMapping& mapping2,
+                                                     const Statistic& statistic, bool independentComparisons = false,
+                                                     const PairFilters& f1 = PairFilters(),
+                                                     const PairFilters& f2 = PairFilters()) {
+    const size_t n1 = mapping1.getNumberOfSites(), n2 = mapping2.getNumberOfSites();
+    if (independentComparisons && n1 != n2)
+      throw Exception("When performing independant comparisons, the two datasets must have the same length.");
+    const Vdouble norms1 = AnalysisTools::computeNorms(mapping1), norms2 = AnalysisTools::computeNorms(mapping2);
+    const Vdouble stat = statistic.getValuesForAllPairs(eng, mapping1, mapping2);
+    std::vector<IntraStatRow> rows;
+    for (size_t i = 0; i < n1; i++) {
+      const int iClass = mapping1.rateClasses[i];
+      const double iRate = mapping1.posteriorRates[i];
+      if (iClass < f1.minRateClass || iRate < f1.minRate) continue;
+      const size_t begin = independentComparisons ? i : 0, end = independentComparisons ? i + 1 : n2;
+      for (size_t j = begin; j < end; j++) {
+        const int jClass = mapping2.rateClasses[j];
+        const double jRate = mapping2.posteriorRates[j];
+        if (jClass < f2.minRateClass || jRate < f2.minRate) continue;
+        if (f1.maxRateClassDiff >= 0 && std::abs(jClass - iClass) > f1.maxRateClassDiff) continue;
+        if (f1.maxRateDiff >= 0. && std::fabs(jRate - iRate) > f1.maxRateDiff) continue;
+        const double s = stat[i * n2 + j];
+        if (std::fabs(s) < f1.minStatistic) continue;
+        IntraStatRow r;
+        r.i = i; r.j = j; r.stat = s;
+        r.rcMin = std::min(iClass, jClass);
+        r.prMin = std::min(iRate, jRate);
+        r.nMin = std::min(norms1[i], norms2[j]);
+        r.pValue = std::numeric_limits<double>::quiet_NaN();
+        r.nSim = 0;
+        rows.push_back(r);
+      }
+    }
+    return rows;
+  }
 };
+
+// ------------------------------------------------------------------------------------------------ text outputs
+// The files either side of the path, written with default ostream formatting exactly as the reference does.
+namespace io {
+// LegacySubstitutionMappingTools::writeToStream as called at CoETools.cpp:408-412 (format: one row per branch)
+inline void writeToStream(const ProbabilisticSubstitutionMapping& mapping, const Vdouble& branchLengths,
+                          const std::vector<int>& coordinates, size_t type, std::ostream& out) {
+  if (coordinates.size() != mapping.getNumberOfSites())
+    throw DimensionException("writeToStream: site coordinates.", coordinates.size(), mapping.getNumberOfSites());
+  if (branchLengths.size() < mapping.getNumberOfBranches())
+    throw DimensionException("writeToStream: branch lengths.", branchLengths.size(), mapping.getNumberOfBranches());
+  out << "Branches" << "\t" << "Mean";
+  for (int c : coordinates) out << "\tSite" << c;
+  out << std::endl;
+  for (size_t b = 0; b < mapping.getNumberOfBranches(); ++b) {
+    out << b << "\t" << branchLengths[b];
+    for (size_t i = 0; i < mapping.getNumberOfSites(); ++i) out << "\t" << mapping(b, i, type);
+    out << std::endl;
+  }
+}
+// statistics.txt rows of CoETools.cpp:698-722
+inline void writeIntraStats(const std::vector<IntraStatRow>& rows, const std::vector<int>& coordinates, bool withNull,
+                            std::ostream& out, const std::vector<int>* coordinates2 = nullptr) {
+  out << "Group\tStat\tRCmin\tPRmin\tNmin";
+  if (withNull) out << "\tPValue\tNsim";
+  out << std::endl;
+  const std::vector<int>& c2 = coordinates2 ? *coordinates2 : coordinates;
+  for (const IntraStatRow& r : rows) {
+    out << "[" << coordinates[r.i] << ";" << c2[r.j] << "]\t" << r.stat << "\t" << r.rcMin << "\t" << r.prMin << "\t"
+        << r.nMin;
+    if (withNull) {
+      if (std::isnan(r.pValue)) out << "\tNA\t0";
+      else out << "\t" << r.pValue << "\t" << r.nSim;
+    }
+    out << std::endl;
+  }
+}
+// statistics.null.txt: AnalysisTools.cpp:580, 642 (inter: :680, 732)
+inline void writeNull(const std::vector<NullDistributionRow>& rows, std::ostream& out) {
+  out << "Stat\tRCmin\tPRmin\tNmin" << std::endl;
+  for (const NullDistributionRow& r : rows) out << r.stat << "\t" << r.rcMin << "\t" << r.prMin << "\t" << r.nMin << std::endl;
+}
+}  // namespace io
 
 }  // namespace cmx
 #endif  // COMAP_MI355X_ADAPTER_HPP

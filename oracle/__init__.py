@@ -136,6 +136,26 @@ def pair_stats_inter(kind, c1, c2, params=None):
     return out
 
 
+def null_inter(m1, m2, kind, seed, rep_begin, rep_end, repRAM, params=None):
+    """AnalysisTools::getNullDistributionInterDR (CoMap/AnalysisTools.cpp:662-735) composed from the oracle's pieces:
+    per replicate simulate + map repRAM sites under each data set, score site j against site j.  Simulated-site indices
+    as in orc_null_intra: g = ((rep*2 + h)*repRAM + j), h = 0 for data set 1 and 1 for data set 2."""
+    stat, rcmin, prmin, nmin = [], [], [], []
+    for rep in range(rep_begin, rep_end):
+        res = []
+        for h, m in enumerate((m1, m2)):
+            aln, _ = simulate(m, seed, (rep * 2 + h) * repRAM, repRAM)
+            res.append(map_sites(m, aln))
+        a, b = res
+        for j in range(repRAM):
+            stat.append(stat_pair(kind, a["counts"][j], b["counts"][j], params))
+        rcmin.append(np.minimum(a["rate_class"], b["rate_class"]))
+        prmin.append(np.minimum(a["post_rate"], b["post_rate"]))
+        nmin.append(np.minimum(a["norm"], b["norm"]))
+    return dict(stat=np.array(stat), rcmin=np.concatenate(rcmin).astype(np.int32), prmin=np.concatenate(prmin),
+                nmin=np.concatenate(nmin))
+
+
 def null_intra(m, kind, seed, rep_begin, rep_end, repRAM, supplied=None, params=None):
     n = (rep_end - rep_begin) * repRAM
     stat, prmin, nmin = np.zeros(n), np.zeros(n), np.zeros(n)

@@ -1,6 +1,8 @@
 // Test driver for include/comap_mi355x_adapter.hpp (the C++ mirror of the reference's interface).
 //   adapter_main domain <lo> <hi> <n> <x>...         -> prints getIndex(x) or -1 per x (host logic only, no GPU)
 //   adapter_main run <input.bin> <output.bin>        -> getVectors + computeIntraStats with null on the GPU
+//   adapter_main vec <input.bin>                     -> cmx::io::writeToStream of a mapping to stdout (host only);
+//      input.bin: int32 N, B; int32 coords[N]; f64 blen[B]; f64 counts[N*B] (site-major)
 // input.bin (little endian): int32 nn, T, S, C, N, repCPU, repRAM, nclasses; uint64 seed;
 //   int32 parent[nn]; f64 blen[nn]; int32 lot[T]; f64 Q[S*S], pi[S], rates[C], probs[C]; uint8 aln[T*N]
 // output.bin: int64 nrows; per row: int64 i, j; f64 stat, prMin, nMin, pValue; int32 rcMin, nSim;
@@ -64,6 +66,21 @@ int main(int argc, char** argv) {
       wr(out, mapping->data(), static_cast<size_t>(N) * eng.getNumberOfBranches());
       cmx::Vdouble norms = cmx::AnalysisTools::computeNorms(*mapping);
       wr(out, norms.data(), norms.size());
+      return 0;
+    }
+    if (argc == 3 && std::strcmp(argv[1], "vec") == 0) {
+      std::ifstream in(argv[2], std::ios::binary);
+      int32_t h[2];
+      rd(in, h, 2);
+      const size_t N = h[0], B = h[1];
+      std::vector<int> coords(N);
+      cmx::Vdouble bl(B);
+      rd(in, coords.data(), N); rd(in, bl.data(), B);
+      cmx::ProbabilisticSubstitutionMapping mapping(N, B, 1);
+      rd(in, mapping.data(), N * B);
+      cmx::io::writeToStream(mapping, bl, coords, 0, std::cout);
+      std::vector<cmx::NullDistributionRow> nul = {{0.5, 1, 0.25, 3.5}, {-1e-7, 0, 2., 0.125}};
+      cmx::io::writeNull(nul, std::cerr);
       return 0;
     }
     std::cerr << "usage: adapter_main domain lo hi n x... | run in.bin out.bin\n";

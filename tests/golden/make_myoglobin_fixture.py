@@ -106,6 +106,11 @@ def main():
             ll.append(float(f[5]))
     assert np.array_equal(np.array(cs), coords)
     out.update(infos_rc=np.array(rc, dtype=np.int32), infos_pr=np.array(pr), infos_logl=np.array(ll))
+    # the first lines of the committed text outputs, verbatim (DATA): pin the .vec / .infos writers' formatting
+    with open(f"{bench}/Myo_unif.vec") as fh:
+        out["vec_unif_text_head"] = np.array("".join([fh.readline() for _ in range(4)]))
+    with open(f"{bench}/Myo.infos") as fh:
+        out["infos_text_head"] = np.array("".join([fh.readline() for _ in range(6)]))
     np.savez_compressed(os.path.join(HERE, "myoglobin.npz"), **out)
     print("sites", len(keep), "taxa", T, "nodes", len(parent), "->", os.path.join(HERE, "myoglobin.npz"))
 

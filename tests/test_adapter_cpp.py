@@ -51,6 +51,19 @@ def test_errors_surface_as_exceptions(adapter_exe, tmp_path):
     assert r.returncode == 1 and "nstates" in r.stderr
 
 
+def test_cpp_vec_writer_reproduces_reference_text(adapter_exe, tmp_path, myo):
+    """cmx::io::writeToStream (the C++ side of SURVEY 8f row 1) against the first lines of the reference's Myo_unif.vec"""
+    counts = np.ascontiguousarray(myo["vec_unif"].T)       # [N, B] site-major
+    inp = tmp_path / "vec.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<2i", counts.shape[0], counts.shape[1]))
+        f.write(myo["coords"].astype(np.int32).tobytes() + myo["vec_blen"].astype(np.float64).tobytes())
+        f.write(counts.astype(np.float64).tobytes())
+    r = subprocess.run([adapter_exe, "vec", str(inp)], capture_output=True, text=True, check=True)
+    assert r.stdout.startswith(str(myo["vec_unif_text_head"]))
+    assert r.stderr == "Stat\tRCmin\tPRmin\tNmin\n0.5\t1\t0.25\t3.5\n-1e-07\t0\t2\t0.125\n"
+
+
 @pytest.mark.gpu
 def test_reference_call_sequence_matches_oracle(adapter_exe, tmp_path):
     case = make_case(9, 70, 20, 61)

@@ -161,6 +161,43 @@ def test_null_intra_supplied_and_simulated_match_oracle():
         rel_close(gs["stat"], os_["stat"], 1e-6, 1e-12)
 
 
+def test_null_inter_two_data_sets_match_oracle():
+    """getNullDistributionInterDR (AnalysisTools.cpp:662-735): same tree topology, different branch lengths and rate
+    distributions for the two data sets."""
+    c1 = make_case(10, 8, 20, 61)
+    c2 = dict(c1)
+    rng = np.random.default_rng(3)
+    c2["blen"] = c1["blen"] * rng.uniform(0.5, 1.5, size=len(c1["blen"]))
+    mdl2 = synthetic.protein_model(0.9, 3)
+    c2.update(rates=mdl2["rates"], probs=mdl2["probs"])
+    e1, e2, o1, o2 = _engine(c1), _engine(c2), _omodel(c1), _omodel(c2)
+    nrep, rep_ram = 2, 70
+    for kind in (0, 1):
+        g = e1.null_inter(e2, kind, 4242, 1, 1 + nrep, rep_ram)
+        o = oracle.null_inter(o1, o2, kind, 4242, 1, 1 + nrep, rep_ram)
+        rel_close(g["stat"], o["stat"], 1e-6, 1e-12)
+        rel_close(g["prmin"], o["prmin"], 1e-9)
+        rel_close(g["nmin"], o["nmin"], 1e-6)
+        assert np.array_equal(g["rcmin"], o["rcmin"])
+
+
+def test_map_sites_dna_iupac_ambiguity_rows():
+    """ambiguity ids are extra rows of the leaf operators: 11 IUPAC codes + gap for nucleotides"""
+    case = make_case(9, 130, 4, 71)
+    masks = np.array([1, 2, 4, 8, 5, 10, 6, 9, 12, 3, 14, 13, 11, 7, 15, 15], dtype=np.uint32)   # A C G T R Y S W K M B D H V N -
+    aln = case["aln"].copy()
+    rng = np.random.default_rng(5)
+    hit = rng.random(aln.shape) < 0.15
+    aln[hit] = rng.integers(4, 16, size=int(hit.sum()), dtype=np.uint8)
+    r = _engine(case).map_sites(aln, masks=masks)
+    _check_map(r, oracle.map_sites(_omodel(case), aln, masks))
+    # a second call without a table falls back to "every code >= S is fully ambiguous"
+    r0 = _engine(case).map_sites(np.where(aln >= 4, 14, aln).astype(np.uint8))
+    _check_map(r0, oracle.map_sites(_omodel(case), np.where(aln >= 4, 14, aln).astype(np.uint8)))
+    with pytest.raises(engine.CmxError):     # more ambiguity ids than the operators carry rows for
+        _engine(case).map_sites(aln, masks=np.concatenate([masks, [15]]).astype(np.uint32))
+
+
 def test_pvalues_bit_exact_counts_and_na_rule():
     case = make_case(10, 90, 20, 51)
     eng, om = _engine(case), _omodel(case)
