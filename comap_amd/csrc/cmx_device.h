@@ -109,8 +109,16 @@ hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norm
                           int32_t* d_nsim, hipStream_t stream);
 hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in, double* d_stat_tmp, uint32_t* d_cls_in,
                               uint32_t* d_cls_tmp, size_t n, hipStream_t stream);
+// scratch of the MFMA Mica path (all device pointers; H1 null = LDS-table kernel only)
+struct MicaWork {
+  _Float16 *H1, *H2;       // one-hot [n][32][Tp] f16
+  uint8_t *flag1, *flag2;  // [n] column has ambiguous symbols
+  double *S1, *S2;         // [n] sum_a f(count_a)
+  double* ftab;            // [T + 1] c ln c
+  int Tp;                  // T rounded up to a multiple of 16
+};
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
-                             size_t ldo, double* d_h1, double* d_h2, hipStream_t stream);
+                             size_t ldo, double* d_h1, double* d_h2, const MicaWork* work, hipStream_t stream);
 
 }  // namespace cmx

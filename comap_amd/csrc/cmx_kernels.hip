@@ -1233,7 +1233,15 @@ __global__ __launch_bounds__(64) void mi_columns_kernel(int T, const uint32_t* _
                                                         const uint8_t* __restrict__ aln1, size_t n1, size_t ld1,
                                                         const uint8_t* __restrict__ aln2, size_t n2, size_t ld2,
                                                         int intra, double* __restrict__ mi, double* __restrict__ hj,
-                                                        size_t ldo) {
+                                                        size_t ldo, const uint8_t* __restrict__ flag1,
+                                                        const uint8_t* __restrict__ flag2) {
+  // with flags (MFMA path active) this kernel only serves pairs that involve a column with ambiguous symbols
+  if (flag1) {
+    const size_t j0 = (size_t)blockIdx.x * 16;
+    bool any = flag1[blockIdx.y] != 0;
+    for (size_t q = j0; !any && q < j0 + 16 && q < n2; ++q) any = flag2[q] != 0;
+    if (!any) return;
+  }
   // LDS: joint table [A*A][16 lanes] fp64 per quarter-wave = A*A*16*8 B (51 KB for A = 20): 16 pairs per block pass
   extern __shared__ double tab[];
   const int lane = threadIdx.x;
@@ -1282,11 +1290,119 @@ __global__ __launch_bounds__(64) void mi_columns_kernel(int T, const uint32_t* _
           h -= pab * log(pab);
         }
       }
-    if (j < n2) {
+    if (j < n2 && (!flag1 || flag1[i] || flag2[j])) {
       mi[i * ldo + j] = valid ? s : __builtin_nan("");
       hj[i * ldo + j] = valid ? h : __builtin_nan("");
     }
   }
+}
+
+// ---- MFMA path (SURVEY 8d "Mica MI"): for columns without ambiguous symbols the joint table of a column pair is one
+// 32x32 block of the Gram matrix of one-hot matrices, H_i (32 x T) . H_j^T, exact in f16 x f16 -> f32.  With integer
+// counts c the entropies need no logarithm at run time: sum_ab p_ab ln p_ab = (1/T) sum_ab f(c_ab) - ln T with
+// f(c) = c ln c read from a (T+1)-entry table, so MI = ln T + (sum_ab f(c_ab) - sum_a f(c_a) - sum_b f(c_b)) / T and
+// the epilogue is a layout-free sum over the accumulator registers.
+typedef _Float16 cmx_h8 __attribute__((ext_vector_type(8)));
+typedef float cmx_f16v __attribute__((ext_vector_type(16)));
+
+// one block per column: one-hot rows H[col][a][t] (a < 32, t < Tp, zero padded), flag = column has a code >= A,
+// S[col] = sum_a f(count_a)
+__global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, const uint8_t* __restrict__ aln, size_t ld,
+                                                          _Float16* __restrict__ H, uint8_t* __restrict__ flag,
+                                                          double* __restrict__ S) {
+  __shared__ int cnt[32];
+  __shared__ int amb;
+  const size_t i = blockIdx.x;
+  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) amb = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+    const unsigned c = t < T ? aln[(size_t)t * ld + i] : 255u;
+    if (t < T) {
+      if (c < (unsigned)A) atomicAdd(&cnt[c], 1);
+      else amb = 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 32; ++a) H[(i * 32 + a) * (size_t)Tp + t] = (_Float16)((c == (unsigned)a) ? 1.0f : 0.0f);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int a = 0; a < A; ++a)
+      if (cnt[a] > 1) s += (double)cnt[a] * log((double)cnt[a]);
+    S[i] = s;
+    flag[i] = (uint8_t)amb;
+  }
+}
+
+__global__ void mica_ftable_kernel(int T, double* __restrict__ f) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c <= T) f[c] = c > 1 ? (double)c * log((double)c) : 0.0;
+}
+
+// one wave per TI x TJ tile of column pairs; operands straight from L2 (16 bytes per lane and operand and k-step)
+template <int TI, int TJ>
+__global__ __launch_bounds__(64) void mica_mfma_kernel(int T, int Tp, const _Float16* __restrict__ H1, size_t n1,
+                                                       const uint8_t* __restrict__ flag1, const double* __restrict__ S1,
+                                                       const _Float16* __restrict__ H2, size_t n2,
+                                                       const uint8_t* __restrict__ flag2, const double* __restrict__ S2,
+                                                       const double* __restrict__ ftab_g, int intra,
+                                                       double* __restrict__ mi, double* __restrict__ hj, size_t ldo) {
+  extern __shared__ double ftab[];
+  const int lane = threadIdx.x;
+  for (int c = lane; c <= T; c += 64) ftab[c] = ftab_g[c];
+  __syncthreads();
+  const size_t i0 = (size_t)blockIdx.y * TI, j0 = (size_t)blockIdx.x * TJ;
+  if (intra && j0 + TJ <= i0 + 1) {     // no pair with j > i in this tile: only the NaN convention of the intra layout
+    const size_t i = i0 + lane / TJ, j = j0 + lane % TJ;
+    if (lane < TI * TJ && i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
+      mi[i * ldo + j] = __builtin_nan("");
+      hj[i * ldo + j] = __builtin_nan("");
+    }
+    return;
+  }
+  const int r = lane & 31, g = lane >> 5;
+  const _Float16* pa[TI];
+  const _Float16* pb[TJ];
+#pragma unroll
+  for (int ii = 0; ii < TI; ++ii) pa[ii] = H1 + (((i0 + ii < n1 ? i0 + ii : n1 - 1) * 32 + r) * (size_t)Tp + 8 * g);
+#pragma unroll
+  for (int jj = 0; jj < TJ; ++jj) pb[jj] = H2 + (((j0 + jj < n2 ? j0 + jj : n2 - 1) * 32 + r) * (size_t)Tp + 8 * g);
+  cmx_f16v acc[TI][TJ];
+#pragma unroll
+  for (int ii = 0; ii < TI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[ii][jj][v] = 0.0f;
+  for (int ks = 0; ks < Tp; ks += 16) {
+    cmx_h8 a[TI], b[TJ];
+#pragma unroll
+    for (int ii = 0; ii < TI; ++ii) a[ii] = *reinterpret_cast<const cmx_h8*>(pa[ii] + ks);
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) b[jj] = *reinterpret_cast<const cmx_h8*>(pb[jj] + ks);
+#pragma unroll
+    for (int ii = 0; ii < TI; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < TJ; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
+  }
+  const double lnT = log((double)T), invT = 1.0 / (double)T;
+#pragma unroll
+  for (int ii = 0; ii < TI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) {
+      double s = 0.0;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) s += ftab[(int)acc[ii][jj][v]];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      const size_t i = i0 + ii, j = j0 + jj;
+      if (lane == 0 && i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
+        const bool valid = !intra || j > i;
+        mi[i * ldo + j] = valid ? lnT + (s - S1[i] - S2[j]) * invT : __builtin_nan("");
+        hj[i * ldo + j] = valid ? lnT - s * invT : __builtin_nan("");
+      }
+    }
 }
 
 template <int A>
@@ -1314,17 +1430,34 @@ __global__ void column_entropy_kernel(int T, const uint32_t* __restrict__ masks,
 
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
-                             size_t ldo, double* d_h1, double* d_h2, hipStream_t stream) {
+                             size_t ldo, double* d_h1, double* d_h2, const MicaWork* work, hipStream_t stream) {
   dim3 grid((unsigned)((n2 + 15) / 16), (unsigned)n1);
   const size_t lds = sizeof(double) * A * A * 16;
+  // MFMA path for the columns without ambiguous symbols (work->H1 etc. non-null); the LDS kernel then only serves
+  // the pairs that involve an ambiguous column.
+  const uint8_t *f1 = nullptr, *f2 = nullptr;
+  if (work && work->H1) {
+    const int Tp = work->Tp;
+    hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)(T / 256 + 1)), dim3(256), 0, stream, T, work->ftab);
+    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_aln1, ld1, work->H1, work->flag1, work->S1);
+    if (!intra)
+      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_aln2, ld2, work->H2, work->flag2, work->S2);
+    constexpr int TI = 4, TJ = 4;
+    dim3 g2((unsigned)((n2 + TJ - 1) / TJ), (unsigned)((n1 + TI - 1) / TI));
+    hipLaunchKernelGGL((mica_mfma_kernel<TI, TJ>), g2, dim3(64), sizeof(double) * (size_t)(T + 1), stream, T, Tp, work->H1, n1,
+                       work->flag1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
+                       intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
+    f1 = work->flag1;
+    f2 = intra ? work->flag1 : work->flag2;
+  }
   if (A == 20) {
     hipLaunchKernelGGL((mi_columns_kernel<20>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, n1, ld1, d_aln2, n2,
-                       ld2, intra, d_mi, d_hj, ldo);
+                       ld2, intra, d_mi, d_hj, ldo, f1, f2);
     if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
     if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
   } else if (A == 4) {
     hipLaunchKernelGGL((mi_columns_kernel<4>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, n1, ld1, d_aln2, n2,
-                       ld2, intra, d_mi, d_hj, ldo);
+                       ld2, intra, d_mi, d_hj, ldo, f1, f2);
     if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
     if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
   } else {

@@ -218,6 +218,47 @@ def test_pvalues_bit_exact_counts_and_na_rule():
     assert (ns0 == 0).all() and np.all(pv0[iu] == 1.0)                   # (0 - 0 + 1)/(0 + 1)
 
 
+@pytest.mark.parametrize("A,T,n1,n2", [(20, 40, 37, 21), (20, 256, 9, 70), (4, 33, 18, 18)])
+def test_mi_columns_mfma_path_resolved_and_mixed_columns(A, T, n1, n2):
+    """fully resolved columns go through the one-hot MFMA Gram, columns with ambiguous symbols through the LDS-table
+    kernel; tile overhangs (n % 4 != 0) and T % 16 != 0 are exercised"""
+    rng = np.random.default_rng(A * 1000 + T)
+    a1 = rng.integers(0, A, size=(T, n1)).astype(np.uint8)
+    a2 = rng.integers(0, max(2, A // 3), size=(T, n2)).astype(np.uint8)
+    a2[:, 0] = a2[0, 0]                                   # a constant column: H = 0, MI = 0
+    a1[rng.integers(0, T, 3), rng.integers(0, n1, 3)] = A + 1    # three columns of a1 become ambiguous
+    eng = engine.Engine()
+    g = eng.mi_columns(a1, a2, A)
+    o = oracle.mi_columns(a1, a2, A)
+    rel_close(g["mi"], o["mi"], 1e-6, 1e-12)
+    rel_close(g["hjoint"], o["hjoint"], 1e-6, 1e-12)
+    rel_close(g["h1"], o["h1"], 1e-9, 1e-12)
+    gi = eng.mi_columns(a2, None, A)
+    oi = oracle.mi_columns(a2, a2, A)
+    iu = np.triu_indices(n2, 1)
+    rel_close(gi["mi"][iu], oi["mi"][iu], 1e-6, 1e-12)
+    assert np.isnan(gi["mi"][np.tril_indices(n2)]).all()
+
+
+def test_mi_columns_configuration5_shape_identities():
+    """BASELINE configs[4] shape (T = 256 taxa, protein), reduced column counts; size-independent properties:
+    MI = H1 + H2 - Hjoint with the entropies of the independent column kernel, MI >= 0, MI(i, i') symmetric"""
+    rng = np.random.default_rng(20260103)
+    T, n1, n2 = 256, 600, 500
+    base = rng.integers(0, 20, size=(T, 1))
+    a1 = np.where(rng.random((T, n1)) < 0.7, base, rng.integers(0, 20, size=(T, n1))).astype(np.uint8)
+    a2 = np.where(rng.random((T, n2)) < 0.5, base, rng.integers(0, 20, size=(T, n2))).astype(np.uint8)
+    eng = engine.Engine()
+    g = eng.mi_columns(a1, a2, 20)
+    ident = g["h1"][:, None] + g["h2"][None, :] - g["hjoint"]
+    assert np.max(np.abs(g["mi"] - ident)) < 1e-11
+    assert g["mi"].min() > -1e-12
+    gt = eng.mi_columns(a2, a1, 20)
+    assert np.max(np.abs(gt["mi"] - g["mi"].T)) < 1e-12
+    sub = oracle.mi_columns(a1[:, :8], a2[:, :8], 20)
+    rel_close(g["mi"][:8, :8], sub["mi"], 1e-6, 1e-12)
+
+
 def test_mi_columns_matches_oracle_with_ambiguity():
     rng = np.random.default_rng(3)
     T, n1, n2 = 40, 37, 21
