@@ -182,7 +182,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
     // per-wave workspaces: 1 wave per SIMD on every CU for the null; a quarter of that for observed alignments
-    ctx->grid_blocks = ctx->cu_count * CMX_WAVES_PER_SIMD;   // 4-wave workgroups, CMX_WAVES_PER_SIMD per CU
+    ctx->grid_blocks = ctx->cu_count * map_waves_per_simd(h.S);   // 4-wave workgroups, that many per CU
     ctx->waves = ctx->grid_blocks * kWavesPerBlock;
     ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
     auto alloc_ws = [&](Workspace* ws, size_t w, size_t* bytes) -> cmx_status {

@@ -14,8 +14,12 @@ constexpr int kWavesPerBlock = 4;   // mapping kernels: 4 independent waves per 
 constexpr int max_ambig(int S) { return S == 4 ? 12 : 4; }
 constexpr int mat_unit(int S) { return (S + max_ambig(S)) * S; }   // doubles per device matrix
 #ifndef CMX_WAVES_PER_SIMD
-#define CMX_WAVES_PER_SIMD 2       // resident mapping waves per SIMD (1: 512-register budget, 2: 256)
+#define CMX_WAVES_PER_SIMD 2       // resident mapping waves per SIMD for 20 states (1: 512-register budget, 2: 256)
 #endif
+#ifndef CMX_WAVES_PER_SIMD_S4
+#define CMX_WAVES_PER_SIMD_S4 3    // nucleotide vectors are 8 registers: the kernel is latency-bound, more waves help
+#endif
+constexpr int map_waves_per_simd(int S) { return S == 4 ? CMX_WAVES_PER_SIMD_S4 : CMX_WAVES_PER_SIMD; }
 
 // Device-resident model + tree program.  All pointers are device pointers.
 struct DevModel {

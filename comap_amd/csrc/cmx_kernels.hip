@@ -327,7 +327,20 @@ struct ConstModel {
 // code issued and knows about (DMA rows, vector stores); an asynchronous transfer remembers vs right after its issue,
 // and "wait for X" is s_waitcnt vmcnt(vs - X_seq): VMEM completes in order, so the instructions issued after X may stay
 // in flight.  Instructions that are not counted only make the wait stricter.
+// CMX_TIMING builds (scripts/build_ablations.sh "t"): wave 0 accumulates s_memtime deltas per phase and prints them
+#ifdef CMX_TIMING
+#define CMX_TIC() const long long tic_ = (long long)__builtin_readcyclecounter()
+#define CMX_TOC(slot) os.tm[slot] += (long long)__builtin_readcyclecounter() - tic_; os.tn[slot] += 1
+#else
+#define CMX_TIC() do {} while (0)
+#define CMX_TOC(slot) do {} while (0)
+#endif
+enum { TM_OPWAIT = 0, TM_POPWAIT = 1, TM_MV = 2, TM_LEAF = 3, TM_SLOAD = 4, TM_STORE = 5, TM_PASS = 6, TM_SIM = 7, TM_N = 8 };
 struct OpState {
+#ifdef CMX_TIMING
+  long long tm[TM_N];
+  long long tn[TM_N];
+#endif
   unsigned par;      // stage buffer / code slot of the current op
   unsigned vs;       // counted VMEM instructions issued so far
   unsigned cur_seq;  // vs right after the current op's operator (and symbols) were requested
@@ -342,7 +355,7 @@ struct OpState {
 #define CMX_POP(dst)                                                        \
   do {                                                                      \
     if (pend) {                                                             \
-      wait_vm<S>((int)(os.vs - pf_seq));                                    \
+      { CMX_TIC(); wait_vm<S>((int)(os.vs - pf_seq)); CMX_TOC(TM_POPWAIT); } \
       read_vec_lds<S>(pfl, lane, dst);                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
     } else {                                                                \
@@ -363,7 +376,7 @@ struct OpState {
   } while (0)
 #define CMX_STORE(ptr, v)     \
   do {                        \
-    store_vec<S>(ptr, v);     \
+    { CMX_TIC(); store_vec<S>(ptr, v); CMX_TOC(TM_STORE); } \
     os.vs += S / 2;           \
   } while (0)
 
@@ -402,14 +415,14 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   const bool more_ = (mi + 1 < m.nmv);                                                                   \
   const int cn_ = more_ ? c : ((c + 1 < C) ? c + 1 : 0);                                                 \
   int emat_, etx_;                                                                                       \
-  sload_i32x2(cm.msched + 2 * (more_ ? mi + 1 : 0), emat_, etx_); /* lgkmcnt(0): the other buffer is read */ \
+  { CMX_TIC(); sload_i32x2(cm.msched + 2 * (more_ ? mi + 1 : 0), emat_, etx_); CMX_TOC(TM_SLOAD); } /* lgkmcnt(0): the other buffer is read */ \
   mat_dma<S>(m.MAT + ((size_t)cn_ * m.MC + (size_t)emat_) * MatStage<S>::UNIT, stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane); \
   unsigned issued_ = MatStage<S>::ROWS;                                                                  \
   if (etx_ >= 0 && (more_ || c + 1 < C)) {                                                               \
     code_dma(gcodes + (size_t)etx_ * gstride, cslot + (os.par ^ 1u) * kCodeSlotBytes);                   \
     issued_ += 1;                                                                                        \
   }                                                                                                      \
-  if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S>((int)(os.vs - os.cur_seq + issued_));                                  \
+  { CMX_TIC(); if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S>((int)(os.vs - os.cur_seq + issued_)); CMX_TOC(TM_OPWAIT); } \
   os.vs += issued_;                                                                                      \
   const unsigned nseq_ = os.vs;                                                                          \
   const uint8_t* buf_ = stage + os.par * MatStage<S>::BYTES
@@ -420,15 +433,18 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #define CMX_MV(TR, in, out)                     \
   do {                                          \
     CMX_OP_BEGIN();                             \
-    matvec_stage<S, TR>(buf_, lane, in, out);   \
+    { CMX_TIC(); matvec_stage<S, TR>(buf_, lane, in, out); asm volatile("" :: "v"(out[0]), "v"(out[S - 1])); CMX_TOC(TM_MV); } \
     CMX_OP_END();                               \
   } while (0)
 // leaf edge the op stream names (P or P o N^k of a taxon, transposed): out = message, out = message o in, tot = <in, message>
 #define CMX_LEAF_OP(MODE_, in, out, tot)                                                     \
   do {                                                                                       \
     CMX_OP_BEGIN();                                                                          \
+    CMX_TIC();                                                                               \
     const unsigned code_ = *(cslot + os.par * kCodeSlotBytes + 4 * lane);                    \
     tot = leaf_apply<S, MODE_>(buf_, code_, in, out);                               \
+    asm volatile("" :: "v"(tot), "v"(out[0]), "v"(out[S - 1]));                              \
+    CMX_TOC(TM_LEAF);                                                                        \
     CMX_OP_END();                                                                            \
   } while (0)
 #define CMX_LEAF(out)          do { double z_; CMX_LEAF_OP(LEAF_SET, out, out, z_); (void)z_; } while (0)
@@ -444,6 +460,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     _Pragma("unroll") for (int i_ = 0; i_ < S; ++i_) out = __builtin_fma(x_[i_], y_[i_], out); \
   } while (0)
   for (int c = 0; c < C; ++c) {
+    CMX_TIC();
     const double pc = cm.probs[c];
     double* pcnt = part + (size_t)c * m.B * K * kWave + lane;
     double d[S], t[S];  // popped vector / matvec result
@@ -657,6 +674,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       CMX_KILL(t);
       CMX_KILL(u);
     }
+    CMX_TOC(TM_PASS);
   }
 #undef CMX_GET_D
 #undef CMX_CHERRY_COUNTS
@@ -748,14 +766,11 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
   return pair_stat_strided(kind, param, B, K, c1, (size_t)kWave, c2, (size_t)kWave);
 }
 
-#ifndef CMX_WAVES_PER_SIMD
-#define CMX_WAVES_PER_SIMD 2
-#endif
 template <int S>
 constexpr int map_lds_per_wave() { return S * kWave * 8 + 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }
 
 template <int S, int MODE>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void map_kernel(const MapArgs a) {
+__global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void map_kernel(const MapArgs a) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
   const int lane = threadIdx.x & (kWave - 1);
@@ -771,6 +786,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void ma
   const size_t nblocks = (a.nsites + kWave - 1) / kWave;
   // request the first op's operator (class 0, entry 0); every op then requests the next one
   OpState os;
+#ifdef CMX_TIMING
+  for (int q = 0; q < TM_N; ++q) { os.tm[q] = 0; os.tn[q] = 0; }
+  const long long tk0_ = (long long)__builtin_readcyclecounter();
+#endif
   os.par = 0;
   {
     int mat0, tx0;
@@ -841,6 +860,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, CMX_WAVES_PER_SIMD) void ma
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last op left an operator DMA in flight
+#ifdef CMX_TIMING
+  if (MODE == kModeNull && lane == 0 && (wave == 0 || wave == 777)) {
+    const long long tot_ = (long long)__builtin_readcyclecounter() - tk0_;
+    printf("wave %d total %lld | opwait %lld/%lld popwait %lld/%lld mv %lld/%lld leaf %lld/%lld sload %lld/%lld store %lld/%lld pass %lld/%lld\n",
+           wave, tot_, os.tm[0], os.tn[0], os.tm[1], os.tn[1], os.tm[2], os.tn[2], os.tm[3], os.tn[3], os.tm[4], os.tn[4],
+           os.tm[5], os.tn[5], os.tm[6], os.tn[6]);
+  }
+#endif
 }
 
 size_t map_lds_bytes(int S) {
@@ -850,7 +877,7 @@ size_t map_lds_bytes(int S) {
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream) {
   dim3 grid(grid_blocks), block(kWave * kWavesPerBlock);
   const size_t lds = map_lds_bytes(a.m.S);
-  const int lim = 160 * 1024 / CMX_WAVES_PER_SIMD;  // dynamic LDS a workgroup may use (CMX_WAVES_PER_SIMD workgroups per CU)
+  const int lim = 160 * 1024 / map_waves_per_simd(a.m.S);  // dynamic LDS a workgroup may use (that many workgroups per CU)
   if ((int)lds > lim) return hipErrorInvalidValue;
 #define CMX_LAUNCH(S_, MODE_)                                                                                 \
   do {                                                                                                        \
