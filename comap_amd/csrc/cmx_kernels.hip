@@ -6,16 +6,18 @@
 //   Replaces, per site: DRHomogeneousTreeLikelihood::initialize (post-order "inside" pass), the pre-order
 //   "outside" pass, LegacySubstitutionMappingTools::computeSubstitutionVectors and computeNormForSite
 //   (call sites CoMap/CoETools.cpp:397, CoMap/AnalysisTools.cpp:592-612; algorithm SURVEY.md A.2/A.3/A.6).
-//   The SxS operators of an edge are the same for all 64 lanes, so they are streamed through the SCALAR path
-//   (s_load_dwordx16 ping-pong into SGPRs, v_fma_f64 with an SGPR operand): no LDS or VGPR traffic for the
-//   matrix, 400 fp64 FMAs per 20x20 product.  Matrices are packed host-side in 4x4 blocks so that one copy serves
-//   both P.d (inside) and P^T.u (outside) with four independent accumulation chains per 16-value tile.
-//   Inside vectors of internal nodes are spilled to a per-wave HBM workspace in [state][lane] order, i.e. every
-//   access is one 512-byte fully coalesced row.
+//   The SxS operator of an edge is the same for all 64 lanes: every operator use of a class pass (products on
+//   internal edges, row gathers by observed symbol on leaf edges) is listed by the host in one op stream and staged
+//   in LDS by LDS-DMA one op ahead; products apply 4x4 tiles with DPP-broadcast fp64 FMAs (400 per 20x20 product).
+//   Matrices are packed host-side in 4x4 blocks so that one copy serves both P.d (inside) and P^T.u (outside).
+//   Inside vectors / outside messages that must survive go to a per-wave HBM workspace as [S/2][lane][2]: every
+//   access is one fully coalesced 1 KiB row; loads are prefetched into LDS by DMA under a host-built schedule.
+//   DESIGN.md 4.1 has the full description and the measurements.
 //   MODE == kModeNull fuses simulate -> map (x2 batches) -> per-pair statistic of
 //   AnalysisTools::getNullDistributionIntraDR (CoMap/AnalysisTools.cpp:587-653).
 // pair_gram_kernel: all-pairs statistic as X.X^T on v_mfma_f64_16x16x4_f64 with per-statistic epilogues
 //   (CoMap/Statistics.h:164-329; loops CoMap/CoETools.cpp:672-692, 786-810).
+// mica_mfma_kernel: column mutual information as a one-hot Gram on v_mfma_f32_32x32x16_f16 (CoMap/Mica.cpp:349-361).
 #include <algorithm>
 #include <cstring>
 #include <hip/hip_runtime.h>
