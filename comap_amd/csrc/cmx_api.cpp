@@ -290,7 +290,19 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   }
   a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.norm = d_norm;
-  const size_t blocks_needed = ((nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
+  const size_t nblocks = (nsites + kWave - 1) / kWave;
+  const size_t obs_waves = (size_t)ctx->obs_blocks * kWavesPerBlock;
+  if (nblocks * (size_t)ctx->hm.C <= obs_waves && ctx->hm.C > 1) {
+    // small alignment: one (site block, class) per wave, classes summed by a second kernel (same arithmetic order)
+    const size_t ntasks = nblocks * (size_t)ctx->hm.C, BK = (size_t)ctx->hm.B * ctx->hm.K;
+    if ((s = scratch(ctx, "split_part", sizeof(double) * ntasks * BK * kWave, (void**)&a.split_part)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "split_lc", sizeof(double) * 2 * ntasks * kWave, (void**)&a.split_lc)) != CMX_OK) return s;
+    const int grid = (int)((ntasks + kWavesPerBlock - 1) / kWavesPerBlock);
+    HIP_TRY(ctx, launch_map(a, kModeObservedSplit, grid, (hipStream_t)stream));
+    HIP_TRY(ctx, launch_map_finalize(a, (hipStream_t)stream));
+    return CMX_OK;
+  }
+  const size_t blocks_needed = (nblocks + kWavesPerBlock - 1) / kWavesPerBlock;
   const int grid = (int)std::min<size_t>(blocks_needed, (size_t)ctx->obs_blocks);
   HIP_TRY(ctx, launch_map(a, kModeObserved, grid, (hipStream_t)stream));
   return CMX_OK;

@@ -62,7 +62,9 @@ struct Workspace {
   int waves;
 };
 
-enum MapMode { kModeObserved = 0, kModeNull = 1 };
+// kModeObservedSplit: one (site block, rate class) per wave-task for small alignments (an alignment of 2 000 sites is
+// 32 site blocks: one task per wave would be four class passes of pure latency), classes summed by map_finalize_kernel
+enum MapMode { kModeObserved = 0, kModeNull = 1, kModeObservedSplit = 2 };
 
 struct MapArgs {
   DevModel m;
@@ -77,6 +79,9 @@ struct MapArgs {
   double* post_rate;
   int32_t* rate_class;
   double* norm;
+  // class-split observed mode: [nblocks][C][B*K][64] per-class counts, [2][nblocks][C][64] p_c L_c and r_c p_c L_c
+  double* split_part;
+  double* split_lc;
   // null mode
   int stat_kind;
   double stat_param;       // discrete-MI threshold
@@ -92,6 +97,7 @@ struct MapArgs {
 // launchers (cmx_kernels.hip)
 size_t map_lds_bytes(int S);
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream);
+hipError_t launch_map_finalize(const MapArgs& a, hipStream_t stream);
 // fills rows S.. of every leaf operator from d_masks[S .. S+max_ambig(S)) (null: every state compatible)
 hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, hipStream_t stream);
 hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* c1, size_t ld1, const double* c2, size_t ld2,

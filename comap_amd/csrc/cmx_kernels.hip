@@ -383,7 +383,10 @@ struct OpState {
   } while (0)
 
 // Maps the 64 sites of this wave (symbol of taxon t at gcodes[t * gstride], per lane) for all rate classes.
-// On return cnt[(b*K+k)*64 + lane] holds the final counts n(b, site, k) and the scalars are per lane.
+// Classes [c_begin, c_end) are processed; c_after is the class of the first pass that follows this call (its first
+// operator is requested by the last op here).  With finalize, on return cnt[(b*K+k)*64 + lane] holds the final counts
+// n(b, site, k) and the scalars are per lane; without (class-split observed mode) only part[] and L_out = sum of
+// p_c L_c over the processed classes are produced.
 // part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
 // The loop nest below is mirrored statement for statement by build_load_schedule() / verify_traversal() in
 // cmx_host_model.cpp: the op stream decides WHICH operator every CMX_MV / CMX_LEAF applies.
@@ -392,7 +395,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
                                                double* __restrict__ part, double* __restrict__ cnt, int lds_off,
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
                                                OpState& os, double& L_out, double& pr_out, int& rc_out,
-                                               double& norm_out) {
+                                               double& norm_out, int c_begin, int c_end, int c_after, bool finalize) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
   uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, S*64*8 bytes
@@ -415,12 +418,12 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 // class / next site block -- into the other buffer, then wait for this op's operator.
 #define CMX_OP_BEGIN()                                                                                   \
   const bool more_ = (mi + 1 < m.nmv);                                                                   \
-  const int cn_ = more_ ? c : ((c + 1 < C) ? c + 1 : 0);                                                 \
+  const int cn_ = more_ ? c : ((c + 1 < c_end) ? c + 1 : c_after);                                        \
   int emat_, etx_;                                                                                       \
   { CMX_TIC(); sload_i32x2(cm.msched + 2 * (more_ ? mi + 1 : 0), emat_, etx_); CMX_TOC(TM_SLOAD); } /* lgkmcnt(0): the other buffer is read */ \
   mat_dma<S>(m.MAT + ((size_t)cn_ * m.MC + (size_t)emat_) * MatStage<S>::UNIT, stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane); \
   unsigned issued_ = MatStage<S>::ROWS;                                                                  \
-  if (etx_ >= 0 && (more_ || c + 1 < C)) {                                                               \
+  if (etx_ >= 0 && (more_ || c + 1 < c_end)) {                                                           \
     code_dma(gcodes + (size_t)etx_ * gstride, cslot + (os.par ^ 1u) * kCodeSlotBytes);                   \
     issued_ += 1;                                                                                        \
   }                                                                                                      \
@@ -461,7 +464,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     out = 0.0;                                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < S; ++i_) out = __builtin_fma(x_[i_], y_[i_], out); \
   } while (0)
-  for (int c = 0; c < C; ++c) {
+  for (int c = c_begin; c < c_end; ++c) {
     CMX_TIC();
     const double pc = cm.probs[c];
     double* pcnt = part + (size_t)c * m.B * K * kWave + lane;
@@ -690,19 +693,41 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #undef CMX_STORE
 #undef CMX_DOT
 #undef CMX_KILL
+  if (!finalize) {
+    L_out = Lsum;
+    pr_out = prsum;
+    rc_out = bestc;
+    norm_out = 0.0;
+    return;
+  }
   // ---------------- sum the classes in class order, divide by the site likelihood, norm (computeNormForSite)
-  double nrm = 0.0;
-  for (int b = 0; b < m.B; ++b) {
-    double tot = 0.0;
-    for (int k = 0; k < K; ++k) {
-      const double* pp = part + ((size_t)b * K + k) * kWave + lane;
-      double v = 0.0;
-      for (int c = 0; c < C; ++c) v += pp[(size_t)c * m.B * K * kWave];
-      v /= Lsum;
-      cnt[((size_t)b * K + k) * kWave + lane] = v;
-      tot += v;
+  // Rows r = b*K + k are taken eight at a time so that eight independent loads are in flight per class; the sums run
+  // in the same order as a plain (b, k, c) loop nest.
+  double nrm = 0.0, tot = 0.0;
+  const int BK = m.B * K;
+  int kk = 0;  // r % K
+  for (int r0 = 0; r0 < BK; r0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const double* pp = part + ((size_t)c * BK + r0) * kWave + lane;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] += pp[(size_t)(r0 + u < BK ? u : 0) * kWave];
     }
-    nrm = __builtin_fma(tot, tot, nrm);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (r0 + u < BK) {
+        const double q = v[u] / Lsum;
+        cnt[(size_t)(r0 + u) * kWave + lane] = q;
+        tot += q;
+        if (++kk == K) {
+          nrm = __builtin_fma(tot, tot, nrm);
+          tot = 0.0;
+          kk = 0;
+        }
+      }
+    }
   }
   L_out = Lsum;
   pr_out = prsum / Lsum;
@@ -796,10 +821,28 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   {
     int mat0, tx0;
     sload_i32x2(cm.msched, mat0, tx0);
-    mat_dma<S>(m.MAT + (size_t)mat0 * MatStage<S>::UNIT, cmx_smem + lds_off + S * kWave * 8, lane);
+    const int c0 = (MODE == kModeObservedSplit) ? wave % m.C : 0;   // class of this wave's first pass
+    mat_dma<S>(m.MAT + ((size_t)c0 * m.MC + (size_t)mat0) * MatStage<S>::UNIT, cmx_smem + lds_off + S * kWave * 8, lane);
   }
   os.vs = MatStage<S>::ROWS;
   os.cur_seq = os.vs;
+  if (MODE == kModeObservedSplit) {
+    const size_t ntasks = nblocks * (size_t)m.C, BK = (size_t)m.B * m.K;
+    for (size_t task = wave; task < ntasks; task += nwaves) {
+      const size_t sb = task / m.C;
+      const int c = (int)(task % m.C);
+      const size_t site = sb * kWave + lane;
+      const size_t s = site < a.nsites ? site : a.nsites - 1;
+      double L, pr, nrm;
+      int rc;
+      map_sites_wave<S>(a, wsD, wsU, a.split_part + sb * m.C * BK * kWave, nullptr, lds_off, a.aln + s, a.ld, lane, os, L, pr,
+                        rc, nrm, c, c + 1, (int)((task + nwaves) % m.C), false);
+      a.split_lc[task * kWave + lane] = L;
+      a.split_lc[(ntasks + task) * kWave + lane] = pr;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   for (size_t sb = wave; sb < nblocks; sb += nwaves) {
     const size_t site = sb * kWave + lane;
     const bool active = site < a.nsites;
@@ -807,7 +850,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
     if (MODE == kModeObserved) {
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm);
+      map_sites_wave<S>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
@@ -830,25 +873,30 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
           gstride = a.rep_ram;
         } else {
           const size_t rep = a.rep_begin + rep_local;
-          uint8_t* st = a.ws.st + (size_t)wave * m.nn * kWave + lane;
           uint8_t* al = a.ws.aln + (size_t)wave * m.T * kWave + lane;
           gbase = al;
           gstride = kWave;
           const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
           const int c = draw_index(philox_uniform(a.seed, g, 0), cm.cum_probs, m.C);
-          st[(size_t)m.root * kWave] = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S);
+          // states of the nodes: in the (idle) workspace prefetch buffer when nn * 64 bytes fit, else in HBM
+          const bool st_lds = m.nn * kWave <= S * kWave * 8;
+          uint8_t* stl = cmx_smem + lds_off + lane;
+          uint8_t* stg = a.ws.st + (size_t)wave * m.nn * kWave + lane;
+          const uint8_t x0 = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S);
+          if (st_lds) stl[(size_t)m.root * kWave] = x0; else stg[(size_t)m.root * kWave] = x0;
           for (int node = m.nn - 2; node >= 0; --node) {
-            const int x = st[(size_t)cm.parent[node] * kWave];
+            const int pn = cm.parent[node];
+            const int x = st_lds ? stl[(size_t)pn * kWave] : stg[(size_t)pn * kWave];
             const double u = philox_uniform(a.seed, g, 2u + (uint32_t)node);
             const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S + x) * S, S);
-            st[(size_t)node * kWave] = (uint8_t)y;
+            if (st_lds) stl[(size_t)node * kWave] = (uint8_t)y; else stg[(size_t)node * kWave] = (uint8_t)y;
             const int tx = cm.taxon_of[node];
             if (tx >= 0) al[(size_t)tx * kWave] = (uint8_t)y;
           }
         }
         double L, pr, nrm;
         int rc;
-        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm);
+        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
         if (h == 0) { prmin = pr; nmin = nrm; rcmin = rc; }
         else { prmin = pr < prmin ? pr : prmin; nmin = nrm < nmin ? nrm : nmin; rcmin = rc < rcmin ? rc : rcmin; }
       }
@@ -892,13 +940,57 @@ hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t s
     hipLaunchKernelGGL((map_kernel<S_, MODE_>), grid, block, lds, stream, a);                                 \
   } while (0)
   if (a.m.S == 20) {
-    if (mode == kModeObserved) CMX_LAUNCH(20, kModeObserved); else CMX_LAUNCH(20, kModeNull);
+    if (mode == kModeObserved) CMX_LAUNCH(20, kModeObserved);
+    else if (mode == kModeObservedSplit) CMX_LAUNCH(20, kModeObservedSplit);
+    else CMX_LAUNCH(20, kModeNull);
   } else if (a.m.S == 4) {
-    if (mode == kModeObserved) CMX_LAUNCH(4, kModeObserved); else CMX_LAUNCH(4, kModeNull);
+    if (mode == kModeObserved) CMX_LAUNCH(4, kModeObserved);
+    else if (mode == kModeObservedSplit) CMX_LAUNCH(4, kModeObservedSplit);
+    else CMX_LAUNCH(4, kModeNull);
 #undef CMX_LAUNCH
   } else {
     return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// class-split observed mode: sums the per-class results in class order exactly as map_sites_wave's own epilogue does
+__global__ void map_finalize_kernel(const MapArgs a) {
+  const DevModel& m = a.m;
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.nsites) return;
+  const size_t sb = s / kWave, lane = s % kWave, BK = (size_t)m.B * m.K;
+  const size_t nblocks = (a.nsites + kWave - 1) / kWave, ntasks = nblocks * (size_t)m.C;
+  double Lsum = 0.0, prsum = 0.0, best = -1.0;
+  int bestc = 0;
+  for (int c = 0; c < m.C; ++c) {
+    const double v = a.split_lc[(sb * m.C + c) * kWave + lane];
+    Lsum += v;
+    prsum += a.split_lc[(ntasks + sb * m.C + c) * kWave + lane];
+    if (v > best) { best = v; bestc = c; }
+  }
+  const double* part = a.split_part + sb * m.C * BK * kWave + lane;
+  double nrm = 0.0;
+  for (int b = 0; b < m.B; ++b) {
+    double tot = 0.0;
+    for (int k = 0; k < m.K; ++k) {
+      const size_t r = (size_t)b * m.K + k;
+      double v = 0.0;
+      for (int c = 0; c < m.C; ++c) v += part[((size_t)c * BK + r) * kWave];
+      v /= Lsum;
+      if (a.counts) a.counts[r * a.ldc + s] = v;
+      tot += v;
+    }
+    nrm = __builtin_fma(tot, tot, nrm);
+  }
+  if (a.logL) a.logL[s] = log(Lsum);
+  if (a.post_rate) a.post_rate[s] = prsum / Lsum;
+  if (a.rate_class) a.rate_class[s] = bestc;
+  if (a.norm) a.norm[s] = sqrt(nrm);
+}
+
+hipError_t launch_map_finalize(const MapArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(map_finalize_kernel, dim3((unsigned)((a.nsites + 63) / 64)), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -50,6 +50,14 @@ def test_map_sites_protein_ragged_sizes(nsites):
     _check_map(r, oracle.map_sites(_omodel(case), case["aln"]))
 
 
+def test_map_sites_large_alignment_takes_the_fused_class_loop():
+    """below 512 (site block, class) tasks the observed mapping runs one class per wave-task + a finalize kernel; a
+    9 000-site alignment exercises the other path (all classes in one wave), same results required"""
+    case = make_case(7, 9000, 20, 77)
+    r = _engine(case).map_sites(case["aln"])
+    _check_map(r, oracle.map_sites(_omodel(case), case["aln"]))
+
+
 def test_map_sites_dna_five_classes_multifurcating_root():
     case = make_case(33, 300, 4, 7, alpha=0.8, ncat=5)
     r = _engine(case).map_sites(case["aln"])
