@@ -115,13 +115,19 @@ __device__ __forceinline__ void code_dma(const uint8_t* p, uint8_t* slot) {
 template <int S>
 __device__ __forceinline__ void wait_vm(int allowed) {
   if constexpr (S >= 16) {
-    if (allowed >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (allowed >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else if (allowed >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (allowed >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (allowed >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (allowed >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // most frequent first: nothing but the next operator's DMA (4 or 5 instructions) was issued since
+    if (allowed < 8) {
+      if (allowed >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (allowed < 14) {
+      if (allowed >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (allowed < 24) {
+      asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    }
   } else {
     if (allowed >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (allowed >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
