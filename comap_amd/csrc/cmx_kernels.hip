@@ -349,6 +349,7 @@ struct OpState {
   long long tm[TM_N];
   long long tn[TM_N];
 #endif
+  int pre_mat, pre_tx;  // op-stream entry of the NEXT op, loaded one op early (its latency hides behind the current op)
   unsigned par;      // stage buffer / code slot of the current op
   unsigned vs;       // counted VMEM instructions issued so far
   unsigned cur_seq;  // vs right after the current op's operator (and symbols) were requested
@@ -425,13 +426,20 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #define CMX_OP_BEGIN()                                                                                   \
   const bool more_ = (mi + 1 < m.nmv);                                                                   \
   const int cn_ = more_ ? c : ((c + 1 < c_end) ? c + 1 : c_after);                                        \
-  int emat_, etx_;                                                                                       \
-  { CMX_TIC(); sload_i32x2(cm.msched + 2 * (more_ ? mi + 1 : 0), emat_, etx_); CMX_TOC(TM_SLOAD); } /* lgkmcnt(0): the other buffer is read */ \
+  const int emat_ = os.pre_mat, etx_ = os.pre_tx;                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the LDS reads of the other buffer are done */    \
   mat_dma<S>(m.MAT + ((size_t)cn_ * m.MC + (size_t)emat_) * MatStage<S>::UNIT, stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane); \
   unsigned issued_ = MatStage<S>::ROWS;                                                                  \
   if (etx_ >= 0 && (more_ || c + 1 < c_end)) {                                                           \
     code_dma(gcodes + (size_t)etx_ * gstride, cslot + (os.par ^ 1u) * kCodeSlotBytes);                   \
     issued_ += 1;                                                                                        \
+  }                                                                                                      \
+  {                                                                                                      \
+    int i2_ = mi + 2;                                                                                    \
+    if (i2_ >= m.nmv) i2_ -= m.nmv;                                                                      \
+    if (i2_ >= m.nmv) i2_ = 0;                                                                           \
+    os.pre_mat = cm.msched[2 * i2_];                                                                     \
+    os.pre_tx = cm.msched[2 * i2_ + 1];                                                                  \
   }                                                                                                      \
   { CMX_TIC(); if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S>((int)(os.vs - os.cur_seq + issued_)); CMX_TOC(TM_OPWAIT); } \
   os.vs += issued_;                                                                                      \
@@ -832,6 +840,11 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   }
   os.vs = MatStage<S>::ROWS;
   os.cur_seq = os.vs;
+  {
+    const int i1 = m.nmv > 1 ? 1 : 0;
+    os.pre_mat = cm.msched[2 * i1];
+    os.pre_tx = cm.msched[2 * i1 + 1];
+  }
   if (MODE == kModeObservedSplit) {
     const size_t ntasks = nblocks * (size_t)m.C, BK = (size_t)m.B * m.K;
     for (size_t task = wave; task < ntasks; task += nwaves) {
