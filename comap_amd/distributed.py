@@ -24,11 +24,14 @@ def gather_null(local_stat, local_nmin, nrep, rep_ram, group=None):
     world = dist.get_world_size(group)
     sizes = [(e - b) * rep_ram for b, e in (replicate_shard(r, world, nrep) for r in range(world))]
     mx = max(sizes)
-    send = torch.full((2, mx), float("nan"), dtype=torch.float64, device=local_stat.device)
+    # RCCL moves device memory; gloo (CPU tests, one-GPU rehearsals) wants host tensors
+    dev = local_stat.device
+    xdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+    send = torch.full((2, mx), float("nan"), dtype=torch.float64, device=xdev)
     send[0, : local_stat.numel()] = local_stat
     send[1, : local_nmin.numel()] = local_nmin
-    recv = torch.empty((world, 2, mx), dtype=torch.float64, device=local_stat.device)
+    recv = torch.empty((world, 2, mx), dtype=torch.float64, device=xdev)
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
-    stat = torch.cat([recv[r, 0, : sizes[r]] for r in range(world)])
-    nmin = torch.cat([recv[r, 1, : sizes[r]] for r in range(world)])
+    stat = torch.cat([recv[r, 0, : sizes[r]] for r in range(world)]).to(dev)
+    nmin = torch.cat([recv[r, 1, : sizes[r]] for r in range(world)]).to(dev)
     return stat, nmin
