@@ -158,7 +158,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     if (!ctx->has_model) return CMX_OK;
     const HostModel& h = ctx->hm;
     DevModel& d = ctx->dm;
-    d.S = h.S; d.C = h.C; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.NV = h.NV; d.root = h.root;
+    d.S = h.dS; d.C = h.dC; d.S0 = h.S; d.C0 = h.C; d.fuse = h.fuse; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.NV = h.NV; d.root = h.root;
 #define UP(field) if ((s = upload(ctx, h.field, &d.field)) != CMX_OK) return s
     UP(int_post); UP(first_child); UP(next_sib); UP(taxon_of); UP(slot); UP(parent);
     {
@@ -182,13 +182,13 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
     // per-wave workspaces: 1 wave per SIMD on every CU for the null; a quarter of that for observed alignments
-    ctx->grid_blocks = ctx->cu_count * map_waves_per_simd(h.S);   // 4-wave workgroups, that many per CU
+    ctx->grid_blocks = ctx->cu_count * map_waves_per_simd(h.dS);   // 4-wave workgroups, that many per CU
     ctx->waves = ctx->grid_blocks * kWavesPerBlock;
     ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
     auto alloc_ws = [&](Workspace* ws, size_t w, size_t* bytes) -> cmx_status {
-      const size_t bD = w * h.NI * h.S * kWave * sizeof(double);
+      const size_t bD = w * h.NI * h.dS * kWave * sizeof(double);
       const size_t bC = w * 2 * h.B * h.K * kWave * sizeof(double);
-      const size_t bP = w * h.C * h.B * h.K * kWave * sizeof(double);
+      const size_t bP = w * h.dC * h.B * h.K * kWave * sizeof(double);
       const size_t bS = w * h.nn * kWave, bA = w * h.T * kWave;
       HIP_TRY(ctx, hipMalloc((void**)&ws->D, bD));
       HIP_TRY(ctx, hipMalloc((void**)&ws->U, bD));
@@ -292,11 +292,11 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   a.norm = d_norm;
   const size_t nblocks = (nsites + kWave - 1) / kWave;
   const size_t obs_waves = (size_t)ctx->obs_blocks * kWavesPerBlock;
-  if (nblocks * (size_t)ctx->hm.C <= obs_waves && ctx->hm.C > 1) {
+  if (nblocks * (size_t)ctx->hm.dC <= obs_waves && ctx->hm.dC > 1) {
     // small alignment: one (site block, class) per wave, classes summed by a second kernel (same arithmetic order)
-    const size_t ntasks = nblocks * (size_t)ctx->hm.C, BK = (size_t)ctx->hm.B * ctx->hm.K;
+    const size_t ntasks = nblocks * (size_t)ctx->hm.dC, BK = (size_t)ctx->hm.B * ctx->hm.K;
     if ((s = scratch(ctx, "split_part", sizeof(double) * ntasks * BK * kWave, (void**)&a.split_part)) != CMX_OK) return s;
-    if ((s = scratch(ctx, "split_lc", sizeof(double) * 2 * ntasks * kWave, (void**)&a.split_lc)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "split_lc", sizeof(double) * 4 * ntasks * kWave, (void**)&a.split_lc)) != CMX_OK) return s;
     const int grid = (int)((ntasks + kWavesPerBlock - 1) / kWavesPerBlock);
     HIP_TRY(ctx, launch_map(a, kModeObservedSplit, grid, (hipStream_t)stream));
     HIP_TRY(ctx, launch_map_finalize(a, (hipStream_t)stream));

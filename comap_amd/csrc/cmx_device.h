@@ -24,6 +24,9 @@ constexpr int map_waves_per_simd(int S) { return S == 4 ? CMX_WAVES_PER_SIMD_S4 
 // Device-resident model + tree program.  All pointers are device pointers.
 struct DevModel {
   int S, C, K, nn, B, T, NI, NV, root;  // NI internal nodes (slots), NV of them visited by the traversal
+  // S, C are the DEVICE view: with fuse > 1 (nucleotides, >= 4 rate classes) S = S0 * fuse concatenated per-class states
+  // and C = ceil(C0 / fuse) passes; S0, C0 are the model's own state and class counts (simulator, rates, probs, pi)
+  int S0, C0, fuse;
   // tree program (wave-uniform, read through the scalar cache)
   const int* int_post;     // [NI]  internal nodes in post-order, root last
   const int* first_child;  // [nn]

@@ -488,11 +488,16 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   const int NI = hm->NI;
   const int MC = NI + NI * K + T + K * T;
   hm->MC = MC;
-  const size_t MU = (size_t)mat_unit(S);   // doubles per device matrix: S*S plus max_ambig(S) extra leaf rows
-  hm->MAT.assign((size_t)C * MC * MU, 0.0);
+  hm->fuse = (S == 4 && C >= 4) ? (C == 4 ? 4 : 5) : 1;
+  const int F = hm->fuse;
+  const int dS = S * F, dC = (C + F - 1) / F;
+  hm->dS = dS;
+  hm->dC = dC;
+  const size_t MU = (size_t)mat_unit(dS);   // doubles per device matrix: dS*dS plus max_ambig(dS) extra leaf rows
+  const size_t dS2 = (size_t)dS * dS;
+  hm->MAT.assign((size_t)dC * MC * MU, 0.0);
   hm->CP.assign((size_t)C * nn * S2, 0.0);
-  for (int c = 0; c < C; ++c) {
-    double* blk = &hm->MAT[(size_t)c * MC * MU];
+  for (int c = 0; c < C; ++c)
     for (int b = 0; b < B; ++b) {
       const double* P = &hm->P[((size_t)c * B + b) * S2];
       double* cp = &hm->CP[((size_t)c * nn + b) * S2];
@@ -500,22 +505,44 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
         double cum = 0.0;
         for (int y = 0; y < S; ++y) { cum += P[(size_t)x * S + y]; cp[(size_t)x * S + y] = cum; }
       }
+    }
+  Mat dense(dS2);
+  for (int dc = 0; dc < dC; ++dc) {
+    double* blk = &hm->MAT[(size_t)dc * MC * MU];
+    for (int b = 0; b < B; ++b) {
+      // operator of edge b for device class dc: diagonal blocks g = 0..F-1 <-> true class dc*F + g (classes beyond C
+      // pad the last group: identity transition, zero weight).  which = -1: P, k >= 0: w_c (P o N^k), w_c = class
+      // probability when fused (the kernel then uses weight 1 per pass), else 1.
+      auto block = [&](int g, int which) -> const double* {
+        const int c = dc * F + g;
+        if (c >= C) return nullptr;
+        return which < 0 ? &hm->P[((size_t)c * B + b) * S2] : &hm->PN[(((size_t)c * B + b) * K + which) * S2];
+      };
+      auto weight = [&](int g, int which) { return (which >= 0 && F > 1) ? hm->probs[dc * F + g] : 1.0; };
       if (hm->taxon_of[b] >= 0) {
         const int tx = hm->taxon_of[b];
-        double* lpt = blk + (size_t)(NI + NI * K + tx) * MU;
-        for (int x = 0; x < S; ++x)
-          for (int z = 0; z < S; ++z) lpt[(size_t)z * S + x] = P[(size_t)x * S + z];
-        for (int k = 0; k < K; ++k) {
-          const double* PNk = &hm->PN[(((size_t)c * B + b) * K + k) * S2];
-          double* ljt = blk + (size_t)(NI + NI * K + T + k * T + tx) * MU;
-          for (int x = 0; x < S; ++x)
-            for (int z = 0; z < S; ++z) ljt[(size_t)z * S + x] = PNk[(size_t)x * S + z];
+        for (int which = -1; which < K; ++which) {
+          double* lt = blk + (size_t)(which < 0 ? NI + NI * K + tx : NI + NI * K + T + which * T + tx) * MU;
+          for (int g = 0; g < F; ++g) {
+            const double* M = block(g, which);
+            for (int x = 0; x < S; ++x)
+              for (int z = 0; z < S; ++z)   // row = observed state z, column = (class g, state x): transposed
+                lt[(size_t)z * dS + g * S + x] = M ? weight(g, which) * M[(size_t)x * S + z] : (which < 0 && x == z ? 1.0 : 0.0);
+          }
         }
       } else {
         const int sl = hm->slot[b];
-        pack_blocks(S, P, blk + (size_t)sl * MU);
-        for (int k = 0; k < K; ++k)
-          pack_blocks(S, &hm->PN[(((size_t)c * B + b) * K + k) * S2], blk + (size_t)(NI + sl * K + k) * MU);
+        for (int which = -1; which < K; ++which) {
+          std::fill(dense.begin(), dense.end(), 0.0);
+          for (int g = 0; g < F; ++g) {
+            const double* M = block(g, which);
+            for (int x = 0; x < S; ++x)
+              for (int y = 0; y < S; ++y)
+                dense[(size_t)(g * S + x) * dS + g * S + y] =
+                    M ? weight(g, which) * M[(size_t)x * S + y] : (which < 0 && x == y ? 1.0 : 0.0);
+          }
+          pack_blocks(dS, dense.data(), blk + (size_t)(which < 0 ? sl : NI + sl * K + which) * MU);
+        }
       }
     }
   }

@@ -14,12 +14,17 @@ namespace cmx {
 
 struct HostModel {
   int S = 0, C = 0, K = 0, nn = 0, B = 0, T = 0, NI = 0, NV = 0, root = 0;  // NV = visited (non-inlined) internal nodes
+  // Device view.  Nucleotide models with >= 4 rate classes are mapped `fuse` classes at a time: the per-class 4-vectors
+  // of a site are concatenated into one dS = 4*fuse vector and the per-class operators become the diagonal blocks of
+  // one dS x dS operator (class probabilities folded into the count operators), so that one pass of the 20-state
+  // machinery does the work of `fuse` class passes.  Otherwise dS = S, dC = C, fuse = 1.
+  int dS = 0, dC = 0, fuse = 1;
   std::vector<int> parent, first_child, next_sib, taxon_of, slot, int_post;
   std::vector<double> blen, pi, rates, probs, cum_pi, cum_probs;
   std::vector<double> P;    // [C][B][S*S] row-major (x -> y)
   std::vector<double> PN;   // [C][B][K][S*S] P o N^k
   std::vector<double> MAT;  // [C][MC][S*S]     device matrices: packed P | packed PN | leaf P^T | leaf PN^T (cmx_host_model.cpp)
-  int MC = 0;               // matrices per class block = NI + NI*K + T + K*T
+  int MC = 0;               // matrices per (device) class block = NI + NI*K + T + K*T
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
   std::vector<int> ldsched; // workspace-load schedule of one class pass (DevModel::ldsched)
   std::vector<int> msched;  // matrix uses of one class pass in program order: (matrix index, taxon or -1) pairs

@@ -112,29 +112,27 @@ __device__ __forceinline__ void code_dma(const uint8_t* p, uint8_t* slot) {
 }
 
 // s_waitcnt vmcnt(n) needs an immediate: pick the largest supported threshold <= allowed (waiting for more is safe)
+template <int N>
+__device__ __forceinline__ void waitcnt_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 template <int S>
 __device__ __forceinline__ void wait_vm(int allowed) {
-  if constexpr (S >= 16) {
-    // most frequent first: nothing but the next operator's DMA (4 or 5 instructions) was issued since
-    if (allowed < 8) {
-      if (allowed >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (allowed < 14) {
-      if (allowed >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (allowed < 24) {
-      asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    }
+  // what can have been issued after X: the next operator (R DMA rows, +1 with symbols), a workspace prefetch or a
+  // vector store (H instructions each).  Most frequent first.
+  constexpr int R = MatStage<S>::ROWS, H = S / 2;
+  static_assert(R + 1 + 2 * H < 64, "vmcnt is a 6-bit counter");
+  if (allowed < H && R + 1 < H) {
+    if (allowed >= R + 1) waitcnt_vm<R + 1>();
+    else if (allowed == R) waitcnt_vm<R>();
+    else waitcnt_vm<0>();
+  } else if (allowed < R + H) {
+    if (allowed >= H) waitcnt_vm<H>();
+    else if (allowed >= R) waitcnt_vm<R>();
+    else waitcnt_vm<0>();
+  } else if (allowed < R + 2 * H) {
+    if (allowed >= R + 1 + H) waitcnt_vm<R + 1 + H>();
+    else waitcnt_vm<R + H>();
   } else {
-    if (allowed >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (allowed >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (allowed >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (allowed >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (allowed >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    waitcnt_vm<R + 2 * H>();
   }
 }
 
@@ -397,7 +395,7 @@ struct OpState {
 // part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
 // The loop nest below is mirrored statement for statement by build_load_schedule() / verify_traversal() in
 // cmx_host_model.cpp: the op stream decides WHICH operator every CMX_MV / CMX_LEAF applies.
-template <int S>
+template <int S, int FUSE>
 __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
                                                double* __restrict__ part, double* __restrict__ cnt, int lds_off,
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
@@ -480,7 +478,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   } while (0)
   for (int c = c_begin; c < c_end; ++c) {
     CMX_TIC();
-    const double pc = cm.probs[c];
+    const double pc = FUSE > 1 ? 1.0 : cm.probs[c];  // fused: the class probabilities are folded into the count operators
+    double Lg[FUSE];   // site likelihood per fused class at the root
     double* pcnt = part + (size_t)c * m.B * K * kWave + lane;
     double d[S], t[S];  // popped vector / matvec result
     int fi = 0;         // next schedule entry
@@ -570,16 +569,35 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       if (n != root) {
         CMX_STORE(wsD + (size_t)r[REC_SLOT] * S * kWave + 2 * lane, acc);
       } else {
+        constexpr int S0 = S / FUSE;
 #pragma unroll
-        for (int x = 0; x < S; ++x) Lc = __builtin_fma(cm.pi[x], acc[x], Lc);
+        for (int g = 0; g < FUSE; ++g) {
+          Lg[g] = 0.0;
+#pragma unroll
+          for (int x = 0; x < S0; ++x) Lg[g] = __builtin_fma(cm.pi[x], acc[g * S0 + x], Lg[g]);
+        }
+        Lc = Lg[0];
       }
       CMX_KILL(d);
       CMX_KILL(t);
     }
     CMX_KILL(acc);
-    Lsum += pc * Lc;
-    prsum += cm.rates[c] * pc * Lc;
-    if (pc * Lc > best) { best = pc * Lc; bestc = c; }  // first maximum wins (getRateClassWithMaxPostProbPerSite)
+    if constexpr (FUSE == 1) {
+      Lsum += pc * Lc;
+      prsum += cm.rates[c] * pc * Lc;
+      if (pc * Lc > best) { best = pc * Lc; bestc = c; }  // first maximum wins (getRateClassWithMaxPostProbPerSite)
+    } else {
+#pragma unroll
+      for (int g = 0; g < FUSE; ++g) {
+        const int cc = c * FUSE + g;
+        if (cc < m.C0) {
+          const double pg = cm.probs[cc];
+          Lsum += pg * Lg[g];
+          prsum += cm.rates[cc] * pg * Lg[g];
+          if (pg * Lg[g] > best) { best = pg * Lg[g]; bestc = cc; }
+        }
+      }
+    }
     // ---------------- outside (pre-order) pass + joint counts.  acc carries the outside message Up_f.
     for (int idx = m.NV - 1; idx >= 0; --idx) {
       cmx_i16 r, r2;
@@ -587,7 +605,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       const int f = r[REC_N];
       if (f == root) {
 #pragma unroll
-        for (int x = 0; x < S; ++x) acc[x] = cm.pi[x];
+        for (int x = 0; x < S; ++x) acc[x] = cm.pi[x % (S / FUSE)];
       } else if (!(r[REC_FLAGS] & FLAG_UP_IN_ACC)) {  // otherwise Up_f was left in acc by the parent
         CMX_POP(acc);
       }
@@ -707,11 +725,11 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #undef CMX_STORE
 #undef CMX_DOT
 #undef CMX_KILL
-  if (!finalize) {
+  if (!finalize) {   // class-split mode: the pass's sums, its best class and that class's weight
     L_out = Lsum;
     pr_out = prsum;
     rc_out = bestc;
-    norm_out = 0.0;
+    norm_out = best;
     return;
   }
   // ---------------- sum the classes in class order, divide by the site likelihood, norm (computeNormForSite)
@@ -810,7 +828,7 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
 template <int S>
 constexpr int map_lds_per_wave() { return S * kWave * 8 + 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }
 
-template <int S, int MODE>
+template <int S, int MODE, int FUSE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void map_kernel(const MapArgs a) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
@@ -854,10 +872,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
       const size_t s = site < a.nsites ? site : a.nsites - 1;
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S>(a, wsD, wsU, a.split_part + sb * m.C * BK * kWave, nullptr, lds_off, a.aln + s, a.ld, lane, os, L, pr,
+      map_sites_wave<S, FUSE>(a, wsD, wsU, a.split_part + sb * m.C * BK * kWave, nullptr, lds_off, a.aln + s, a.ld, lane, os, L, pr,
                         rc, nrm, c, c + 1, (int)((task + nwaves) % m.C), false);
       a.split_lc[task * kWave + lane] = L;
       a.split_lc[(ntasks + task) * kWave + lane] = pr;
+      a.split_lc[(2 * ntasks + task) * kWave + lane] = nrm;          // weight of the pass's best class
+      a.split_lc[(3 * ntasks + task) * kWave + lane] = (double)rc;   // ... and its index
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
@@ -869,7 +889,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
     if (MODE == kModeObserved) {
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
+      map_sites_wave<S, FUSE>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
@@ -896,18 +916,19 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
           gbase = al;
           gstride = kWave;
           const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
-          const int c = draw_index(philox_uniform(a.seed, g, 0), cm.cum_probs, m.C);
+          const int S0 = S / FUSE;
+          const int c = draw_index(philox_uniform(a.seed, g, 0), cm.cum_probs, m.C0);
           // states of the nodes: in the (idle) workspace prefetch buffer when nn * 64 bytes fit, else in HBM
           const bool st_lds = m.nn * kWave <= S * kWave * 8;
           uint8_t* stl = cmx_smem + lds_off + lane;
           uint8_t* stg = a.ws.st + (size_t)wave * m.nn * kWave + lane;
-          const uint8_t x0 = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S);
+          const uint8_t x0 = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S0);
           if (st_lds) stl[(size_t)m.root * kWave] = x0; else stg[(size_t)m.root * kWave] = x0;
           for (int node = m.nn - 2; node >= 0; --node) {
             const int pn = cm.parent[node];
             const int x = st_lds ? stl[(size_t)pn * kWave] : stg[(size_t)pn * kWave];
             const double u = philox_uniform(a.seed, g, 2u + (uint32_t)node);
-            const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S + x) * S, S);
+            const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S0 + x) * S0, S0);
             if (st_lds) stl[(size_t)node * kWave] = (uint8_t)y; else stg[(size_t)node * kWave] = (uint8_t)y;
             const int tx = cm.taxon_of[node];
             if (tx >= 0) al[(size_t)tx * kWave] = (uint8_t)y;
@@ -915,7 +936,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
         }
         double L, pr, nrm;
         int rc;
-        map_sites_wave<S>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
+        map_sites_wave<S, FUSE>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
         if (h == 0) { prmin = pr; nmin = nrm; rcmin = rc; }
         else { prmin = pr < prmin ? pr : prmin; nmin = nrm < nmin ? nrm : nmin; rcmin = rc < rcmin ? rc : rcmin; }
       }
@@ -940,7 +961,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
 }
 
 size_t map_lds_bytes(int S) {
-  return (size_t)kWavesPerBlock * (size_t)(S == 20 ? map_lds_per_wave<20>() : map_lds_per_wave<4>());
+  const int per_wave = S == 20 ? map_lds_per_wave<20>() : (S == 16 ? map_lds_per_wave<16>() : map_lds_per_wave<4>());
+  return (size_t)kWavesPerBlock * (size_t)per_wave;
 }
 
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream) {
@@ -948,28 +970,29 @@ hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t s
   const size_t lds = map_lds_bytes(a.m.S);
   const int lim = 160 * 1024 / map_waves_per_simd(a.m.S);  // dynamic LDS a workgroup may use (that many workgroups per CU)
   if ((int)lds > lim) return hipErrorInvalidValue;
-#define CMX_LAUNCH(S_, MODE_)                                                                                 \
+#define CMX_LAUNCH(S_, MODE_, F_)                                                                             \
   do {                                                                                                        \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<S_, MODE_>),                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<S_, MODE_, F_>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim);                             \
       attr_set = true;                                                                                        \
     }                                                                                                         \
-    hipLaunchKernelGGL((map_kernel<S_, MODE_>), grid, block, lds, stream, a);                                 \
+    hipLaunchKernelGGL((map_kernel<S_, MODE_, F_>), grid, block, lds, stream, a);                             \
   } while (0)
-  if (a.m.S == 20) {
-    if (mode == kModeObserved) CMX_LAUNCH(20, kModeObserved);
-    else if (mode == kModeObservedSplit) CMX_LAUNCH(20, kModeObservedSplit);
-    else CMX_LAUNCH(20, kModeNull);
-  } else if (a.m.S == 4) {
-    if (mode == kModeObserved) CMX_LAUNCH(4, kModeObserved);
-    else if (mode == kModeObservedSplit) CMX_LAUNCH(4, kModeObservedSplit);
-    else CMX_LAUNCH(4, kModeNull);
+#define CMX_LAUNCH_MODES(S_, F_)                                            \
+  do {                                                                      \
+    if (mode == kModeObserved) CMX_LAUNCH(S_, kModeObserved, F_);           \
+    else if (mode == kModeObservedSplit) CMX_LAUNCH(S_, kModeObservedSplit, F_); \
+    else CMX_LAUNCH(S_, kModeNull, F_);                                     \
+  } while (0)
+  if (a.m.S == 20 && a.m.fuse == 1) CMX_LAUNCH_MODES(20, 1);
+  else if (a.m.S == 20 && a.m.fuse == 5) CMX_LAUNCH_MODES(20, 5);
+  else if (a.m.S == 16 && a.m.fuse == 4) CMX_LAUNCH_MODES(16, 4);
+  else if (a.m.S == 4 && a.m.fuse == 1) CMX_LAUNCH_MODES(4, 1);
+  else return hipErrorInvalidValue;
+#undef CMX_LAUNCH_MODES
 #undef CMX_LAUNCH
-  } else {
-    return hipErrorInvalidValue;
-  }
   return hipGetLastError();
 }
 
@@ -983,10 +1006,11 @@ __global__ void map_finalize_kernel(const MapArgs a) {
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
   for (int c = 0; c < m.C; ++c) {
-    const double v = a.split_lc[(sb * m.C + c) * kWave + lane];
-    Lsum += v;
-    prsum += a.split_lc[(ntasks + sb * m.C + c) * kWave + lane];
-    if (v > best) { best = v; bestc = c; }
+    const size_t t = sb * m.C + c;
+    Lsum += a.split_lc[t * kWave + lane];
+    prsum += a.split_lc[(ntasks + t) * kWave + lane];
+    const double bv = a.split_lc[(2 * ntasks + t) * kWave + lane];
+    if (bv > best) { best = bv; bestc = (int)a.split_lc[(3 * ntasks + t) * kWave + lane]; }
   }
   const double* part = a.split_part + sb * m.C * BK * kWave + lane;
   double nrm = 0.0;
@@ -1013,30 +1037,31 @@ hipError_t launch_map_finalize(const MapArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// Rows S .. S+A-1 of every transposed leaf operator: sum of the rows of the states compatible with ambiguity id a
-// (what the DR likelihood's leaf initialisation does for B/Z/X/gap).  One thread per (class, leaf operator, a, x).
-__global__ void extend_leaf_rows_kernel(double* MAT, int C, int MC, int first_leaf, int nleaf, int S, int A, int unit,
-                                        const uint32_t* __restrict__ masks) {
+// Rows S0 .. S0+A-1 of every transposed leaf operator: sum of the rows of the states compatible with ambiguity id a
+// (what the DR likelihood's leaf initialisation does for B/Z/X/gap).  One thread per (class, leaf operator, a, x);
+// a row has `rowlen` values (= S0, or S0 * fuse for the class-fused nucleotide layout).
+__global__ void extend_leaf_rows_kernel(double* MAT, int C, int MC, int first_leaf, int nleaf, int S0, int rowlen, int A,
+                                        int unit, const uint32_t* __restrict__ masks) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)C * nleaf * A * S;
+  const size_t total = (size_t)C * nleaf * A * rowlen;
   if (i >= total) return;
-  const int x = (int)(i % S);
-  const int a = (int)((i / S) % A);
-  const int l = (int)((i / ((size_t)S * A)) % nleaf);
-  const int c = (int)(i / ((size_t)S * A * nleaf));
+  const int x = (int)(i % rowlen);
+  const int a = (int)((i / rowlen) % A);
+  const int l = (int)((i / ((size_t)rowlen * A)) % nleaf);
+  const int c = (int)(i / ((size_t)rowlen * A * nleaf));
   double* M = MAT + ((size_t)c * MC + first_leaf + l) * unit;
-  const uint32_t mk = masks ? masks[S + a] : 0xffffffffu;
+  const uint32_t mk = masks ? masks[S0 + a] : 0xffffffffu;
   double v = 0.0;
-  for (int z = 0; z < S; ++z)
-    if ((mk >> z) & 1u) v += M[(size_t)z * S + x];
-  M[(size_t)(S + a) * S + x] = v;
+  for (int z = 0; z < S0; ++z)
+    if ((mk >> z) & 1u) v += M[(size_t)z * rowlen + x];
+  M[(size_t)(S0 + a) * rowlen + x] = v;
 }
 
 hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, hipStream_t stream) {
-  const int A = max_ambig(m.S), nleaf = m.T + m.K * m.T;
+  const int A = max_ambig(m.S0), nleaf = m.T + m.K * m.T;
   const size_t total = (size_t)m.C * nleaf * A * m.S;
   hipLaunchKernelGGL(extend_leaf_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, m.MAT, m.C, m.MC,
-                     m.NI + m.NI * m.K, nleaf, m.S, A, mat_unit(m.S), d_masks);
+                     m.NI + m.NI * m.K, nleaf, m.S0, m.S, A, mat_unit(m.S), d_masks);
   return hipGetLastError();
 }
 
@@ -1071,8 +1096,8 @@ __global__ void simulate_kernel(const DevModel m, uint64_t seed, uint64_t g0, si
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const uint64_t g = g0 + j;
-  const int S = m.S;
-  const int c = draw_index(philox_uniform(seed, g, 0), m.cum_probs, m.C);
+  const int S = m.S0;
+  const int c = draw_index(philox_uniform(seed, g, 0), m.cum_probs, m.C0);
   if (classes) classes[j] = c;
   states[(size_t)m.root * ld + j] = (uint8_t)draw_index(philox_uniform(seed, g, 1), m.cum_pi, S);
   for (int node = m.nn - 2; node >= 0; --node) {
