@@ -667,11 +667,11 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
   // MFMA path (one-hot Gram) whenever the c ln c table fits the kernel's LDS; columns with ambiguous symbols are
   // left to the LDS-table kernel pair by pair
   MicaWork w{};
-  const bool mfma = ntaxa <= 4095;
+  const bool mfma = ntaxa <= 2047;   // table + operand buffers within 64 KiB of LDS
   if (mfma) {
     cmx_status s;
-    w.Tp = (ntaxa + 15) / 16 * 16;
-    const size_t hb = sizeof(_Float16) * 32 * (size_t)w.Tp;
+    w.Tp = (ntaxa + 31) / 32 * 32;
+    const size_t hb = 32 * (size_t)w.Tp;
     if ((s = scratch(ctx, "mica_H1", hb * n1, (void**)&w.H1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_f1", n1, (void**)&w.flag1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_S1", sizeof(double) * n1, (void**)&w.S1)) != CMX_OK) return s;
@@ -681,6 +681,7 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
       if ((s = scratch(ctx, "mica_S2", sizeof(double) * n2, (void**)&w.S2)) != CMX_OK) return s;
     }
     if ((s = scratch(ctx, "mica_ftab", sizeof(double) * (size_t)(ntaxa + 1), (void**)&w.ftab)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "mica_any", sizeof(int), (void**)&w.anyflag)) != CMX_OK) return s;
   }
   HIP_TRY(ctx, launch_mi_columns(nalpha, ntaxa, d_masks, d_aln1, n1, ld1, d_aln2, n2, ld2, intra ? 1 : 0, d_mi, d_hjoint,
                                  ldo, d_h1, intra ? nullptr : d_h2, mfma ? &w : nullptr, (hipStream_t)stream));

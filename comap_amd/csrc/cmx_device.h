@@ -124,11 +124,12 @@ hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in,
                               uint32_t* d_cls_tmp, size_t n, hipStream_t stream);
 // scratch of the MFMA Mica path (all device pointers; H1 null = LDS-table kernel only)
 struct MicaWork {
-  _Float16 *H1, *H2;       // one-hot [n][32][Tp] f16
+  int8_t *H1, *H2;         // one-hot [n][32][Tp] int8
   uint8_t *flag1, *flag2;  // [n] column has ambiguous symbols
   double *S1, *S2;         // [n] sum_a f(count_a)
   double* ftab;            // [T + 1] c ln c
-  int Tp;                  // T rounded up to a multiple of 16
+  int* anyflag;            // some column of either alignment has ambiguous symbols
+  int Tp;                  // T rounded up to a multiple of 32 (taxa per MFMA step)
 };
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,

@@ -1399,82 +1399,89 @@ __global__ __launch_bounds__(64) void mi_columns_kernel(int T, const uint32_t* _
                                                         const uint8_t* __restrict__ aln2, size_t n2, size_t ld2,
                                                         int intra, double* __restrict__ mi, double* __restrict__ hj,
                                                         size_t ldo, const uint8_t* __restrict__ flag1,
-                                                        const uint8_t* __restrict__ flag2) {
-  // with flags (MFMA path active) this kernel only serves pairs that involve a column with ambiguous symbols
-  if (flag1) {
-    const size_t j0 = (size_t)blockIdx.x * 16;
-    bool any = flag1[blockIdx.y] != 0;
-    for (size_t q = j0; !any && q < j0 + 16 && q < n2; ++q) any = flag2[q] != 0;
-    if (!any) return;
-  }
+                                                        const uint8_t* __restrict__ flag2, const int* __restrict__ anyflag) {
+  // with flags (MFMA path active) this kernel only serves pairs that involve a column with ambiguous symbols; when no
+  // column at all is flagged every workgroup leaves after one load
+  if (anyflag && *anyflag == 0) return;
   // LDS: joint table [A*A][16 lanes] fp64 per quarter-wave = A*A*16*8 B (51 KB for A = 20): 16 pairs per block pass
   extern __shared__ double tab[];
   const int lane = threadIdx.x;
   const int sub = lane & 15;       // pair slot
   const int part = lane >> 4;      // 4 lanes cooperate on one pair: taxa are split in 4 strides
-  const size_t i = blockIdx.y;
-  const size_t j = (size_t)blockIdx.x * 16 + sub;
-  const bool valid = j < n2 && (!intra || j > i);
-  const size_t jj = j < n2 ? j : n2 - 1;
-  for (int q = lane; q < A * A * 16; q += 64) tab[q] = 0.0;
-  __syncthreads();
-  for (int t = part; t < T; t += 4) {
-    const unsigned c1 = aln1[(size_t)t * ld1 + i], c2 = aln2[(size_t)t * ld2 + jj];
-    if (c1 < (unsigned)A && c2 < (unsigned)A) {
-      atomicAdd(&tab[(c1 * A + c2) * 16 + sub], 1.0);
-    } else {
-      const uint32_t m1 = c1 < (unsigned)A ? (1u << c1) : masks[c1], m2 = c2 < (unsigned)A ? (1u << c2) : masks[c2];
-      const double w = 1.0 / (double)(__popc(m1) * __popc(m2));
-      for (int a = 0; a < A; ++a)
-        if ((m1 >> a) & 1u)
-          for (int b = 0; b < A; ++b)
-            if ((m2 >> b) & 1u) atomicAdd(&tab[(a * A + b) * 16 + sub], w);
+  const size_t nbj = (n2 + 15) / 16, ntiles = nbj * n1;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t i = tile / nbj;
+    const size_t jb = tile % nbj;
+    if (flag1) {
+      bool any = flag1[i] != 0;
+      for (size_t q = jb * 16; !any && q < jb * 16 + 16 && q < n2; ++q) any = flag2[q] != 0;
+      if (!any) continue;
     }
-  }
-  __syncthreads();
-  if (part == 0) {
-    double p1[A], p2[A];
-#pragma unroll
-    for (int a = 0; a < A; ++a) { p1[a] = 0.0; p2[a] = 0.0; }
-#pragma unroll
-    for (int a = 0; a < A; ++a)
-#pragma unroll
-      for (int b = 0; b < A; ++b) {
-        const double v = tab[(a * A + b) * 16 + sub];
-        p1[a] += v;
-        p2[b] += v;
+    const size_t j = jb * 16 + sub;
+    const bool valid = j < n2 && (!intra || j > i);
+    const size_t jj = j < n2 ? j : n2 - 1;
+    __syncthreads();   // the previous tile's readers are done with the table
+    for (int q = lane; q < A * A * 16; q += 64) tab[q] = 0.0;
+    __syncthreads();
+    for (int t = part; t < T; t += 4) {
+      const unsigned c1 = aln1[(size_t)t * ld1 + i], c2 = aln2[(size_t)t * ld2 + jj];
+      if (c1 < (unsigned)A && c2 < (unsigned)A) {
+        atomicAdd(&tab[(c1 * A + c2) * 16 + sub], 1.0);
+      } else {
+        const uint32_t m1 = c1 < (unsigned)A ? (1u << c1) : masks[c1], m2 = c2 < (unsigned)A ? (1u << c2) : masks[c2];
+        const double w = 1.0 / (double)(__popc(m1) * __popc(m2));
+        for (int a = 0; a < A; ++a)
+          if ((m1 >> a) & 1u)
+            for (int b = 0; b < A; ++b)
+              if ((m2 >> b) & 1u) atomicAdd(&tab[(a * A + b) * 16 + sub], w);
       }
-    double s = 0.0, h = 0.0;
+    }
+    __syncthreads();
+    if (part == 0) {
+      double p1[A], p2[A];
 #pragma unroll
-    for (int a = 0; a < A; ++a)
+      for (int a = 0; a < A; ++a) { p1[a] = 0.0; p2[a] = 0.0; }
 #pragma unroll
-      for (int b = 0; b < A; ++b) {
-        const double pab = tab[(a * A + b) * 16 + sub] / T;
-        if (pab > 0.0) {
-          s += pab * log(pab / ((p1[a] / T) * (p2[b] / T)));
-          h -= pab * log(pab);
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+          const double v = tab[(a * A + b) * 16 + sub];
+          p1[a] += v;
+          p2[b] += v;
         }
+      double s = 0.0, h = 0.0;
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+          const double pab = tab[(a * A + b) * 16 + sub] / T;
+          if (pab > 0.0) {
+            s += pab * log(pab / ((p1[a] / T) * (p2[b] / T)));
+            h -= pab * log(pab);
+          }
+        }
+      if (j < n2 && (!flag1 || flag1[i] || flag2[j])) {
+        mi[i * ldo + j] = valid ? s : __builtin_nan("");
+        hj[i * ldo + j] = valid ? h : __builtin_nan("");
       }
-    if (j < n2 && (!flag1 || flag1[i] || flag2[j])) {
-      mi[i * ldo + j] = valid ? s : __builtin_nan("");
-      hj[i * ldo + j] = valid ? h : __builtin_nan("");
     }
   }
 }
 
 // ---- MFMA path (SURVEY 8d "Mica MI"): for columns without ambiguous symbols the joint table of a column pair is one
-// 32x32 block of the Gram matrix of one-hot matrices, H_i (32 x T) . H_j^T, exact in f16 x f16 -> f32.  With integer
+// 32x32 block of the Gram matrix of one-hot matrices, H_i (32 x T) . H_j^T, exact in int8 x int8 -> int32.  With integer
 // counts c the entropies need no logarithm at run time: sum_ab p_ab ln p_ab = (1/T) sum_ab f(c_ab) - ln T with
 // f(c) = c ln c read from a (T+1)-entry table, so MI = ln T + (sum_ab f(c_ab) - sum_a f(c_a) - sum_b f(c_b)) / T and
 // the epilogue is a layout-free sum over the accumulator registers.
-typedef _Float16 cmx_h8 __attribute__((ext_vector_type(8)));
-typedef float cmx_f16v __attribute__((ext_vector_type(16)));
+typedef int cmx_i4 __attribute__((ext_vector_type(4)));
+typedef int cmx_i16v __attribute__((ext_vector_type(16)));
+constexpr int kMicaK = 32;   // taxa per MFMA step (v_mfma_i32_32x32x32_i8)
 
 // one block per column: one-hot rows H[col][a][t] (a < 32, t < Tp, zero padded), flag = column has a code >= A,
 // S[col] = sum_a f(count_a)
 __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, const uint8_t* __restrict__ aln, size_t ld,
-                                                          _Float16* __restrict__ H, uint8_t* __restrict__ flag,
-                                                          double* __restrict__ S) {
+                                                          int8_t* __restrict__ H, uint8_t* __restrict__ flag,
+                                                          double* __restrict__ S, int* __restrict__ anyflag) {
   __shared__ int cnt[32];
   __shared__ int amb;
   const size_t i = blockIdx.x;
@@ -1488,7 +1495,7 @@ __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, 
       else amb = 1;
     }
 #pragma unroll
-    for (int a = 0; a < 32; ++a) H[(i * 32 + a) * (size_t)Tp + t] = (_Float16)((c == (unsigned)a) ? 1.0f : 0.0f);
+    for (int a = 0; a < 32; ++a) H[(i * 32 + a) * (size_t)Tp + t] = (int8_t)((c == (unsigned)a) ? 1 : 0);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1497,71 +1504,94 @@ __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, 
       if (cnt[a] > 1) s += (double)cnt[a] * log((double)cnt[a]);
     S[i] = s;
     flag[i] = (uint8_t)amb;
+    if (amb) atomicOr(anyflag, 1);
   }
 }
 
-__global__ void mica_ftable_kernel(int T, double* __restrict__ f) {
+__global__ void mica_ftable_kernel(int T, double* __restrict__ f, int* __restrict__ anyflag) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) *anyflag = 0;
   if (c <= T) f[c] = c > 1 ? (double)c * log((double)c) : 0.0;
 }
 
-// one wave per TI x TJ tile of column pairs; operands straight from L2 (16 bytes per lane and operand and k-step)
-template <int TI, int TJ>
-__global__ __launch_bounds__(64) void mica_mfma_kernel(int T, int Tp, const _Float16* __restrict__ H1, size_t n1,
-                                                       const uint8_t* __restrict__ flag1, const double* __restrict__ S1,
-                                                       const _Float16* __restrict__ H2, size_t n2,
-                                                       const uint8_t* __restrict__ flag2, const double* __restrict__ S2,
-                                                       const double* __restrict__ ftab_g, int intra,
-                                                       double* __restrict__ mi, double* __restrict__ hj, size_t ldo) {
-  extern __shared__ double ftab[];
-  const int lane = threadIdx.x;
-  for (int c = lane; c <= T; c += 64) ftab[c] = ftab_g[c];
-  __syncthreads();
-  const size_t i0 = (size_t)blockIdx.y * TI, j0 = (size_t)blockIdx.x * TJ;
-  if (intra && j0 + TJ <= i0 + 1) {     // no pair with j > i in this tile: only the NaN convention of the intra layout
-    const size_t i = i0 + lane / TJ, j = j0 + lane % TJ;
-    if (lane < TI * TJ && i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
-      mi[i * ldo + j] = __builtin_nan("");
-      hj[i * ldo + j] = __builtin_nan("");
+// One workgroup (8 waves) per 8 x 8 tile of column pairs, wave w owns the 2 x 4 sub-tile (rows 2*(w/2).., columns
+// 4*(w%2)..): 128 accumulator registers, two waves per SIMD so that one wave's table epilogue overlaps another's MFMAs.
+// The 16 operand tiles of a k-step (8 columns of each alignment, 64 lanes x 16 B each) go through LDS once per
+// workgroup: 4 KiB of L2 traffic per pair at T = 256 instead of 16 KiB when every wave fetches its own operands.
+constexpr int kMicaTile = 8;
+__global__ __launch_bounds__(512, 1) void mica_mfma_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
+                                                           const uint8_t* __restrict__ flag1, const double* __restrict__ S1,
+                                                           const int8_t* __restrict__ H2, size_t n2,
+                                                           const uint8_t* __restrict__ flag2, const double* __restrict__ S2,
+                                                           const double* __restrict__ ftab_g, int intra,
+                                                           double* __restrict__ mi, double* __restrict__ hj, size_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t mica_smem[];
+  double* ftab = reinterpret_cast<double*>(mica_smem);                       // [T + 1]
+  cmx_i4* ops = reinterpret_cast<cmx_i4*>(mica_smem + (((size_t)(T + 1) * 8 + 15) & ~(size_t)15));  // [2][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
+  for (int c = tid; c <= T; c += 512) ftab[c] = ftab_g[c];
+  const size_t i0 = (size_t)blockIdx.y * kMicaTile, j0 = (size_t)blockIdx.x * kMicaTile;
+  if (intra && j0 + kMicaTile <= i0 + 1) {   // no pair with j > i in this tile: only the NaN convention of the intra layout
+    if (tid < kMicaTile * kMicaTile) {
+      const size_t i = i0 + tid / kMicaTile, j = j0 + tid % kMicaTile;
+      if (i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
+        mi[i * ldo + j] = __builtin_nan("");
+        hj[i * ldo + j] = __builtin_nan("");
+      }
     }
     return;
   }
-  const int r = lane & 31, g = lane >> 5;
-  const _Float16* pa[TI];
-  const _Float16* pb[TJ];
+  // loader role of this thread: operand tile q = tid / 32 of the k-step (q < 8: column i0 + q of H1, else column
+  // j0 + q - 8 of H2), lanes 2 * (tid % 32) and + 1 of that tile; a lane's 16 bytes are row (lane % 32), taxa group
+  // (lane / 32) of the one-hot matrix
+  const int q = tid >> 5;
+  const size_t col = q < 8 ? (i0 + q < n1 ? i0 + q : n1 - 1) : (j0 + q - 8 < n2 ? j0 + q - 8 : n2 - 1);
+  const int8_t* Hq = (q < 8 ? H1 : H2) + col * 32 * (size_t)Tp;
+  const int l0 = 2 * (tid & 31);
+  cmx_i16v acc[2][4];
 #pragma unroll
-  for (int ii = 0; ii < TI; ++ii) pa[ii] = H1 + (((i0 + ii < n1 ? i0 + ii : n1 - 1) * 32 + r) * (size_t)Tp + 8 * g);
+  for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-  for (int jj = 0; jj < TJ; ++jj) pb[jj] = H2 + (((j0 + jj < n2 ? j0 + jj : n2 - 1) * 32 + r) * (size_t)Tp + 8 * g);
-  cmx_f16v acc[TI][TJ];
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-  for (int ii = 0; ii < TI; ++ii)
+      for (int v = 0; v < 16; ++v) acc[ii][jj][v] = 0;
+  cmx_i4 st[2];
+  auto fetch = [&](int ks) {
 #pragma unroll
-    for (int jj = 0; jj < TJ; ++jj)
+    for (int u = 0; u < 2; ++u) {
+      const int l = l0 + u;
+      st[u] = *reinterpret_cast<const cmx_i4*>(Hq + (size_t)(l & 31) * Tp + ks + 16 * (l >> 5));
+    }
+  };
+  fetch(0);
+  int buf = 0;
+  for (int ks = 0; ks < Tp; ks += kMicaK) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[ii][jj][v] = 0.0f;
-  for (int ks = 0; ks < Tp; ks += 16) {
-    cmx_h8 a[TI], b[TJ];
+    for (int u = 0; u < 2; ++u) ops[(buf * 16 + q) * 64 + l0 + u] = st[u];
+    __syncthreads();
+    if (ks + kMicaK < Tp) fetch(ks + kMicaK);
+    cmx_i4 a[2], b[4];
 #pragma unroll
-    for (int ii = 0; ii < TI; ++ii) a[ii] = *reinterpret_cast<const cmx_h8*>(pa[ii] + ks);
+    for (int ii = 0; ii < 2; ++ii) a[ii] = ops[(buf * 16 + 2 * wi + ii) * 64 + lane];
 #pragma unroll
-    for (int jj = 0; jj < TJ; ++jj) b[jj] = *reinterpret_cast<const cmx_h8*>(pb[jj] + ks);
+    for (int jj = 0; jj < 4; ++jj) b[jj] = ops[(buf * 16 + 8 + 4 * wj + jj) * 64 + lane];
 #pragma unroll
-    for (int ii = 0; ii < TI; ++ii)
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int jj = 0; jj < TJ; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
+      for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
+    buf ^= 1;
   }
   const double lnT = log((double)T), invT = 1.0 / (double)T;
 #pragma unroll
-  for (int ii = 0; ii < TI; ++ii)
+  for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-    for (int jj = 0; jj < TJ; ++jj) {
+    for (int jj = 0; jj < 4; ++jj) {
       double s = 0.0;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) s += ftab[(int)acc[ii][jj][v]];
+      for (int v = 0; v < 16; ++v) s += ftab[acc[ii][jj][v]];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      const size_t i = i0 + ii, j = j0 + jj;
+      const size_t i = i0 + 2 * wi + ii, j = j0 + 4 * wj + jj;
       if (lane == 0 && i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
         const bool valid = !intra || j > i;
         mi[i * ldo + j] = valid ? lnT + (s - S1[i] - S2[j]) * invT : __builtin_nan("");
@@ -1596,20 +1626,22 @@ __global__ void column_entropy_kernel(int T, const uint32_t* __restrict__ masks,
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
                              size_t ldo, double* d_h1, double* d_h2, const MicaWork* work, hipStream_t stream) {
-  dim3 grid((unsigned)((n2 + 15) / 16), (unsigned)n1);
+  const size_t ntiles = ((n2 + 15) / 16) * n1;
+  dim3 grid((unsigned)std::min<size_t>(ntiles, 8192));
   const size_t lds = sizeof(double) * A * A * 16;
+  const int* anyf = (work && work->H1) ? work->anyflag : nullptr;
   // MFMA path for the columns without ambiguous symbols (work->H1 etc. non-null); the LDS kernel then only serves
   // the pairs that involve an ambiguous column.
   const uint8_t *f1 = nullptr, *f2 = nullptr;
   if (work && work->H1) {
     const int Tp = work->Tp;
-    hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)(T / 256 + 1)), dim3(256), 0, stream, T, work->ftab);
-    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_aln1, ld1, work->H1, work->flag1, work->S1);
+    hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)(T / 256 + 1)), dim3(256), 0, stream, T, work->ftab, work->anyflag);
+    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_aln1, ld1, work->H1, work->flag1, work->S1, work->anyflag);
     if (!intra)
-      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_aln2, ld2, work->H2, work->flag2, work->S2);
-    constexpr int TI = 4, TJ = 4;
-    dim3 g2((unsigned)((n2 + TJ - 1) / TJ), (unsigned)((n1 + TI - 1) / TI));
-    hipLaunchKernelGGL((mica_mfma_kernel<TI, TJ>), g2, dim3(64), sizeof(double) * (size_t)(T + 1), stream, T, Tp, work->H1, n1,
+      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_aln2, ld2, work->H2, work->flag2, work->S2, work->anyflag);
+    dim3 g2((unsigned)((n2 + kMicaTile - 1) / kMicaTile), (unsigned)((n1 + kMicaTile - 1) / kMicaTile));
+    const size_t lds2 = (((size_t)(T + 1) * 8 + 15) & ~(size_t)15) + 2 * 16 * 64 * sizeof(cmx_i4);
+    hipLaunchKernelGGL(mica_mfma_kernel, g2, dim3(512), lds2, stream, T, Tp, work->H1, n1,
                        work->flag1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
                        intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
     f1 = work->flag1;
@@ -1617,12 +1649,12 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
   }
   if (A == 20) {
     hipLaunchKernelGGL((mi_columns_kernel<20>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, n1, ld1, d_aln2, n2,
-                       ld2, intra, d_mi, d_hj, ldo, f1, f2);
+                       ld2, intra, d_mi, d_hj, ldo, f1, f2, anyf);
     if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
     if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
   } else if (A == 4) {
     hipLaunchKernelGGL((mi_columns_kernel<4>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, n1, ld1, d_aln2, n2,
-                       ld2, intra, d_mi, d_hj, ldo, f1, f2);
+                       ld2, intra, d_mi, d_hj, ldo, f1, f2, anyf);
     if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
     if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
   } else {
