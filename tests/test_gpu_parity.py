@@ -50,6 +50,33 @@ def test_map_sites_protein_ragged_sizes(nsites):
     _check_map(r, oracle.map_sites(_omodel(case), case["aln"]))
 
 
+@pytest.mark.parametrize("ntaxa,nstates", [(3, 20), (4, 20), (5, 20), (3, 4), (4, 4), (6, 4)])
+def test_tiny_trees_map_and_null(ntaxa, nstates):
+    """smallest trees (a star of three leaves upward): op streams of a handful of entries, no stored vectors at all"""
+    case = make_case(ntaxa, 70, nstates, 900 + ntaxa)
+    eng, om = _engine(case), _omodel(case)
+    _check_map(eng.map_sites(case["aln"]), oracle.map_sites(om, case["aln"]))
+    g, o = eng.null_intra(0, 5, 0, 2, 33), oracle.null_intra(om, 0, 5, 0, 2, 33)
+    rel_close(g["stat"], o["stat"], 1e-6, 1e-12)
+    assert np.array_equal(g["rcmin"], o["rcmin"])
+
+
+def test_large_trees_150_and_600_taxa():
+    """600 taxa = 1 197 branches: op stream of ~5 000 entries per class pass, 12 MB of workspace per wave.  Like the
+    reference's DR likelihood the engine does not rescale: at 600 taxa site likelihoods underflow to 0 in both
+    implementations (log = -inf, counts NaN) and must do so identically; 150 taxa stay finite."""
+    case = make_case(150, 40, 20, 4322)
+    r = _engine(case).map_sites(case["aln"])
+    assert np.isfinite(r["counts"]).all() and np.isfinite(r["logL"]).all()
+    _check_map(r, oracle.map_sites(_omodel(case), case["aln"]))
+    case = make_case(600, 40, 20, 4321)
+    eng, om = _engine(case), _omodel(case)
+    with np.errstate(invalid="ignore"):
+        _check_map(eng.map_sites(case["aln"]), oracle.map_sites(om, case["aln"]))
+    info = eng.info()
+    assert info["nbranches"] == 1197 and info["workspace_bytes"] < 80 * 2 ** 30
+
+
 def test_map_sites_large_alignment_takes_the_fused_class_loop():
     """below 512 (site block, class) tasks the observed mapping runs one class per wave-task + a finalize kernel; a
     9 000-site alignment exercises the other path (all classes in one wave), same results required"""
