@@ -644,6 +644,81 @@ cmx_status cmx_intra_pvalues(cmx_ctx* ctx, const double* stat, const double* nor
   return CMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ compacted rows
+cmx_status cmx_intra_rows_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, const double* d_pvalue, const int32_t* d_nsim,
+                              size_t n, const int32_t* d_rate_class, const double* d_post_rate, const double* d_norm,
+                              const cmx_pair_filters* filters, cmx_pair_row* d_rows, size_t capacity, uint64_t* d_count,
+                              void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!d_stat || n == 0 || ldo < n || !d_rate_class || !d_post_rate || !d_norm || !d_count || (capacity && !d_rows) ||
+      n > 0x7fffffffull)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_intra_rows: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  cmx_pair_filters f{0, -1, 0.0, -1.0, 0.0};
+  if (filters) f = *filters;
+  unsigned long long* rowcount;
+  cmx_status s;
+  if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (n + 1), (void**)&rowcount)) != CMX_OK) return s;
+  size_t tmp_bytes = 0;
+  HIP_TRY(ctx, launch_pair_rows(d_stat, ldo, d_pvalue, d_nsim, n, d_rate_class, d_post_rate, d_norm, f, rowcount, nullptr,
+                                tmp_bytes, d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), (hipStream_t)stream));
+  void* tmp = nullptr;
+  if ((s = scratch(ctx, "rows_scan", tmp_bytes ? tmp_bytes : 16, &tmp)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_pair_rows(d_stat, ldo, d_pvalue, d_nsim, n, d_rate_class, d_post_rate, d_norm, f, rowcount, tmp,
+                                tmp_bytes, d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), (hipStream_t)stream));
+  return CMX_OK;
+}
+
+cmx_status cmx_intra_rows(cmx_ctx* ctx, int kind, const double* params, const double* counts, size_t n,
+                          const int32_t* rate_class, const double* post_rate, const double* norm, const double* null_stat,
+                          const double* null_nmin, size_t nnull, int nclasses, const cmx_pair_filters* filters,
+                          cmx_pair_row* rows, size_t capacity, uint64_t* count) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!counts || n == 0 || !rate_class || !post_rate || !norm || !count || (capacity && !rows) ||
+      (null_stat && (!null_nmin || nclasses < 1)))
+    return fail(ctx, CMX_ERR_INVALID, "cmx_intra_rows: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t BK = (size_t)ctx->hm.B * ctx->hm.K;
+  TmpDev tmp;
+  std::vector<double> bm;
+  to_branch_major(counts, n, BK, &bm);
+  double *d_cnt, *d_stat, *d_pr, *d_nm, *d_pv = nullptr, *d_ns = nullptr, *d_nn = nullptr;
+  int32_t *d_rc, *d_nsim = nullptr;
+  cmx_pair_row* d_rows = nullptr;
+  uint64_t* d_count;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_cnt, bm.size() * sizeof(double)));
+  HIP_TRY(ctx, hipMemcpy(d_cnt, bm.data(), bm.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_stat, n * n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_pr, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_nm, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_rc, n * sizeof(int32_t)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_count, sizeof(uint64_t)));
+  if (capacity) HIP_TRY(ctx, tmp.alloc((void**)&d_rows, capacity * sizeof(cmx_pair_row)));
+  HIP_TRY(ctx, hipMemcpy(d_pr, post_rate, n * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_nm, norm, n * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_rc, rate_class, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if ((s = cmx_pair_stats_dev(ctx, kind, params, d_cnt, n, n, nullptr, 0, 0, d_stat, n, nullptr)) != CMX_OK) return s;
+  if (null_stat) {
+    HIP_TRY(ctx, tmp.alloc((void**)&d_pv, n * n * sizeof(double)));
+    HIP_TRY(ctx, tmp.alloc((void**)&d_nsim, n * n * sizeof(int32_t)));
+    if (nnull) {
+      HIP_TRY(ctx, tmp.alloc((void**)&d_ns, nnull * sizeof(double)));
+      HIP_TRY(ctx, tmp.alloc((void**)&d_nn, nnull * sizeof(double)));
+      HIP_TRY(ctx, hipMemcpy(d_ns, null_stat, nnull * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_nn, null_nmin, nnull * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if ((s = cmx_intra_pvalues_dev(ctx, d_stat, n, d_nm, n, nclasses, d_ns, d_nn, nnull, d_pv, d_nsim, nullptr)) != CMX_OK) return s;
+  }
+  if ((s = cmx_intra_rows_dev(ctx, d_stat, n, d_pv, d_nsim, n, d_rc, d_pr, d_nm, filters, d_rows, capacity, d_count, nullptr)) != CMX_OK)
+    return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(count, d_count, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  const size_t nw = std::min<size_t>((size_t)*count, capacity);
+  if (nw) HIP_TRY(ctx, hipMemcpy(rows, d_rows, nw * sizeof(cmx_pair_row), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Mica MI
 cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* d_masks, const uint8_t* d_aln1,
                               size_t n1, size_t ld1, const uint8_t* d_aln2, size_t n2, size_t ld2, double* d_mi,

@@ -1,6 +1,8 @@
 // Shared host/device declarations of the MI355X engine (internal; the public surface is include/comap_mi355x.h).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "../../include/comap_mi355x.h"
 #include <stddef.h>
 #include <stdint.h>
 
@@ -122,6 +124,10 @@ hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norm
                           int32_t* d_nsim, hipStream_t stream);
 hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in, double* d_stat_tmp, uint32_t* d_cls_in,
                               uint32_t* d_cls_tmp, size_t n, hipStream_t stream);
+hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pvalue, const int32_t* d_nsim, size_t n,
+                            const int32_t* d_rc, const double* d_pr, const double* d_norm, const cmx_pair_filters& f,
+                            unsigned long long* d_rowcount /*[n + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
+                            size_t capacity, unsigned long long* d_count, hipStream_t stream);
 // scratch of the MFMA Mica path (all device pointers; H1 null = LDS-table kernel only)
 struct MicaWork {
   int8_t *H1, *H2;         // one-hot [n][32][Tp] int8

@@ -1387,6 +1387,81 @@ hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norm
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ compacted pair rows
+// CoETools.cpp:672-724 as two passes of one wave per row i: count the pairs (i, j > i) that pass the filters, exclusive
+// scan of the row counts (rocPRIM), then write the rows at their final position -- the reference's (i, j) order.
+__device__ __forceinline__ bool pair_passes(const cmx_pair_filters& f, int ci, double ri, int cj, double rj, double st) {
+  if (cj < f.min_rate_class || rj < f.min_rate) return false;
+  if (f.max_rate_class_diff >= 0 && abs(cj - ci) > f.max_rate_class_diff) return false;
+  if (f.max_rate_diff >= 0.0 && fabs(rj - ri) > f.max_rate_diff) return false;
+  return !(fabs(st) < f.min_statistic);
+}
+template <bool WRITE>
+__global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict__ stat, size_t ldo,
+                                                       const double* __restrict__ pvalue, const int32_t* __restrict__ nsim,
+                                                       size_t n, const int32_t* __restrict__ rc, const double* __restrict__ pr,
+                                                       const double* __restrict__ norm, cmx_pair_filters f,
+                                                       unsigned long long* __restrict__ rowcount /* counts, then offsets */,
+                                                       cmx_pair_row* __restrict__ rows, size_t capacity) {
+  const size_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int ci = rc[i];
+  const double ri = pr[i];
+  unsigned long long run = WRITE ? rowcount[i] : 0ull;
+  const bool row_ok = !(ci < f.min_rate_class || ri < f.min_rate);
+  if (row_ok)
+    for (size_t j0 = i + 1; j0 < n; j0 += 64) {
+      const size_t j = j0 + lane;
+      bool ok = false;
+      double st = 0.0;
+      if (j < n) {
+        st = stat[i * ldo + j];
+        ok = pair_passes(f, ci, ri, rc[j], pr[j], st);
+      }
+      const unsigned long long m = __ballot(ok);
+      if (WRITE && ok) {
+        const unsigned long long pos = run + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < capacity) {
+          cmx_pair_row r;
+          r.i = (int32_t)i; r.j = (int32_t)j; r.stat = st;
+          r.rc_min = ci < rc[j] ? ci : rc[j];
+          r.pr_min = ri < pr[j] ? ri : pr[j];
+          r.n_min = norm[i] < norm[j] ? norm[i] : norm[j];
+          r.pvalue = pvalue ? pvalue[i * ldo + j] : __builtin_nan("");
+          r.nsim = nsim ? nsim[i * ldo + j] : 0;
+          rows[pos] = r;
+        }
+      }
+      run += __popcll(m);
+    }
+  if (!WRITE && lane == 0) rowcount[i] = run;
+}
+
+__global__ void pair_rows_total_kernel(const unsigned long long* __restrict__ offsets, const unsigned long long* __restrict__ last_count,
+                                       size_t n, unsigned long long* __restrict__ total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *total = offsets[n - 1] + *last_count;
+}
+
+hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pvalue, const int32_t* d_nsim, size_t n,
+                            const int32_t* d_rc, const double* d_pr, const double* d_norm, const cmx_pair_filters& f,
+                            unsigned long long* d_rowcount /*[n + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
+                            size_t capacity, unsigned long long* d_count, hipStream_t stream) {
+  if (d_tmp == nullptr) {
+    return rocprim::exclusive_scan(nullptr, tmp_bytes, d_rowcount, d_rowcount, 0ull, n, rocprim::plus<unsigned long long>(), stream);
+  }
+  hipLaunchKernelGGL((pair_rows_kernel<false>), dim3((unsigned)n), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
+                     d_pr, d_norm, f, d_rowcount, d_rows, capacity);
+  // keep the last row's count (the scan overwrites it) to form the total
+  hipError_t e = hipMemcpyAsync(d_rowcount + n, d_rowcount + n - 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) return e;
+  e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_rowcount, d_rowcount, 0ull, n, rocprim::plus<unsigned long long>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(pair_rows_total_kernel, dim3(1), dim3(64), 0, stream, d_rowcount, d_rowcount + n, n, d_count);
+  hipLaunchKernelGGL((pair_rows_kernel<true>), dim3((unsigned)n), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
+                     d_pr, d_norm, f, d_rowcount, d_rows, capacity);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ Mica column MI
 // SiteTools::mutualInformation / jointEntropy / entropy (resolveUnknowns = true), natural log (Mica.cpp:93-95).
 // v1: one wave per (i, 64 columns j): lane = column j; joint table in LDS as [a][b][lane] would be A*A*64*8 bytes

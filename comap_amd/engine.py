@@ -25,7 +25,7 @@ EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
     "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_traversal", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
-    "cmx_null_inter_dev", "cmx_intra_pvalues",
+    "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev",
 ]
 
@@ -48,6 +48,19 @@ class _Model(ctypes.Structure):
 class _Tree(ctypes.Structure):
     _fields_ = [("nnodes", ctypes.c_int32), ("parent", ctypes.c_void_p), ("blen", ctypes.c_void_p),
                 ("ntaxa", ctypes.c_int32), ("leaf_of_taxon", ctypes.c_void_p)]
+
+
+class PairFilters(ctypes.Structure):
+    """cmx_pair_filters: the pair filters of CoETools::computeIntraStats (CoETools.cpp:674-693)."""
+    _fields_ = [("min_rate_class", ctypes.c_int32), ("max_rate_class_diff", ctypes.c_int32), ("min_rate", ctypes.c_double),
+                ("max_rate_diff", ctypes.c_double), ("min_statistic", ctypes.c_double)]
+
+    def __init__(self, min_rate_class=0, max_rate_class_diff=-1, min_rate=0.0, max_rate_diff=-1.0, min_statistic=0.0):
+        super().__init__(min_rate_class, max_rate_class_diff, min_rate, max_rate_diff, min_statistic)
+
+
+PAIR_ROW = np.dtype([("i", np.int32), ("j", np.int32), ("stat", np.float64), ("rc_min", np.int32), ("nsim", np.int32),
+                     ("pr_min", np.float64), ("n_min", np.float64), ("pvalue", np.float64)], align=True)
 
 
 class _Info(ctypes.Structure):
@@ -243,6 +256,25 @@ class Engine:
         self._check(self._lib.cmx_intra_pvalues(self._ctx, _vp(stat), _vp(norms), _sz(n), int(nclasses), _vp(ns),
                                                 _vp(nm), _sz(len(ns)), _vp(pv), _vp(nsim)))
         return pv, nsim
+
+    def intra_rows(self, kind, counts, rate_class, post_rate, norm, null_stat=None, null_nmin=None, nclasses=10,
+                   filters=None, capacity=None, threshold=0.99):
+        """statistics.txt rows (structured array PAIR_ROW, reference order), compacted on the device."""
+        c = _f64(counts).reshape(len(counts), self.B, self.K)
+        n = c.shape[0]
+        rc = np.ascontiguousarray(rate_class, dtype=np.int32)
+        pr, nm = _f64(post_rate), _f64(norm)
+        ns = None if null_stat is None else _f64(null_stat)
+        nn = None if null_nmin is None else _f64(null_nmin)
+        cap = n * (n - 1) // 2 if capacity is None else int(capacity)
+        rows = np.zeros(max(cap, 1), dtype=PAIR_ROW)
+        count = ctypes.c_uint64(0)
+        f = filters if filters is not None else PairFilters()
+        params = _f64([threshold])
+        self._check(self._lib.cmx_intra_rows(self._ctx, int(kind), _vp(params), _vp(c), _sz(n), _vp(rc), _vp(pr), _vp(nm),
+                                             _vp(ns), _vp(nn), _sz(0 if ns is None else len(ns)), int(nclasses),
+                                             ctypes.byref(f), _vp(rows), _sz(cap), ctypes.byref(count)))
+        return rows[: min(cap, count.value)], count.value
 
     def mi_columns(self, aln1, aln2=None, nalpha=20, masks=None):
         a1 = np.ascontiguousarray(aln1, dtype=np.uint8)

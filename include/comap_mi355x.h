@@ -159,6 +159,35 @@ cmx_status cmx_intra_pvalues_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo,
                                  int nclasses, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
                                  double* d_pvalue, int32_t* d_nsim, void* stream);
 
+/* ---- the rows of statistics.txt, compacted on the device: the pair loop of CoETools::computeIntraStats
+ * (CoMap/CoETools.cpp:672-724) with its filters (:674-693: min rate class / rate per site, max differences per pair,
+ * |stat| >= statistic.min) applied to the dense statistic (and p-value / Nsim) matrices; rows come out in the
+ * reference's (i, j) order, j > i.  pvalue NaN == "NA" (Nsim 0).  *count receives the number of rows that pass;
+ * at most `capacity` of them are written. */
+typedef struct cmx_pair_filters {
+  int32_t min_rate_class;      /* statistic.min_rate_class, CoETools.cpp:420-433 */
+  int32_t max_rate_class_diff; /* < 0: off */
+  double min_rate;             /* statistic.min_rate */
+  double max_rate_diff;        /* < 0: off */
+  double min_statistic;        /* statistic.min, CoETools.cpp:693 */
+} cmx_pair_filters;
+typedef struct cmx_pair_row {
+  int32_t i, j;                /* site indices (the caller maps them to coordinates, CoETools.cpp:699-703) */
+  double stat;
+  int32_t rc_min, nsim;
+  double pr_min, n_min, pvalue;
+} cmx_pair_row;
+cmx_status cmx_intra_rows_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, const double* d_pvalue /*or NULL*/,
+                              const int32_t* d_nsim /*or NULL*/, size_t n, const int32_t* d_rate_class,
+                              const double* d_post_rate, const double* d_norm, const cmx_pair_filters* filters,
+                              cmx_pair_row* d_rows, size_t capacity, uint64_t* d_count, void* stream);
+/* host pointers: counts [N][B][K] -> statistic -> (optional) p-values from a null -> compacted rows; only the rows
+ * cross PCIe on the way back.  null_stat == NULL: no p-values (pvalue NaN, Nsim 0 in every row). */
+cmx_status cmx_intra_rows(cmx_ctx* ctx, int kind, const double* params, const double* counts, size_t n,
+                          const int32_t* rate_class, const double* post_rate, const double* norm,
+                          const double* null_stat, const double* null_nmin, size_t nnull, int nclasses,
+                          const cmx_pair_filters* filters, cmx_pair_row* rows, size_t capacity, uint64_t* count);
+
 /* ---- Mica: mutual information between alignment columns over taxa (Mica.cpp:93-95, 349-361, 646-660).
  * aln2 == NULL: intra.  Outputs dense [n1][n2] (mi, hjoint) and per-column entropies; nalpha = alphabet size. */
 cmx_status cmx_mi_columns(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks,

@@ -335,43 +335,31 @@ class CoETools {
                                                      size_t nbRateClasses = 10, const PairFilters& f = PairFilters()) {
     const size_t n = mapping.getNumberOfSites();
     const Vdouble norms = AnalysisTools::computeNorms(mapping);
-    Vdouble stat = statistic.getValuesForAllPairs(eng, mapping);
-    Vdouble pv;
-    std::vector<int32_t> nsim;
+    Vdouble ns, nm;
     if (computeNull) {
       const size_t nn = nbRepCPU * nbRepRAM;
-      Vdouble ns(nn), nm(nn);
+      ns.resize(nn);
+      nm.resize(nn);
       eng.check(cmx_null_intra(eng.ctx(), statistic.kind(), statistic.params(), seed, 0, nbRepCPU, nbRepRAM, nullptr,
                                ns.data(), nullptr, nullptr, nm.data()));
-      pv.resize(n * n);
-      nsim.resize(n * n);
-      eng.check(cmx_intra_pvalues(eng.ctx(), stat.data(), norms.data(), n, static_cast<int>(nbRateClasses), ns.data(),
-                                  nm.data(), nn, pv.data(), nsim.data()));
     }
-    std::vector<IntraStatRow> rows;
-    for (size_t i = 0; i < n; i++) {
-      const int iClass = mapping.rateClasses[i];
-      const double iRate = mapping.posteriorRates[i];
-      if (iClass < f.minRateClass) continue;
-      if (iRate < f.minRate) continue;
-      for (size_t j = i + 1; j < n; j++) {
-        const int jClass = mapping.rateClasses[j];
-        const double jRate = mapping.posteriorRates[j];
-        if (jClass < f.minRateClass) continue;
-        if (jRate < f.minRate) continue;
-        if (f.maxRateClassDiff >= 0 && std::abs(jClass - iClass) > f.maxRateClassDiff) continue;
-        if (f.maxRateDiff >= 0. && std::fabs(jRate - iRate) > f.maxRateDiff) continue;
-        const double s = stat[i * n + j];
-        if (std::fabs(s) < f.minStatistic) continue;
-        IntraStatRow r;
-        r.i = i; r.j = j; r.stat = s;
-        r.rcMin = std::min(iClass, jClass);
-        r.prMin = std::min(iRate, jRate);
-        r.nMin = std::min(norms[i], norms[j]);
-        r.pValue = computeNull ? pv[i * n + j] : std::numeric_limits<double>::quiet_NaN();
-        r.nSim = computeNull ? nsim[i * n + j] : 0;
-        rows.push_back(r);
-      }
+    // statistic, p-values, filters and the (i, j) ordering all happen on the device (cmx_intra_rows): only the rows
+    // that the reference would write come back
+    cmx_pair_filters pf;
+    pf.min_rate_class = f.minRateClass; pf.max_rate_class_diff = f.maxRateClassDiff;
+    pf.min_rate = f.minRate; pf.max_rate_diff = f.maxRateDiff; pf.min_statistic = f.minStatistic;
+    std::vector<cmx_pair_row> raw(n * (n - 1) / 2 + 1);
+    uint64_t count = 0;
+    eng.check(cmx_intra_rows(eng.ctx(), statistic.kind(), statistic.params(), mapping.data(), n, mapping.rateClasses.data(),
+                             mapping.posteriorRates.data(), norms.data(), computeNull ? ns.data() : nullptr,
+                             computeNull ? nm.data() : nullptr, ns.size(), static_cast<int>(nbRateClasses), &pf, raw.data(),
+                             raw.size(), &count));
+    std::vector<IntraStatRow> rows(static_cast<size_t>(count));
+    for (size_t q = 0; q < rows.size(); ++q) {
+      IntraStatRow& r = rows[q];
+      r.i = static_cast<size_t>(raw[q].i); r.j = static_cast<size_t>(raw[q].j); r.stat = raw[q].stat;
+      r.rcMin = raw[q].rc_min; r.prMin = raw[q].pr_min; r.nMin = raw[q].n_min;
+      r.pValue = raw[q].pvalue; r.nSim = raw[q].nsim;
     }
     return rows;
   }

@@ -19,7 +19,9 @@ EXE = os.path.join(ROOT, "tests", "cpp", "adapter_main")
 @pytest.fixture(scope="module")
 def adapter_exe():
     src = os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp")
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(engine.LIB_PATH)):
+    deps = [src, engine.LIB_PATH, os.path.join(ROOT, "include", "comap_mi355x_adapter.hpp"),
+            os.path.join(ROOT, "include", "comap_mi355x.h")]
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
                                "-L", os.path.dirname(engine.LIB_PATH), "-lcomap_mi355x",
                                "-Wl,-rpath," + os.path.dirname(engine.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])

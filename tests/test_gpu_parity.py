@@ -294,6 +294,39 @@ def test_mi_columns_configuration5_shape_identities():
     rel_close(g["mi"][:8, :8], sub["mi"], 1e-6, 1e-12)
 
 
+def test_compacted_rows_equal_the_reference_pair_loop():
+    """cmx_intra_rows == CoETools.cpp:672-724 (filters, (i, j) order, NA rule) applied on the host to the dense matrices"""
+    from comap_amd import formats
+    case = make_case(10, 150, 20, 81)
+    eng = _engine(case)
+    m = eng.map_sites(case["aln"])
+    st = eng.pair_stats(0, m["counts"])
+    nl = eng.null_intra(0, 11, 0, 30, 64)
+    pv, ns = eng.intra_pvalues(st, m["norm"], 6, nl["stat"], nl["nmin"])
+    coords = np.arange(150) + 1
+    for f in (engine.PairFilters(), engine.PairFilters(min_rate_class=1, max_rate_class_diff=1, min_rate=0.3,
+                                                       max_rate_diff=1.5, min_statistic=0.2)):
+        rows, count = eng.intra_rows(0, m["counts"], m["rate_class"], m["post_rate"], m["norm"], nl["stat"], nl["nmin"], 6, f)
+        assert count == len(rows)
+        ref = formats.to_text(formats.write_intra_stats, coords, st, m["rate_class"], m["post_rate"], m["norm"], pv, ns,
+                              f.min_rate_class, f.min_rate, f.max_rate_class_diff, f.max_rate_diff, f.min_statistic)
+        pvm, nsm = np.full((150, 150), np.nan), np.zeros((150, 150), dtype=np.int32)
+        stm = np.full((150, 150), np.nan)
+        stm[rows["i"], rows["j"]] = rows["stat"]
+        pvm[rows["i"], rows["j"]] = rows["pvalue"]
+        nsm[rows["i"], rows["j"]] = rows["nsim"]
+        # writing the compacted rows (already filtered, already ordered) gives the same text
+        lines = ["Group\tStat\tRCmin\tPRmin\tNmin\tPValue\tNsim"]
+        for r in rows:
+            p = ["NA", "0"] if np.isnan(r["pvalue"]) else [formats.fmt(r["pvalue"]), str(r["nsim"])]
+            lines.append("\t".join(["[%d;%d]" % (coords[r["i"]], coords[r["j"]]), formats.fmt(r["stat"]), str(r["rc_min"]),
+                                    formats.fmt(r["pr_min"]), formats.fmt(r["n_min"])] + p))
+        assert "\n".join(lines) + "\n" == ref
+    # capacity smaller than the row count: count still reports all rows
+    few, total = eng.intra_rows(0, m["counts"], m["rate_class"], m["post_rate"], m["norm"], capacity=10)
+    assert len(few) == 10 and total == 150 * 149 // 2 and np.isnan(few["pvalue"]).all()
+
+
 def test_mi_columns_matches_oracle_with_ambiguity():
     rng = np.random.default_rng(3)
     T, n1, n2 = 40, 37, 21
