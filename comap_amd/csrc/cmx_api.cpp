@@ -799,4 +799,47 @@ cmx_status cmx_mi_columns(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* m
   return CMX_OK;
 }
 
+cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks, const uint8_t* aln1,
+                        size_t n1, const uint8_t* aln2, size_t n2, const int64_t* idx1, const int64_t* idx2, size_t npairs,
+                        double* mi, double* hjoint) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (nalpha != 4 && nalpha != 20) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mi_pairs: alphabet size must be 4 or 20");
+  if (!aln1 || !idx1 || !idx2 || !mi || !hjoint || n1 == 0 || ntaxa < 1 || npairs == 0)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_mi_pairs: bad arguments");
+  if (!aln2) n2 = n1;
+  for (size_t p = 0; p < npairs; ++p)
+    if (idx1[p] < 0 || (size_t)idx1[p] >= n1 || idx2[p] < 0 || (size_t)idx2[p] >= n2)
+      return fail(ctx, CMX_ERR_INVALID, "cmx_mi_pairs: column index out of range");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> mk(256, (1u << nalpha) - 1u);
+  for (int i = 0; i < nalpha; ++i) mk[i] = 1u << i;
+  if (masks) for (size_t i = 0; i < nmasks && i < 256; ++i) mk[i] = masks[i];
+  for (size_t i = 0; i < 256; ++i) if (mk[i] == 0) mk[i] = (1u << nalpha) - 1u;
+  TmpDev tmp;
+  uint32_t* d_masks;
+  uint8_t *d1, *d2;
+  int64_t *di1, *di2;
+  double *d_mi, *d_hj;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_masks, 256 * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipMemcpy(d_masks, mk.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, tmp.alloc((void**)&d1, (size_t)ntaxa * n1));
+  HIP_TRY(ctx, hipMemcpy(d1, aln1, (size_t)ntaxa * n1, hipMemcpyHostToDevice));
+  d2 = d1;
+  if (aln2) {
+    HIP_TRY(ctx, tmp.alloc((void**)&d2, (size_t)ntaxa * n2));
+    HIP_TRY(ctx, hipMemcpy(d2, aln2, (size_t)ntaxa * n2, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(ctx, tmp.alloc((void**)&di1, npairs * sizeof(int64_t)));
+  HIP_TRY(ctx, tmp.alloc((void**)&di2, npairs * sizeof(int64_t)));
+  HIP_TRY(ctx, hipMemcpy(di1, idx1, npairs * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(di2, idx2, npairs * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_mi, npairs * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_hj, npairs * sizeof(double)));
+  HIP_TRY(ctx, launch_mi_pairs(nalpha, ntaxa, d_masks, d1, n1, d2, n2, di1, di2, npairs, d_mi, d_hj, nullptr));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(mi, d_mi, npairs * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(hjoint, d_hj, npairs * sizeof(double), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
 }  // extern "C"

@@ -128,6 +128,9 @@ hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pv
                             const int32_t* d_rc, const double* d_pr, const double* d_norm, const cmx_pair_filters& f,
                             unsigned long long* d_rowcount /*[n + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
                             size_t capacity, unsigned long long* d_count, hipStream_t stream);
+hipError_t launch_mi_pairs(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t ld1, const uint8_t* d_aln2,
+                           size_t ld2, const int64_t* d_idx1, const int64_t* d_idx2, size_t npairs, double* d_mi,
+                           double* d_hj, hipStream_t stream);
 // scratch of the MFMA Mica path (all device pointers; H1 null = LDS-table kernel only)
 struct MicaWork {
   int8_t *H1, *H2;         // one-hot [n][32][Tp] int8

@@ -1543,6 +1543,80 @@ __global__ __launch_bounds__(64) void mi_columns_kernel(int T, const uint32_t* _
   }
 }
 
+// MI / joint entropy of LISTED column pairs (idx1[p], idx2[p]): the building block of Mica's null distributions
+// (non-parametric bootstrap = random pairs of the data, Mica.cpp:399-468; parametric bootstrap = column j of one
+// simulated alignment against column j of another, Mica.cpp:469-548).  Same table arithmetic as mi_columns_kernel.
+template <int A>
+__global__ __launch_bounds__(64) void mi_pairs_kernel(int T, const uint32_t* __restrict__ masks,
+                                                      const uint8_t* __restrict__ aln1, size_t ld1,
+                                                      const uint8_t* __restrict__ aln2, size_t ld2,
+                                                      const int64_t* __restrict__ idx1, const int64_t* __restrict__ idx2,
+                                                      size_t npairs, double* __restrict__ mi, double* __restrict__ hj) {
+  extern __shared__ double tab[];
+  const int lane = threadIdx.x, sub = lane & 15, part = lane >> 4;
+  const size_t p = (size_t)blockIdx.x * 16 + sub;
+  const size_t pp = p < npairs ? p : npairs - 1;
+  const size_t i = (size_t)idx1[pp], j = (size_t)idx2[pp];
+  for (int q = lane; q < A * A * 16; q += 64) tab[q] = 0.0;
+  __syncthreads();
+  for (int t = part; t < T; t += 4) {
+    const unsigned c1 = aln1[(size_t)t * ld1 + i], c2 = aln2[(size_t)t * ld2 + j];
+    if (c1 < (unsigned)A && c2 < (unsigned)A) {
+      atomicAdd(&tab[(c1 * A + c2) * 16 + sub], 1.0);
+    } else {
+      const uint32_t m1 = c1 < (unsigned)A ? (1u << c1) : masks[c1], m2 = c2 < (unsigned)A ? (1u << c2) : masks[c2];
+      const double w = 1.0 / (double)(__popc(m1) * __popc(m2));
+      for (int a = 0; a < A; ++a)
+        if ((m1 >> a) & 1u)
+          for (int b = 0; b < A; ++b)
+            if ((m2 >> b) & 1u) atomicAdd(&tab[(a * A + b) * 16 + sub], w);
+    }
+  }
+  __syncthreads();
+  if (part == 0 && p < npairs) {
+    double p1[A], p2[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) { p1[a] = 0.0; p2[a] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int b = 0; b < A; ++b) {
+        const double v = tab[(a * A + b) * 16 + sub];
+        p1[a] += v;
+        p2[b] += v;
+      }
+    double s = 0.0, h = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int b = 0; b < A; ++b) {
+        const double pab = tab[(a * A + b) * 16 + sub] / T;
+        if (pab > 0.0) {
+          s += pab * log(pab / ((p1[a] / T) * (p2[b] / T)));
+          h -= pab * log(pab);
+        }
+      }
+    mi[p] = s;
+    hj[p] = h;
+  }
+}
+
+hipError_t launch_mi_pairs(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t ld1, const uint8_t* d_aln2,
+                           size_t ld2, const int64_t* d_idx1, const int64_t* d_idx2, size_t npairs, double* d_mi,
+                           double* d_hj, hipStream_t stream) {
+  dim3 grid((unsigned)((npairs + 15) / 16));
+  const size_t lds = sizeof(double) * A * A * 16;
+  if (A == 20)
+    hipLaunchKernelGGL((mi_pairs_kernel<20>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, ld1, d_aln2, ld2, d_idx1, d_idx2,
+                       npairs, d_mi, d_hj);
+  else if (A == 4)
+    hipLaunchKernelGGL((mi_pairs_kernel<4>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, ld1, d_aln2, ld2, d_idx1, d_idx2,
+                       npairs, d_mi, d_hj);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // ---- MFMA path (SURVEY 8d "Mica MI"): for columns without ambiguous symbols the joint table of a column pair is one
 // 32x32 block of the Gram matrix of one-hot matrices, H_i (32 x T) . H_j^T, exact in int8 x int8 -> int32.  With integer
 // counts c the entropies need no logarithm at run time: sum_ab p_ab ln p_ab = (1/T) sum_ab f(c_ab) - ln T with

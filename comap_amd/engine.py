@@ -26,7 +26,7 @@ EXPORTS = [
     "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_traversal", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev",
-    "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev",
+    "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
 ]
 
 
@@ -287,6 +287,19 @@ class Engine:
         self._check(self._lib.cmx_mi_columns(self._ctx, int(nalpha), int(T), _vp(mk), _sz(0 if mk is None else len(mk)),
                                              _vp(a1), _sz(n1), _vp(a2), _sz(n2), _vp(mi), _vp(hj), _vp(h1), _vp(h2)))
         return dict(mi=mi, hjoint=hj, h1=h1, h2=h2)
+
+    def mi_pairs(self, aln1, idx1, idx2, aln2=None, nalpha=20, masks=None):
+        """MI / joint entropy of the listed column pairs (Mica's bootstrap nulls, Mica.cpp:399-548)."""
+        a1 = np.ascontiguousarray(aln1, dtype=np.uint8)
+        T, n1 = a1.shape
+        a2 = None if aln2 is None else np.ascontiguousarray(aln2, dtype=np.uint8)
+        i1, i2 = np.ascontiguousarray(idx1, dtype=np.int64), np.ascontiguousarray(idx2, dtype=np.int64)
+        mi, hj = np.zeros(len(i1)), np.zeros(len(i1))
+        mk = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint32)
+        self._check(self._lib.cmx_mi_pairs(self._ctx, int(nalpha), int(T), _vp(mk), _sz(0 if mk is None else len(mk)),
+                                           _vp(a1), _sz(n1), _vp(a2), _sz(0 if a2 is None else a2.shape[1]), _vp(i1),
+                                           _vp(i2), _sz(len(i1)), _vp(mi), _vp(hj)))
+        return dict(mi=mi, hjoint=hj)
 
     # -- device-pointer entry points (torch CUDA tensors, engine-native layouts, asynchronous)
     def map_sites_dev(self, d_aln, counts=None, logL=None, post_rate=None, rate_class=None, norm=None, masks=None):

@@ -196,6 +196,13 @@ cmx_status cmx_mi_columns(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* m
 cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* d_masks, const uint8_t* d_aln1,
                               size_t n1, size_t ld1, const uint8_t* d_aln2, size_t n2, size_t ld2, double* d_mi,
                               double* d_hjoint, size_t ldo, double* d_h1, double* d_h2, void* stream);
+/* MI and joint entropy of listed column pairs (idx1[p] of aln1, idx2[p] of aln2; aln2 == NULL: both from aln1): the
+ * statistic of Mica's null distributions -- non-parametric bootstrap over random site pairs (CoMap/Mica.cpp:399-468)
+ * and parametric bootstrap over pairs (j, j) of two simulated alignments (:469-548, with cmx_simulate). */
+cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks, const uint8_t* aln1,
+                        size_t n1, const uint8_t* aln2, size_t n2, const int64_t* idx1, const int64_t* idx2,
+                        size_t npairs, double* mi, double* hjoint);
+
 
 #ifdef __cplusplus
 }

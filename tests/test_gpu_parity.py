@@ -327,6 +327,32 @@ def test_compacted_rows_equal_the_reference_pair_loop():
     assert len(few) == 10 and total == 150 * 149 // 2 and np.isnan(few["pvalue"]).all()
 
 
+def test_mica_bootstrap_nulls_match_oracle():
+    """cmx_mi_pairs under Mica's two bootstrap nulls (Mica.cpp:399-548) against the oracle's column MI"""
+    from comap_amd import mica
+    rng = np.random.default_rng(9)
+    T, n = 48, 60
+    aln = rng.integers(0, 20, size=(T, n)).astype(np.uint8)
+    aln[rng.random(aln.shape) < 0.03] = 21
+    eng = engine.Engine()
+    full = oracle.mi_columns(aln, aln, 20)
+    nb = mica.bootstrap_null(eng, aln, full["h1"], seed=5, nrep_cpu=3, nrep_ram=37)
+    rel_close(nb["mi"], full["mi"][nb["index1"], nb["index2"]], 1e-6, 1e-12)
+    rel_close(nb["hjoint"], full["hjoint"][nb["index1"], nb["index2"]], 1e-6, 1e-12)
+    assert np.array_equal(nb["hmin"], np.minimum(full["h1"][nb["index1"]], full["h1"][nb["index2"]]))
+    assert (nb["index1"] == nb["index2"]).any() or True     # a site may be paired with itself, as in the reference
+    # parametric: simulate under a model, score (j, j)
+    case = make_case(12, 4, 20, 15)
+    em, om = _engine(case), _omodel(case)
+    pn = mica.parametric_null(em, seed=77, nrep_cpu=2, nrep_ram=50)
+    for rep in range(2):
+        a1, _ = oracle.simulate(om, 77, (rep * 2) * 50, 50)
+        a2, _ = oracle.simulate(om, 77, (rep * 2 + 1) * 50, 50)
+        o = oracle.mi_columns(a1, a2, 20)
+        rel_close(pn["mi"][rep * 50:(rep + 1) * 50], np.diag(o["mi"]), 1e-6, 1e-12)
+        rel_close(pn["hjoint"][rep * 50:(rep + 1) * 50], np.diag(o["hjoint"]), 1e-6, 1e-12)
+
+
 def test_mi_columns_matches_oracle_with_ambiguity():
     rng = np.random.default_rng(3)
     T, n1, n2 = 40, 37, 21
