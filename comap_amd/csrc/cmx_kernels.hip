@@ -136,27 +136,53 @@ __device__ __forceinline__ void wait_vm(int allowed) {
   }
 }
 
-// Tiles are read two ahead of their use: an LDS read takes ~100+ cycles, the 16 FMAs of a tile 64, and hipcc keeps
-// a ds_read right in front of the asm that consumes it unless the source orders them (the empty asm is a compiler
-// barrier for memory operations only; the s_waitcnt for a tile lands in front of its own FMAs, two tiles later).
-template <int S, bool TR, int T>
-__device__ __forceinline__ void stage_steps(const uint8_t* tile0 /* buffer + (lane & 15) * 8 */, double m0, double m1,
-                                            const double (&x)[S], double (&y)[S]) {
+// ---- Matrix-core layout of an S-vector of the wave's 64 sites.  v_mfma_f64_4x4x4_4b computes four independent
+// D[4x4] += A[4x4] . B[4x4]; measured on gfx950 (scripts/probe_mfma_f64_4x4x4.hip): A lane = 16 k + 4 blk + i,
+// B lane = 16 k + 4 blk + n, D lane = 16 i + 4 blk + n.  With i / k = state inside a 4-state tile and (blk, n) = site inside
+// a group of 16, B and D share one layout:
+//     register v[sb * 4 + g] of lane l holds state 4 sb + (l >> 4) of site 16 g + (l & 15)
+// (sb = state tile, g = site group).  A product is one MFMA per (output tile, input tile, site group): 100 matrix
+// instructions instead of 400 DPP-broadcast FMAs, the accumulators of the four site groups are independent chains, and
+// the other wave's vector work issues while they run.  The operator tile is read from the same packed 4x4 blocks as
+// before, each lane taking the one element its A slot needs.  Elementwise work is layout-blind; sums over states
+// become a reduce-scatter over the lane bits 4 and 5 that leaves lane l with the total of site l.
+template <int S>
+__device__ __forceinline__ int vidx(int sb, int g) { return sb * 4 + g; }
+
+// reduce-scatter of per-site-group partial sums over the four state-in-tile lanes: lane l returns the total of site l
+__device__ __forceinline__ double reduce_sites(double p0, double p1, double p2, double p3, int lane) {
+  const bool hi = (lane & 32) != 0, lo = (lane & 16) != 0;
+  const double s0 = hi ? p0 : p2, s1 = hi ? p1 : p3;          // what the partner (lane ^ 32) keeps
+  double k0 = hi ? p2 : p0, k1 = hi ? p3 : p1;                // site groups 2 hi + {0, 1}
+  k0 += __shfl_xor(s0, 32, 64);
+  k1 += __shfl_xor(s1, 32, 64);
+  const double s = lo ? k0 : k1;
+  double k = lo ? k1 : k0;                                     // site group 2 hi + lo = lane >> 4
+  k += __shfl_xor(s, 16, 64);
+  return k;
+}
+
+// step q of a product: output tile o = q / NB, input tile i = q % NB; the stored tile is (o, i), or (i, o) for the
+// transposed product.  Tiles are read two steps ahead of their use (an LDS read takes ~100+ cycles, the four MFMAs of a
+// step 64); the empty asm pins the read in front of the MFMAs it overlaps.
+template <int S, bool TR>
+__device__ __forceinline__ constexpr int mfma_tile(int q) {
+  return TR ? (q % (S / 4)) * (S / 4) + q / (S / 4) : q;
+}
+template <int S, bool TR, int Q>
+__device__ __forceinline__ void mfma_steps(const uint8_t* tile0, double m0, double m1, const double (&x)[S], double (&y)[S]) {
   constexpr int NB = S / 4, NT = NB * NB;
-  if constexpr (T < NT) {
-    constexpr int bi = T / NB, bj = T % NB;
+  if constexpr (Q < NT) {
+    constexpr int o = Q / NB, i = Q % NB;
     double m2 = 0.0;
-    if constexpr (T + 2 < NT) {
-      m2 = *reinterpret_cast<const double*>(tile0 + (T + 2) * 128);
+    if constexpr (Q + 2 < NT) {
+      m2 = *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(Q + 2) * 128);
       asm volatile("" ::: "memory");
     }
-    if constexpr (!TR)
-      dpp_tile_f(y[4 * bi], y[4 * bi + 1], y[4 * bi + 2], y[4 * bi + 3], m0, x[4 * bj], x[4 * bj + 1], x[4 * bj + 2],
-                 x[4 * bj + 3]);
-    else
-      dpp_tile_t(y[4 * bj], y[4 * bj + 1], y[4 * bj + 2], y[4 * bj + 3], m0, x[4 * bi], x[4 * bi + 1], x[4 * bi + 2],
-                 x[4 * bi + 3]);
-    stage_steps<S, TR, T + 1>(tile0, m1, m2, x, y);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      y[o * 4 + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(m0, x[i * 4 + g], i == 0 ? 0.0 : y[o * 4 + g], 0, 0, 0);
+    mfma_steps<S, TR, Q + 1>(tile0, m1, m2, x, y);
   }
 }
 
@@ -169,43 +195,49 @@ __device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const
     for (int i = 0; i < S; ++i) y[i] = x[i] * 0.5;
     return;
   }
-  const uint8_t* tile0 = buf + (lane & 15) * 8;
-  const double m0 = *reinterpret_cast<const double*>(tile0);
-  double m1 = 0.0;
-  if constexpr ((S / 4) * (S / 4) > 1) m1 = *reinterpret_cast<const double*>(tile0 + 128);
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < S; ++i) y[i] = 0.0;
-  stage_steps<S, TR, 0>(tile0, m0, m1, x, y);
+  constexpr int NB = S / 4;
+  // element (row r, column c) of a packed tile sits at (4 r + c) * 8; the A slot of lane l is row l & 3, column l >> 4
+  // (transposed product: the transposed tile, i.e. row l >> 4, column l & 3)
+  const uint8_t* tile0 = buf + (TR ? (4 * (lane >> 4) + (lane & 3)) : (4 * (lane & 3) + (lane >> 4))) * 8;
+  mfma_steps<S, TR, 0>(tile0, *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(0) * 128),
+                       NB * NB > 1 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(1) * 128) : 0.0, x, y);
 }
 
 // Message of a leaf edge from the transposed operator staged in buf ([z][x] = M[x][z], rows >= S: ambiguity ids):
-// row `symbol`, consumed 16 bytes at a time as it arrives from LDS so that no S-vector of temporaries is live.
-// SET out = row, MUL out = row o in (in may be out), DOT returns sum_x in[x] * row[x] (x ascending, one FMA chain).
+// lane l needs, for each site group g, element 4 sb + (l >> 4) of the row named by the symbol of site 16 g + (l & 15).
+// SET out = row, MUL out = row o in (in may be out), DOT returns sum_x in[x] * row[x] of site l (reduce_sites).
 enum { LEAF_SET = 0, LEAF_MUL = 1, LEAF_DOT = 2 };
 template <int S, int MODE>
-__device__ __forceinline__ double leaf_apply(const uint8_t* buf, unsigned code, const double (&in)[S], double (&out)[S]) {
-  double dot = 0.0;
-  if (CMX_ABLATE == 1 || CMX_ABLATE == 4 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
+__device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* codes /* slot + 4 * (lane & 15) */, int lane,
+                                             const double (&in)[S], double (&out)[S]) {
+  constexpr int NB = S / 4;
+  double part[4];
 #pragma unroll
-    for (int x = 0; x < S; ++x) {
-      const double v = 0.05 + 0.001 * code;
-      if (MODE == LEAF_SET) out[x] = v;
-      else if (MODE == LEAF_MUL) out[x] = v * in[x];
-      else dot = __builtin_fma(in[x], v, dot);
+  for (int g = 0; g < 4; ++g) {
+    const unsigned code = codes[g * 64];   // symbol of site 16 g + (lane & 15): one dword per site in the slot
+    part[g] = 0.0;
+    if (CMX_ABLATE == 1 || CMX_ABLATE == 4 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
+#pragma unroll
+      for (int sb = 0; sb < NB; ++sb) {
+        const double v = 0.05 + 0.001 * code;
+        if (MODE == LEAF_SET) out[sb * 4 + g] = v;
+        else if (MODE == LEAF_MUL) out[sb * 4 + g] = v * in[sb * 4 + g];
+        else part[g] = __builtin_fma(in[sb * 4 + g], v, part[g]);
+      }
+      continue;
     }
-    return dot;
-  }
-  const unsigned row = code < (unsigned)MatStage<S>::NROW ? code : (unsigned)(MatStage<S>::NROW - 1);
-  const d2* r = reinterpret_cast<const d2*>(buf + row * (S * 8));
+    const unsigned row = code < (unsigned)MatStage<S>::NROW ? code : (unsigned)(MatStage<S>::NROW - 1);
+    const double* r = reinterpret_cast<const double*>(buf + row * (S * 8)) + (lane >> 4);
 #pragma unroll
-  for (int q = 0; q < S / 2; ++q) {
-    const d2 v = r[q];
-    if (MODE == LEAF_SET) { out[2 * q] = v[0]; out[2 * q + 1] = v[1]; }
-    else if (MODE == LEAF_MUL) { out[2 * q] = v[0] * in[2 * q]; out[2 * q + 1] = v[1] * in[2 * q + 1]; }
-    else { dot = __builtin_fma(in[2 * q], v[0], dot); dot = __builtin_fma(in[2 * q + 1], v[1], dot); }
+    for (int sb = 0; sb < NB; ++sb) {
+      const double v = r[4 * sb];
+      if (MODE == LEAF_SET) out[sb * 4 + g] = v;
+      else if (MODE == LEAF_MUL) out[sb * 4 + g] = v * in[sb * 4 + g];
+      else part[g] = __builtin_fma(in[sb * 4 + g], v, part[g]);
+    }
   }
-  return dot;
+  if (MODE != LEAF_DOT) return 0.0;
+  return reduce_sites(part[0], part[1], part[2], part[3], lane);
 }
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -458,8 +490,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   do {                                                                                       \
     CMX_OP_BEGIN();                                                                          \
     CMX_TIC();                                                                               \
-    const unsigned code_ = *(cslot + os.par * kCodeSlotBytes + 4 * lane);                    \
-    tot = leaf_apply<S, MODE_>(buf_, code_, in, out);                               \
+    tot = leaf_apply<S, MODE_>(buf_, cslot + os.par * kCodeSlotBytes + 4 * (lane & 15), lane, in, out); \
     asm volatile("" :: "v"(tot), "v"(out[0]), "v"(out[S - 1]));                              \
     CMX_TOC(TM_LEAF);                                                                        \
     CMX_OP_END();                                                                            \
@@ -473,8 +504,11 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   do { _Pragma("unroll") for (int i_ = 0; i_ < S; ++i_) asm volatile("" : "=v"(v[i_])); } while (0)
 #define CMX_DOT(x_, y_, out)                                                          \
   do {                                                                                \
-    out = 0.0;                                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < S; ++i_) out = __builtin_fma(x_[i_], y_[i_], out); \
+    double p_[4] = {0.0, 0.0, 0.0, 0.0};                                              \
+    _Pragma("unroll") for (int sb_ = 0; sb_ < S / 4; ++sb_)                           \
+      _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                \
+        p_[g_] = __builtin_fma(x_[sb_ * 4 + g_], y_[sb_ * 4 + g_], p_[g_]);           \
+    out = reduce_sites(p_[0], p_[1], p_[2], p_[3], lane);                             \
   } while (0)
   for (int c = c_begin; c < c_end; ++c) {
     CMX_TIC();
@@ -569,12 +603,21 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       if (n != root) {
         CMX_STORE(wsD + (size_t)r[REC_SLOT] * S * kWave + 2 * lane, acc);
       } else {
-        constexpr int S0 = S / FUSE;
+        // lane l holds state 4 sb + (l >> 4) of its four sites: weight it with that state's frequency
+        if constexpr (FUSE == 1) {
+          double p_[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int g = 0; g < FUSE; ++g) {
-          Lg[g] = 0.0;
+          for (int sb = 0; sb < S / 4; ++sb) {
+            const double pv = m.pi[4 * sb + (lane >> 4)];
 #pragma unroll
-          for (int x = 0; x < S0; ++x) Lg[g] = __builtin_fma(cm.pi[x], acc[g * S0 + x], Lg[g]);
+            for (int g = 0; g < 4; ++g) p_[g] = __builtin_fma(pv, acc[sb * 4 + g], p_[g]);
+          }
+          Lg[0] = reduce_sites(p_[0], p_[1], p_[2], p_[3], lane);
+        } else {   // one 4-state tile per fused class
+          const double pv = m.pi[lane >> 4];
+#pragma unroll
+          for (int sb = 0; sb < FUSE; ++sb)
+            Lg[sb] = reduce_sites(pv * acc[sb * 4 + 0], pv * acc[sb * 4 + 1], pv * acc[sb * 4 + 2], pv * acc[sb * 4 + 3], lane);
         }
         Lc = Lg[0];
       }
@@ -605,7 +648,11 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       const int f = r[REC_N];
       if (f == root) {
 #pragma unroll
-        for (int x = 0; x < S; ++x) acc[x] = cm.pi[x % (S / FUSE)];
+        for (int sb = 0; sb < S / 4; ++sb) {
+          const double pv = m.pi[(4 * sb + (lane >> 4)) % (S / FUSE)];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[sb * 4 + g] = pv;
+        }
       } else if (!(r[REC_FLAGS] & FLAG_UP_IN_ACC)) {  // otherwise Up_f was left in acc by the parent
         CMX_POP(acc);
       }
