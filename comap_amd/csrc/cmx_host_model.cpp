@@ -526,8 +526,12 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
           for (int g = 0; g < F; ++g) {
             const double* M = block(g, which);
             for (int x = 0; x < S; ++x)
-              for (int z = 0; z < S; ++z)   // row = observed state z, column = (class g, state x): transposed
-                lt[(size_t)z * dS + g * S + x] = M ? weight(g, which) * M[(size_t)x * S + z] : (which < 0 && x == z ? 1.0 : 0.0);
+              for (int z = 0; z < S; ++z) {  // row = observed state z, column = device state X = (class g, state x): transposed.
+                // Columns are stored state-in-tile major (X % 4) * (dS / 4) + X / 4: the values one lane of the
+                // matrix-core layout needs from a row are contiguous.
+                const int X = g * S + x, pos = (X % 4) * (dS / 4) + X / 4;
+                lt[(size_t)z * dS + pos] = M ? weight(g, which) * M[(size_t)x * S + z] : (which < 0 && x == z ? 1.0 : 0.0);
+              }
           }
         }
       } else {

@@ -149,17 +149,31 @@ __device__ __forceinline__ void wait_vm(int allowed) {
 template <int S>
 __device__ __forceinline__ int vidx(int sb, int g) { return sb * 4 + g; }
 
-// reduce-scatter of per-site-group partial sums over the four state-in-tile lanes: lane l returns the total of site l
+// reduce-scatter of per-site-group partial sums over the four state-in-tile lanes: lane l returns the total of site l.
+// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second one,
+// v_permlane16_swap does the same for the odd / even rows of 16 lanes: after swap(a, b) the sum a + b holds, in the
+// lanes that keep a's site group, own + partner's a, and in the others own + partner's b -- no LDS round trip.
+__device__ __forceinline__ void swap32(double& a, double& b) {
+  const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  a = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+  b = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+__device__ __forceinline__ void swap16(double& a, double& b) {
+  const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  a = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+  b = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
 __device__ __forceinline__ double reduce_sites(double p0, double p1, double p2, double p3, int lane) {
-  const bool hi = (lane & 32) != 0, lo = (lane & 16) != 0;
-  const double s0 = hi ? p0 : p2, s1 = hi ? p1 : p3;          // what the partner (lane ^ 32) keeps
-  double k0 = hi ? p2 : p0, k1 = hi ? p3 : p1;                // site groups 2 hi + {0, 1}
-  k0 += __shfl_xor(s0, 32, 64);
-  k1 += __shfl_xor(s1, 32, 64);
-  const double s = lo ? k0 : k1;
-  double k = lo ? k1 : k0;                                     // site group 2 hi + lo = lane >> 4
-  k += __shfl_xor(s, 16, 64);
-  return k;
+  (void)lane;
+  swap32(p0, p2);            // lanes < 32: own p0, partner's p0   | lanes >= 32: partner's p2, own p2
+  swap32(p1, p3);
+  double k0 = p0 + p2, k1 = p1 + p3;   // site groups 0 / 1 in the lower half of the wave, 2 / 3 in the upper
+  swap16(k0, k1);            // even rows: own k0, partner's k0    | odd rows: partner's k1, own k1
+  return k0 + k1;            // site group lane >> 4
 }
 
 // step q of a product: output tile o = q / NB, input tile i = q % NB; the stored tile is (o, i), or (i, o) for the
@@ -227,10 +241,11 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
       continue;
     }
     const unsigned row = code < (unsigned)MatStage<S>::NROW ? code : (unsigned)(MatStage<S>::NROW - 1);
-    const double* r = reinterpret_cast<const double*>(buf + row * (S * 8)) + (lane >> 4);
+    // rows are stored state-in-tile major: state 4 sb + s4 at position s4 * NB + sb (cmx_host_model.cpp)
+    const double* r = reinterpret_cast<const double*>(buf + row * (S * 8)) + (lane >> 4) * NB;
 #pragma unroll
     for (int sb = 0; sb < NB; ++sb) {
-      const double v = r[4 * sb];
+      const double v = r[sb];
       if (MODE == LEAF_SET) out[sb * 4 + g] = v;
       else if (MODE == LEAF_MUL) out[sb * 4 + g] = v * in[sb * 4 + g];
       else part[g] = __builtin_fma(in[sb * 4 + g], v, part[g]);
