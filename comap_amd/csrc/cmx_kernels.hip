@@ -8,7 +8,8 @@
 //   (call sites CoMap/CoETools.cpp:397, CoMap/AnalysisTools.cpp:592-612; algorithm SURVEY.md A.2/A.3/A.6).
 //   The SxS operator of an edge is the same for all 64 lanes: every operator use of a class pass (products on
 //   internal edges, row gathers by observed symbol on leaf edges) is listed by the host in one op stream and staged
-//   in LDS by LDS-DMA one op ahead; products apply 4x4 tiles with DPP-broadcast fp64 FMAs (400 per 20x20 product).
+//   in LDS by LDS-DMA one op ahead; products run on the matrix cores (v_mfma_f64_4x4x4_4b, 100 per 20x20 product) in
+//   a layout where lane = (state inside a 4-state tile, site of a group of 16).
 //   Matrices are packed host-side in 4x4 blocks so that one copy serves both P.d (inside) and P^T.u (outside).
 //   Inside vectors / outside messages that must survive go to a per-wave HBM workspace as [S/2][lane][2]: every
 //   access is one fully coalesced 1 KiB row; loads are prefetched into LDS by DMA under a host-built schedule.
@@ -49,7 +50,6 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // TFLOP/s in isolation) needed either fixed registers -- amdgpu_num_vgpr turned out not to be a hard limit, the
 // compiler reused them under pressure -- or 50 more loop-carried registers than two waves per SIMD can afford;
 // gathering leaf rows straight from L2 (lane-divergent 160-byte rows, latency exposed at every leaf) cost 5 of 21 ms.
-#include "cmx_ring_tiles.inc"
 
 typedef __attribute__((address_space(1))) const void* cmx_gptr;
 typedef __attribute__((address_space(3))) void* cmx_lptr;
