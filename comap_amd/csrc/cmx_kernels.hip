@@ -42,13 +42,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // internal edges, a row gather by observed symbol on leaf edges.  The sequence of operators of a class pass is known
 // (host-built op stream, m.msched), so each operator is DMAed into LDS one op ahead: two S*S*8-byte stage buffers per
 // wave, op i reads buffer i&1 while the DMA of op i+1 fills the other (global_load_lds_dwordx4, 1 KiB per
-// instruction, no VGPRs).  A product reads one 4x4 block ("tile", 16 values) per ds_read_b64 into every DPP row of a
-// VGPR pair and v_fmac_f64_dpp row_newbcast:k multiplies by element k -- 400 fp64 FMAs per 20x20 product, no SGPR
-// operand traffic, two transient VGPRs.  A leaf op reads row `symbol` of the transposed matrix (S/2 ds_read_b128).
-// The symbols of the next leaf op are DMAed the same way (global_load_lds_ubyte into a 256-byte slot).
-// History: an s_load-fed v_fma_f64 version ran at 39 TFLOP/s; keeping the tiles in a VGPR ring (53
-// TFLOP/s in isolation) needed either fixed registers -- amdgpu_num_vgpr turned out not to be a hard limit, the
-// compiler reused them under pressure -- or 50 more loop-carried registers than two waves per SIMD can afford;
+// instruction, no VGPRs).  A product reads the A operand of each 4x4 tile with one ds_read_b64 and runs on
+// v_mfma_f64_4x4x4_4b (see "Matrix-core layout" below); a leaf op reads the values its lane holds of row `symbol` of
+// the transposed matrix.  The symbols of the next leaf op are DMAed the same way (global_load_lds_ubyte into a
+// 256-byte slot).
+// History: an s_load-fed v_fma_f64 version ran at 39 TFLOP/s; tiles in a VGPR ring applied with
+// v_fmac_f64_dpp row_newbcast (53 TFLOP/s in isolation) needed either fixed registers -- amdgpu_num_vgpr turned out not
+// to be a hard limit, the compiler reused them under pressure -- or 50 more loop-carried registers than two waves per
+// SIMD can afford; the LDS-staged DPP version (lane = site) reached 16.7 ms per launch, the matrix-core layout 15.5 ms;
 // gathering leaf rows straight from L2 (lane-divergent 160-byte rows, latency exposed at every leaf) cost 5 of 21 ms.
 
 typedef __attribute__((address_space(1))) const void* cmx_gptr;
