@@ -43,7 +43,7 @@ struct DevModel {
   // matrix uses of one class pass in program order: pairs (matrix index in the class block, taxon or -1)
   const int* msched;
   int nmv;                 // number of pairs
-  const int* nrec;         // [NV][32] per-visited-node records (enum REC_* in cmx_kernels.hip)
+  const int* nrec;         // [NV][16] per-visited-node records (enum REC_* in cmx_kernels.hip)
   // simulator: running sums of the rows of P, [C][nn][S(x)][S]
   const double* CP;
   const double* pi;        // [S]

@@ -96,31 +96,33 @@ void build_load_schedule(HostModel* hm) {
   for (int idx = 0; idx < NI; ++idx) if (!inlined[hm->int_post[idx]]) visited.push_back(hm->int_post[idx]);
   const int NV = (int)visited.size();
   hm->NV = NV;
-  hm->nrec.assign((size_t)NV * 32, -1);
+  hm->nrec.assign((size_t)NV * 16, -1);
+  // child descriptor, 5 ints: kind, node (= branch), slot (stored) / taxon (leaf), and for an inlined cherry its two
+  // leaf nodes (their taxa are named by the op stream)
   auto fill_child = [&](int* r, int e) {
     r[0] = kind(e); r[1] = e;
     r[2] = internal(e) ? hm->slot[e] : hm->taxon_of[e];
     if (kind(e) == 2) {
       const std::vector<int> c = kids(e);
-      r[3] = hm->taxon_of[c[0]]; r[4] = hm->taxon_of[c[1]]; r[5] = c[0]; r[6] = c[1];
+      r[3] = c[0]; r[4] = c[1];
     }
   };
   std::vector<int> Xof(nn, -1), Yof(nn, -1);
   for (int v = 0; v < NV; ++v) {
     const int n = visited[v];
-    int* r = &hm->nrec[(size_t)v * 32];
+    int* r = &hm->nrec[(size_t)v * 16];
     const std::vector<int> c = kids(n);
-    r[0] = n; r[1] = hm->slot[n]; r[2] = (int)c.size(); r[3] = 0; r[30] = -1;
+    r[0] = n; r[1] = hm->slot[n]; r[2] = (int)c.size(); r[3] = 0; r[14] = -1;
     if (c.size() == 2) {
       int y = (kind(c[1]) == 1) ? c[1] : ((kind(c[0]) == 1) ? c[0] : c[1]);
       int x = (y == c[1]) ? c[0] : c[1];
       Xof[n] = x; Yof[n] = y;
       fill_child(r + 4, x);
-      fill_child(r + 16, y);
+      fill_child(r + 9, y);
       if (kind(y) == 1) r[3] |= 2;   // Y's vectors are handed over in registers
     } else {
       const int last = c.back();
-      if (kind(last) == 1) r[30] = last;   // general node: its last child is the node finished right before it
+      if (kind(last) == 1) r[14] = last;   // general node: its last child is the node finished right before it
     }
   }
   // ---- simulate the kernel
@@ -161,7 +163,7 @@ void build_load_schedule(HostModel* hm) {
       edge(x);
       if (kind(y) != 1) edge(y);
     } else {
-      const int carry = hm->nrec[(size_t)v * 32 + 30];
+      const int carry = hm->nrec[(size_t)v * 16 + 14];
       if (carry >= 0) mvP(hm->slot[carry]);
       for (int e : c) {
         if (!internal(e)) leafP(txof(e));
@@ -175,7 +177,7 @@ void build_load_schedule(HostModel* hm) {
   for (int v = NV - 1; v >= 0; --v) {
     const int f = visited[v];
     if (f != root) {
-      if (up_in_acc[f]) hm->nrec[(size_t)v * 32 + 3] |= 4;
+      if (up_in_acc[f]) hm->nrec[(size_t)v * 16 + 3] |= 4;
       else pop(1, hm->slot[f]);
     }
     const std::vector<int> c = kids(f);
@@ -221,7 +223,7 @@ void build_load_schedule(HostModel* hm) {
 // stale access on the GPU, so a context is refused instead (cmx_ctx_create).
 std::string verify_traversal(const HostModel& hm) {
   const int NI = hm.NI, NV = hm.NV, K = hm.K, T = hm.T, nn = hm.nn, root = hm.root;
-  if ((int)hm.nrec.size() != NV * 32) return "nrec size";
+  if ((int)hm.nrec.size() != NV * 16) return "nrec size";
   size_t fi = 0, mi = 0;
   std::vector<char> haveD(NI, 0), haveU(NI, 0), counted((size_t)hm.B * K, 0);
   std::string err;
@@ -257,22 +259,25 @@ std::string verify_traversal(const HostModel& hm) {
     if (node < 0 || node >= nn - 1) return fail("branch out of range");
     for (int k = 0; k < K; ++k) { if (counted[(size_t)node * K + k]) fail("branch counted twice"); counted[(size_t)node * K + k] = 1; }
   };
+  auto tx_of = [&](int node) { return (node >= 0 && node < nn) ? hm.taxon_of[node] : -1; };  // leaf node -> taxon
   auto getD = [&](const int* ch) {
     if (ch[0] == 1) pop(0, ch[2]);
-    else if (ch[0] == 2) { leaf(ch[3]); leaf(ch[4]); }
+    else if (ch[0] == 2) { leaf(tx_of(ch[3])); leaf(tx_of(ch[4])); }
     else fail("bad child kind");
   };
-  auto cherry_counts = [&](const int* ch) { leaf(ch[4]); leafJ(ch[3]); count(ch[5]); leaf(ch[3]); leafJ(ch[4]); count(ch[6]); };
+  auto cherry_counts = [&](const int* ch) {
+    leaf(tx_of(ch[4])); leafJ(tx_of(ch[3])); count(ch[3]); leaf(tx_of(ch[3])); leafJ(tx_of(ch[4])); count(ch[4]);
+  };
   auto kids = [&](int n) { std::vector<int> v; for (int e = hm.first_child[n]; e >= 0; e = hm.next_sib[e]) v.push_back(e); return v; };
   bool acc_is_D_of_prev = false;
   int prev_node = -1;
   // inside pass
   for (int idx = 0; idx < NV && err.empty(); ++idx) {
-    const int* r = &hm.nrec[(size_t)idx * 32];
+    const int* r = &hm.nrec[(size_t)idx * 16];
     const int n = r[0];
     if (n < 0 || n >= nn || r[1] != hm.slot[n]) return "traversal self-check failed: bad node record";
     if (r[2] == 2) {
-      const int* X = r + 4; const int* Y = r + 16;
+      const int* X = r + 4; const int* Y = r + 9;
       if (r[3] & 2) {
         if (!acc_is_D_of_prev || prev_node != Y[1] || Y[0] != 1) fail("Y is not the node finished last");
         mv(false, Y[2]);
@@ -280,7 +285,7 @@ std::string verify_traversal(const HostModel& hm) {
       if (X[0] == 0) leaf(X[2]); else { getD(X); mv(false, X[2]); }
       if (!(r[3] & 2)) { if (Y[0] == 0) leaf(Y[2]); else { if (Y[0] != 2) fail("stored Y not handed over"); getD(Y); mv(false, Y[2]); } }
     } else {
-      const int carry = r[30];
+      const int carry = r[14];
       if (carry >= 0) { if (!acc_is_D_of_prev || prev_node != carry) fail("general carry"); mv(false, hm.slot[carry]); }
       for (int e : kids(n)) {
         if (hm.taxon_of[e] >= 0) leaf(hm.taxon_of[e]);
@@ -294,7 +299,7 @@ std::string verify_traversal(const HostModel& hm) {
   // outside pass
   int up_node_in_acc = -1;
   for (int idx = NV - 1; idx >= 0 && err.empty(); --idx) {
-    const int* r = &hm.nrec[(size_t)idx * 32];
+    const int* r = &hm.nrec[(size_t)idx * 16];
     const int f = r[0];
     if (f != root) {
       if (r[3] & 4) { if (up_node_in_acc != f) fail("outside message not in registers"); }
@@ -302,7 +307,7 @@ std::string verify_traversal(const HostModel& hm) {
     }
     up_node_in_acc = -1;
     if (r[2] == 2) {
-      const int* X = r + 4; const int* Y = r + 16;
+      const int* X = r + 4; const int* Y = r + 9;
       if (Y[0] == 0) leaf(Y[2]); else { getD(Y); mv(false, Y[2]); }
       if (X[0] == 0) { leafJ(X[2]); count(X[1]); leaf(X[2]); }
       else {

@@ -28,7 +28,7 @@ struct HostModel {
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
   std::vector<int> ldsched; // workspace-load schedule of one class pass (DevModel::ldsched)
   std::vector<int> msched;  // matrix uses of one class pass in program order: (matrix index, taxon or -1) pairs
-  std::vector<int> nrec;    // [NV][32] per-visited-node records (DevModel::nrec)
+  std::vector<int> nrec;    // [NV][16] per-visited-node records (DevModel::nrec)
   size_t loads_D = 0, loads_U = 0, stores_D = 0, stores_U = 0;  // per class pass, for traffic accounting
 };
 

@@ -355,17 +355,14 @@ __device__ __forceinline__ void sload_i32x2(cmx_cint p, int& a, int& b) {
   b = v[1];
 }
 
-// per-visited-node record (host-built, cmx_host_model.cpp build_load_schedule): 32 ints, two scalar loads
+// per-visited-node record (host-built, cmx_host_model.cpp build_load_schedule): 16 ints, one scalar load
 typedef int cmx_i16 __attribute__((ext_vector_type(16)));
-enum { REC_N = 0, REC_SLOT = 1, REC_NCH = 2, REC_FLAGS = 3, REC_X = 4 /* ints 4..10 */, REC_Y = 0 /* of the 2nd half: ints 16..22 */,
-       REC_GCARRY = 14 /* of the 2nd half: int 30 */ };
-enum { CH_KIND = 0, CH_NODE = 1, CH_ID = 2, CH_T1 = 3, CH_T2 = 4, CH_L1 = 5, CH_L2 = 6 };  // child descriptor
+enum { REC_N = 0, REC_SLOT = 1, REC_NCH = 2, REC_FLAGS = 3, REC_X = 4 /* ints 4..8 */, REC_Y = 9 /* ints 9..13 */,
+       REC_GCARRY = 14 };
+enum { CH_KIND = 0, CH_NODE = 1, CH_ID = 2, CH_L1 = 3, CH_L2 = 4 };  // child descriptor (L1 / L2: leaves of an inlined cherry)
 enum { FLAG_Y_IN_REGS = 2, FLAG_UP_IN_ACC = 4 };
-__device__ __forceinline__ void sload_rec(cmx_cint p, cmx_i16& lo, cmx_i16& hi) {
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-               : "=&s"(lo), "=&s"(hi)
-               : "s"(p)
-               : "memory");
+__device__ __forceinline__ void sload_rec(cmx_cint p, cmx_i16& r) {
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
 }
 
 struct ConstModel {
@@ -567,8 +564,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     // ---------------- inside (post-order) pass over the visited nodes.  acc leaves each iteration holding D of the
     // node just finished; it is the Y child of the next node whenever FLAG_Y_IN_REGS is set there.
     for (int idx = 0; idx < m.NV; ++idx) {
-      cmx_i16 r, r2;
-      sload_rec(cm.nrec + idx * 32, r, r2);
+      cmx_i16 r;
+      sload_rec(cm.nrec + idx * 16, r);
       const int n = r[REC_N];
       if (r[REC_NCH] == 2) {
         // child Y arrives in acc when it was the node finished last (its message goes to t), child X never does
@@ -585,17 +582,17 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           }
         }
         if (!yreg) {
-          if (r2[REC_Y + CH_KIND] == 0) {
+          if (r[REC_Y + CH_KIND] == 0) {
             CMX_LEAF_MUL(acc, acc);
           } else {  // inlined cherry (a stored Y is always handed over)
-            CMX_GET_D(r2, REC_Y);
+            CMX_GET_D(r, REC_Y);
             CMX_MV(false, d, t);
 #pragma unroll
             for (int x = 0; x < S; ++x) acc[x] *= t[x];
           }
         }
       } else {
-        const int carry = r2[REC_GCARRY];
+        const int carry = r[REC_GCARRY];
         if (carry >= 0) {
           CMX_MV(false, acc, t);
 #pragma unroll
@@ -659,8 +656,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     }
     // ---------------- outside (pre-order) pass + joint counts.  acc carries the outside message Up_f.
     for (int idx = m.NV - 1; idx >= 0; --idx) {
-      cmx_i16 r, r2;
-      sload_rec(cm.nrec + idx * 32, r, r2);
+      cmx_i16 r;
+      sload_rec(cm.nrec + idx * 16, r);
       const int f = r[REC_N];
       if (f == root) {
 #pragma unroll
@@ -673,12 +670,12 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         CMX_POP(acc);
       }
       if (r[REC_NCH] == 2) {
-        const int kx = r[REC_X + CH_KIND], ky = r2[REC_Y + CH_KIND];
+        const int kx = r[REC_X + CH_KIND], ky = r[REC_Y + CH_KIND];
         // ---- message of Y -> U_X = Up_f o M_Y
         if (ky == 0) {
           CMX_LEAF_MUL(acc, u);
         } else {
-          CMX_GET_D(r2, REC_Y);
+          CMX_GET_D(r, REC_Y);
           CMX_MV(false, d, t);
 #pragma unroll
           for (int x = 0; x < S; ++x) u[x] = acc[x] * t[x];
@@ -715,20 +712,20 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           for (int k = 0; k < K; ++k) {
             double tot;
             CMX_LEAF_DOT(t, tot);
-            pcnt[((size_t)r2[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
+            pcnt[((size_t)r[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
           }
           CMX_KILL(acc);
         } else {
-          CMX_GET_D(r2, REC_Y);
+          CMX_GET_D(r, REC_Y);
           for (int k = 0; k < K; ++k) {
             CMX_MV(false, d, u);
             double tot;
             CMX_DOT(t, u, tot);
-            pcnt[((size_t)r2[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
+            pcnt[((size_t)r[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
           }
           CMX_MV(true, t, acc);                        // Up_Y: handed to the next visited node when Y is stored
           if (ky != 1) {
-            CMX_CHERRY_COUNTS(r2, REC_Y, acc, u);
+            CMX_CHERRY_COUNTS(r, REC_Y, acc, u);
             CMX_KILL(acc);
           }
         }

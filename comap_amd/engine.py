@@ -105,7 +105,7 @@ def _sz(x):
 
 
 def debug_traversal(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
-    """Host-side compilation of the tree into the kernel's traversal (no GPU): dict(nrec[NV,32], ldsched, msched, slot)."""
+    """Host-side compilation of the tree into the kernel's traversal (no GPU): dict(nrec[NV,16], ldsched, msched, slot)."""
     lib = load_library()
     keep = [np.ascontiguousarray(parent, dtype=np.int32), _f64(blen), np.ascontiguousarray(leaf_of_taxon, dtype=np.int32),
             _f64(Q), _f64(pi), _f64(rates), _f64(probs), None if Bk is None else _f64(Bk)]
@@ -123,7 +123,7 @@ def debug_traversal(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
                                  _sz(cap), ctypes.byref(n2), _vp(ms), _sz(cap), ctypes.byref(n3), _vp(slot))
     if st != 0:
         raise CmxError(st, lib.cmx_last_error(None).decode())
-    return dict(nrec=nrec[: n1.value].reshape(-1, 32).copy(), ldsched=ld[: n2.value].copy(), msched=ms[: n3.value].copy(),
+    return dict(nrec=nrec[: n1.value].reshape(-1, 16).copy(), ldsched=ld[: n2.value].copy(), msched=ms[: n3.value].copy(),
                 slot=slot)
 
 

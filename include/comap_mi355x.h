@@ -96,7 +96,7 @@ cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info);
 cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P);
 cmx_status cmx_synchronize(cmx_ctx* ctx);
 /* host-side only (no GPU needed): compile the tree into the traversal the mapping kernel walks and copy it out for
- * inspection/tests.  nrec: [nvisited][32] node records; ldsched: workspace loads; msched: matrix products of one
+ * inspection/tests.  nrec: [nvisited][16] node records; ldsched: workspace loads; msched: matrix products of one
  * rate-class pass.  Each *_cap is the capacity (in int32) of the caller's buffer; sizes are returned in *_n. */
 cmx_status cmx_debug_traversal(const cmx_model* model, const cmx_tree* tree, int32_t* nrec, size_t nrec_cap,
                                size_t* nrec_n, int32_t* ldsched, size_t ld_cap, size_t* ld_n, int32_t* msched,
