@@ -1723,12 +1723,12 @@ __global__ void mica_ftable_kernel(int T, double* __restrict__ f, int* __restric
   if (c <= T) f[c] = c > 1 ? (double)c * log((double)c) : 0.0;
 }
 
-// One workgroup (8 waves) per 8 x 8 tile of column pairs, wave w owns the 2 x 4 sub-tile (rows 2*(w/2).., columns
-// 4*(w%2)..): 128 accumulator registers, two waves per SIMD so that one wave's table epilogue overlaps another's MFMAs.
-// The 16 operand tiles of a k-step (8 columns of each alignment, 64 lanes x 16 B each) go through LDS once per
-// workgroup: 4 KiB of L2 traffic per pair at T = 256 instead of 16 KiB when every wave fetches its own operands.
-constexpr int kMicaTile = 8;
-__global__ __launch_bounds__(512, 1) void mica_mfma_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
+// One workgroup (8 waves) per 8 x 4 tile of column pairs (8 columns of the first alignment, 4 of the second), wave w owns
+// the 2 x 2 sub-tile (rows 2*(w/2).., columns 2*(w%2)..): 64 accumulator registers, so that two workgroups share a CU
+// (four waves per SIMD) and one workgroup's barriers and table epilogue overlap the other's MFMAs.  The 12 operand tiles
+// of a k-step (64 lanes x 16 B each) go through LDS once per workgroup.
+constexpr int kMicaTileI = 8, kMicaTileJ = 4;
+__global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
                                                            const uint8_t* __restrict__ flag1, const double* __restrict__ S1,
                                                            const int8_t* __restrict__ H2, size_t n2,
                                                            const uint8_t* __restrict__ flag2, const double* __restrict__ S2,
@@ -1736,13 +1736,14 @@ __global__ __launch_bounds__(512, 1) void mica_mfma_kernel(int T, int Tp, const 
                                                            double* __restrict__ mi, double* __restrict__ hj, size_t ldo) {
   extern __shared__ __attribute__((aligned(16))) uint8_t mica_smem[];
   double* ftab = reinterpret_cast<double*>(mica_smem);                       // [T + 1]
-  cmx_i4* ops = reinterpret_cast<cmx_i4*>(mica_smem + (((size_t)(T + 1) * 8 + 15) & ~(size_t)15));  // [2][16][64]
+  cmx_i4* ops = reinterpret_cast<cmx_i4*>(mica_smem + (((size_t)(T + 1) * 8 + 15) & ~(size_t)15));  // [2][12][64]
+  constexpr int NOP = kMicaTileI + kMicaTileJ;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
   for (int c = tid; c <= T; c += 512) ftab[c] = ftab_g[c];
-  const size_t i0 = (size_t)blockIdx.y * kMicaTile, j0 = (size_t)blockIdx.x * kMicaTile;
-  if (intra && j0 + kMicaTile <= i0 + 1) {   // no pair with j > i in this tile: only the NaN convention of the intra layout
-    if (tid < kMicaTile * kMicaTile) {
-      const size_t i = i0 + tid / kMicaTile, j = j0 + tid % kMicaTile;
+  const size_t i0 = (size_t)blockIdx.y * kMicaTileI, j0 = (size_t)blockIdx.x * kMicaTileJ;
+  if (intra && j0 + kMicaTileJ <= i0 + 1) {   // no pair with j > i in this tile: only the NaN convention of the intra layout
+    if (tid < kMicaTileI * kMicaTileJ) {
+      const size_t i = i0 + tid / kMicaTileJ, j = j0 + tid % kMicaTileJ;
       if (i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
         mi[i * ldo + j] = __builtin_nan("");
         hj[i * ldo + j] = __builtin_nan("");
@@ -1750,57 +1751,62 @@ __global__ __launch_bounds__(512, 1) void mica_mfma_kernel(int T, int Tp, const 
     }
     return;
   }
-  // loader role of this thread: operand tile q = tid / 32 of the k-step (q < 8: column i0 + q of H1, else column
-  // j0 + q - 8 of H2), lanes 2 * (tid % 32) and + 1 of that tile; a lane's 16 bytes are row (lane % 32), taxa group
-  // (lane / 32) of the one-hot matrix
-  const int q = tid >> 5;
-  const size_t col = q < 8 ? (i0 + q < n1 ? i0 + q : n1 - 1) : (j0 + q - 8 < n2 ? j0 + q - 8 : n2 - 1);
-  const int8_t* Hq = (q < 8 ? H1 : H2) + col * 32 * (size_t)Tp;
+  // loader role of this thread: 12 operand tiles x 64 lanes = 768 slots of 16 bytes, threads 0..383 take two each
+  // (operand tile q = slot / 64: q < 8 column i0 + q of H1, else column j0 + q - 8 of H2; a lane's 16 bytes are row
+  // (lane % 32), taxa group (lane / 32) of the one-hot matrix)
+  const bool loader = tid < NOP * 32;
+  const int q = loader ? tid >> 5 : 0;
+  const size_t col = q < kMicaTileI ? (i0 + q < n1 ? i0 + q : n1 - 1) : (j0 + q - kMicaTileI < n2 ? j0 + q - kMicaTileI : n2 - 1);
+  const int8_t* Hq = (q < kMicaTileI ? H1 : H2) + col * 32 * (size_t)Tp;
   const int l0 = 2 * (tid & 31);
-  cmx_i16v acc[2][4];
+  cmx_i16v acc[2][2];
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[ii][jj][v] = 0;
-  cmx_i4 st[2];
+  cmx_i4 st[2] = {};
   auto fetch = [&](int ks) {
+    if (loader) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int l = l0 + u;
-      st[u] = *reinterpret_cast<const cmx_i4*>(Hq + (size_t)(l & 31) * Tp + ks + 16 * (l >> 5));
+      for (int u = 0; u < 2; ++u) {
+        const int l = l0 + u;
+        st[u] = *reinterpret_cast<const cmx_i4*>(Hq + (size_t)(l & 31) * Tp + ks + 16 * (l >> 5));
+      }
     }
   };
   fetch(0);
   int buf = 0;
   for (int ks = 0; ks < Tp; ks += kMicaK) {
+    if (loader) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) ops[(buf * 16 + q) * 64 + l0 + u] = st[u];
+      for (int u = 0; u < 2; ++u) ops[(buf * NOP + q) * 64 + l0 + u] = st[u];
+    }
     __syncthreads();
     if (ks + kMicaK < Tp) fetch(ks + kMicaK);
-    cmx_i4 a[2], b[4];
+    cmx_i4 a[2], b[2];
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) a[ii] = ops[(buf * 16 + 2 * wi + ii) * 64 + lane];
+    for (int ii = 0; ii < 2; ++ii) a[ii] = ops[(buf * NOP + 2 * wi + ii) * 64 + lane];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) b[jj] = ops[(buf * 16 + 8 + 4 * wj + jj) * 64 + lane];
+    for (int jj = 0; jj < 2; ++jj) b[jj] = ops[(buf * NOP + kMicaTileI + 2 * wj + jj) * 64 + lane];
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
+      for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
     buf ^= 1;
   }
   const double lnT = log((double)T), invT = 1.0 / (double)T;
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
+    for (int jj = 0; jj < 2; ++jj) {
       double s = 0.0;
 #pragma unroll
       for (int v = 0; v < 16; ++v) s += ftab[acc[ii][jj][v]];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      const size_t i = i0 + 2 * wi + ii, j = j0 + 4 * wj + jj;
+      const size_t i = i0 + 2 * wi + ii, j = j0 + 2 * wj + jj;
       if (lane == 0 && i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
         const bool valid = !intra || j > i;
         mi[i * ldo + j] = valid ? lnT + (s - S1[i] - S2[j]) * invT : __builtin_nan("");
@@ -1848,8 +1854,8 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
     hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_aln1, ld1, work->H1, work->flag1, work->S1, work->anyflag);
     if (!intra)
       hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_aln2, ld2, work->H2, work->flag2, work->S2, work->anyflag);
-    dim3 g2((unsigned)((n2 + kMicaTile - 1) / kMicaTile), (unsigned)((n1 + kMicaTile - 1) / kMicaTile));
-    const size_t lds2 = (((size_t)(T + 1) * 8 + 15) & ~(size_t)15) + 2 * 16 * 64 * sizeof(cmx_i4);
+    dim3 g2((unsigned)((n2 + kMicaTileJ - 1) / kMicaTileJ), (unsigned)((n1 + kMicaTileI - 1) / kMicaTileI));
+    const size_t lds2 = (((size_t)(T + 1) * 8 + 15) & ~(size_t)15) + 2 * (kMicaTileI + kMicaTileJ) * 64 * sizeof(cmx_i4);
     hipLaunchKernelGGL(mica_mfma_kernel, g2, dim3(512), lds2, stream, T, Tp, work->H1, n1,
                        work->flag1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
                        intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
