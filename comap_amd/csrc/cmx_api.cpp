@@ -186,10 +186,11 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     ctx->waves = ctx->grid_blocks * kWavesPerBlock;
     ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
     auto alloc_ws = [&](Workspace* ws, size_t w, size_t* bytes) -> cmx_status {
-      const size_t bD = w * h.NI * h.dS * kWave * sizeof(double);
-      const size_t bC = w * 2 * h.B * h.K * kWave * sizeof(double);
-      const size_t bP = w * h.dC * h.B * h.K * kWave * sizeof(double);
-      const size_t bS = w * h.nn * kWave, bA = w * h.T * kWave;
+      const size_t ks = (size_t)map_sites_per_wave(h.dS);   // sites per mapping wave
+      const size_t bD = w * h.NI * h.dS * ks * sizeof(double);
+      const size_t bC = w * 2 * h.B * h.K * ks * sizeof(double);
+      const size_t bP = w * h.dC * h.B * h.K * ks * sizeof(double);
+      const size_t bS = w * h.nn * ks, bA = w * h.T * ks;
       HIP_TRY(ctx, hipMalloc((void**)&ws->D, bD));
       HIP_TRY(ctx, hipMalloc((void**)&ws->U, bD));
       HIP_TRY(ctx, hipMalloc((void**)&ws->cnt, bC));
@@ -290,13 +291,14 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   }
   a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.norm = d_norm;
-  const size_t nblocks = (nsites + kWave - 1) / kWave;
+  const size_t ks = (size_t)map_sites_per_wave(ctx->hm.dS);
+  const size_t nblocks = (nsites + ks - 1) / ks;
   const size_t obs_waves = (size_t)ctx->obs_blocks * kWavesPerBlock;
   if (nblocks * (size_t)ctx->hm.dC <= obs_waves && ctx->hm.dC > 1) {
     // small alignment: one (site block, class) per wave, classes summed by a second kernel (same arithmetic order)
     const size_t ntasks = nblocks * (size_t)ctx->hm.dC, BK = (size_t)ctx->hm.B * ctx->hm.K;
-    if ((s = scratch(ctx, "split_part", sizeof(double) * ntasks * BK * kWave, (void**)&a.split_part)) != CMX_OK) return s;
-    if ((s = scratch(ctx, "split_lc", sizeof(double) * 4 * ntasks * kWave, (void**)&a.split_lc)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "split_part", sizeof(double) * ntasks * BK * ks, (void**)&a.split_part)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "split_lc", sizeof(double) * 4 * ntasks * ks, (void**)&a.split_lc)) != CMX_OK) return s;
     const int grid = (int)((ntasks + kWavesPerBlock - 1) / kWavesPerBlock);
     HIP_TRY(ctx, launch_map(a, kModeObservedSplit, grid, (hipStream_t)stream));
     HIP_TRY(ctx, launch_map_finalize(a, (hipStream_t)stream));
@@ -469,7 +471,8 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   a.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
   a.seed = seed; a.rep_begin = rep_begin; a.rep_ram = rep_ram; a.supplied = d_supplied;
   a.null_stat = d_stat; a.null_rcmin = d_rcmin; a.null_prmin = d_prmin; a.null_nmin = d_nmin;
-  const size_t blocks_needed = ((a.nsites + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;
+  const size_t ks = (size_t)map_sites_per_wave(ctx->hm.dS);
+  const size_t blocks_needed = ((a.nsites + ks - 1) / ks + kWavesPerBlock - 1) / kWavesPerBlock;
   const int grid = (int)std::min<size_t>(blocks_needed, (size_t)ctx->grid_blocks);
   HIP_TRY(ctx, launch_map(a, kModeNull, grid, (hipStream_t)stream));
   return CMX_OK;

@@ -21,7 +21,12 @@ constexpr int mat_unit(int S) { return (S + max_ambig(S)) * S; }   // doubles pe
 #ifndef CMX_WAVES_PER_SIMD_S4
 #define CMX_WAVES_PER_SIMD_S4 3    // nucleotide vectors are 8 registers: the kernel is latency-bound, more waves help
 #endif
-constexpr int map_waves_per_simd(int S) { return S == 4 ? CMX_WAVES_PER_SIMD_S4 : CMX_WAVES_PER_SIMD; }
+#ifndef CMX_NG
+#define CMX_NG 4                   // site groups of 16 per mapping wave for >= 16 device states: 4 (64 sites) or 2 (32 sites)
+#endif
+constexpr int map_ng(int S) { return S >= 16 ? CMX_NG : 4; }
+constexpr int map_sites_per_wave(int S) { return 16 * map_ng(S); }
+constexpr int map_waves_per_simd(int S) { return S == 4 ? CMX_WAVES_PER_SIMD_S4 : (map_ng(S) == 2 ? 3 : CMX_WAVES_PER_SIMD); }
 
 // Device-resident model + tree program.  All pointers are device pointers.
 struct DevModel {

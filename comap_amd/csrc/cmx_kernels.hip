@@ -115,11 +115,11 @@ __device__ __forceinline__ void code_dma(const uint8_t* p, uint8_t* slot) {
 // s_waitcnt vmcnt(n) needs an immediate: pick the largest supported threshold <= allowed (waiting for more is safe)
 template <int N>
 __device__ __forceinline__ void waitcnt_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-template <int S>
+template <int S, int VL>
 __device__ __forceinline__ void wait_vm(int allowed) {
   // what can have been issued after X: the next operator (R DMA rows, +1 with symbols), a workspace prefetch or a
   // vector store (H instructions each).  Most frequent first.
-  constexpr int R = MatStage<S>::ROWS, H = S / 2;
+  constexpr int R = MatStage<S>::ROWS, H = VL / 2;
   static_assert(R + 1 + 2 * H < 64, "vmcnt is a 6-bit counter");
   if (allowed < H && R + 1 < H) {
     if (allowed >= R + 1) waitcnt_vm<R + 1>();
@@ -147,8 +147,6 @@ __device__ __forceinline__ void wait_vm(int allowed) {
 // the other wave's vector work issues while they run.  The operator tile is read from the same packed 4x4 blocks as
 // before, each lane taking the one element its A slot needs.  Elementwise work is layout-blind; sums over states
 // become a reduce-scatter over the lane bits 4 and 5 that leaves lane l with the total of site l.
-template <int S>
-__device__ __forceinline__ int vidx(int sb, int g) { return sb * 4 + g; }
 
 // reduce-scatter of per-site-group partial sums over the four state-in-tile lanes: lane l returns the total of site l.
 // v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second one,
@@ -168,13 +166,24 @@ __device__ __forceinline__ void swap16(double& a, double& b) {
   a = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
   b = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
 }
-__device__ __forceinline__ double reduce_sites(double p0, double p1, double p2, double p3, int lane) {
-  (void)lane;
-  swap32(p0, p2);            // lanes < 32: own p0, partner's p0   | lanes >= 32: partner's p2, own p2
-  swap32(p1, p3);
-  double k0 = p0 + p2, k1 = p1 + p3;   // site groups 0 / 1 in the lower half of the wave, 2 / 3 in the upper
-  swap16(k0, k1);            // even rows: own k0, partner's k0    | odd rows: partner's k1, own k1
-  return k0 + k1;            // site group lane >> 4
+template <int NG>
+__device__ __forceinline__ double reduce_sites(const double (&p)[NG]) {
+  if constexpr (NG == 4) {
+    double p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+    swap32(p0, p2);            // lanes < 32: own p0, partner's p0   | lanes >= 32: partner's p2, own p2
+    swap32(p1, p3);
+    double k0 = p0 + p2, k1 = p1 + p3;   // site groups 0 / 1 in the lower half of the wave, 2 / 3 in the upper
+    swap16(k0, k1);            // even rows: own k0, partner's k0    | odd rows: partner's k1, own k1
+    return k0 + k1;            // site group lane >> 4: lane l holds site l
+  } else {
+    // two site groups (32 sites per wave): lanes l and l ^ 16 both end with the total of site 16 (l >> 5) + (l & 15)
+    static_assert(NG == 2, "site groups per wave");
+    double p0 = p[0], p1 = p[1];
+    swap32(p0, p1);            // lanes < 32: own p0, partner's p0   | lanes >= 32: partner's p1, own p1
+    double k = p0 + p1, q = k;
+    swap16(k, q);              // even rows: k own, q = partner's (odd row) k   | odd rows: k = partner's, q own
+    return k + q;
+  }
 }
 
 // step q of a product: output tile o = q / NB, input tile i = q % NB; the stored tile is (o, i), or (i, o) for the
@@ -184,8 +193,9 @@ template <int S, bool TR>
 __device__ __forceinline__ constexpr int mfma_tile(int q) {
   return TR ? (q % (S / 4)) * (S / 4) + q / (S / 4) : q;
 }
-template <int S, bool TR, int Q>
-__device__ __forceinline__ void mfma_steps(const uint8_t* tile0, double m0, double m1, const double (&x)[S], double (&y)[S]) {
+template <int S, bool TR, int NG, int Q>
+__device__ __forceinline__ void mfma_steps(const uint8_t* tile0, double m0, double m1, const double (&x)[S / 4 * NG],
+                                           double (&y)[S / 4 * NG]) {
   constexpr int NB = S / 4, NT = NB * NB;
   if constexpr (Q < NT) {
     constexpr int o = Q / NB, i = Q % NB;
@@ -195,26 +205,27 @@ __device__ __forceinline__ void mfma_steps(const uint8_t* tile0, double m0, doub
       asm volatile("" ::: "memory");
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      y[o * 4 + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(m0, x[i * 4 + g], i == 0 ? 0.0 : y[o * 4 + g], 0, 0, 0);
-    mfma_steps<S, TR, Q + 1>(tile0, m1, m2, x, y);
+    for (int g = 0; g < NG; ++g)
+      y[o * NG + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(m0, x[i * NG + g], i == 0 ? 0.0 : y[o * NG + g], 0, 0, 0);
+    mfma_steps<S, TR, NG, Q + 1>(tile0, m1, m2, x, y);
   }
 }
 
 // y = M x (TR = false) or y = M^T x (TR = true) with M = the packed matrix staged in buf (already landed)
-template <int S, bool TR>
-__device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const double (&x)[S], double (&y)[S]) {
+template <int S, bool TR, int NG>
+__device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const double (&x)[S / 4 * NG],
+                                             double (&y)[S / 4 * NG]) {
   static_assert(S % 4 == 0, "state count must be a multiple of 4");
   if (CMX_ABLATE == 3 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
 #pragma unroll
-    for (int i = 0; i < S; ++i) y[i] = x[i] * 0.5;
+    for (int i = 0; i < S / 4 * NG; ++i) y[i] = x[i] * 0.5;
     return;
   }
   constexpr int NB = S / 4;
   // element (row r, column c) of a packed tile sits at (4 r + c) * 8; the A slot of lane l is row l & 3, column l >> 4
   // (transposed product: the transposed tile, i.e. row l >> 4, column l & 3)
   const uint8_t* tile0 = buf + (TR ? (4 * (lane >> 4) + (lane & 3)) : (4 * (lane & 3) + (lane >> 4))) * 8;
-  mfma_steps<S, TR, 0>(tile0, *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(0) * 128),
+  mfma_steps<S, TR, NG, 0>(tile0, *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(0) * 128),
                        NB * NB > 1 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(1) * 128) : 0.0, x, y);
 }
 
@@ -222,22 +233,23 @@ __device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const
 // lane l needs, for each site group g, element 4 sb + (l >> 4) of the row named by the symbol of site 16 g + (l & 15).
 // SET out = row, MUL out = row o in (in may be out), DOT returns sum_x in[x] * row[x] of site l (reduce_sites).
 enum { LEAF_SET = 0, LEAF_MUL = 1, LEAF_DOT = 2 };
-template <int S, int MODE>
+template <int S, int MODE, int NG>
 __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* codes /* slot + 4 * (lane & 15) */, int lane,
-                                             const double (&in)[S], double (&out)[S]) {
+                                             const double (&in)[S / 4 * NG], double (&out)[S / 4 * NG]) {
   constexpr int NB = S / 4;
-  double part[4];
+  double part[NG];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const unsigned code = codes[g * 64];   // symbol of site 16 g + (lane & 15): one dword per site in the slot
+  for (int g = 0; g < NG; ++g) {
+    // symbol of site (g, lane & 15): one dword per LANE in the slot, the lanes of site group g start at 64 / NG * g
+    const unsigned code = codes[g * (256 / NG)];
     part[g] = 0.0;
     if (CMX_ABLATE == 1 || CMX_ABLATE == 4 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
 #pragma unroll
       for (int sb = 0; sb < NB; ++sb) {
         const double v = 0.05 + 0.001 * code;
-        if (MODE == LEAF_SET) out[sb * 4 + g] = v;
-        else if (MODE == LEAF_MUL) out[sb * 4 + g] = v * in[sb * 4 + g];
-        else part[g] = __builtin_fma(in[sb * 4 + g], v, part[g]);
+        if (MODE == LEAF_SET) out[sb * NG + g] = v;
+        else if (MODE == LEAF_MUL) out[sb * NG + g] = v * in[sb * NG + g];
+        else part[g] = __builtin_fma(in[sb * NG + g], v, part[g]);
       }
       continue;
     }
@@ -247,13 +259,13 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
 #pragma unroll
     for (int sb = 0; sb < NB; ++sb) {
       const double v = r[sb];
-      if (MODE == LEAF_SET) out[sb * 4 + g] = v;
-      else if (MODE == LEAF_MUL) out[sb * 4 + g] = v * in[sb * 4 + g];
-      else part[g] = __builtin_fma(in[sb * 4 + g], v, part[g]);
+      if (MODE == LEAF_SET) out[sb * NG + g] = v;
+      else if (MODE == LEAF_MUL) out[sb * NG + g] = v * in[sb * NG + g];
+      else part[g] = __builtin_fma(in[sb * NG + g], v, part[g]);
     }
   }
   if (MODE != LEAF_DOT) return 0.0;
-  return reduce_sites(part[0], part[1], part[2], part[3], lane);
+  return reduce_sites<NG>(part);
 }
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -400,36 +412,36 @@ struct OpState {
 
 // Workspace vector loads follow a host-built schedule (m.ldsched, one entry per load in program order):
 // bit 30 = array (0: inside D, 1: outside U), low 24 bits = slot.
-#define CMX_SCHED_ADDR(e) (((e) & 0x40000000) ? wsU : wsD) + (size_t)((e) & 0x00ffffff) * S * kWave + 2 * lane
+#define CMX_SCHED_ADDR(e) (((e) & 0x40000000) ? wsU : wsD) + (size_t)((e) & 0x00ffffff) * VL * kWave + 2 * lane
 // pop: take the vector prefetched into LDS (or load it now), then start the LDS-DMA of the next schedule entry if
 // the host marked it prefetchable (bit 31: its producing store precedes this point).  The DMA needs no VGPRs and
 // overlaps the ops that follow; lgkmcnt(0) orders the next DMA behind the LDS read.
 #define CMX_POP(dst)                                                        \
   do {                                                                      \
     if (pend) {                                                             \
-      { CMX_TIC(); wait_vm<S>((int)(os.vs - pf_seq)); CMX_TOC(TM_POPWAIT); } \
-      read_vec_lds<S>(pfl, lane, dst);                                      \
+      { CMX_TIC(); wait_vm<S, VL>((int)(os.vs - pf_seq)); CMX_TOC(TM_POPWAIT); } \
+      read_vec_lds<VL>(pfl, lane, dst);                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
     } else {                                                                \
       const int e_ = sload_i32(cm.ldsched + fi);                            \
-      load_vec<S>(CMX_SCHED_ADDR(e_), dst);                                 \
+      load_vec<VL>(CMX_SCHED_ADDR(e_), dst);                                 \
     }                                                                       \
     ++fi;                                                                   \
     pend = false;                                                           \
     if (fi < m.nloads) {                                                    \
       const int e2_ = sload_i32(cm.ldsched + fi);                           \
       if (e2_ < 0) {                                                        \
-        prefetch_vec_lds<S>(CMX_SCHED_ADDR(e2_), pfl);                      \
+        prefetch_vec_lds<VL>(CMX_SCHED_ADDR(e2_), pfl);                      \
         pend = true;                                                        \
-        os.vs += S / 2;                                                     \
+        os.vs += VL / 2;                                                     \
         pf_seq = os.vs;                                                     \
       }                                                                     \
     }                                                                       \
   } while (0)
 #define CMX_STORE(ptr, v)     \
   do {                        \
-    { CMX_TIC(); store_vec<S>(ptr, v); CMX_TOC(TM_STORE); } \
-    os.vs += S / 2;           \
+    { CMX_TIC(); store_vec<VL>(ptr, v); CMX_TOC(TM_STORE); } \
+    os.vs += VL / 2;           \
   } while (0)
 
 // Maps the 64 sites of this wave (symbol of taxon t at gcodes[t * gstride], per lane) for all rate classes.
@@ -440,7 +452,7 @@ struct OpState {
 // part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
 // The loop nest below is mirrored statement for statement by build_load_schedule() / verify_traversal() in
 // cmx_host_model.cpp: the op stream decides WHICH operator every CMX_MV / CMX_LEAF applies.
-template <int S, int FUSE>
+template <int S, int FUSE, int NG>
 __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
                                                double* __restrict__ part, double* __restrict__ cnt, int lds_off,
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
@@ -448,8 +460,13 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
                                                double& norm_out, int c_begin, int c_end, int c_after, bool finalize) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
-  uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, S*64*8 bytes
-  uint8_t* stage = pfl + S * kWave * 8;                                // two operator buffers
+  constexpr int VL = S / 4 * NG;       // doubles of an S-vector per lane (NG site groups of 16 sites per wave)
+  constexpr int kSites = 16 * NG;      // sites per wave
+  // site of this lane inside the wave's block for per-site scalars and arrays: NG = 4: the lane itself; NG = 2: lanes
+  // l and l ^ 16 both carry site 16 (l >> 5) + (l & 15) and do the per-site work redundantly (identical values)
+  const int sidx = NG == 4 ? lane : (((lane >> 5) << 4) | (lane & 15));
+  uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, VL*64*8 bytes
+  uint8_t* stage = pfl + VL * kWave * 8;                               // two operator buffers
   uint8_t* cslot = stage + 2 * MatStage<S>::BYTES;                     // two symbol slots
   const int C = m.C, K = m.K, root = m.root;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
@@ -484,7 +501,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     os.pre_mat = cm.msched[2 * i2_];                                                                     \
     os.pre_tx = cm.msched[2 * i2_ + 1];                                                                  \
   }                                                                                                      \
-  { CMX_TIC(); if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S>((int)(os.vs - os.cur_seq + issued_)); CMX_TOC(TM_OPWAIT); } \
+  { CMX_TIC(); if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S, VL>((int)(os.vs - os.cur_seq + issued_)); CMX_TOC(TM_OPWAIT); } \
   os.vs += issued_;                                                                                      \
   const unsigned nseq_ = os.vs;                                                                          \
   const uint8_t* buf_ = stage + os.par * MatStage<S>::BYTES
@@ -495,7 +512,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #define CMX_MV(TR, in, out)                     \
   do {                                          \
     CMX_OP_BEGIN();                             \
-    { CMX_TIC(); matvec_stage<S, TR>(buf_, lane, in, out); asm volatile("" :: "v"(out[0]), "v"(out[S - 1])); CMX_TOC(TM_MV); } \
+    { CMX_TIC(); matvec_stage<S, TR, NG>(buf_, lane, in, out); asm volatile("" :: "v"(out[0]), "v"(out[VL - 1])); CMX_TOC(TM_MV); } \
     CMX_OP_END();                               \
   } while (0)
 // leaf edge the op stream names (P or P o N^k of a taxon, transposed): out = message, out = message o in, tot = <in, message>
@@ -503,8 +520,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   do {                                                                                       \
     CMX_OP_BEGIN();                                                                          \
     CMX_TIC();                                                                               \
-    tot = leaf_apply<S, MODE_>(buf_, cslot + os.par * kCodeSlotBytes + 4 * (lane & 15), lane, in, out); \
-    asm volatile("" :: "v"(tot), "v"(out[0]), "v"(out[S - 1]));                              \
+    tot = leaf_apply<S, MODE_, NG>(buf_, cslot + os.par * kCodeSlotBytes + 4 * (lane & 15), lane, in, out); \
+    asm volatile("" :: "v"(tot), "v"(out[0]), "v"(out[VL - 1]));                              \
     CMX_TOC(TM_LEAF);                                                                        \
     CMX_OP_END();                                                                            \
   } while (0)
@@ -514,26 +531,27 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 // tells the compiler a vector is dead here (defines it without an instruction): the four S-vectors are loop-carried
 // variables and would otherwise count as live on paths whose successors never read them
 #define CMX_KILL(v) \
-  do { _Pragma("unroll") for (int i_ = 0; i_ < S; ++i_) asm volatile("" : "=v"(v[i_])); } while (0)
+  do { _Pragma("unroll") for (int i_ = 0; i_ < VL; ++i_) asm volatile("" : "=v"(v[i_])); } while (0)
 #define CMX_DOT(x_, y_, out)                                                          \
   do {                                                                                \
-    double p_[4] = {0.0, 0.0, 0.0, 0.0};                                              \
+    double p_[NG];                                                                    \
+    _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) p_[g_] = 0.0;                   \
     _Pragma("unroll") for (int sb_ = 0; sb_ < S / 4; ++sb_)                           \
-      _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                \
-        p_[g_] = __builtin_fma(x_[sb_ * 4 + g_], y_[sb_ * 4 + g_], p_[g_]);           \
-    out = reduce_sites(p_[0], p_[1], p_[2], p_[3], lane);                             \
+      _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_)                               \
+        p_[g_] = __builtin_fma(x_[sb_ * NG + g_], y_[sb_ * NG + g_], p_[g_]);         \
+    out = reduce_sites<NG>(p_);                                                       \
   } while (0)
   for (int c = c_begin; c < c_end; ++c) {
     CMX_TIC();
     const double pc = FUSE > 1 ? 1.0 : cm.probs[c];  // fused: the class probabilities are folded into the count operators
     double Lg[FUSE];   // site likelihood per fused class at the root
-    double* pcnt = part + (size_t)c * m.B * K * kWave + lane;
-    double d[S], t[S];  // popped vector / matvec result
+    double* pcnt = part + (size_t)c * m.B * K * kSites + sidx;
+    double d[VL], t[VL];  // popped vector / matvec result
     int fi = 0;         // next schedule entry
     int mi = 0;         // matrix products done in this class pass
     bool pend = false;  // the LDS prefetch buffer holds entry fi
     unsigned pf_seq = 0;  // os.vs right after that prefetch was issued
-    double acc[S], u[S];
+    double acc[VL], u[VL];
     double Lc = 0.0;
 // inside vector of a child edge into `d`: kind 1 = stored (pop), kind 2 = inlined cherry (two leaf ops)
 #define CMX_GET_D(r_, off_)                                    \
@@ -552,13 +570,13 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     for (int k = 0; k < K; ++k) {                                                        \
       double tot_;                                                                       \
       CMX_LEAF_DOT(t1_, tot_);                   /* . (P o N^k of leaf 1) */             \
-      pcnt[((size_t)(r_)[(off_) + CH_L1] * K + k) * kWave] = pc * tot_;                  \
+      pcnt[((size_t)(r_)[(off_) + CH_L1] * K + k) * kSites] = pc * tot_;                  \
     }                                                                                    \
     CMX_LEAF_MUL(up, t1_);                       /* up o (P of leaf 1) */                \
     for (int k = 0; k < K; ++k) {                                                        \
       double tot_;                                                                       \
       CMX_LEAF_DOT(t1_, tot_);                   /* . (P o N^k of leaf 2) */             \
-      pcnt[((size_t)(r_)[(off_) + CH_L2] * K + k) * kWave] = pc * tot_;                  \
+      pcnt[((size_t)(r_)[(off_) + CH_L2] * K + k) * kSites] = pc * tot_;                  \
     }                                                                                    \
   } while (0)
     // ---------------- inside (post-order) pass over the visited nodes.  acc leaves each iteration holding D of the
@@ -578,7 +596,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           CMX_MV(false, d, acc);
           if (yreg) {
 #pragma unroll
-            for (int x = 0; x < S; ++x) acc[x] *= t[x];
+            for (int x = 0; x < VL; ++x) acc[x] *= t[x];
           }
         }
         if (!yreg) {
@@ -588,7 +606,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
             CMX_GET_D(r, REC_Y);
             CMX_MV(false, d, t);
 #pragma unroll
-            for (int x = 0; x < S; ++x) acc[x] *= t[x];
+            for (int x = 0; x < VL; ++x) acc[x] *= t[x];
           }
         }
       } else {
@@ -596,10 +614,10 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         if (carry >= 0) {
           CMX_MV(false, acc, t);
 #pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] = t[x];
+          for (int x = 0; x < VL; ++x) acc[x] = t[x];
         } else {
 #pragma unroll
-          for (int x = 0; x < S; ++x) acc[x] = 1.0;
+          for (int x = 0; x < VL; ++x) acc[x] = 1.0;
         }
         for (int e = cm.first_child[n]; e >= 0; e = cm.next_sib[e]) {
           if (cm.taxon_of[e] >= 0) {
@@ -609,28 +627,34 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
             CMX_POP(d);
             CMX_MV(false, d, t);
 #pragma unroll
-            for (int x = 0; x < S; ++x) acc[x] *= t[x];
+            for (int x = 0; x < VL; ++x) acc[x] *= t[x];
           }
         }
       }
       if (n != root) {
-        CMX_STORE(wsD + (size_t)r[REC_SLOT] * S * kWave + 2 * lane, acc);
+        CMX_STORE(wsD + (size_t)r[REC_SLOT] * VL * kWave + 2 * lane, acc);
       } else {
         // lane l holds state 4 sb + (l >> 4) of its four sites: weight it with that state's frequency
         if constexpr (FUSE == 1) {
-          double p_[4] = {0.0, 0.0, 0.0, 0.0};
+          double p_[NG];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) p_[g] = 0.0;
 #pragma unroll
           for (int sb = 0; sb < S / 4; ++sb) {
             const double pv = m.pi[4 * sb + (lane >> 4)];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) p_[g] = __builtin_fma(pv, acc[sb * 4 + g], p_[g]);
+            for (int g = 0; g < NG; ++g) p_[g] = __builtin_fma(pv, acc[sb * NG + g], p_[g]);
           }
-          Lg[0] = reduce_sites(p_[0], p_[1], p_[2], p_[3], lane);
+          Lg[0] = reduce_sites<NG>(p_);
         } else {   // one 4-state tile per fused class
           const double pv = m.pi[lane >> 4];
 #pragma unroll
-          for (int sb = 0; sb < FUSE; ++sb)
-            Lg[sb] = reduce_sites(pv * acc[sb * 4 + 0], pv * acc[sb * 4 + 1], pv * acc[sb * 4 + 2], pv * acc[sb * 4 + 3], lane);
+          for (int sb = 0; sb < FUSE; ++sb) {
+            double p_[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) p_[g] = pv * acc[sb * NG + g];
+            Lg[sb] = reduce_sites<NG>(p_);
+          }
         }
         Lc = Lg[0];
       }
@@ -664,7 +688,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         for (int sb = 0; sb < S / 4; ++sb) {
           const double pv = m.pi[(4 * sb + (lane >> 4)) % (S / FUSE)];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[sb * 4 + g] = pv;
+          for (int g = 0; g < NG; ++g) acc[sb * NG + g] = pv;
         }
       } else if (!(r[REC_FLAGS] & FLAG_UP_IN_ACC)) {  // otherwise Up_f was left in acc by the parent
         CMX_POP(acc);
@@ -678,14 +702,14 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           CMX_GET_D(r, REC_Y);
           CMX_MV(false, d, t);
 #pragma unroll
-          for (int x = 0; x < S; ++x) u[x] = acc[x] * t[x];
+          for (int x = 0; x < VL; ++x) u[x] = acc[x] * t[x];
         }
         // ---- X: counts of its branch, its message -> U_Y, its outside message
         if (kx == 0) {
           for (int k = 0; k < K; ++k) {
             double tot;
             CMX_LEAF_DOT(u, tot);
-            pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kWave] = pc * tot;
+            pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kSites] = pc * tot;
           }
           CMX_LEAF_MUL(acc, t);                        // U_Y = Up_f o M_X
         } else {
@@ -695,14 +719,14 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
             if (k < K) {
               double tot;
               CMX_DOT(u, t, tot);
-              pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kWave] = pc * tot;
+              pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kSites] = pc * tot;
             }
           }
 #pragma unroll
-          for (int x = 0; x < S; ++x) t[x] *= acc[x];  // U_Y
+          for (int x = 0; x < VL; ++x) t[x] *= acc[x];  // U_Y
           CMX_MV(true, u, d);                          // Up_X
           if (kx == 1) {
-            CMX_STORE(wsU + (size_t)r[REC_X + CH_ID] * S * kWave + 2 * lane, d);
+            CMX_STORE(wsU + (size_t)r[REC_X + CH_ID] * VL * kWave + 2 * lane, d);
           } else {
             CMX_CHERRY_COUNTS(r, REC_X, d, acc);       // Up_f is dead here
           }
@@ -712,7 +736,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
           for (int k = 0; k < K; ++k) {
             double tot;
             CMX_LEAF_DOT(t, tot);
-            pcnt[((size_t)r[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
+            pcnt[((size_t)r[REC_Y + CH_NODE] * K + k) * kSites] = pc * tot;
           }
           CMX_KILL(acc);
         } else {
@@ -721,7 +745,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
             CMX_MV(false, d, u);
             double tot;
             CMX_DOT(t, u, tot);
-            pcnt[((size_t)r[REC_Y + CH_NODE] * K + k) * kWave] = pc * tot;
+            pcnt[((size_t)r[REC_Y + CH_NODE] * K + k) * kSites] = pc * tot;
           }
           CMX_MV(true, t, acc);                        // Up_Y: handed to the next visited node when Y is stored
           if (ky != 1) {
@@ -734,7 +758,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         const int ca = cm.first_child[f];
         for (int n = ca; n >= 0; n = cm.next_sib[n]) {
 #pragma unroll
-          for (int x = 0; x < S; ++x) u[x] = acc[x];
+          for (int x = 0; x < VL; ++x) u[x] = acc[x];
           for (int sb = ca; sb >= 0; sb = cm.next_sib[sb]) {
             if (sb == n) continue;
             if (cm.taxon_of[sb] >= 0) {
@@ -743,14 +767,14 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
               CMX_POP(d);
               CMX_MV(false, d, t);
 #pragma unroll
-              for (int x = 0; x < S; ++x) u[x] *= t[x];
+              for (int x = 0; x < VL; ++x) u[x] *= t[x];
             }
           }
           if (cm.taxon_of[n] >= 0) {
             for (int k = 0; k < K; ++k) {
               double tot;
               CMX_LEAF_DOT(u, tot);
-              pcnt[((size_t)n * K + k) * kWave] = pc * tot;
+              pcnt[((size_t)n * K + k) * kSites] = pc * tot;
             }
           } else {
             const int sl = cm.slot[n];
@@ -759,10 +783,10 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
               CMX_MV(false, d, t);
               double tot;
               CMX_DOT(u, t, tot);
-              pcnt[((size_t)n * K + k) * kWave] = pc * tot;
+              pcnt[((size_t)n * K + k) * kSites] = pc * tot;
             }
             CMX_MV(true, u, t);
-            CMX_STORE(wsU + (size_t)sl * S * kWave + 2 * lane, t);
+            CMX_STORE(wsU + (size_t)sl * VL * kWave + 2 * lane, t);
           }
         }
         CMX_KILL(acc);
@@ -803,15 +827,15 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = 0.0;
     for (int c = 0; c < C; ++c) {
-      const double* pp = part + ((size_t)c * BK + r0) * kWave + lane;
+      const double* pp = part + ((size_t)c * BK + r0) * kSites + sidx;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] += pp[(size_t)(r0 + u < BK ? u : 0) * kWave];
+      for (int u = 0; u < 8; ++u) v[u] += pp[(size_t)(r0 + u < BK ? u : 0) * kSites];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (r0 + u < BK) {
         const double q = v[u] / Lsum;
-        cnt[(size_t)(r0 + u) * kWave + lane] = q;
+        cnt[(size_t)(r0 + u) * kSites + sidx] = q;
         tot += q;
         if (++kk == K) {
           nrm = __builtin_fma(tot, tot, nrm);
@@ -885,24 +909,28 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
   return pair_stat_strided(kind, param, B, K, c1, (size_t)kWave, c2, (size_t)kWave);
 }
 
+// site groups of 16 per wave: 4 (64 sites, two waves per SIMD) or 2 (32 sites: the four live S-vectors take 80 registers
+// instead of 160 and three waves fit a SIMD; operators are then staged per 32 sites)
 template <int S>
-constexpr int map_lds_per_wave() { return S * kWave * 8 + 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }
+constexpr int map_lds_per_wave() { return S / 4 * map_ng(S) * kWave * 8 + 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }
 
 template <int S, int MODE, int FUSE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void map_kernel(const MapArgs a) {
+  constexpr int NG = map_ng(S), VL = S / 4 * NG, kSites = 16 * NG;
   const DevModel& m = a.m;
   const ConstModel cm(m);
   const int lane = threadIdx.x & (kWave - 1);
+  const int sidx = NG == 4 ? lane : (((lane >> 5) << 4) | (lane & 15));   // site of this lane in the wave's block
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * kWavesPerBlock;
-  double* wsD = a.ws.D + (size_t)wave * m.NI * S * kWave;
-  double* wsU = a.ws.U + (size_t)wave * m.NI * S * kWave;
-  double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kWave;
-  double* cnt1 = cnt0 + (size_t)m.B * m.K * kWave;
-  double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kWave;
+  double* wsD = a.ws.D + (size_t)wave * m.NI * VL * kWave;
+  double* wsU = a.ws.U + (size_t)wave * m.NI * VL * kWave;
+  double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kSites;
+  double* cnt1 = cnt0 + (size_t)m.B * m.K * kSites;
+  double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kSites;
   // LDS per wave: workspace prefetch buffer (S*64*8 B), two operator stage buffers, two symbol slots
   const int lds_off = (int)(threadIdx.x >> 6) * map_lds_per_wave<S>();
-  const size_t nblocks = (a.nsites + kWave - 1) / kWave;
+  const size_t nblocks = (a.nsites + kSites - 1) / kSites;
   // request the first op's operator (class 0, entry 0); every op then requests the next one
   OpState os;
 #ifdef CMX_TIMING
@@ -914,7 +942,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
     int mat0, tx0;
     sload_i32x2(cm.msched, mat0, tx0);
     const int c0 = (MODE == kModeObservedSplit) ? wave % m.C : 0;   // class of this wave's first pass
-    mat_dma<S>(m.MAT + ((size_t)c0 * m.MC + (size_t)mat0) * MatStage<S>::UNIT, cmx_smem + lds_off + S * kWave * 8, lane);
+    mat_dma<S>(m.MAT + ((size_t)c0 * m.MC + (size_t)mat0) * MatStage<S>::UNIT, cmx_smem + lds_off + VL * kWave * 8, lane);
   }
   os.vs = MatStage<S>::ROWS;
   os.cur_seq = os.vs;
@@ -928,35 +956,35 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
     for (size_t task = wave; task < ntasks; task += nwaves) {
       const size_t sb = task / m.C;
       const int c = (int)(task % m.C);
-      const size_t site = sb * kWave + lane;
+      const size_t site = sb * kSites + sidx;
       const size_t s = site < a.nsites ? site : a.nsites - 1;
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S, FUSE>(a, wsD, wsU, a.split_part + sb * m.C * BK * kWave, nullptr, lds_off, a.aln + s, a.ld, lane, os, L, pr,
+      map_sites_wave<S, FUSE, NG>(a, wsD, wsU, a.split_part + sb * m.C * BK * kSites, nullptr, lds_off, a.aln + s, a.ld, lane, os, L, pr,
                         rc, nrm, c, c + 1, (int)((task + nwaves) % m.C), false);
-      a.split_lc[task * kWave + lane] = L;
-      a.split_lc[(ntasks + task) * kWave + lane] = pr;
-      a.split_lc[(2 * ntasks + task) * kWave + lane] = nrm;          // weight of the pass's best class
-      a.split_lc[(3 * ntasks + task) * kWave + lane] = (double)rc;   // ... and its index
+      a.split_lc[task * kSites + sidx] = L;
+      a.split_lc[(ntasks + task) * kSites + sidx] = pr;
+      a.split_lc[(2 * ntasks + task) * kSites + sidx] = nrm;          // weight of the pass's best class
+      a.split_lc[(3 * ntasks + task) * kSites + sidx] = (double)rc;   // ... and its index
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
   for (size_t sb = wave; sb < nblocks; sb += nwaves) {
-    const size_t site = sb * kWave + lane;
+    const size_t site = sb * kSites + sidx;
     const bool active = site < a.nsites;
     const size_t s = active ? site : a.nsites - 1;
     if (MODE == kModeObserved) {
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S, FUSE>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
+      map_sites_wave<S, FUSE, NG>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
         if (a.rate_class) a.rate_class[s] = rc;
         if (a.norm) a.norm[s] = nrm;
         if (a.counts)
-          for (int r = 0; r < m.B * m.K; ++r) a.counts[(size_t)r * a.ldc + s] = cnt0[(size_t)r * kWave + lane];
+          for (int r = 0; r < m.B * m.K; ++r) a.counts[(size_t)r * a.ldc + s] = cnt0[(size_t)r * kSites + sidx];
       }
     } else {
       // null pair q = s: replicate rep, column j; simulated-site index g_h = ((rep*2 + h)*rep_ram + j).
@@ -972,35 +1000,35 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
           gstride = a.rep_ram;
         } else {
           const size_t rep = a.rep_begin + rep_local;
-          uint8_t* al = a.ws.aln + (size_t)wave * m.T * kWave + lane;
+          uint8_t* al = a.ws.aln + (size_t)wave * m.T * kSites + sidx;
           gbase = al;
-          gstride = kWave;
+          gstride = kSites;
           const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
           const int S0 = S / FUSE;
           const int c = draw_index(philox_uniform(a.seed, g, 0), cm.cum_probs, m.C0);
           // states of the nodes: in the (idle) workspace prefetch buffer when nn * 64 bytes fit, else in HBM
-          const bool st_lds = m.nn * kWave <= S * kWave * 8;
-          uint8_t* stl = cmx_smem + lds_off + lane;
-          uint8_t* stg = a.ws.st + (size_t)wave * m.nn * kWave + lane;
+          const bool st_lds = m.nn * kSites <= VL * kWave * 8;
+          uint8_t* stl = cmx_smem + lds_off + sidx;
+          uint8_t* stg = a.ws.st + (size_t)wave * m.nn * kSites + sidx;
           const uint8_t x0 = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S0);
-          if (st_lds) stl[(size_t)m.root * kWave] = x0; else stg[(size_t)m.root * kWave] = x0;
+          if (st_lds) stl[(size_t)m.root * kSites] = x0; else stg[(size_t)m.root * kSites] = x0;
           for (int node = m.nn - 2; node >= 0; --node) {
             const int pn = cm.parent[node];
-            const int x = st_lds ? stl[(size_t)pn * kWave] : stg[(size_t)pn * kWave];
+            const int x = st_lds ? stl[(size_t)pn * kSites] : stg[(size_t)pn * kSites];
             const double u = philox_uniform(a.seed, g, 2u + (uint32_t)node);
             const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S0 + x) * S0, S0);
-            if (st_lds) stl[(size_t)node * kWave] = (uint8_t)y; else stg[(size_t)node * kWave] = (uint8_t)y;
+            if (st_lds) stl[(size_t)node * kSites] = (uint8_t)y; else stg[(size_t)node * kSites] = (uint8_t)y;
             const int tx = cm.taxon_of[node];
-            if (tx >= 0) al[(size_t)tx * kWave] = (uint8_t)y;
+            if (tx >= 0) al[(size_t)tx * kSites] = (uint8_t)y;
           }
         }
         double L, pr, nrm;
         int rc;
-        map_sites_wave<S, FUSE>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
+        map_sites_wave<S, FUSE, NG>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
         if (h == 0) { prmin = pr; nmin = nrm; rcmin = rc; }
         else { prmin = pr < prmin ? pr : prmin; nmin = nrm < nmin ? nrm : nmin; rcmin = rc < rcmin ? rc : rcmin; }
       }
-      const double stat = pair_stat_lane(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + lane, cnt1 + lane);
+      const double stat = pair_stat_strided(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + sidx, (size_t)kSites, cnt1 + sidx, (size_t)kSites);
       if (active) {
         a.null_stat[s] = stat;
         if (a.null_rcmin) a.null_rcmin[s] = rcmin;
@@ -1061,25 +1089,26 @@ __global__ void map_finalize_kernel(const MapArgs a) {
   const DevModel& m = a.m;
   const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.nsites) return;
-  const size_t sb = s / kWave, lane = s % kWave, BK = (size_t)m.B * m.K;
-  const size_t nblocks = (a.nsites + kWave - 1) / kWave, ntasks = nblocks * (size_t)m.C;
+  const size_t kS = 16 * (size_t)map_ng(m.S);   // sites per wave-task of the mapping kernel
+  const size_t sb = s / kS, lane = s % kS, BK = (size_t)m.B * m.K;
+  const size_t nblocks = (a.nsites + kS - 1) / kS, ntasks = nblocks * (size_t)m.C;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
   for (int c = 0; c < m.C; ++c) {
     const size_t t = sb * m.C + c;
-    Lsum += a.split_lc[t * kWave + lane];
-    prsum += a.split_lc[(ntasks + t) * kWave + lane];
-    const double bv = a.split_lc[(2 * ntasks + t) * kWave + lane];
-    if (bv > best) { best = bv; bestc = (int)a.split_lc[(3 * ntasks + t) * kWave + lane]; }
+    Lsum += a.split_lc[t * kS + lane];
+    prsum += a.split_lc[(ntasks + t) * kS + lane];
+    const double bv = a.split_lc[(2 * ntasks + t) * kS + lane];
+    if (bv > best) { best = bv; bestc = (int)a.split_lc[(3 * ntasks + t) * kS + lane]; }
   }
-  const double* part = a.split_part + sb * m.C * BK * kWave + lane;
+  const double* part = a.split_part + sb * m.C * BK * kS + lane;
   double nrm = 0.0;
   for (int b = 0; b < m.B; ++b) {
     double tot = 0.0;
     for (int k = 0; k < m.K; ++k) {
       const size_t r = (size_t)b * m.K + k;
       double v = 0.0;
-      for (int c = 0; c < m.C; ++c) v += part[((size_t)c * BK + r) * kWave];
+      for (int c = 0; c < m.C; ++c) v += part[((size_t)c * BK + r) * kS];
       v /= Lsum;
       if (a.counts) a.counts[r * a.ldc + s] = v;
       tot += v;
