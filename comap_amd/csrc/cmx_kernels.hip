@@ -398,7 +398,7 @@ struct ConstModel {
 #define CMX_TIC() do {} while (0)
 #define CMX_TOC(slot) do {} while (0)
 #endif
-enum { TM_OPWAIT = 0, TM_POPWAIT = 1, TM_MV = 2, TM_LEAF = 3, TM_SLOAD = 4, TM_STORE = 5, TM_PASS = 6, TM_SIM = 7, TM_N = 8 };
+enum { TM_OPWAIT = 0, TM_POPWAIT = 1, TM_MV = 2, TM_LEAF = 3, TM_SLOAD = 4, TM_STORE = 5, TM_PASS = 6, TM_SIM = 7, TM_OPB = 8, TM_POP = 9, TM_N = 10 };
 struct OpState {
 #ifdef CMX_TIMING
   long long tm[TM_N];
@@ -418,22 +418,25 @@ struct OpState {
 // overlaps the ops that follow; lgkmcnt(0) orders the next DMA behind the LDS read.
 #define CMX_POP(dst)                                                        \
   do {                                                                      \
-    if (pend) {                                                             \
-      { CMX_TIC(); wait_vm<S, VL>((int)(os.vs - pf_seq)); CMX_TOC(TM_POPWAIT); } \
-      read_vec_lds<VL>(pfl, lane, dst);                                      \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
-    } else {                                                                \
+    if (!pend) { /* not prefetchable (its store is too recent): request it now, through the same LDS path -- a plain  \
+                    global load here would be a compiler-visible VMEM load whose pending destination registers make   \
+                    hipcc put conservative vmcnt waits (draining the DMAs in flight) into every following op */       \
       const int e_ = sload_i32(cm.ldsched + fi);                            \
-      load_vec<VL>(CMX_SCHED_ADDR(e_), dst);                                 \
+      prefetch_vec_lds<VL>(CMX_SCHED_ADDR(e_), pfl);                        \
+      os.vs += VL / 2;                                                      \
+      pf_seq = os.vs;                                                       \
     }                                                                       \
+    { CMX_TIC(); wait_vm<S, VL>((int)(os.vs - pf_seq)); CMX_TOC(TM_POPWAIT); } \
+    read_vec_lds<VL>(pfl, lane, dst);                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
     ++fi;                                                                   \
     pend = false;                                                           \
     if (fi < m.nloads) {                                                    \
       const int e2_ = sload_i32(cm.ldsched + fi);                           \
       if (e2_ < 0) {                                                        \
-        prefetch_vec_lds<VL>(CMX_SCHED_ADDR(e2_), pfl);                      \
+        prefetch_vec_lds<VL>(CMX_SCHED_ADDR(e2_), pfl);                     \
         pend = true;                                                        \
-        os.vs += VL / 2;                                                     \
+        os.vs += VL / 2;                                                    \
         pf_seq = os.vs;                                                     \
       }                                                                     \
     }                                                                       \
@@ -483,7 +486,15 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   }
 // One op: request the operator (and symbols) of the NEXT op of the stream -- entry mi + 1, or entry 0 of the next
 // class / next site block -- into the other buffer, then wait for this op's operator.
+#ifdef CMX_TIMING
+#define CMX_TIC2() const long long tic2_ = (long long)__builtin_readcyclecounter()
+#define CMX_TOC2(slot) os.tm[slot] += (long long)__builtin_readcyclecounter() - tic2_; os.tn[slot] += 1
+#else
+#define CMX_TIC2() do {} while (0)
+#define CMX_TOC2(slot) do {} while (0)
+#endif
 #define CMX_OP_BEGIN()                                                                                   \
+  CMX_TIC2();                                                                                            \
   const bool more_ = (mi + 1 < m.nmv);                                                                   \
   const int cn_ = more_ ? c : ((c + 1 < c_end) ? c + 1 : c_after);                                        \
   const int emat_ = os.pre_mat, etx_ = os.pre_tx;                                                        \
@@ -504,7 +515,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   { CMX_TIC(); if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S, VL>((int)(os.vs - os.cur_seq + issued_)); CMX_TOC(TM_OPWAIT); } \
   os.vs += issued_;                                                                                      \
   const unsigned nseq_ = os.vs;                                                                          \
-  const uint8_t* buf_ = stage + os.par * MatStage<S>::BYTES
+  const uint8_t* buf_ = stage + os.par * MatStage<S>::BYTES;                                             \
+  CMX_TOC2(TM_OPB)
 #define CMX_OP_END()   \
   os.par ^= 1u;        \
   os.cur_seq = nseq_;  \
@@ -1041,9 +1053,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
 #ifdef CMX_TIMING
   if (MODE == kModeNull && lane == 0 && (wave == 0 || wave == 777)) {
     const long long tot_ = (long long)__builtin_readcyclecounter() - tk0_;
-    printf("wave %d total %lld | opwait %lld/%lld popwait %lld/%lld mv %lld/%lld leaf %lld/%lld sload %lld/%lld store %lld/%lld pass %lld/%lld\n",
+    printf("wave %d total %lld | opwait %lld/%lld popwait %lld/%lld mv %lld/%lld leaf %lld/%lld sload %lld/%lld store %lld/%lld pass %lld/%lld opbegin %lld/%lld pop %lld/%lld\n",
            wave, tot_, os.tm[0], os.tn[0], os.tm[1], os.tn[1], os.tm[2], os.tn[2], os.tm[3], os.tn[3], os.tm[4], os.tn[4],
-           os.tm[5], os.tn[5], os.tm[6], os.tn[6]);
+           os.tm[5], os.tn[5], os.tm[6], os.tn[6], os.tm[8], os.tn[8], os.tm[9], os.tn[9]);
   }
 #endif
 }
