@@ -98,9 +98,12 @@ __device__ __forceinline__ void dma_rows16(const void* g /* per lane: row 0 addr
 
 // DMA the operator at `src` (global, wave-uniform) into the stage buffer `buf` (LDS, wave-uniform)
 template <int S>
-__device__ __forceinline__ void mat_dma(const double* src, uint8_t* buf, int lane) {
+__device__ __forceinline__ void mat_dma_l(const double* src, uint32_t l, int lane);
+template <int S>
+__device__ __forceinline__ void mat_dma(const double* src, uint8_t* buf, int lane) { mat_dma_l<S>(src, lds_addr(buf), lane); }
+template <int S>
+__device__ __forceinline__ void mat_dma_l(const double* src, uint32_t l /* LDS byte address, wave-uniform */, int lane) {
   const double* g = src + 2 * lane;
-  const uint32_t l = lds_addr(buf);
   if constexpr (MatStage<S>::FULL > 0) dma_rows16<MatStage<S>::FULL>(g, l);
   if constexpr (MatStage<S>::TAIL > 0) {
     if (lane < MatStage<S>::TAIL) dma_rows16<1>(g + MatStage<S>::FULL * 128, l + MatStage<S>::FULL * 1024);
@@ -108,9 +111,10 @@ __device__ __forceinline__ void mat_dma(const double* src, uint8_t* buf, int lan
 }
 // DMA one symbol per lane (address p is per lane) into dword `lane` of the code slot.  The symbols of the null are
 // written by this very wave (simulation) through the same address, hence the L1-bypassing cache policy (sc0 sc1).
-__device__ __forceinline__ void code_dma(const uint8_t* p, uint8_t* slot) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off sc0 sc1" ::"s"(lds_addr(slot)), "v"(p) : "memory");
+__device__ __forceinline__ void code_dma_l(const uint8_t* p, uint32_t l) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off sc0 sc1" ::"s"(l), "v"(p) : "memory");
 }
+__device__ __forceinline__ void code_dma(const uint8_t* p, uint8_t* slot) { code_dma_l(p, lds_addr(slot)); }
 
 // s_waitcnt vmcnt(n) needs an immediate: pick the largest supported threshold <= allowed (waiting for more is safe)
 template <int N>
@@ -471,6 +475,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, VL*64*8 bytes
   uint8_t* stage = pfl + VL * kWave * 8;                               // two operator buffers
   uint8_t* cslot = stage + 2 * MatStage<S>::BYTES;                     // two symbol slots
+  const uint32_t lds_stage = lds_addr(stage), lds_codes = lds_addr(cslot);   // wave-uniform LDS byte addresses (SGPRs)
   const int C = m.C, K = m.K, root = m.root;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
@@ -499,10 +504,12 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   const int cn_ = more_ ? c : ((c + 1 < c_end) ? c + 1 : c_after);                                        \
   const int emat_ = os.pre_mat, etx_ = os.pre_tx;                                                        \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the LDS reads of the other buffer are done */    \
-  mat_dma<S>(m.MAT + ((size_t)cn_ * m.MC + (size_t)emat_) * MatStage<S>::UNIT, stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane); \
+  (void)cn_;                                                                                             \
+  mat_dma_l<S>((more_ ? mat_c : mat_after) + (size_t)emat_ * MatStage<S>::UNIT,                          \
+               lds_stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane);                                    \
   unsigned issued_ = MatStage<S>::ROWS;                                                                  \
   if (etx_ >= 0 && (more_ || c + 1 < c_end)) {                                                           \
-    code_dma(gcodes + (size_t)etx_ * gstride, cslot + (os.par ^ 1u) * kCodeSlotBytes);                   \
+    code_dma_l(gcodes + (size_t)etx_ * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);             \
     issued_ += 1;                                                                                        \
   }                                                                                                      \
   {                                                                                                      \
@@ -555,6 +562,9 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   } while (0)
   for (int c = c_begin; c < c_end; ++c) {
     CMX_TIC();
+    // operators of this class and of the class of the pass that follows (its first operator is requested by our last op)
+    const double* mat_c = m.MAT + (size_t)c * m.MC * MatStage<S>::UNIT;
+    const double* mat_after = m.MAT + (size_t)((c + 1 < c_end) ? c + 1 : c_after) * m.MC * MatStage<S>::UNIT;
     const double pc = FUSE > 1 ? 1.0 : cm.probs[c];  // fused: the class probabilities are folded into the count operators
     double Lg[FUSE];   // site likelihood per fused class at the root
     double* pcnt = part + (size_t)c * m.B * K * kSites + sidx;
