@@ -242,30 +242,39 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
                                              const double (&in)[S / 4 * NG], double (&out)[S / 4 * NG]) {
   constexpr int NB = S / 4;
   double part[NG];
+  // all symbols first (one LDS round trip), then per site group the row values and their use: the reads of the next
+  // group do not depend on anything computed for the previous one
+  unsigned code[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) code[g] = codes[g * (256 / NG)];   // one dword per LANE in the slot, group g at 64 / NG * g
+  const double* r[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    // symbol of site (g, lane & 15): one dword per LANE in the slot, the lanes of site group g start at 64 / NG * g
-    const unsigned code = codes[g * (256 / NG)];
+    const unsigned row = code[g] < (unsigned)MatStage<S>::NROW ? code[g] : (unsigned)(MatStage<S>::NROW - 1);
+    // rows are stored state-in-tile major: state 4 sb + s4 at position s4 * NB + sb (cmx_host_model.cpp)
+    r[g] = reinterpret_cast<const double*>(buf + row * (S * 8)) + (lane >> 4) * NB;
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
     part[g] = 0.0;
     if (CMX_ABLATE == 1 || CMX_ABLATE == 4 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
 #pragma unroll
       for (int sb = 0; sb < NB; ++sb) {
-        const double v = 0.05 + 0.001 * code;
+        const double v = 0.05 + 0.001 * code[g];
         if (MODE == LEAF_SET) out[sb * NG + g] = v;
         else if (MODE == LEAF_MUL) out[sb * NG + g] = v * in[sb * NG + g];
         else part[g] = __builtin_fma(in[sb * NG + g], v, part[g]);
       }
       continue;
     }
-    const unsigned row = code < (unsigned)MatStage<S>::NROW ? code : (unsigned)(MatStage<S>::NROW - 1);
-    // rows are stored state-in-tile major: state 4 sb + s4 at position s4 * NB + sb (cmx_host_model.cpp)
-    const double* r = reinterpret_cast<const double*>(buf + row * (S * 8)) + (lane >> 4) * NB;
+    double v[NB];
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) v[sb] = r[g][sb];
 #pragma unroll
     for (int sb = 0; sb < NB; ++sb) {
-      const double v = r[sb];
-      if (MODE == LEAF_SET) out[sb * NG + g] = v;
-      else if (MODE == LEAF_MUL) out[sb * NG + g] = v * in[sb * NG + g];
-      else part[g] = __builtin_fma(in[sb * NG + g], v, part[g]);
+      if (MODE == LEAF_SET) out[sb * NG + g] = v[sb];
+      else if (MODE == LEAF_MUL) out[sb * NG + g] = v[sb] * in[sb * NG + g];
+      else part[g] = __builtin_fma(in[sb * NG + g], v[sb], part[g]);
     }
   }
   if (MODE != LEAF_DOT) return 0.0;
