@@ -167,7 +167,17 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       d.MAT = const_cast<double*>(mat);
     }
     d.MC = h.MC;
-    UP(msched);
+    {  // device copy of the op stream: operator indices premultiplied to element offsets, and the first two entries
+       // repeated after the last one so that "the entry two ops ahead" never needs a wrap test
+      std::vector<int> ms(h.msched);
+      const int unit = mat_unit(h.dS);
+      for (size_t i = 0; i < ms.size(); i += 2) ms[i] *= unit;
+      const size_t n2 = ms.size();
+      for (size_t i = 0; i < 4; ++i) ms.push_back(ms[i % n2]);
+      const int* dms = nullptr;
+      if ((s = upload(ctx, ms, &dms)) != CMX_OK) return s;
+      d.msched = dms;
+    }
     UP(nrec);
     d.nmv = (int)(h.msched.size() / 2);
     UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);

@@ -514,17 +514,15 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   const int emat_ = os.pre_mat, etx_ = os.pre_tx;                                                        \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the LDS reads of the other buffer are done */    \
   (void)cn_;                                                                                             \
-  mat_dma_l<S>((more_ ? mat_c : mat_after) + (size_t)emat_ * MatStage<S>::UNIT,                          \
+  mat_dma_l<S>((more_ ? mat_c : mat_after) + emat_ /* element offset, premultiplied on the host */,      \
                lds_stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane);                                    \
   unsigned issued_ = MatStage<S>::ROWS;                                                                  \
   if (etx_ >= 0 && (more_ || c + 1 < c_end)) {                                                           \
     code_dma_l(gcodes + (size_t)etx_ * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);             \
     issued_ += 1;                                                                                        \
   }                                                                                                      \
-  {                                                                                                      \
-    int i2_ = mi + 2;                                                                                    \
-    if (i2_ >= m.nmv) i2_ -= m.nmv;                                                                      \
-    if (i2_ >= m.nmv) i2_ = 0;                                                                           \
+  { /* entry two ops ahead; the stream carries its first two entries again after the last (no wrap test) */ \
+    const int i2_ = more_ ? mi + 2 : 1;                                                                  \
     os.pre_mat = cm.msched[2 * i2_];                                                                     \
     os.pre_tx = cm.msched[2 * i2_ + 1];                                                                  \
   }                                                                                                      \
@@ -973,14 +971,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
     int mat0, tx0;
     sload_i32x2(cm.msched, mat0, tx0);
     const int c0 = (MODE == kModeObservedSplit) ? wave % m.C : 0;   // class of this wave's first pass
-    mat_dma<S>(m.MAT + ((size_t)c0 * m.MC + (size_t)mat0) * MatStage<S>::UNIT, cmx_smem + lds_off + VL * kWave * 8, lane);
+    mat_dma<S>(m.MAT + (size_t)c0 * m.MC * MatStage<S>::UNIT + mat0, cmx_smem + lds_off + VL * kWave * 8, lane);
   }
   os.vs = MatStage<S>::ROWS;
   os.cur_seq = os.vs;
   {
-    const int i1 = m.nmv > 1 ? 1 : 0;
-    os.pre_mat = cm.msched[2 * i1];
-    os.pre_tx = cm.msched[2 * i1 + 1];
+    os.pre_mat = cm.msched[2];   // entry 1 (the stream is padded with copies of its first entries)
+    os.pre_tx = cm.msched[3];
   }
   if (MODE == kModeObservedSplit) {
     const size_t ntasks = nblocks * (size_t)m.C, BK = (size_t)m.B * m.K;
