@@ -181,7 +181,14 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     UP(nrec);
     d.nmv = (int)(h.msched.size() / 2);
     UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
-    UP(ldsched);
+    {  // two zero entries (not prefetchable) after the last load: the kernel reads one entry ahead without a bounds test
+      std::vector<int> ld(h.ldsched);
+      ld.push_back(0);
+      ld.push_back(0);
+      const int* dld = nullptr;
+      if ((s = upload(ctx, ld, &dld)) != CMX_OK) return s;
+      d.ldsched = dld;
+    }
 #undef UP
     d.nloads = (int)h.ldsched.size();
     // ambiguity rows of the leaf operators: default "every state compatible" until a call brings a mask table

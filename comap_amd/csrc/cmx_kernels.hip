@@ -434,8 +434,7 @@ struct OpState {
     if (!pend) { /* not prefetchable (its store is too recent): request it now, through the same LDS path -- a plain  \
                     global load here would be a compiler-visible VMEM load whose pending destination registers make   \
                     hipcc put conservative vmcnt waits (draining the DMAs in flight) into every following op */       \
-      const int e_ = sload_i32(cm.ldsched + fi);                            \
-      prefetch_vec_lds<VL>(CMX_SCHED_ADDR(e_), pfl);                        \
+      prefetch_vec_lds<VL>(CMX_SCHED_ADDR(ld_cur), pfl);                    \
       os.vs += VL / 2;                                                      \
       pf_seq = os.vs;                                                       \
     }                                                                       \
@@ -443,15 +442,13 @@ struct OpState {
     read_vec_lds<VL>(pfl, lane, dst);                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
     ++fi;                                                                   \
-    pend = false;                                                           \
-    if (fi < m.nloads) {                                                    \
-      const int e2_ = sload_i32(cm.ldsched + fi);                           \
-      if (e2_ < 0) {                                                        \
-        prefetch_vec_lds<VL>(CMX_SCHED_ADDR(e2_), pfl);                     \
-        pend = true;                                                        \
-        os.vs += VL / 2;                                                    \
-        pf_seq = os.vs;                                                     \
-      }                                                                     \
+    ld_cur = ld_next;                 /* entry fi, loaded one pop early */  \
+    ld_next = cm.ldsched[fi + 1];     /* the schedule ends with two zero entries: no bounds test */ \
+    pend = ld_cur < 0;                                                      \
+    if (pend) {                                                             \
+      prefetch_vec_lds<VL>(CMX_SCHED_ADDR(ld_cur), pfl);                    \
+      os.vs += VL / 2;                                                      \
+      pf_seq = os.vs;                                                       \
     }                                                                       \
   } while (0)
 #define CMX_STORE(ptr, v)     \
@@ -577,6 +574,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     double* pcnt = part + (size_t)c * m.B * K * kSites + sidx;
     double d[VL], t[VL];  // popped vector / matvec result
     int fi = 0;         // next schedule entry
+    int ld_cur = cm.ldsched[0], ld_next = cm.ldsched[1];   // its word and the following one
     int mi = 0;         // matrix products done in this class pass
     bool pend = false;  // the LDS prefetch buffer holds entry fi
     unsigned pf_seq = 0;  // os.vs right after that prefetch was issued
