@@ -1,0 +1,131 @@
+"""Host logic without a GPU: the tree program the mapping kernel executes (records, op stream, workspace-load schedule)
+is compiled and self-checked by cmx_debug_traversal for many tree shapes -- binary, caterpillar, star, random
+multifurcations.  The self-check (verify_traversal, cmx_host_model.cpp) dry-runs the kernel's control flow against the
+tree: every load must name a vector stored before, every op must find its operator, every branch is counted once."""
+import numpy as np
+import pytest
+
+from comap_amd import engine, synthetic as sy
+
+
+def _model():
+    m = sy.protein_model(0.5, 4)
+    return m["Q"], m["pi"], m["rates"], m["probs"]
+
+
+def _random_multifurcating(ntaxa, seed):
+    """post-order parent array of a random tree whose internal nodes have 2..5 children (root >= 3)"""
+    rng = np.random.default_rng(seed)
+    # grow by merging random groups of subtrees until one root remains
+    roots, parent, blen = list(range(ntaxa)), {}, {}
+    nxt = ntaxa
+    while len(roots) > 1:
+        k = int(min(len(roots), rng.integers(2, 6)))
+        if len(roots) - k == 1:        # avoid a final binary root: merge everything that is left
+            k = len(roots)
+        pick = list(rng.choice(len(roots), size=k, replace=False))
+        kids = [roots[i] for i in pick]
+        for c in kids:
+            parent[c] = nxt
+        roots = [r for i, r in enumerate(roots) if i not in pick] + [nxt]
+        nxt += 1
+    root = roots[0]
+    # relabel in post-order
+    children = {}
+    for c, p in parent.items():
+        children.setdefault(p, []).append(c)
+    order = []
+
+    def visit(u):
+        for c in children.get(u, []):
+            visit(c)
+        order.append(u)
+
+    visit(root)
+    new = {old: i for i, old in enumerate(order)}
+    nn = len(order)
+    par = np.full(nn, -1, dtype=np.int32)
+    for c, p in parent.items():
+        par[new[c]] = new[p]
+    bl = rng.exponential(0.1, nn) + 1e-6
+    bl[nn - 1] = 0.0
+    lot = np.array([new[t] for t in range(ntaxa)], dtype=np.int32)
+    return par, bl, lot
+
+
+@pytest.mark.parametrize("ntaxa", [3, 4, 5, 9, 33, 64, 257])
+def test_binary_trees_compile(ntaxa):
+    Q, pi, rates, probs = _model()
+    parent, blen, lot = sy.random_tree(ntaxa, 1000 + ntaxa)
+    d = engine.debug_traversal(parent, blen, lot, Q, pi, rates, probs)
+    nn = len(parent)
+    ninternal = nn - ntaxa
+    assert d["nrec"].shape[1] == 16 and 1 <= d["nrec"].shape[0] <= ninternal
+    ops = d["msched"].reshape(-1, 2)
+    assert ((ops[:, 1] >= -1) & (ops[:, 1] < ntaxa)).all()
+    leaf_ops = ops[ops[:, 1] >= 0]
+    assert set(leaf_ops[:, 1]) == set(range(ntaxa))            # every leaf edge is applied
+    # per class pass: every leaf needs its transition operator on the way down and up, and its count operator once
+    assert len(leaf_ops) >= 3 * ntaxa
+    # every stored vector is loaded at least once; at most four times (children of the multifurcating root)
+    if len(d["ldsched"]):
+        slots, counts = np.unique(d["ldsched"] & 0x40ffffff, return_counts=True)
+        assert counts.max() <= 4
+
+
+def test_caterpillar_and_star():
+    Q, pi, rates, probs = _model()
+    n = 20
+    # caterpillar: ((((a,b),c),d),...) with a trifurcating root
+    parent = np.full(2 * n - 2, -1, dtype=np.int32)
+    lot = np.zeros(n, dtype=np.int32)
+    # nodes: leaves interleaved in post-order: a, b, i1, c, i2, d, ..., last two leaves hang off the root
+    idx, last = 0, None
+    lot[0], lot[1] = 0, 1
+    idx = 2
+    cur = idx          # first internal node
+    parent[0] = parent[1] = cur
+    idx += 1
+    for t in range(2, n - 2):
+        lot[t] = idx
+        leaf = idx
+        idx += 1
+        parent[cur] = parent[leaf] = idx
+        cur = idx
+        idx += 1
+    root = 2 * n - 3
+    for t in (n - 2, n - 1):
+        lot[t] = idx
+        parent[idx] = root
+        idx += 1
+    parent[cur] = root
+    assert idx == root
+    blen = np.full(2 * n - 2, 0.05)
+    engine.debug_traversal(parent, blen, lot, Q, pi, rates, probs)
+    # star tree: all leaves on the root
+    parent = np.array([n] * n + [-1], dtype=np.int32)
+    d = engine.debug_traversal(parent, np.full(n + 1, 0.1), np.arange(n, dtype=np.int32), Q, pi, rates, probs)
+    assert d["nrec"].shape[0] == 1 and len(d["ldsched"]) == 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_multifurcating_trees_compile(seed):
+    Q, pi, rates, probs = _model()
+    ntaxa = int(np.random.default_rng(seed).integers(4, 70))
+    parent, blen, lot = _random_multifurcating(ntaxa, seed)
+    d = engine.debug_traversal(parent, blen, lot, Q, pi, rates, probs)
+    ops = d["msched"].reshape(-1, 2)
+    assert set(ops[ops[:, 1] >= 0][:, 1]) == set(range(ntaxa))
+
+
+def test_malformed_trees_are_rejected():
+    Q, pi, rates, probs = _model()
+    parent, blen, lot = sy.random_tree(8, 3)
+    bad = parent.copy()
+    bad[0], bad[1] = bad[1], bad[0] if bad[0] != bad[1] else bad[0]
+    bad2 = parent.copy()
+    bad2[2] = 1                          # parent id below the child id: not post-order
+    with pytest.raises(engine.CmxError):
+        engine.debug_traversal(bad2, blen, lot, Q, pi, rates, probs)
+    with pytest.raises(engine.CmxError):
+        engine.debug_traversal(parent, -blen, lot, Q, pi, rates, probs)
