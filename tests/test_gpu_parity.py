@@ -77,6 +77,21 @@ def test_large_trees_150_and_600_taxa():
     assert info["nbranches"] == 1197 and info["workspace_bytes"] < 80 * 2 ** 30
 
 
+@pytest.mark.parametrize("seed,nstates", [(1, 20), (2, 20), (3, 4), (4, 4)])
+def test_multifurcating_trees_map_and_null(seed, nstates):
+    """internal nodes with 2..5 children everywhere (the kernel's general-node path, not only at the root)"""
+    from test_traversal_program import _random_multifurcating
+    ntaxa = 15 + 7 * seed
+    parent, blen, lot = _random_multifurcating(ntaxa, seed)
+    mdl = synthetic.protein_model(0.5, 4) if nstates == 20 else synthetic.dna_model(0.5, 4)
+    om = oracle.Model(parent, blen, lot, mdl["Q"], mdl["pi"], mdl["rates"], mdl["probs"])
+    eng = engine.Engine(parent, blen, lot, mdl["Q"], mdl["pi"], mdl["rates"], mdl["probs"])
+    aln, _ = oracle.simulate(om, 50 + seed, 0, 90)
+    _check_map(eng.map_sites(aln), oracle.map_sites(om, aln))
+    g, o = eng.null_intra(1, 9, 0, 2, 40), oracle.null_intra(om, 1, 9, 0, 2, 40)
+    rel_close(g["stat"], o["stat"], 1e-6, 1e-12)
+
+
 def test_map_sites_large_alignment_takes_the_fused_class_loop():
     """below 512 (site block, class) tasks the observed mapping runs one class per wave-task + a finalize kernel; a
     9 000-site alignment exercises the other path (all classes in one wave), same results required"""
