@@ -401,7 +401,19 @@ cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint
 
 // ------------------------------------------------------------------------------------------------ pair statistics
 static cmx_status check_kind(cmx_ctx* ctx, int kind) {
-  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_DISCRETE_MI) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
+  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_CORRECTED_CORRELATION) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
+  return CMX_OK;
+}
+// CorrectedCorrelation: params = the two mean vectors [2][B] in host memory -> device copy (null for other kinds)
+static cmx_status stat_mean_vectors(cmx_ctx* ctx, int kind, const double* params, const double** d_mean) {
+  *d_mean = nullptr;
+  if (kind != CMX_STAT_CORRECTED_CORRELATION) return CMX_OK;
+  if (!params) return fail(ctx, CMX_ERR_INVALID, "CorrectedCorrelation needs its mean vectors: params = [2][nbranches]");
+  void* p = nullptr;
+  cmx_status s = scratch(ctx, "stat_mean", sizeof(double) * 2 * ctx->hm.B, &p);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipMemcpy(p, params, sizeof(double) * 2 * ctx->hm.B, hipMemcpyHostToDevice));
+  *d_mean = static_cast<const double*>(p);
   return CMX_OK;
 }
 
@@ -420,21 +432,24 @@ cmx_status cmx_pair_stats_dev(cmx_ctx* ctx, int kind, const double* params, cons
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  const double* d_mean = nullptr;
+  if ((s = stat_mean_vectors(ctx, kind, params, &d_mean)) != CMX_OK) return s;
+  const int gk = kind == CMX_STAT_CORRECTED_CORRELATION ? CMX_STAT_CORRELATION : kind;   // same Gram + epilogue
   const int Bp = (h.B + 3) / 4 * 4;
   const size_t ldx1 = (n1 + 15) / 16 * 16, ldx2 = (n2 + 15) / 16 * 16;
   double *X1, *s1, *r1, *X2, *s2, *r2;
   if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx1, (void**)&X1)) != CMX_OK) return s;
   if ((s = scratch(ctx, "pair_s1", sizeof(double) * n1, (void**)&s1)) != CMX_OK) return s;
   if ((s = scratch(ctx, "pair_r1", sizeof(double) * n1, (void**)&r1)) != CMX_OK) return s;
-  HIP_TRY(ctx, launch_pair_prep(kind, param, d_counts1, n1, ld1, h.B, h.K, X1, ldx1, Bp, s1, r1, st));
+  HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts1, n1, ld1, h.B, h.K, X1, ldx1, Bp, s1, r1, d_mean, st));
   if (intra) { X2 = X1; s2 = s1; r2 = r1; }
   else {
     if ((s = scratch(ctx, "pair_X2", sizeof(double) * Bp * ldx2, (void**)&X2)) != CMX_OK) return s;
     if ((s = scratch(ctx, "pair_s2", sizeof(double) * n2, (void**)&s2)) != CMX_OK) return s;
     if ((s = scratch(ctx, "pair_r2", sizeof(double) * n2, (void**)&r2)) != CMX_OK) return s;
-    HIP_TRY(ctx, launch_pair_prep(kind, param, d_counts2, n2, ld2, h.B, h.K, X2, ldx2, Bp, s2, r2, st));
+    HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts2, n2, ld2, h.B, h.K, X2, ldx2, Bp, s2, r2, d_mean ? d_mean + h.B : nullptr, st));
   }
-  HIP_TRY(ctx, launch_pair_gram(kind, h.B, Bp, X1, s1, r1, n1, ldx1, X2, s2, r2, n2, intra ? ldx1 : ldx2, intra ? 1 : 0,
+  HIP_TRY(ctx, launch_pair_gram(gk, h.B, Bp, X1, s1, r1, n1, ldx1, X2, s2, r2, n2, intra ? ldx1 : ldx2, intra ? 1 : 0,
                                 d_out, ldo, st));
   return CMX_OK;
 }
@@ -486,6 +501,7 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   a.nsites = (rep_end - rep_begin) * rep_ram;
   a.stat_kind = kind;
   a.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  if ((s = stat_mean_vectors(ctx, kind, params, &a.stat_mean)) != CMX_OK) return s;
   a.seed = seed; a.rep_begin = rep_begin; a.rep_ram = rep_ram; a.supplied = d_supplied;
   a.null_stat = d_stat; a.null_rcmin = d_rcmin; a.null_prmin = d_prmin; a.null_nmin = d_nmin;
   const size_t ks = (size_t)map_sites_per_wave(ctx->hm.dS);
@@ -572,8 +588,10 @@ cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const doub
     if (s != CMX_OK) { if (c != ctx1) ctx1->err = c->err; return s; }
   }
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  const double* d_mean = nullptr;
+  if ((s = stat_mean_vectors(ctx1, kind, params, &d_mean)) != CMX_OK) return s;
   HIP_TRY(ctx1, launch_pair_diag(kind, param, ctx1->hm.B, ctx1->hm.K, cnt[0], n, cnt[1], n, n, rc[0], rc[1], pr[0], pr[1],
-                                 nm[0], nm[1], d_stat, d_rcmin, d_prmin, d_nmin, st));
+                                 nm[0], nm[1], d_stat, d_rcmin, d_prmin, d_nmin, d_mean, st));
   return CMX_OK;
 }
 

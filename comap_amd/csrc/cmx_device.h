@@ -95,6 +95,7 @@ struct MapArgs {
   // null mode
   int stat_kind;
   double stat_param;       // discrete-MI threshold
+  const double* stat_mean; // CorrectedCorrelation: [2][B] mean vectors of the two operands (device), else null
   uint64_t seed;
   size_t rep_begin, rep_ram;
   const uint8_t* supplied; // [nrep][2][T][rep_ram] or null
@@ -113,11 +114,12 @@ hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, h
 hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* c1, size_t ld1, const double* c2, size_t ld2,
                             size_t n, const int32_t* rc1, const int32_t* rc2, const double* pr1, const double* pr2,
                             const double* nm1, const double* nm2, double* stat, int32_t* rcmin, double* prmin, double* nmin,
-                            hipStream_t stream);
+                            const double* d_mean, hipStream_t stream);
 hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
                            int32_t* d_classes, uint8_t* d_states /*[nn][ld]*/, hipStream_t stream);
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,
-                            double* d_X, size_t ldx, int Bp, double* d_s, double* d_r, hipStream_t stream);
+                            double* d_X, size_t ldx, int Bp, double* d_s, double* d_r, const double* d_mvec,
+                            hipStream_t stream);
 hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const double* d_s1, const double* d_r1,
                             size_t n1, size_t ldx1, const double* d_X2, const double* d_s2, const double* d_r2,
                             size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream);

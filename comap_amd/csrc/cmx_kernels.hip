@@ -880,15 +880,22 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 
 // per-lane statistic between two count columns (row strides ld1 / ld2), CoMap/Statistics.h
 __device__ __forceinline__ double pair_stat_strided(int kind, double param, int B, int K, const double* __restrict__ c1,
-                                                    size_t ld1, const double* __restrict__ c2, size_t ld2) {
+                                                    size_t ld1, const double* __restrict__ c2, size_t ld2,
+                                                    const double* __restrict__ mv = nullptr /* [2][B], kind 6 */) {
   switch (kind) {
-    case 0: case 4: {  // Correlation / Covariance: VectorTools::cor, two-pass on type 0
+    case 0: case 4: case 6: {  // Correlation / Covariance / CorrectedCorrelation: VectorTools::cor, two-pass on type 0
+      // CorrectedCorrelation (Statistics.h:176-204) first subtracts a per-branch mean vector from either operand
+      const double* u1 = kind == 6 ? mv : nullptr;
+      const double* u2 = kind == 6 ? mv + B : nullptr;
       double m1 = 0, m2 = 0;
-      for (int b = 0; b < B; ++b) { m1 += c1[(size_t)b * K * ld1]; m2 += c2[(size_t)b * K * ld2]; }
+      for (int b = 0; b < B; ++b) {
+        m1 += c1[(size_t)b * K * ld1] - (u1 ? u1[b] : 0.0);
+        m2 += c2[(size_t)b * K * ld2] - (u2 ? u2[b] : 0.0);
+      }
       m1 /= B; m2 /= B;
       double sxy = 0, sxx = 0, syy = 0;
       for (int b = 0; b < B; ++b) {
-        const double dx = c1[(size_t)b * K * ld1] - m1, dy = c2[(size_t)b * K * ld2] - m2;
+        const double dx = c1[(size_t)b * K * ld1] - (u1 ? u1[b] : 0.0) - m1, dy = c2[(size_t)b * K * ld2] - (u2 ? u2[b] : 0.0) - m2;
         sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
       }
       const double cov = sxy / (B - 1);
@@ -1054,7 +1061,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
         if (h == 0) { prmin = pr; nmin = nrm; rcmin = rc; }
         else { prmin = pr < prmin ? pr : prmin; nmin = nrm < nmin ? nrm : nmin; rcmin = rc < rcmin ? rc : rcmin; }
       }
-      const double stat = pair_stat_strided(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + sidx, (size_t)kSites, cnt1 + sidx, (size_t)kSites);
+      const double stat = pair_stat_strided(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + sidx, (size_t)kSites, cnt1 + sidx, (size_t)kSites, a.stat_mean);
       if (active) {
         a.null_stat[s] = stat;
         if (a.null_rcmin) a.null_rcmin[s] = rcmin;
@@ -1187,10 +1194,10 @@ __global__ void pair_diag_kernel(int kind, double param, int B, int K, const dou
                                  const int32_t* __restrict__ rc2, const double* __restrict__ pr1,
                                  const double* __restrict__ pr2, const double* __restrict__ nm1,
                                  const double* __restrict__ nm2, double* __restrict__ stat, int32_t* __restrict__ rcmin,
-                                 double* __restrict__ prmin, double* __restrict__ nmin) {
+                                 double* __restrict__ prmin, double* __restrict__ nmin, const double* __restrict__ mv) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  stat[j] = pair_stat_strided(kind, param, B, K, c1 + j, ld1, c2 + j, ld2);
+  stat[j] = pair_stat_strided(kind, param, B, K, c1 + j, ld1, c2 + j, ld2, mv);
   if (rcmin) rcmin[j] = rc1[j] < rc2[j] ? rc1[j] : rc2[j];
   if (prmin) prmin[j] = pr1[j] < pr2[j] ? pr1[j] : pr2[j];
   if (nmin) nmin[j] = nm1[j] < nm2[j] ? nm1[j] : nm2[j];
@@ -1199,9 +1206,9 @@ __global__ void pair_diag_kernel(int kind, double param, int B, int K, const dou
 hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* c1, size_t ld1, const double* c2, size_t ld2,
                             size_t n, const int32_t* rc1, const int32_t* rc2, const double* pr1, const double* pr2,
                             const double* nm1, const double* nm2, double* stat, int32_t* rcmin, double* prmin, double* nmin,
-                            hipStream_t stream) {
+                            const double* d_mean, hipStream_t stream) {
   hipLaunchKernelGGL(pair_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, param, B, K, c1, ld1,
-                     c2, ld2, n, rc1, rc2, pr1, pr2, nm1, nm2, stat, rcmin, prmin, nmin);
+                     c2, ld2, n, rc1, rc2, pr1, pr2, nm1, nm2, stat, rcmin, prmin, nmin, d_mean);
   return hipGetLastError();
 }
 
@@ -1238,19 +1245,19 @@ hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t
 //   2: X = [total >= 1];  5: X = [total >= threshold], r = sum X, s = NaN flag when a total leaves [0, 10000)
 __global__ void pair_prep_kernel(int kind, double param, const double* __restrict__ counts, size_t n, size_t ldc, int B,
                                  int K, double* __restrict__ X, size_t ldx, int Bp, double* __restrict__ sv,
-                                 double* __restrict__ rv) {
+                                 double* __restrict__ rv, const double* __restrict__ mvec /* [B] or null */) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double mean = 0.0;
-  if (kind == 0 || kind == 4) {
-    for (int b = 0; b < B; ++b) mean += counts[(size_t)b * K * ldc + i];
+  if (kind == 0 || kind == 4) {   // (CorrectedCorrelation arrives as kind 0 with its mean vector in mvec)
+    for (int b = 0; b < B; ++b) mean += counts[(size_t)b * K * ldc + i] - (mvec ? mvec[b] : 0.0);
     mean /= B;
   }
   double s = 0.0, r = 0.0;
   bool bad = false;
   for (int b = 0; b < B; ++b) {
     double v;
-    if (kind == 0 || kind == 4) v = counts[(size_t)b * K * ldc + i] - mean;
+    if (kind == 0 || kind == 4) v = counts[(size_t)b * K * ldc + i] - (mvec ? mvec[b] : 0.0) - mean;
     else if (kind == 3) v = counts[(size_t)b * K * ldc + i];
     else {
       double t = 0.0;
@@ -1272,10 +1279,11 @@ __global__ void pair_prep_kernel(int kind, double param, const double* __restric
 }
 
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,
-                            double* d_X, size_t ldx, int Bp, double* d_s, double* d_r, hipStream_t stream) {
+                            double* d_X, size_t ldx, int Bp, double* d_s, double* d_r, const double* d_mvec,
+                            hipStream_t stream) {
   const int block = 256;
   hipLaunchKernelGGL(pair_prep_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, stream, kind, param,
-                     d_counts, n, ldc, B, K, d_X, ldx, Bp, d_s, d_r);
+                     d_counts, n, ldc, B, K, d_X, ldx, Bp, d_s, d_r, d_mvec);
   return hipGetLastError();
 }
 

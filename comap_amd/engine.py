@@ -13,12 +13,27 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COMAP_MI355X_LIB", os.path.join(_HERE, "libcomap_mi355x.so"))  # override: diagnostic builds
 
-STAT_CORRELATION, STAT_COMPENSATION, STAT_COSUBSTITUTION, STAT_COSINUS, STAT_COVARIANCE, STAT_DISCRETE_MI = range(6)
+STAT_CORRELATION, STAT_COMPENSATION, STAT_COSUBSTITUTION, STAT_COSINUS, STAT_COVARIANCE, STAT_DISCRETE_MI, \
+    STAT_CORRECTED_CORRELATION = range(7)
 STAT_BY_NAME = {
     # names of the reference's `statistic=` option (CoMap/CoETools.cpp:540-599)
     "Correlation": STAT_CORRELATION, "Compensation": STAT_COMPENSATION, "Cosubstitution": STAT_COSUBSTITUTION,
     "Cosinus": STAT_COSINUS, "Covariance": STAT_COVARIANCE, "MI": STAT_DISCRETE_MI,
+    "CorrectedCorrelation": STAT_CORRECTED_CORRELATION,
 }
+
+
+def _stat_params(kind, threshold, mean_vectors):
+    """host parameter block of a statistic: the MI threshold, or for CorrectedCorrelation the two per-branch mean
+    vectors [2][B] (Statistics.h:176-204; one vector given = used for both operands, CoMap.cpp:350-359)"""
+    if int(kind) == STAT_CORRECTED_CORRELATION:
+        if mean_vectors is None:
+            raise CmxError(-1, "CorrectedCorrelation needs mean_vectors")
+        mv = _f64(mean_vectors)
+        if mv.ndim == 1:
+            mv = np.stack([mv, mv])
+        return np.ascontiguousarray(mv)
+    return _f64([threshold])
 COUNT_EXPECTED, COUNT_NAIVE = 0, 1
 
 EXPORTS = [
@@ -211,18 +226,18 @@ class Engine:
                                            _vp(cls)))
         return aln, cls
 
-    def pair_stats(self, kind, counts1, counts2=None, threshold=0.99):
+    def pair_stats(self, kind, counts1, counts2=None, threshold=0.99, mean_vectors=None):
         c1 = _f64(counts1).reshape(len(counts1), self.B, self.K)
         n1 = c1.shape[0]
         c2 = None if counts2 is None else _f64(counts2).reshape(len(counts2), self.B, self.K)
         n2 = n1 if c2 is None else c2.shape[0]
         out = np.zeros((n1, n2))
-        params = _f64([threshold])
+        params = _stat_params(kind, threshold, mean_vectors)
         self._check(self._lib.cmx_pair_stats(self._ctx, int(kind), _vp(params), _vp(c1), _sz(n1), _vp(c2), _sz(n2),
                                              _vp(out)))
         return out
 
-    def null_intra(self, kind, seed, rep_begin, rep_end, rep_ram, supplied=None, threshold=0.99):
+    def null_intra(self, kind, seed, rep_begin, rep_end, rep_ram, supplied=None, threshold=0.99, mean_vectors=None):
         n = (rep_end - rep_begin) * rep_ram
         stat, prmin, nmin = np.zeros(n), np.zeros(n), np.zeros(n)
         rcmin = np.zeros(n, dtype=np.int32)
@@ -231,18 +246,18 @@ class Engine:
             sup = np.ascontiguousarray(supplied, dtype=np.uint8)
             if sup.shape != (rep_end - rep_begin, 2, self.T, rep_ram):
                 raise CmxError(-1, "supplied alignments must be [nrep, 2, T, rep_ram]")
-        params = _f64([threshold])
+        params = _stat_params(kind, threshold, mean_vectors)
         self._check(self._lib.cmx_null_intra(self._ctx, int(kind), _vp(params), ctypes.c_uint64(seed), _sz(rep_begin),
                                              _sz(rep_end), _sz(rep_ram), _vp(sup), _vp(stat), _vp(rcmin), _vp(prmin),
                                              _vp(nmin)))
         return dict(stat=stat, rcmin=rcmin, prmin=prmin, nmin=nmin)
 
-    def null_inter(self, other, kind, seed, rep_begin, rep_end, rep_ram, threshold=0.99):
+    def null_inter(self, other, kind, seed, rep_begin, rep_end, rep_ram, threshold=0.99, mean_vectors=None):
         """AnalysisTools::getNullDistributionInterDR: self = data set 1, other = data set 2 (same branches)."""
         n = (rep_end - rep_begin) * rep_ram
         stat, prmin, nmin = np.zeros(n), np.zeros(n), np.zeros(n)
         rcmin = np.zeros(n, dtype=np.int32)
-        params = _f64([threshold])
+        params = _stat_params(kind, threshold, mean_vectors)
         self._check(self._lib.cmx_null_inter(self._ctx, other._ctx, int(kind), _vp(params), ctypes.c_uint64(seed),
                                              _sz(rep_begin), _sz(rep_end), _sz(rep_ram), _vp(stat), _vp(rcmin),
                                              _vp(prmin), _vp(nmin)))
@@ -258,7 +273,7 @@ class Engine:
         return pv, nsim
 
     def intra_rows(self, kind, counts, rate_class, post_rate, norm, null_stat=None, null_nmin=None, nclasses=10,
-                   filters=None, capacity=None, threshold=0.99):
+                   filters=None, capacity=None, threshold=0.99, mean_vectors=None):
         """statistics.txt rows (structured array PAIR_ROW, reference order), compacted on the device."""
         c = _f64(counts).reshape(len(counts), self.B, self.K)
         n = c.shape[0]
@@ -270,7 +285,7 @@ class Engine:
         rows = np.zeros(max(cap, 1), dtype=PAIR_ROW)
         count = ctypes.c_uint64(0)
         f = filters if filters is not None else PairFilters()
-        params = _f64([threshold])
+        params = _stat_params(kind, threshold, mean_vectors)
         self._check(self._lib.cmx_intra_rows(self._ctx, int(kind), _vp(params), _vp(c), _sz(n), _vp(rc), _vp(pr), _vp(nm),
                                              _vp(ns), _vp(nn), _sz(0 if ns is None else len(ns)), int(nclasses),
                                              ctypes.byref(f), _vp(rows), _sz(cap), ctypes.byref(count)))
@@ -309,8 +324,8 @@ class Engine:
                                                 _vp(counts), _sz(0 if counts is None else counts.stride(0)), _vp(logL),
                                                 _vp(post_rate), _vp(rate_class), _vp(norm), self._stream()))
 
-    def pair_stats_dev(self, kind, counts1, out, counts2=None, threshold=0.99):
-        params = _f64([threshold])
+    def pair_stats_dev(self, kind, counts1, out, counts2=None, threshold=0.99, mean_vectors=None):
+        params = _stat_params(kind, threshold, mean_vectors)
         n1 = counts1.shape[1]
         n2 = n1 if counts2 is None else counts2.shape[1]
         self._check(self._lib.cmx_pair_stats_dev(self._ctx, int(kind), _vp(params), _vp(counts1), _sz(n1),
@@ -319,15 +334,15 @@ class Engine:
                                                  _sz(out.stride(0)), self._stream()))
 
     def null_intra_dev(self, kind, seed, rep_begin, rep_end, rep_ram, stat, rcmin=None, prmin=None, nmin=None,
-                       supplied=None, threshold=0.99):
-        params = _f64([threshold])
+                       supplied=None, threshold=0.99, mean_vectors=None):
+        params = _stat_params(kind, threshold, mean_vectors)
         self._check(self._lib.cmx_null_intra_dev(self._ctx, int(kind), _vp(params), ctypes.c_uint64(seed),
                                                  _sz(rep_begin), _sz(rep_end), _sz(rep_ram), _vp(supplied), _vp(stat),
                                                  _vp(rcmin), _vp(prmin), _vp(nmin), self._stream()))
 
     def null_inter_dev(self, other, kind, seed, rep_begin, rep_end, rep_ram, stat, rcmin=None, prmin=None, nmin=None,
-                       threshold=0.99):
-        params = _f64([threshold])
+                       threshold=0.99, mean_vectors=None):
+        params = _stat_params(kind, threshold, mean_vectors)
         self._check(self._lib.cmx_null_inter_dev(self._ctx, other._ctx, int(kind), _vp(params), ctypes.c_uint64(seed),
                                                  _sz(rep_begin), _sz(rep_end), _sz(rep_ram), _vp(stat), _vp(rcmin),
                                                  _vp(prmin), _vp(nmin), self._stream()))

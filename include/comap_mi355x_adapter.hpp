@@ -215,6 +215,36 @@ class DiscreteMutualInformationStatistic : public Statistic {  // bounds {0, thr
   double threshold_;
 };
 
+// Statistics.h:176-204: correlation of the vectors minus a per-branch mean vector; CoMap.cpp:350-359 sets it to the mean
+// total substitution vector of the data (computeMeanVector below)
+class CorrectedCorrelationStatistic : public Statistic {
+ public:
+  CorrectedCorrelationStatistic() {}
+  explicit CorrectedCorrelationStatistic(const Vdouble& meanVector) { setMeanVector(meanVector); }
+  CorrectedCorrelationStatistic(const Vdouble& meanVector1, const Vdouble& meanVector2) { setMeanVectors(meanVector1, meanVector2); }
+  void setMeanVector(const Vdouble& meanVector) { setMeanVectors(meanVector, meanVector); }
+  void setMeanVectors(const Vdouble& meanVector1, const Vdouble& meanVector2) {
+    if (meanVector1.size() != meanVector2.size())
+      throw DimensionException("CorrectedCorrelationStatistic::setMeanVectors.", meanVector2.size(), meanVector1.size());
+    means_ = meanVector1;
+    means_.insert(means_.end(), meanVector2.begin(), meanVector2.end());
+  }
+  int kind() const override { return CMX_STAT_CORRECTED_CORRELATION; }
+  const double* params() const override { return means_.empty() ? nullptr : means_.data(); }
+  // CoMap.cpp:350-359: mean over the sites of computeTotalSubstitutionVectorForSitePerBranch (sum over types)
+  static Vdouble computeMeanVector(const ProbabilisticSubstitutionMapping& mapping) {
+    Vdouble mv(mapping.getNumberOfBranches(), 0.);
+    for (size_t i = 0; i < mapping.getNumberOfSites(); ++i)
+      for (size_t b = 0; b < mv.size(); ++b)
+        for (size_t k = 0; k < mapping.getNumberOfSubstitutionTypes(); ++k) mv[b] += mapping(b, i, k);
+    for (double& v : mv) v /= static_cast<double>(mapping.getNumberOfSites());
+    return mv;
+  }
+
+ private:
+  Vdouble means_;   // [2][B]
+};
+
 // CoMap/Distance.h:316-370 (comp - stat) and :372-424 (1 - stat); matrix fill loops CoMap/CoMap.cpp:432-440
 class StatisticBasedDistance {
  public:

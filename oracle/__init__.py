@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ST_CORRELATION, ST_COMPENSATION, ST_COSUBSTITUTION, ST_COSINUS, ST_COVARIANCE, ST_DISCRETE_MI = range(6)
+ST_CORRELATION, ST_COMPENSATION, ST_COSUBSTITUTION, ST_COSINUS, ST_COVARIANCE, ST_DISCRETE_MI, ST_CORRECTED_CORRELATION = range(7)
 METHOD_UNIF, METHOD_DECOMP, METHOD_NAIVE = 0, 1, 2
 
 

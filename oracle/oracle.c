@@ -406,7 +406,7 @@ int orc_domain_index_bounds(const double* bounds, int nb, double x) {
 
 /* ------------------------------------------------------------------ statistics (CoMap/Statistics.h) */
 enum { ST_CORRELATION = 0, ST_COMPENSATION = 1, ST_COSUBSTITUTION = 2, ST_COSINUS = 3, ST_COVARIANCE = 4,
-       ST_DISCRETE_MI = 5 };
+       ST_DISCRETE_MI = 5, ST_CORRECTED_CORRELATION = 6 };
 
 static double vsum(const double* v, int K) {
   double s = 0;
@@ -430,6 +430,17 @@ double orc_stat_pair(int kind, int B, int K, const double* v1, const double* v2,
       double cov = sxy / (B - 1);
       if (kind == ST_COVARIANCE) return cov;
       return cov / (sqrt(sxx / (B - 1)) * sqrt(syy / (B - 1)));
+    }
+    case ST_CORRECTED_CORRELATION: { /* Statistics.h:176-204: cor(v1 - meanVector1_, v2 - meanVector2_), params = [2][B] */
+      double m1 = 0, m2 = 0;
+      for (int b = 0; b < B; b++) { m1 += v1[(size_t)b * K] - params[b]; m2 += v2[(size_t)b * K] - params[B + b]; }
+      m1 /= B; m2 /= B;
+      double sxy = 0, sxx = 0, syy = 0;
+      for (int b = 0; b < B; b++) {
+        double dx = v1[(size_t)b * K] - params[b] - m1, dy = v2[(size_t)b * K] - params[B + b] - m2;
+        sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
+      }
+      return (sxy / (B - 1)) / (sqrt(sxx / (B - 1)) * sqrt(syy / (B - 1)));
     }
     case ST_COSINUS: { /* Statistics.h:218-228 */
       double sxy = 0, sxx = 0, syy = 0;

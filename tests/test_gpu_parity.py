@@ -177,6 +177,26 @@ def test_pair_stats_all_kinds_intra_and_inter(kind):
         assert np.nanmax(np.abs(g[iu])) <= 1 + 1e-12
 
 
+def test_corrected_correlation_statistic_all_paths():
+    """Statistics.h:176-204 with the mean vector of CoMap.cpp:350-359: all-pairs, inter with two vectors, the fused null"""
+    case = make_case(11, 70, 20, 91)
+    eng, om = _engine(case), _omodel(case)
+    counts = oracle.map_sites(om, case["aln"])["counts"]
+    mv = counts.sum(axis=2).mean(axis=0)                       # mean total substitution vector [B]
+    mv2 = mv * 0.5 + 0.01
+    p1, p2 = np.concatenate([mv, mv]), np.concatenate([mv, mv2])
+    g = eng.pair_stats(6, counts, mean_vectors=mv)
+    rel_close(g, oracle.pair_stats_intra(6, counts, p1), 1e-6, 1e-12)
+    gi = eng.pair_stats(6, counts[:30], counts[30:], mean_vectors=np.stack([mv, mv2]))
+    rel_close(gi, oracle.pair_stats_inter(6, counts[:30], counts[30:], p2), 1e-6, 1e-12)
+    assert np.nanmax(np.abs(g - eng.pair_stats(0, counts))) > 1e-3      # it is not the plain correlation
+    gn = eng.null_intra(6, 13, 0, 2, 50, mean_vectors=mv)
+    on = oracle.null_intra(om, 6, 13, 0, 2, 50, params=p1)
+    rel_close(gn["stat"], on["stat"], 1e-6, 1e-12)
+    with pytest.raises(engine.CmxError):
+        eng.pair_stats(6, counts)
+
+
 def test_pair_stats_on_reference_fixture_vectors(myo):
     """Feed the reference's own Myo_unif.vec (197 x 129) through the Gram kernel: all 8256 correlations."""
     case = dict(parent=myo["parent"], blen=myo["blen"], lot=myo["leaf_of_taxon"])
