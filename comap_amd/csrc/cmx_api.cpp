@@ -401,7 +401,7 @@ cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint
 
 // ------------------------------------------------------------------------------------------------ pair statistics
 static cmx_status check_kind(cmx_ctx* ctx, int kind) {
-  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_CORRECTED_CORRELATION) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
+  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_EUCLIDIAN_DISTANCE) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
   return CMX_OK;
 }
 // CorrectedCorrelation: params = the two mean vectors [2][B] in host memory -> device copy (null for other kinds)

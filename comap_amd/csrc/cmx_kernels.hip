@@ -910,6 +910,15 @@ __device__ __forceinline__ double pair_stat_strided(int kind, double param, int 
       }
       return sxy / (sqrt(sxx) * sqrt(syy));
     }
+    case 7: {  // EuclidianDistance
+      double d = 0;
+      for (int b = 0; b < B; ++b) {
+        double t1 = 0, t2 = 0;
+        for (int k = 0; k < K; ++k) { t1 += c1[((size_t)b * K + k) * ld1]; t2 += c2[((size_t)b * K + k) * ld2]; }
+        d = __builtin_fma(t2 - t1, t2 - t1, d);
+      }
+      return sqrt(d);
+    }
     case 1: case 2: case 5: {
       double s1 = 0, s2 = 0, s3 = 0, cc = 0, n11 = 0, r1 = 0, r2 = 0;
       bool bad = false;
@@ -1262,7 +1271,7 @@ __global__ void pair_prep_kernel(int kind, double param, const double* __restric
     else {
       double t = 0.0;
       for (int k = 0; k < K; ++k) t += counts[((size_t)b * K + k) * ldc + i];
-      if (kind == 1) v = t;
+      if (kind == 1 || kind == 7) v = t;
       else if (kind == 2) v = t >= 1.0 ? 1.0 : 0.0;
       else {
         v = t >= param ? 1.0 : 0.0;
@@ -1387,9 +1396,30 @@ __global__ __launch_bounds__(kWave) void pair_gram_kernel(int kind, int B, int B
   }
 }
 
+// EuclidianDistance (CoMap/Distance.h:157-171): sqrt(sum_b (tot2_b - tot1_b)^2) over the per-branch totals.  Computed from
+// the differences themselves, not from the Gram matrix: ||a||^2 + ||b||^2 - 2 a.b loses all digits for near-identical
+// vectors.  X = the totals operand of pair_prep_kernel (kind 1), [Bp][ldx]; one thread per pair, row i broadcast.
+__global__ __launch_bounds__(64) void pair_euclid_kernel(int B, const double* __restrict__ X1, size_t n1, size_t ldx1,
+                                                         const double* __restrict__ X2, size_t n2, size_t ldx2, int intra,
+                                                         double* __restrict__ out, size_t ldo) {
+  const size_t i = blockIdx.y, j = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (j >= n2) return;
+  double d = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double t = X2[(size_t)b * ldx2 + j] - X1[(size_t)b * ldx1 + i];
+    d = __builtin_fma(t, t, d);
+  }
+  out[i * ldo + j] = (!intra || j > i) ? sqrt(d) : __builtin_nan("");
+}
+
 hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const double* d_s1, const double* d_r1,
                             size_t n1, size_t ldx1, const double* d_X2, const double* d_s2, const double* d_r2,
                             size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream) {
+  if (kind == CMX_STAT_EUCLIDIAN_DISTANCE) {
+    hipLaunchKernelGGL(pair_euclid_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)n1), dim3(64), 0, stream, B, d_X1, n1,
+                       ldx1, d_X2, n2, ldx2, intra, d_out, ldo);
+    return hipGetLastError();
+  }
   dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 63) / 64));
   hipLaunchKernelGGL(pair_gram_kernel, grid, dim3(kWave), 0, stream, kind, B, Bp, d_X1, d_s1, d_r1, n1, ldx1, d_X2,
                      d_s2, d_r2, n2, ldx2, intra, d_out, ldo);

@@ -14,12 +14,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COMAP_MI355X_LIB", os.path.join(_HERE, "libcomap_mi355x.so"))  # override: diagnostic builds
 
 STAT_CORRELATION, STAT_COMPENSATION, STAT_COSUBSTITUTION, STAT_COSINUS, STAT_COVARIANCE, STAT_DISCRETE_MI, \
-    STAT_CORRECTED_CORRELATION = range(7)
+    STAT_CORRECTED_CORRELATION, STAT_EUCLIDIAN_DISTANCE = range(8)
 STAT_BY_NAME = {
     # names of the reference's `statistic=` option (CoMap/CoETools.cpp:540-599)
     "Correlation": STAT_CORRELATION, "Compensation": STAT_COMPENSATION, "Cosubstitution": STAT_COSUBSTITUTION,
     "Cosinus": STAT_COSINUS, "Covariance": STAT_COVARIANCE, "MI": STAT_DISCRETE_MI,
-    "CorrectedCorrelation": STAT_CORRECTED_CORRELATION,
+    "CorrectedCorrelation": STAT_CORRECTED_CORRELATION, "EuclidianDistance": STAT_EUCLIDIAN_DISTANCE,
 }
 
 

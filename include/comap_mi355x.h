@@ -51,6 +51,7 @@ typedef enum {
   CMX_STAT_COSINUS = 3,        /* Statistics.h:218-228 */
   CMX_STAT_COVARIANCE = 4,     /* Statistics.h:206-216 */
   CMX_STAT_DISCRETE_MI = 5,    /* Statistics.h:307-327 with bounds {0, threshold, 10000} (CoETools.cpp:590-593) */
+  CMX_STAT_EUCLIDIAN_DISTANCE = 7, /* Distance.h:157-171: sqrt(sum_b (total2_b - total1_b)^2), a distance (clustering) */
   CMX_STAT_CORRECTED_CORRELATION = 6 /* Statistics.h:176-204: correlation after subtracting a per-branch mean vector from
                                         either operand; params = [2][nbranches] (meanVector1_, meanVector2_; CoMap.cpp:350-359
                                         sets both to the mean total substitution vector of the data) */

@@ -259,6 +259,16 @@ class StatisticBasedDistance {
   std::shared_ptr<Statistic> stat_;
   double comp_;
 };
+// CoMap/Distance.h:150-173
+class EuclidianDistance {
+ public:
+  Vdouble getDistancesForAllPairs(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping) const {
+    const size_t n = mapping.getNumberOfSites();
+    Vdouble out(n * n);
+    eng.check(cmx_pair_stats(eng.ctx(), CMX_STAT_EUCLIDIAN_DISTANCE, nullptr, mapping.data(), n, nullptr, 0, out.data()));
+    return out;
+  }
+};
 class CompensationDistance : public StatisticBasedDistance {
  public:
   CompensationDistance() : StatisticBasedDistance(std::make_shared<CompensationStatistic>(), 1.) {}

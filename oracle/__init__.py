@@ -10,7 +10,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ST_CORRELATION, ST_COMPENSATION, ST_COSUBSTITUTION, ST_COSINUS, ST_COVARIANCE, ST_DISCRETE_MI, ST_CORRECTED_CORRELATION = range(7)
+ST_CORRELATION, ST_COMPENSATION, ST_COSUBSTITUTION, ST_COSINUS, ST_COVARIANCE, ST_DISCRETE_MI, ST_CORRECTED_CORRELATION, \
+    ST_EUCLIDIAN_DISTANCE = range(8)
 METHOD_UNIF, METHOD_DECOMP, METHOD_NAIVE = 0, 1, 2
 
 

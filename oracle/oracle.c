@@ -406,7 +406,7 @@ int orc_domain_index_bounds(const double* bounds, int nb, double x) {
 
 /* ------------------------------------------------------------------ statistics (CoMap/Statistics.h) */
 enum { ST_CORRELATION = 0, ST_COMPENSATION = 1, ST_COSUBSTITUTION = 2, ST_COSINUS = 3, ST_COVARIANCE = 4,
-       ST_DISCRETE_MI = 5, ST_CORRECTED_CORRELATION = 6 };
+       ST_DISCRETE_MI = 5, ST_CORRECTED_CORRELATION = 6, ST_EUCLIDIAN_DISTANCE = 7 };
 
 static double vsum(const double* v, int K) {
   double s = 0;
@@ -441,6 +441,14 @@ double orc_stat_pair(int kind, int B, int K, const double* v1, const double* v2,
         sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
       }
       return (sxy / (B - 1)) / (sqrt(sxx / (B - 1)) * sqrt(syy / (B - 1)));
+    }
+    case ST_EUCLIDIAN_DISTANCE: { /* Distance.h:157-171 */
+      double d = 0;
+      for (int b = 0; b < B; b++) {
+        double sv1 = vsum(v1 + (size_t)b * K, K), sv2 = vsum(v2 + (size_t)b * K, K);
+        d += pow(sv2 - sv1, 2);
+      }
+      return sqrt(d);
     }
     case ST_COSINUS: { /* Statistics.h:218-228 */
       double sxy = 0, sxx = 0, syy = 0;

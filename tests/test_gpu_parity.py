@@ -159,6 +159,19 @@ def test_simulator_bit_exact_and_distribution():
     assert np.array_equal(a2, a[:, 1000:1010])            # counter-based: any sub-range reproduces
 
 
+def test_euclidian_distance_is_exact_for_near_identical_vectors():
+    """Distance.h:157-171 from the differences (a Gram form would lose every digit here)"""
+    case = make_case(10, 40, 20, 33)
+    eng, om = _engine(case), _omodel(case)
+    counts = oracle.map_sites(om, case["aln"])["counts"]
+    counts[1] = counts[0] * (1 + 1e-9)                 # two almost identical sites
+    counts[2] = counts[0]
+    g, o = eng.pair_stats(7, counts), oracle.pair_stats_intra(7, counts)
+    rel_close(g, o, 1e-6, 1e-300)
+    assert g[0, 2] == 0.0 and 0 < g[0, 1] < 1e-7
+    rel_close(eng.pair_stats(7, counts[:15], counts[15:]), oracle.pair_stats_inter(7, counts[:15], counts[15:]), 1e-6, 1e-300)
+
+
 @pytest.mark.parametrize("kind", range(6))
 def test_pair_stats_all_kinds_intra_and_inter(kind):
     case = make_case(14, 150, 20, 31)
