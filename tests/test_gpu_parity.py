@@ -92,6 +92,44 @@ def test_multifurcating_trees_map_and_null(seed, nstates):
     rel_close(g["stat"], o["stat"], 1e-6, 1e-12)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configurations_against_oracle(seed):
+    """seeded sweep over tree shape, taxa, sites, alphabet, number of rate classes (1..6: plain, fused-4, fused-5 with
+    padding), substitution types and ambiguity"""
+    from test_traversal_program import _random_multifurcating
+    rng = np.random.default_rng(7000 + seed)
+    ntaxa = int(rng.integers(3, 41))
+    nstates = 20 if seed % 2 == 0 else 4
+    ncat = int(rng.integers(1, 7))
+    nsites = int(rng.integers(1, 200))
+    if rng.random() < 0.4 and ntaxa >= 4:
+        parent, blen, lot = _random_multifurcating(ntaxa, seed)
+    else:
+        parent, blen, lot = synthetic.random_tree(ntaxa, 7000 + seed)
+    mdl = synthetic.protein_model(float(rng.uniform(0.3, 2.0)), ncat) if nstates == 20 else \
+        synthetic.dna_model(float(rng.uniform(0.3, 2.0)), ncat)
+    Bk = None
+    if rng.random() < 0.4:       # two weighted substitution types
+        W = rng.uniform(-1, 1, size=(2, nstates, nstates))
+        Bk = np.stack([synthetic.weighted_register(mdl["Q"], W[0]), synthetic.weighted_register(mdl["Q"], W[1])])
+    kw = dict(Bk=Bk) if Bk is not None else {}
+    om = oracle.Model(parent, blen, lot, mdl["Q"], mdl["pi"], mdl["rates"], mdl["probs"], nonneg=Bk is None, **kw)
+    eng = engine.Engine(parent, blen, lot, mdl["Q"], mdl["pi"], mdl["rates"], mdl["probs"], clamp_negative=Bk is None, **kw)
+    aln, _ = oracle.simulate(om, 99 + seed, 0, nsites)
+    masks = None
+    if rng.random() < 0.5:       # sprinkle one ambiguity id
+        masks = oracle.default_masks(nstates)
+        masks[nstates] = (1 << int(rng.integers(0, nstates))) | (1 << int(rng.integers(0, nstates)))
+        aln = aln.copy()
+        aln[rng.random(aln.shape) < 0.05] = nstates
+    r = eng.map_sites(aln, masks=None if masks is None else masks[: nstates + 1])
+    _check_map(r, oracle.map_sites(om, aln, masks))
+    kind = int(rng.integers(0, 6))
+    g, o = eng.null_intra(kind, 3 + seed, 0, 2, 37), oracle.null_intra(om, kind, 3 + seed, 0, 2, 37)
+    rel_close(g["stat"], o["stat"], 1e-6, 1e-12)
+    assert np.array_equal(g["rcmin"], o["rcmin"])
+
+
 def test_map_sites_large_alignment_takes_the_fused_class_loop():
     """below 512 (site block, class) tasks the observed mapping runs one class per wave-task + a finalize kernel; a
     9 000-site alignment exercises the other path (all classes in one wave), same results required"""
