@@ -880,4 +880,179 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
   return CMX_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ clustering
+static cmx_status check_cluster(cmx_ctx* ctx, int dist_kind, int linkage, size_t n) {
+  if (dist_kind < CMX_DIST_CORRELATION || dist_kind > CMX_DIST_EUCLIDIAN) return fail(ctx, CMX_ERR_INVALID, "unknown clustering distance");
+  if (linkage < CMX_LINK_COMPLETE || linkage > CMX_LINK_AVERAGE) return fail(ctx, CMX_ERR_INVALID, "unknown clustering method");
+  if (n < 2) return fail(ctx, CMX_ERR_INVALID, "clustering needs at least two sites");
+  if (n > CMX_CLUSTER_MAX_SITES)
+    return fail(ctx, CMX_ERR_UNSUPPORTED, "clustering is limited to " + std::to_string(CMX_CLUSTER_MAX_SITES) + " sites per matrix");
+  return CMX_OK;
+}
+
+cmx_status cmx_hclust_dev(cmx_ctx* ctx, int linkage, double* d_dist, size_t n, size_t ld, size_t batch, int32_t* d_merge,
+                          double* d_dmax, int32_t* d_size, void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  cmx_status s = check_cluster(ctx, CMX_DIST_CORRELATION, linkage, n);
+  if (s != CMX_OK) return s;
+  if (!d_dist || ld < n || batch == 0 || !d_merge || !d_dmax || !d_size) return fail(ctx, CMX_ERR_INVALID, "cmx_hclust: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  double* rmin;
+  int* nn;
+  if ((s = scratch(ctx, "hc_rmin", sizeof(double) * batch * n, (void**)&rmin)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "hc_nn", sizeof(int) * batch * n, (void**)&nn)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_hclust(linkage, d_dist, n, ld, n * ld, batch, rmin, nn, d_merge, d_dmax, d_size, (hipStream_t)stream));
+  return CMX_OK;
+}
+
+cmx_status cmx_hclust(cmx_ctx* ctx, int linkage, const double* dist, size_t n, size_t batch, int32_t* merge, double* dmax,
+                      int32_t* size) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!dist || !merge || !dmax || !size || batch == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_hclust: bad arguments");
+  cmx_status s = check_cluster(ctx, CMX_DIST_CORRELATION, linkage, n);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  TmpDev tmp;
+  double *d_D, *d_dm;
+  int32_t *d_mg, *d_sz;
+  const size_t nm = batch * (n - 1);
+  HIP_TRY(ctx, tmp.alloc((void**)&d_D, sizeof(double) * batch * n * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_dm, sizeof(double) * nm));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_mg, sizeof(int32_t) * 2 * nm));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_sz, sizeof(int32_t) * nm));
+  HIP_TRY(ctx, hipMemcpy(d_D, dist, sizeof(double) * batch * n * n, hipMemcpyHostToDevice));
+  if ((s = cmx_hclust_dev(ctx, linkage, d_D, n, n, batch, d_mg, d_dm, d_sz, nullptr)) != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(merge, d_mg, sizeof(int32_t) * 2 * nm, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(dmax, d_dm, sizeof(double) * nm, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(size, d_sz, sizeof(int32_t) * nm, hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+// `batch` replicates of n sites each in consecutive column blocks of d_counts / d_norm: statistic (upper triangles) ->
+// distances -> agglomeration -> group properties.  d_dist_out (batch == 1 only): copy of the distance matrix.
+static cmx_status cluster_batch_dev(cmx_ctx* ctx, int dist_kind, int linkage, const double* d_counts, size_t ldc, size_t n,
+                                    size_t batch, const double* d_norm, double* d_dist_out, int32_t* d_merge, double* d_dmax,
+                                    int32_t* d_size, double* d_stat, double* d_nmin, hipStream_t st) {
+  cmx_status s;
+  const HostModel& h = ctx->hm;
+  double *D, *sigma = nullptr;
+  if ((s = scratch(ctx, "cl_D", sizeof(double) * batch * n * n, (void**)&D)) != CMX_OK) return s;
+  const int stat_kind = dist_kind == CMX_DIST_CORRELATION ? CMX_STAT_CORRELATION
+                        : dist_kind == CMX_DIST_COMPENSATION ? CMX_STAT_COMPENSATION : CMX_STAT_EUCLIDIAN_DISTANCE;
+  for (size_t r = 0; r < batch; ++r)
+    if ((s = cmx_pair_stats_dev(ctx, stat_kind, nullptr, d_counts + r * n, n, ldc, nullptr, 0, 0, D + r * n * n, n, st)) != CMX_OK)
+      return s;
+  HIP_TRY(ctx, launch_dist_finish(dist_kind, D, n, n, n * n, batch, st));
+  if (d_dist_out) HIP_TRY(ctx, hipMemcpyAsync(d_dist_out, D, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
+  if ((s = cmx_hclust_dev(ctx, linkage, D, n, n, batch, d_merge, d_dmax, d_size, st)) != CMX_OK) return s;
+  if (dist_kind == CMX_DIST_COMPENSATION &&
+      (s = scratch(ctx, "cl_sigma", sizeof(double) * batch * (2 * n - 1) * h.B, (void**)&sigma)) != CMX_OK)
+    return s;
+  HIP_TRY(ctx, launch_cluster_props(dist_kind, (int)n, h.B, h.K, batch, d_merge, d_dmax, d_norm, d_counts, ldc, n, sigma, d_stat,
+                                    d_nmin, st));
+  return CMX_OK;
+}
+
+cmx_status cmx_cluster_sites_dev(cmx_ctx* ctx, int dist_kind, int linkage, const double* d_counts, size_t n, size_t ldc,
+                                 const double* d_norm, double* d_dist_out, int32_t* d_merge, double* d_dmax, int32_t* d_size,
+                                 double* d_stat, double* d_nmin, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_cluster(ctx, dist_kind, linkage, n)) != CMX_OK) return s;
+  if (!d_counts || ldc < n || !d_norm || !d_merge || !d_dmax || !d_size || !d_stat || !d_nmin)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_cluster_sites: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return cluster_batch_dev(ctx, dist_kind, linkage, d_counts, ldc, n, 1, d_norm, d_dist_out, d_merge, d_dmax, d_size, d_stat,
+                           d_nmin, (hipStream_t)stream);
+}
+
+cmx_status cmx_cluster_sites(cmx_ctx* ctx, int dist_kind, int linkage, const double* counts, size_t n, double* dist_out,
+                             int32_t* merge, double* dmax, int32_t* size, double* stat, double* nmin) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_cluster(ctx, dist_kind, linkage, n)) != CMX_OK) return s;
+  if (!counts || !merge || !dmax || !size || !stat || !nmin) return fail(ctx, CMX_ERR_INVALID, "cmx_cluster_sites: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const HostModel& h = ctx->hm;
+  const size_t BK = (size_t)h.B * h.K, nm = n - 1;
+  std::vector<double> bm, norm(n);
+  to_branch_major(counts, n, BK, &bm);
+  for (size_t i = 0; i < n; ++i) {       // computeNormForSite: sqrt(sum_b (sum_k n_bk)^2)
+    double q = 0.0;
+    for (int b = 0; b < h.B; ++b) {
+      double t = 0.0;
+      for (int k = 0; k < h.K; ++k) t += counts[i * BK + (size_t)b * h.K + k];
+      q += t * t;
+    }
+    norm[i] = std::sqrt(q);
+  }
+  TmpDev tmp;
+  double *d_c, *d_norm, *d_dist = nullptr, *d_dm, *d_st, *d_nmn;
+  int32_t *d_mg, *d_sz;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_c, sizeof(double) * bm.size()));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_norm, sizeof(double) * n));
+  if (dist_out) HIP_TRY(ctx, tmp.alloc((void**)&d_dist, sizeof(double) * n * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_dm, sizeof(double) * nm));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_st, sizeof(double) * nm));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_nmn, sizeof(double) * nm));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_mg, sizeof(int32_t) * 2 * nm));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_sz, sizeof(int32_t) * nm));
+  HIP_TRY(ctx, hipMemcpy(d_c, bm.data(), sizeof(double) * bm.size(), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_norm, norm.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  if ((s = cmx_cluster_sites_dev(ctx, dist_kind, linkage, d_c, n, n, d_norm, d_dist, d_mg, d_dm, d_sz, d_st, d_nmn, nullptr)) != CMX_OK)
+    return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  if (dist_out) HIP_TRY(ctx, hipMemcpy(dist_out, d_dist, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(merge, d_mg, sizeof(int32_t) * 2 * nm, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(dmax, d_dm, sizeof(double) * nm, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(size, d_sz, sizeof(int32_t) * nm, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(stat, d_st, sizeof(double) * nm, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(nmin, d_nmn, sizeof(double) * nm, hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+cmx_status cmx_cluster_null(cmx_ctx* ctx, int dist_kind, int linkage, uint64_t seed, size_t rep_begin, size_t rep_end,
+                            size_t nsites, int32_t* merge, double* dmax, int32_t* size, double* stat, double* nmin) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_cluster(ctx, dist_kind, linkage, nsites)) != CMX_OK) return s;
+  if (rep_end <= rep_begin || !merge || !dmax || !size || !stat || !nmin) return fail(ctx, CMX_ERR_INVALID, "cmx_cluster_null: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const HostModel& h = ctx->hm;
+  const size_t n = nsites, nm = n - 1, nrep = rep_end - rep_begin, BK = (size_t)h.B * h.K;
+  // replicates per batch: every replicate keeps its own n x n matrix in HBM; 16 GiB of them at most
+  const size_t per_rep = sizeof(double) * (n * n + BK * n) + (size_t)(h.T + h.nn) * n;
+  const size_t R = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nrep, 1024), ((size_t)16 << 30) / per_rep));
+  const size_t N = R * n;
+  uint8_t *d_aln, *d_states;
+  int32_t *d_cls, *d_mg, *d_sz;
+  double *d_cnt, *d_norm, *d_dm, *d_st, *d_nmn;
+  if ((s = scratch(ctx, "cl_aln", (size_t)h.T * N, (void**)&d_aln)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_states", (size_t)h.nn * N, (void**)&d_states)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_cls", sizeof(int32_t) * N, (void**)&d_cls)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_cnt", sizeof(double) * BK * N, (void**)&d_cnt)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_norm", sizeof(double) * N, (void**)&d_norm)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_merge", sizeof(int32_t) * 2 * R * nm, (void**)&d_mg)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_size", sizeof(int32_t) * R * nm, (void**)&d_sz)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_dmax", sizeof(double) * R * nm, (void**)&d_dm)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_stat", sizeof(double) * R * nm, (void**)&d_st)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cl_nmin", sizeof(double) * R * nm, (void**)&d_nmn)) != CMX_OK) return s;
+  for (size_t r0 = 0; r0 < nrep; r0 += R) {
+    const size_t rb = std::min(R, nrep - r0), nb = rb * n;
+    HIP_TRY(ctx, launch_simulate(ctx->dm, seed, (uint64_t)(rep_begin + r0) * n, nb, d_aln, nb, d_cls, d_states, nullptr));
+    if ((s = cmx_map_sites_dev(ctx, d_aln, nb, nb, nullptr, d_cnt, nb, nullptr, nullptr, nullptr, d_norm, nullptr)) != CMX_OK) return s;
+    if ((s = cluster_batch_dev(ctx, dist_kind, linkage, d_cnt, nb, n, rb, d_norm, nullptr, d_mg, d_dm, d_sz, d_st, d_nmn, nullptr)) != CMX_OK)
+      return s;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(merge + 2 * r0 * nm, d_mg, sizeof(int32_t) * 2 * rb * nm, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(size + r0 * nm, d_sz, sizeof(int32_t) * rb * nm, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(dmax + r0 * nm, d_dm, sizeof(double) * rb * nm, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(stat + r0 * nm, d_st, sizeof(double) * rb * nm, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(nmin + r0 * nm, d_nmn, sizeof(double) * rb * nm, hipMemcpyDeviceToHost));
+  }
+  return CMX_OK;
+}
+
 }  // extern "C"

@@ -115,6 +115,16 @@ hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* 
                             size_t n, const int32_t* rc1, const int32_t* rc2, const double* pr1, const double* pr2,
                             const double* nm1, const double* nm2, double* stat, int32_t* rcmin, double* prmin, double* nmin,
                             const double* d_mean, hipStream_t stream);
+// clustering (cmx_cluster.hip)
+size_t hclust_lds_bytes(int n);
+size_t cluster_props_lds_bytes(int n);
+hipError_t launch_dist_finish(int dist_kind, double* d_D, size_t n, size_t ld, size_t mat_stride, size_t batch,
+                              hipStream_t stream);
+hipError_t launch_hclust(int linkage, double* d_D, size_t n, size_t ld, size_t mat_stride, size_t batch, double* d_rmin,
+                         int* d_nn, int32_t* d_merge, double* d_dmax, int32_t* d_size, hipStream_t stream);
+hipError_t launch_cluster_props(int dist_kind, int n, int B, int K, size_t batch, const int32_t* d_merge, const double* d_dmax,
+                                const double* d_norm, const double* d_counts, size_t ldc, size_t site_stride, double* d_sigma,
+                                double* d_stat, double* d_nmin, hipStream_t stream);
 hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
                            int32_t* d_classes, uint8_t* d_states /*[nn][ld]*/, hipStream_t stream);
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,

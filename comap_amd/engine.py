@@ -42,7 +42,15 @@ EXPORTS = [
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
+    "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
 ]
+# clustering.distance / clustering.method options of the reference (CoMap/CoMap.cpp:402-428, :460-472)
+DIST_CORRELATION, DIST_COMPENSATION, DIST_EUCLIDIAN = range(3)
+LINK_COMPLETE, LINK_SINGLE, LINK_AVERAGE = range(3)
+DIST_BY_NAME = {"cor": DIST_CORRELATION, "Correlation": DIST_CORRELATION, "comp": DIST_COMPENSATION,
+                "Compensation": DIST_COMPENSATION, "euclidian": DIST_EUCLIDIAN, "Euclidian": DIST_EUCLIDIAN}
+LINK_BY_NAME = {"complete": LINK_COMPLETE, "single": LINK_SINGLE, "average": LINK_AVERAGE}
+CLUSTER_MAX_SITES = 5000
 
 
 class CmxError(RuntimeError):
@@ -315,6 +323,42 @@ class Engine:
                                            _vp(a1), _sz(n1), _vp(a2), _sz(0 if a2 is None else a2.shape[1]), _vp(i1),
                                            _vp(i2), _sz(len(i1)), _vp(mi), _vp(hj)))
         return dict(mi=mi, hjoint=hj)
+
+    # -- clustering analysis
+    def hclust(self, dist, linkage):
+        """dist [n, n] or [batch, n, n] -> dict(merge [.., n-1, 2], dmax, size)"""
+        d = _f64(dist)
+        single = d.ndim == 2
+        d = d.reshape((-1,) + d.shape[-2:])
+        batch, n = d.shape[0], d.shape[1]
+        merge = np.zeros((batch, n - 1, 2), dtype=np.int32)
+        dmax = np.zeros((batch, n - 1))
+        size = np.zeros((batch, n - 1), dtype=np.int32)
+        self._check(self._lib.cmx_hclust(self._ctx, int(linkage), _vp(d), _sz(n), _sz(batch), _vp(merge), _vp(dmax), _vp(size)))
+        out = dict(merge=merge, dmax=dmax, size=size)
+        return {k: v[0] for k, v in out.items()} if single else out
+
+    def cluster_sites(self, dist_kind, linkage, counts, want_dist=True):
+        """counts [N, B, K] -> dict(dist [N, N], merge, dmax, size, stat, nmin) (CoMap.cpp:432-550)"""
+        c = _f64(counts)
+        n = c.shape[0]
+        dist = np.zeros((n, n)) if want_dist else None
+        merge = np.zeros((n - 1, 2), dtype=np.int32)
+        size = np.zeros(n - 1, dtype=np.int32)
+        dmax, stat, nmin = np.zeros(n - 1), np.zeros(n - 1), np.zeros(n - 1)
+        self._check(self._lib.cmx_cluster_sites(self._ctx, int(dist_kind), int(linkage), _vp(c), _sz(n), _vp(dist), _vp(merge),
+                                                _vp(dmax), _vp(size), _vp(stat), _vp(nmin)))
+        return dict(dist=dist, merge=merge, dmax=dmax, size=size, stat=stat, nmin=nmin)
+
+    def cluster_null(self, dist_kind, linkage, seed, rep_begin, rep_end, nsites):
+        """ClusterTools::computeGlobalDistanceDistribution: dict of [nrep, nsites-1] arrays (merge: [.., 2])"""
+        nrep, nm = rep_end - rep_begin, nsites - 1
+        merge = np.zeros((nrep, nm, 2), dtype=np.int32)
+        size = np.zeros((nrep, nm), dtype=np.int32)
+        dmax, stat, nmin = np.zeros((nrep, nm)), np.zeros((nrep, nm)), np.zeros((nrep, nm))
+        self._check(self._lib.cmx_cluster_null(self._ctx, int(dist_kind), int(linkage), ctypes.c_uint64(seed), _sz(rep_begin),
+                                               _sz(rep_end), _sz(nsites), _vp(merge), _vp(dmax), _vp(size), _vp(stat), _vp(nmin)))
+        return dict(merge=merge, dmax=dmax, size=size, stat=stat, nmin=nmin)
 
     # -- device-pointer entry points (torch CUDA tensors, engine-native layouts, asynchronous)
     def map_sites_dev(self, d_aln, counts=None, logL=None, post_rate=None, rate_class=None, norm=None, masks=None):

@@ -207,6 +207,40 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
                         size_t n1, const uint8_t* aln2, size_t n2, const int64_t* idx1, const int64_t* idx2,
                         size_t npairs, double* mi, double* hjoint);
 
+/* ---- clustering analysis (CoMap/CoMap.cpp:395-560; null: ClusterTools::computeGlobalDistanceDistribution,
+ * CoMap/ClusterTools.cpp:200-294).  Distances of CoMap.cpp:402-428: 1 - correlation (StatisticBasedDistance(cor, 1.),
+ * Distance.h:321-336), 1 - compensation (CompensationDistance, Distance.h:376-385), Euclidian (Distance.h:161-181).
+ * Agglomeration = bpp::HierarchicalClustering as constructed at CoMap.cpp:460-472.
+ * A clustering tree over n sites is returned as its n-1 joins in the order they were made: leaves are 0..n-1, join m
+ * creates node n+m with sons merge[m][0], merge[m][1] (the reference's son order); dmax[m] is the distance at which
+ * the two were joined (= 2 * node height = the "Dmax" column), size[m] the number of sites below, stat[m] / nmin[m]
+ * the "Stat" / "Nmin" node properties (Distance.h:113-126, :353-366, :393-413; ClusterTools.cpp:302-320).
+ * ClusterTools::getGroups (ClusterTools.cpp:61-113) is a post-order walk of these joins (adapter / comap_amd.formats).
+ * Ties between equal distances go to the first pair in index order (CoMap/Cluster.cpp:55-79); NaN distances are
+ * treated as +inf.  n is limited to CMX_CLUSTER_MAX_SITES (the per-matrix state lives in LDS). */
+enum { CMX_DIST_CORRELATION = 0, CMX_DIST_COMPENSATION = 1, CMX_DIST_EUCLIDIAN = 2 };
+enum { CMX_LINK_COMPLETE = 0, CMX_LINK_SINGLE = 1, CMX_LINK_AVERAGE = 2 };
+#define CMX_CLUSTER_MAX_SITES 5000
+/* agglomeration only: `batch` independent symmetric n x n matrices (row stride ld, matrix stride n*ld); the device
+ * variant overwrites them.  Needs no model: works on a context created with model == NULL. */
+cmx_status cmx_hclust_dev(cmx_ctx* ctx, int linkage, double* d_dist, size_t n, size_t ld, size_t batch, int32_t* d_merge,
+                          double* d_dmax, int32_t* d_size, void* stream);
+cmx_status cmx_hclust(cmx_ctx* ctx, int linkage, const double* dist, size_t n, size_t batch, int32_t* merge, double* dmax,
+                      int32_t* size);
+/* observed data: substitution vectors -> distance matrix (optionally returned, [n][n], zero diagonal: the matrix of
+ * clustering.output.matrix.file) -> clustering tree with its group properties.  counts as in cmx_pair_stats(_dev);
+ * d_norm from cmx_map_sites_dev. */
+cmx_status cmx_cluster_sites_dev(cmx_ctx* ctx, int dist_kind, int linkage, const double* d_counts, size_t n, size_t ldc,
+                                 const double* d_norm, double* d_dist_out, int32_t* d_merge, double* d_dmax,
+                                 int32_t* d_size, double* d_stat, double* d_nmin, void* stream);
+cmx_status cmx_cluster_sites(cmx_ctx* ctx, int dist_kind, int linkage, const double* counts, size_t n, double* dist_out,
+                             int32_t* merge, double* dmax, int32_t* size, double* stat, double* nmin);
+/* the null: replicates [rep_begin, rep_end), each one simulates nsites sites (global site indices rep*nsites ..),
+ * maps them, builds their distance matrix and clusters it, all on the device; replicates are processed in batches
+ * of independent matrices, one workgroup per matrix.  Host outputs, [(rep_end-rep_begin)][nsites-1] (merge: [..][2]). */
+cmx_status cmx_cluster_null(cmx_ctx* ctx, int dist_kind, int linkage, uint64_t seed, size_t rep_begin, size_t rep_end,
+                            size_t nsites, int32_t* merge, double* dmax, int32_t* size, double* stat, double* nmin);
+
 
 #ifdef __cplusplus
 }
