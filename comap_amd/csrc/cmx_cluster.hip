@@ -6,8 +6,8 @@
 //
 // The agglomeration is a chain of n-1 dependent steps; what a step costs is latency, not bandwidth.  Per step the
 // owning workgroup (a) finds the closest pair from per-row minima kept in LDS, (b) rewrites row/column i of its
-// matrix in HBM with the linkage update while collecting the new minimum of row i on the fly, (c) rescans only
-// the rows whose cached nearest neighbour was invalidated.  Ties go to the first pair in index order, as the
+// matrix in HBM with the linkage update while collecting the new minimum of row i on the fly, (c) rescans a row
+// whose cached minimum was invalidated only if it becomes the head of the queue (lazy row minima).  Ties go to the first pair in index order, as the
 // reference's scan does (CoMap/Cluster.cpp:55-79).  All integer/compare work plus one fp64 formula per element that
 // is evaluated with explicit roundings, so the result is bit-identical to the CPU restatement.
 #include <hip/hip_runtime.h>
@@ -22,19 +22,58 @@ namespace cmx {
 
 namespace {
 
-constexpr int kHcThreads = 512;
+#ifndef HC_ABLATE
+#define HC_ABLATE 0   // timing diagnostics only (wrong results): 1 no column store, 2 no matrix stores, 3 no matrix traffic
+#endif
+#ifndef HC_THREADS
+#define HC_THREADS 512
+#endif
+constexpr int kHcThreads = HC_THREADS;
 constexpr int kHcWaves = kHcThreads / kWave;
+constexpr int kHcMaxPerThread = (CMX_CLUSTER_MAX_SITES + kHcThreads - 1) / kHcThreads;   // columns of a row per thread
+constexpr int kHcSeg = 512;       // columns of one rescan unit: 8 loads in flight per lane
+constexpr int kHcMaxSeg = (CMX_CLUSTER_MAX_SITES + kHcSeg - 1) / kHcSeg;
 
 __device__ __forceinline__ bool key_less(double v1, int c1, double v2, int c2) { return v1 < v2 || (v1 == v2 && c1 < c2); }
 
-// lexicographic (value, index) minimum across the wave; every lane ends up with the result
+// Wave-wide minimum without LDS round trips: xor-butterfly over lane bits 0..3 with DPP (quad_perm / row_ror inside a
+// row of 16 lanes), bits 4 and 5 with v_permlane16_swap / v_permlane32_swap.  Every lane ends up with the result.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRor4 = 0x124, kDppRor8 = 0x128;
+__device__ __forceinline__ double wave_min_f64(double v) {
+  v = fmin(v, dpp_f64<kDppXor1>(v));
+  v = fmin(v, dpp_f64<kDppXor2>(v));
+  v = fmin(v, dpp_f64<kDppRor4>(v));
+  v = fmin(v, dpp_f64<kDppRor8>(v));
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = fmin(__hiloint2double((int)h16[0], (int)l16[0]), __hiloint2double((int)h16[1], (int)l16[1]));
+  const unsigned lo2 = (unsigned)__double2loint(v), hi2 = (unsigned)__double2hiint(v);
+  const auto l32 = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);
+  const auto h32 = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+  return fmin(__hiloint2double((int)h32[0], (int)l32[0]), __hiloint2double((int)h32[1], (int)l32[1]));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, dpp_i32<kDppXor1>(v));
+  v = min(v, dpp_i32<kDppXor2>(v));
+  v = min(v, dpp_i32<kDppRor4>(v));
+  v = min(v, dpp_i32<kDppRor8>(v));
+  const auto s16 = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  v = min((int)s16[0], (int)s16[1]);
+  const auto s32 = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return min((int)s32[0], (int)s32[1]);
+}
+// lexicographic (value, index) minimum across the wave (values are never NaN here; indices are >= 0 or INT_MAX)
 __device__ __forceinline__ void wave_argmin(double& v, int& c) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) {
-    const double ov = __shfl_xor(v, off);
-    const int oc = __shfl_xor(c, off);
-    if (key_less(ov, oc, v, c)) { v = ov; c = oc; }
-  }
+  const double m = wave_min_f64(v);
+  c = wave_min_i32(v == m ? c : INT_MAX);
+  v = m;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -112,22 +151,39 @@ __device__ __forceinline__ double linkage_update(double x, double y, double ni, 
   return s / (ni + nj);
 }
 
+// Row minima are kept LAZILY (the scheme of Muellner's generic linkage algorithm, arXiv:1109.2378 sec. 3.3): when a
+// join removes or enlarges the cached minimum of a row, the row is only marked stale and its old minimum kept as a
+// lower bound -- for these three linkages the entries of a row never drop below the row's previous minimum unless
+// the new entry itself is the smaller one, which is handled on the spot.  A stale row is rescanned when (and only
+// when) its bound makes it the head of the queue.  Exactness of the tie rule: the head is the smallest (bound, row);
+// a stale row elsewhere has true minimum >= its bound, so it cannot precede a fresh head in (value, row) order.
+// Barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store of the wave
+// (s_waitcnt vmcnt(0)); inside a step nobody reads what was just stored to the matrix or to the outputs, so that wait
+// is taken once per step -- at the full barrier that precedes the next loads from the matrix -- instead of three times.
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kStale = -2;   // nn[r]: minimum unknown, rmin[r] is a lower bound
+constexpr int kNone = -1;    // nn[r]: no live column right of the diagonal
+
 template <int LINK>
 __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
   extern __shared__ double hc_smem[];
   const int n = a.n;
-  double* rmin = hc_smem;                          // [n] smallest distance right of the diagonal in row r
-  int* nn = reinterpret_cast<int*>(rmin + n);      // [n] its column, -1: none
+  double* rmin = hc_smem;                          // [n] smallest distance right of the diagonal in row r (or a bound)
+  int* nn = reinterpret_cast<int*>(rmin + n);      // [n] its column, kNone, kStale
   int* cid = nn + n;                               // [n] node id of the cluster living in slot r, -1: merged away
   int* csz = cid + n;                              // [n] its number of leaves
-  int* list = csz + n;                             // [n] rows to rescan this step
   __shared__ double pv[2][kHcWaves];
   __shared__ int pi[2][kHcWaves];
-  __shared__ int lcount;
+  __shared__ double sv[kHcMaxSeg];
+  __shared__ int sc[kHcMaxSeg];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* D = a.D + (size_t)blockIdx.x * a.mat_stride;
   const size_t ld = a.ld;
   const size_t ob = (size_t)blockIdx.x * (size_t)(n - 1);
+  const int nseg = (n + kHcSeg - 1) / kHcSeg;
+  const int per = (n + kHcThreads - 1) / kHcThreads;   // columns of a row per thread
+  const unsigned ld32 = (unsigned)ld;                  // n <= CMX_CLUSTER_MAX_SITES: element offsets fit 32 bits
   for (int r = tid; r < n; r += kHcThreads) {
     rmin[r] = a.grmin[(size_t)blockIdx.x * n + r];
     nn[r] = a.gnn[(size_t)blockIdx.x * n + r];
@@ -136,53 +192,113 @@ __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
   }
   __syncthreads();
   for (int step = 0; step < n - 1; ++step) {
-    // ---- closest pair: rows carry their own minimum, so this is a reduction over n LDS entries
-    double bv = INFINITY;
-    int br = INT_MAX;
-    for (int r = tid; r < n; r += kHcThreads)
-      if (cid[r] >= 0 && nn[r] >= 0 && key_less(rmin[r], r, bv, br)) { bv = rmin[r]; br = r; }
-    wave_argmin(bv, br);
-    if (lane == 0) { pv[0][wave] = bv; pi[0][wave] = br; }
-    if (tid == 0) lcount = 0;
-    __syncthreads();
-    double gv = pv[0][0];
-    int i = pi[0][0];
+    // ---- head of the queue: a reduction over n LDS entries; rescan it while it is stale (each pass freshens one row)
+    double gv;
+    int i;
+    for (;;) {
+      double bv = INFINITY;
+      int br = INT_MAX;
+      for (int r = tid; r < n; r += kHcThreads)
+        if (cid[r] >= 0 && nn[r] != kNone && key_less(rmin[r], r, bv, br)) { bv = rmin[r]; br = r; }
+      wave_argmin(bv, br);
+      if (lane == 0) { pv[0][wave] = bv; pi[0][wave] = br; }
+      __syncthreads();   // full: the matrix stores of the previous step are complete before anyone loads from it
+      gv = pv[0][0];
+      i = pi[0][0];
 #pragma unroll
-    for (int w = 1; w < kHcWaves; ++w)
-      if (key_less(pv[0][w], pi[0][w], gv, i)) { gv = pv[0][w]; i = pi[0][w]; }
+      for (int w = 1; w < kHcWaves; ++w)
+        if (key_less(pv[0][w], pi[0][w], gv, i)) { gv = pv[0][w]; i = pi[0][w]; }
+      if (nn[i] != kStale) break;
+      // one wave per segment of kHcSeg columns, all loads of a segment in flight together
+      for (int u = wave; u < nseg; u += kHcWaves) {
+        const int base = i + 1 + u * kHcSeg;
+        const double* row = D + (size_t)i * ld;
+        double x[kHcSeg / kWave];
+#pragma unroll
+        for (int t = 0; t < kHcSeg / kWave; ++t) {
+          const int k = base + lane + t * kWave;
+          x[t] = (k < n && cid[k < n ? k : 0] >= 0) ? row[k] : INFINITY;
+        }
+        double v = INFINITY;
+        int c = INT_MAX;
+#pragma unroll
+        for (int t = 0; t < kHcSeg / kWave; ++t) {
+          const int k = base + lane + t * kWave;
+          if (k < n && cid[k < n ? k : 0] >= 0 && key_less(x[t], k, v, c)) { v = x[t]; c = k; }
+        }
+        wave_argmin(v, c);
+        if (lane == 0) { sv[u] = v; sc[u] = c; }
+      }
+      barrier_lds();
+      if (tid == 0) {
+        double v = sv[0];
+        int c = sc[0];
+        for (int g = 1; g < nseg; ++g)
+          if (key_less(sv[g], sc[g], v, c)) { v = sv[g]; c = sc[g]; }
+        rmin[i] = v;
+        nn[i] = c == INT_MAX ? kNone : c;
+      }
+      barrier_lds();
+    }
     const int j = nn[i];
     const double ni = (double)csz[i], nj = (double)csz[j];
-    // ---- linkage update of row/column i; the new minimum of row i falls out of the same loop
+    // ---- linkage update of row/column i; the new minimum of row i falls out of the same loop.  All loads of the
+    // step are issued before the first store (the compiler cannot prove the stores do not alias the next loads)
     double cv = INFINITY;
     int cc = INT_MAX;
-    for (int k = tid; k < n; k += kHcThreads) {
-      if (k == i || k == j || cid[k] < 0) continue;
-      const double nw = linkage_update<LINK>(D[(size_t)i * ld + k], D[(size_t)j * ld + k], ni, nj);
+    double xi[kHcMaxPerThread], xj[kHcMaxPerThread];
+    const double* rowi = D + (size_t)i * ld;
+    const double* rowj = D + (size_t)j * ld;
+    double* coli = D + i;
+#pragma unroll
+    for (int t = 0; t < kHcMaxPerThread; ++t) {
+      const int k = tid + t * kHcThreads;
+      const bool on = t < per && k < n && k != i && k != j && cid[k < n ? k : 0] >= 0;
+      if (t < per) {
+#if HC_ABLATE < 3
+        xi[t] = on ? rowi[k] : 0.0;
+        xj[t] = on ? rowj[k] : 0.0;
+#else
+        xi[t] = 1.0 + (double)((k * 7919 + step * 104729) & 1023);
+        xj[t] = 2.0 + (double)((k * 104729 + step * 7919) & 1023);
+#endif
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kHcMaxPerThread; ++t) {
+      const int k = tid + t * kHcThreads;
+      if (t >= per || k >= n || k == i || k == j || cid[k] < 0) continue;
+      const double nw = linkage_update<LINK>(xi[t], xj[t], ni, nj);
+#if HC_ABLATE < 2
       D[(size_t)i * ld + k] = nw;
-      D[(size_t)k * ld + i] = nw;
+#endif
+#if HC_ABLATE < 1
+      coli[(unsigned)k * ld32] = nw;
+#endif
       if (k > i) {
         if (key_less(nw, k, cv, cc)) { cv = nw; cc = k; }
-        if (k < j && nn[k] == j) list[atomicAdd(&lcount, 1)] = k;     // its neighbour disappears
+        if (k < j && nn[k] == j) nn[k] = kStale;                     // its neighbour disappears; the bound stands
       } else {
         const int nk = nn[k];
         if (nk == i || nk == j) {
           // (k, i) took the place of the cached minimum: still the minimum unless it grew
           if (nw <= rmin[k]) { rmin[k] = nw; nn[k] = i; }
-          else list[atomicAdd(&lcount, 1)] = k;
+          else nn[k] = kStale;
+        } else if (nk == kStale) {
+          if (nw < rmin[k]) { rmin[k] = nw; nn[k] = i; }              // below every other entry of the row: fresh again
         } else if (key_less(nw, i, rmin[k], nk)) { rmin[k] = nw; nn[k] = i; }
       }
     }
     wave_argmin(cv, cc);
     if (lane == 0) { pv[1][wave] = cv; pi[1][wave] = cc; }
-    __syncthreads();
-    // ---- bookkeeping (one lane) and rescans (one wave per invalidated row)
+    barrier_lds();
     if (tid == 0) {
       double v = pv[1][0];
       int c = pi[1][0];
       for (int w = 1; w < kHcWaves; ++w)
         if (key_less(pv[1][w], pi[1][w], v, c)) { v = pv[1][w]; c = pi[1][w]; }
       rmin[i] = v;
-      nn[i] = c == INT_MAX ? -1 : c;
+      nn[i] = c == INT_MAX ? kNone : c;
       a.merge[(ob + step) * 2] = cid[i];
       a.merge[(ob + step) * 2 + 1] = cid[j];
       a.dmax[ob + step] = gv;
@@ -192,18 +308,7 @@ __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
       cid[i] = n + step;
       cid[j] = -1;
     }
-    const int nl = lcount;
-    for (int idx = wave; idx < nl; idx += kHcWaves) {
-      const int r = list[idx];
-      const double* row = D + (size_t)r * ld;
-      double v = INFINITY;
-      int c = INT_MAX;
-      for (int k = r + 1 + lane; k < n; k += kWave)
-        if (k != j && cid[k] >= 0 && key_less(row[k], k, v, c)) { v = row[k]; c = k; }
-      wave_argmin(v, c);
-      if (lane == 0) { rmin[r] = v; nn[r] = c == INT_MAX ? -1 : c; }
-    }
-    __syncthreads();
+    barrier_lds();
   }
 }
 
@@ -269,7 +374,7 @@ __global__ __launch_bounds__(256) void cluster_props_kernel(PropArgs a) {
 
 }  // namespace
 
-size_t hclust_lds_bytes(int n) { return (size_t)n * (sizeof(double) + 4 * sizeof(int)); }
+size_t hclust_lds_bytes(int n) { return (size_t)n * (sizeof(double) + 3 * sizeof(int)); }
 size_t cluster_props_lds_bytes(int n) { return (size_t)(2 * n - 1) * 2 * sizeof(double); }
 
 hipError_t launch_dist_finish(int dist_kind, double* d_D, size_t n, size_t ld, size_t mat_stride, size_t batch,

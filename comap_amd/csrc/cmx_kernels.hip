@@ -1333,7 +1333,11 @@ __global__ __launch_bounds__(kWave) void pair_gram_kernel(int kind, int B, int B
                                                          size_t n1, size_t ldx1, const double* __restrict__ X2,
                                                          const double* __restrict__ s2, const double* __restrict__ r2,
                                                          size_t n2, size_t ldx2, int intra, double* __restrict__ out,
-                                                         size_t ldo) {
+                                                         size_t ldo, size_t zsite, size_t zout) {
+  // blockIdx.z: independent blocks of sites side by side in the same operand arrays (clustering null: one per replicate)
+  X1 += blockIdx.z * zsite; s1 += blockIdx.z * zsite; r1 += blockIdx.z * zsite;
+  X2 += blockIdx.z * zsite; s2 += blockIdx.z * zsite; r2 += blockIdx.z * zsite;
+  out += blockIdx.z * zout;
   const int lane = threadIdx.x;
   const size_t ti = blockIdx.y, tj = blockIdx.x;
   const size_t i0 = ti * 64, j0 = tj * 64;
@@ -1401,7 +1405,9 @@ __global__ __launch_bounds__(kWave) void pair_gram_kernel(int kind, int B, int B
 // vectors.  X = the totals operand of pair_prep_kernel (kind 1), [Bp][ldx]; one thread per pair, row i broadcast.
 __global__ __launch_bounds__(64) void pair_euclid_kernel(int B, const double* __restrict__ X1, size_t n1, size_t ldx1,
                                                          const double* __restrict__ X2, size_t n2, size_t ldx2, int intra,
-                                                         double* __restrict__ out, size_t ldo) {
+                                                         double* __restrict__ out, size_t ldo, size_t zsite,
+                                                         size_t zout) {
+  X1 += blockIdx.z * zsite; X2 += blockIdx.z * zsite; out += blockIdx.z * zout;
   const size_t i = blockIdx.y, j = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (j >= n2) return;
   double d = 0.0;
@@ -1412,18 +1418,27 @@ __global__ __launch_bounds__(64) void pair_euclid_kernel(int B, const double* __
   out[i * ldo + j] = (!intra || j > i) ? sqrt(d) : __builtin_nan("");
 }
 
+// nblk > 1: nblk independent site blocks of n1 (= n2) sites, block z at site offset z * zsite, output at z * zout
 hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const double* d_s1, const double* d_r1,
                             size_t n1, size_t ldx1, const double* d_X2, const double* d_s2, const double* d_r2,
-                            size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream) {
-  if (kind == CMX_STAT_EUCLIDIAN_DISTANCE) {
-    hipLaunchKernelGGL(pair_euclid_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)n1), dim3(64), 0, stream, B, d_X1, n1,
-                       ldx1, d_X2, n2, ldx2, intra, d_out, ldo);
-    return hipGetLastError();
+                            size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream,
+                            size_t nblk, size_t zsite, size_t zout) {
+  for (size_t z0 = 0; z0 < nblk; z0 += 65535) {     // grid.z limit
+    const unsigned gz = (unsigned)std::min<size_t>(65535, nblk - z0);
+    const size_t so = z0 * zsite;
+    double* out = d_out + z0 * zout;
+    if (kind == CMX_STAT_EUCLIDIAN_DISTANCE) {
+      hipLaunchKernelGGL(pair_euclid_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)n1, gz), dim3(64), 0, stream, B,
+                         d_X1 + so, n1, ldx1, d_X2 + so, n2, ldx2, intra, out, ldo, zsite, zout);
+    } else {
+      dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 63) / 64), gz);
+      hipLaunchKernelGGL(pair_gram_kernel, grid, dim3(kWave), 0, stream, kind, B, Bp, d_X1 + so, d_s1 + so, d_r1 + so, n1,
+                         ldx1, d_X2 + so, d_s2 + so, d_r2 + so, n2, ldx2, intra, out, ldo, zsite, zout);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
-  dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 63) / 64));
-  hipLaunchKernelGGL(pair_gram_kernel, grid, dim3(kWave), 0, stream, kind, B, Bp, d_X1, d_s1, d_r1, n1, ldx1, d_X2,
-                     d_s2, d_r2, n2, ldx2, intra, d_out, ldo);
-  return hipGetLastError();
+  return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------ p-values

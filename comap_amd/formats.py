@@ -173,6 +173,39 @@ def write_null(out, stat, rcmin, prmin, nmin):
             fh.close()
 
 
+# --------------------------------------------------------------------------------------------------------- clustering
+def write_groups(out, groups, coords, is_constant, dmax, stat, nmin):
+    """clustering.output.groups.file: the DataTable of CoMap/CoMap.cpp:493-548 (no row names, tab separated).
+    groups: comap_amd.cluster.get_groups(merge, clustering.maximum_group_size); dmax / stat / nmin: per join."""
+    fh, close = _open(out, "w")
+    try:
+        fh.write("Group\tSize\tIsConstant\tDmax\tStat\tNmin\n")
+        for m, mem in groups:
+            const = any(bool(is_constant[i]) for i in mem)
+            fh.write("\t".join(["[" + ";".join(str(int(coords[i])) for i in mem) + "]", str(len(mem)),
+                                "yes" if const else "no", fmt(dmax[m]), fmt(stat[m]), fmt(nmin[m])]) + "\n")
+    finally:
+        if close:
+            fh.close()
+
+
+def write_cluster_null(out, null, max_group_size, rep_begin=0):
+    """clustering.null.output.file: ClusterTools::computeGlobalDistanceDistribution (CoMap/ClusterTools.cpp:219-220,
+    :283-289); groups are named by the position of their sites in the simulated data set.
+    null: engine.cluster_null(...) (arrays [nrep, nsites-1])."""
+    from .cluster import get_groups
+    fh, close = _open(out, "w")
+    try:
+        fh.write("Rep\tGroup\tSize\tDmax\tStat\tNmin\n")
+        for k in range(null["merge"].shape[0]):
+            for m, mem in get_groups(null["merge"][k], max_group_size):
+                fh.write("\t".join([str(rep_begin + k), "[" + ";".join(str(i) for i in mem) + "]", str(len(mem)),
+                                    fmt(null["dmax"][k][m]), fmt(null["stat"][k][m]), fmt(null["nmin"][k][m])]) + "\n")
+    finally:
+        if close:
+            fh.close()
+
+
 def to_text(writer, *args, **kw):
     buf = io.StringIO()
     writer(buf, *args, **kw)

@@ -249,6 +249,12 @@ class CorrectedCorrelationStatistic : public Statistic {
 class StatisticBasedDistance {
  public:
   StatisticBasedDistance(std::shared_ptr<Statistic> stat, double comp) : stat_(stat), comp_(comp) {}
+  // the distance as the device names it (CMX_DIST_*); only the distances CoMap.cpp:402-428 can construct exist there
+  int distanceKind() const {
+    if (stat_->kind() == CMX_STAT_CORRELATION && comp_ == 1.) return CMX_DIST_CORRELATION;
+    if (stat_->kind() == CMX_STAT_COMPENSATION && comp_ == 1.) return CMX_DIST_COMPENSATION;
+    throw Exception("StatisticBasedDistance: only 1 - Correlation and 1 - Compensation are clustering distances");
+  }
   Vdouble getDistancesForAllPairs(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping) const {
     Vdouble d = stat_->getValuesForAllPairs(eng, mapping);
     for (double& v : d) v = comp_ - v;
@@ -262,6 +268,7 @@ class StatisticBasedDistance {
 // CoMap/Distance.h:150-173
 class EuclidianDistance {
  public:
+  int distanceKind() const { return CMX_DIST_EUCLIDIAN; }
   Vdouble getDistancesForAllPairs(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping) const {
     const size_t n = mapping.getNumberOfSites();
     Vdouble out(n * n);
@@ -446,6 +453,118 @@ class CoETools {
 
 // ------------------------------------------------------------------------------------------------ text outputs
 // The files either side of the path, written with default ostream formatting exactly as the reference does.
+// ------------------------------------------------------------------------------------------------ clustering
+// bpp::HierarchicalClustering's method names as CoMap.cpp:460-472 passes them
+struct HierarchicalClustering {
+  static constexpr int COMPLETE = CMX_LINK_COMPLETE, SINGLE = CMX_LINK_SINGLE, AVERAGE = CMX_LINK_AVERAGE;
+};
+
+// The clustering tree with the node properties the reference attaches to it ("Stat", "Nmin"; Dmax = 2 * height):
+// leaves 0..n-1, join m creates node n+m with sons merge[2m], merge[2m+1] (include/comap_mi355x.h).
+struct ClusteringTree {
+  size_t n = 0;
+  std::vector<int32_t> merge, size;
+  Vdouble dmax, stat, nmin;
+  Vdouble distances;   // [n][n], only if asked for (clustering.output.matrix.file, CoMap.cpp:442-449)
+};
+
+// CoMap/ClusterTools.h:57-143 (the parts its callers read)
+struct Group {
+  std::vector<size_t> sites;   // positions in the mapping, in son order
+  size_t join = 0;             // index of the inner node
+  double dmax = 0, stat = 0, nmin = 0;
+  size_t size() const { return sites.size(); }
+  double getHeight() const { return dmax / 2.; }
+  std::string toString() const {
+    std::string t = "[";
+    for (size_t i = 0; i < sites.size(); ++i) t += (i ? ";" : "") + std::to_string(sites[i]);
+    return t + "]";
+  }
+  std::string toString(const std::vector<std::string>& names) const {
+    std::string t = "[";
+    for (size_t i = 0; i < sites.size(); ++i) t += (i ? ";" : "") + names[sites[i]];
+    return t + "]";
+  }
+};
+
+class ClusterTools {
+ public:
+  // distance matrix + clustering + node properties of the observed mapping: CoMap.cpp:432-491
+  template <class DistanceT>
+  static ClusteringTree cluster(const Engine& eng, const DistanceT& distance, int method,
+                                const ProbabilisticSubstitutionMapping& mapping, bool wantMatrix = false) {
+    ClusteringTree t;
+    t.n = mapping.getNumberOfSites();
+    if (t.n < 2) throw Exception("ClusterTools::cluster: at least two sites are needed");
+    t.merge.resize(2 * (t.n - 1)); t.size.resize(t.n - 1);
+    t.dmax.resize(t.n - 1); t.stat.resize(t.n - 1); t.nmin.resize(t.n - 1);
+    if (wantMatrix) t.distances.resize(t.n * t.n);
+    eng.check(cmx_cluster_sites(eng.ctx(), distance.distanceKind(), method, mapping.data(), t.n,
+                                wantMatrix ? t.distances.data() : nullptr, t.merge.data(), t.dmax.data(), t.size.data(),
+                                t.stat.data(), t.nmin.data()));
+    return t;
+  }
+
+  // ClusterTools::getGroups (ClusterTools.cpp:55-113): one group per inner node, sons first; members in son order
+  static std::vector<Group> getGroups(size_t n, const int32_t* merge, const double* dmax, const double* stat,
+                                      const double* nmin) {
+    std::vector<Group> groups;
+    if (n < 2) return groups;
+    std::vector<std::vector<size_t>> members(2 * n - 1);
+    for (size_t i = 0; i < n; ++i) members[i] = {i};
+    // joins are already in an order where sons precede their parent; the reference's order is the post-order walk
+    std::vector<std::pair<size_t, bool>> stack{{2 * n - 2, false}};
+    while (!stack.empty()) {
+      auto [node, seen] = stack.back();
+      stack.pop_back();
+      if (node < n) continue;
+      const size_t a = static_cast<size_t>(merge[2 * (node - n)]), b = static_cast<size_t>(merge[2 * (node - n) + 1]);
+      if (!seen) {
+        stack.push_back({node, true});
+        stack.push_back({b, false});
+        stack.push_back({a, false});
+      } else {
+        members[node] = members[a];
+        members[node].insert(members[node].end(), members[b].begin(), members[b].end());
+        if (a >= n) std::vector<size_t>().swap(members[a]);
+        if (b >= n) std::vector<size_t>().swap(members[b]);
+        Group g;
+        g.sites = members[node];
+        g.join = node - n;
+        g.dmax = dmax[g.join]; g.stat = stat[g.join]; g.nmin = nmin[g.join];
+        groups.push_back(std::move(g));
+      }
+    }
+    return groups;
+  }
+  static std::vector<Group> getGroups(const ClusteringTree& t) {
+    return getGroups(t.n, t.merge.data(), t.dmax.data(), t.stat.data(), t.nmin.data());
+  }
+
+  // ClusterTools::computeGlobalDistanceDistribution (ClusterTools.cpp:200-294): the rows of the null file go to *out
+  // (may be null).  All replicates are simulated, mapped and clustered on the device; seed replaces the reference's
+  // global RandomTools state.
+  template <class DistanceT>
+  static void computeGlobalDistanceDistribution(const Engine& eng, const DistanceT& distance, int method, uint64_t seed,
+                                                size_t sizeOfDataSet, size_t nrep, size_t maxGroupSize,
+                                                std::ostream* out) {
+    if (sizeOfDataSet < 2 || nrep == 0) throw Exception("computeGlobalDistanceDistribution: nothing to do");
+    const size_t nm = sizeOfDataSet - 1;
+    std::vector<int32_t> merge(2 * nm * nrep), size(nm * nrep);
+    Vdouble dmax(nm * nrep), stat(nm * nrep), nmin(nm * nrep);
+    eng.check(cmx_cluster_null(eng.ctx(), distance.distanceKind(), method, seed, 0, nrep, sizeOfDataSet, merge.data(),
+                               dmax.data(), size.data(), stat.data(), nmin.data()));
+    if (!out) return;
+    *out << "Rep\tGroup\tSize\tDmax\tStat\tNmin" << std::endl;
+    for (size_t k = 0; k < nrep; ++k)
+      for (const Group& g : getGroups(sizeOfDataSet, &merge[2 * nm * k], &dmax[nm * k], &stat[nm * k], &nmin[nm * k])) {
+        if (g.size() > maxGroupSize) continue;
+        *out << k << "\t" << g.toString() << "\t" << g.size() << "\t" << g.dmax << "\t" << g.stat << "\t" << g.nmin
+             << std::endl;
+      }
+  }
+};
+
 namespace io {
 // LegacySubstitutionMappingTools::writeToStream as called at CoETools.cpp:408-412 (format: one row per branch)
 inline void writeToStream(const ProbabilisticSubstitutionMapping& mapping, const Vdouble& branchLengths,
@@ -481,6 +600,19 @@ inline void writeIntraStats(const std::vector<IntraStatRow>& rows, const std::ve
   }
 }
 // statistics.null.txt: AnalysisTools.cpp:580, 642 (inter: :680, 732)
+// clustering.output.groups.file: the DataTable of CoMap.cpp:493-548
+inline void writeGroups(const std::vector<Group>& groups, const std::vector<std::string>& siteNames,
+                        const std::vector<bool>& isConstant, size_t maxGroupSize, std::ostream& out) {
+  out << "Group\tSize\tIsConstant\tDmax\tStat\tNmin\n";
+  for (const Group& g : groups) {
+    if (g.size() > maxGroupSize) continue;
+    bool c = false;
+    for (size_t s : g.sites) c = c || isConstant[s];
+    out << g.toString(siteNames) << "\t" << g.size() << "\t" << (c ? "yes" : "no") << "\t" << g.dmax << "\t" << g.stat
+        << "\t" << g.nmin << "\n";
+  }
+}
+
 inline void writeNull(const std::vector<NullDistributionRow>& rows, std::ostream& out) {
   out << "Stat\tRCmin\tPRmin\tNmin" << std::endl;
   for (const NullDistributionRow& r : rows) out << r.stat << "\t" << r.rcMin << "\t" << r.prMin << "\t" << r.nMin << std::endl;

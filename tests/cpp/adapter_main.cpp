@@ -1,6 +1,9 @@
 // Test driver for include/comap_mi355x_adapter.hpp (the C++ mirror of the reference's interface).
 //   adapter_main domain <lo> <hi> <n> <x>...         -> prints getIndex(x) or -1 per x (host logic only, no GPU)
 //   adapter_main run <input.bin> <output.bin>        -> getVectors + computeIntraStats with null on the GPU
+//   adapter_main groups <tree.bin>                   -> ClusterTools::getGroups + io::writeGroups to stdout (host only);
+//      tree.bin: int32 n, maxGroupSize; int32 merge[2(n-1)]; f64 dmax, stat, nmin [n-1]; int32 coords[n], isConstant[n]
+//   adapter_main clusternull <input.bin> cor|euclidian <method> <nsites> <nrep> <maxsize>   -> null groups file (GPU)
 //   adapter_main vec <input.bin>                     -> cmx::io::writeToStream of a mapping to stdout (host only);
 //      input.bin: int32 N, B; int32 coords[N]; f64 blen[B]; f64 counts[N*B] (site-major)
 // input.bin (little endian): int32 nn, T, S, C, N, repCPU, repRAM, nclasses; uint64 seed;
@@ -66,6 +69,49 @@ int main(int argc, char** argv) {
       wr(out, mapping->data(), static_cast<size_t>(N) * eng.getNumberOfBranches());
       cmx::Vdouble norms = cmx::AnalysisTools::computeNorms(*mapping);
       wr(out, norms.data(), norms.size());
+      return 0;
+    }
+    if (argc == 3 && std::strcmp(argv[1], "groups") == 0) {   // host only: a clustering tree -> the groups table
+      std::ifstream in(argv[2], std::ios::binary);
+      int32_t h[2];
+      rd(in, h, 2);
+      const size_t n = h[0], maxSize = h[1];
+      cmx::ClusteringTree t;
+      t.n = n;
+      t.merge.resize(2 * (n - 1)); t.dmax.resize(n - 1); t.stat.resize(n - 1); t.nmin.resize(n - 1);
+      std::vector<int32_t> coords(n), isc(n);
+      rd(in, t.merge.data(), t.merge.size()); rd(in, t.dmax.data(), n - 1); rd(in, t.stat.data(), n - 1);
+      rd(in, t.nmin.data(), n - 1); rd(in, coords.data(), n); rd(in, isc.data(), n);
+      std::vector<std::string> names(n);
+      std::vector<bool> isConst(n);
+      for (size_t i = 0; i < n; ++i) { names[i] = std::to_string(coords[i]); isConst[i] = isc[i] != 0; }
+      cmx::io::writeGroups(cmx::ClusterTools::getGroups(t), names, isConst, maxSize, std::cout);
+      return 0;
+    }
+    if (argc == 8 && std::strcmp(argv[1], "clusternull") == 0) {   // GPU: <input.bin of "run"> dist method nsites nrep maxsize
+      std::ifstream in(argv[2], std::ios::binary);
+      int32_t h[8];
+      uint64_t seed;
+      rd(in, h, 8);
+      rd(in, &seed, 1);
+      const int nn = h[0], T = h[1], S = h[2], C = h[3];
+      cmx::TreeArrays t;
+      cmx::ModelArrays m;
+      t.parent.resize(nn); t.branchLengths.resize(nn); t.leafOfTaxon.resize(T);
+      rd(in, t.parent.data(), nn); rd(in, t.branchLengths.data(), nn); rd(in, t.leafOfTaxon.data(), T);
+      m.nbStates = S;
+      m.generator.resize(S * S); m.frequencies.resize(S); m.rates.resize(C); m.rateProbabilities.resize(C);
+      rd(in, m.generator.data(), S * S); rd(in, m.frequencies.data(), S); rd(in, m.rates.data(), C);
+      rd(in, m.rateProbabilities.data(), C);
+      cmx::Engine eng(t, m, 0);
+      const int method = std::atoi(argv[4]);
+      const size_t nsites = std::atoi(argv[5]), nrep = std::atoi(argv[6]), maxSize = std::atoi(argv[7]);
+      if (std::strcmp(argv[3], "euclidian") == 0)
+        cmx::ClusterTools::computeGlobalDistanceDistribution(eng, cmx::EuclidianDistance(), method, seed, nsites, nrep, maxSize, &std::cout);
+      else
+        cmx::ClusterTools::computeGlobalDistanceDistribution(
+            eng, cmx::StatisticBasedDistance(std::make_shared<cmx::CorrelationStatistic>(), 1.), method, seed, nsites, nrep,
+            maxSize, &std::cout);
       return 0;
     }
     if (argc == 3 && std::strcmp(argv[1], "vec") == 0) {

@@ -161,3 +161,31 @@ def test_cluster_null_does_not_depend_on_how_replicates_are_sharded():
     c = eng.cluster_null(oc.DIST_CORRELATION, oc.LINK_COMPLETE, 9, 3, 6, 50)
     for k in a:
         assert np.array_equal(a[k], np.concatenate([b[k], c[k]]))
+
+
+def test_cpp_cluster_null_writes_the_same_table_as_python(tmp_path):
+    """cmx::ClusterTools::computeGlobalDistanceDistribution (C++ mirror) == engine.cluster_null + formats writer"""
+    import struct
+    import subprocess
+    from comap_amd import formats
+    from conftest import make_case
+    from test_adapter_cpp import EXE, ROOT
+    import os
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+                           "-L", os.path.dirname(engine.LIB_PATH), "-lcomap_mi355x",
+                           "-Wl,-rpath," + os.path.dirname(engine.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    case = make_case(9, 4, 20, 61)
+    nn, T, S, C = len(case["parent"]), len(case["lot"]), 20, 4
+    seed, nsites, nrep, maxsize = 99, 45, 3, 6
+    inp = tmp_path / "in.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<8i", nn, T, S, C, 4, 1, 1, 1) + struct.pack("<Q", seed))
+        f.write(case["parent"].astype(np.int32).tobytes() + case["blen"].tobytes() + case["lot"].astype(np.int32).tobytes())
+        f.write(case["Q"].tobytes() + case["pi"].tobytes() + case["rates"].tobytes() + case["probs"].tobytes())
+    eng = engine.Engine(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    for name, dist in (("cor", oc.DIST_CORRELATION), ("euclidian", oc.DIST_EUCLIDIAN)):
+        got = subprocess.run([EXE, "clusternull", str(inp), name, str(oc.LINK_AVERAGE), str(nsites), str(nrep), str(maxsize)],
+                             capture_output=True, text=True, check=True).stdout
+        exp = formats.to_text(formats.write_cluster_null, eng.cluster_null(dist, oc.LINK_AVERAGE, seed, 0, nrep, nsites), maxsize)
+        assert got == exp and got.count("\n") > nrep
