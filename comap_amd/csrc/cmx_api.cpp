@@ -881,6 +881,72 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
 }
 
 
+// ------------------------------------------------------------------------------------------------ Mica post-processing
+cmx_status cmx_mica_average_mi_dev(cmx_ctx* ctx, const double* d_mi, size_t n, size_t ldo, double* d_average,
+                                   double* d_full_average, void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!d_mi || n < 2 || ldo < n || !d_average || !d_full_average) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_average_mi: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, launch_mica_average(d_mi, n, ldo, d_average, d_full_average, (hipStream_t)stream));
+  return CMX_OK;
+}
+
+cmx_status cmx_mica_average_mi(cmx_ctx* ctx, const double* mi, size_t n, double* average, double* full_average) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!mi || n < 2 || !average || !full_average) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_average_mi: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  TmpDev tmp;
+  double *d_mi, *d_avg, *d_full;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_mi, sizeof(double) * n * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_avg, sizeof(double) * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_full, sizeof(double)));
+  HIP_TRY(ctx, hipMemcpy(d_mi, mi, sizeof(double) * n * n, hipMemcpyHostToDevice));
+  cmx_status s = cmx_mica_average_mi_dev(ctx, d_mi, n, n, d_avg, d_full, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(average, d_avg, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(full_average, d_full, sizeof(double), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+cmx_status cmx_mica_zscore_null_dev(cmx_ctx* ctx, int which, const double* d_mi, size_t n, size_t ldo, const double* d_average,
+                                    const double* d_full_average, const double* d_key, double* d_null_stat,
+                                    double* d_null_key, void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (which < CMX_MICA_MI || which > CMX_MICA_MIC) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_zscore_null: unknown statistic");
+  if (!d_mi || n < 2 || ldo < n || !d_key || !d_null_stat || !d_null_key || (which != CMX_MICA_MI && (!d_average || !d_full_average)))
+    return fail(ctx, CMX_ERR_INVALID, "cmx_mica_zscore_null: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, launch_mica_zscore(which, d_mi, n, ldo, d_average, d_full_average, d_key, d_null_stat, d_null_key,
+                                  (hipStream_t)stream));
+  return CMX_OK;
+}
+
+cmx_status cmx_mica_zscore_null(cmx_ctx* ctx, int which, const double* mi, size_t n, const double* key, double* null_stat,
+                                double* null_key) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!mi || n < 2 || !key || !null_stat || !null_key) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_zscore_null: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t np = n * (n - 1) / 2;
+  TmpDev tmp;
+  double *d_mi, *d_avg, *d_full, *d_key, *d_ns, *d_nk;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_mi, sizeof(double) * n * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_avg, sizeof(double) * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_full, sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_key, sizeof(double) * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_ns, sizeof(double) * np));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_nk, sizeof(double) * np));
+  HIP_TRY(ctx, hipMemcpy(d_mi, mi, sizeof(double) * n * n, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_key, key, sizeof(double) * n, hipMemcpyHostToDevice));
+  cmx_status s = cmx_mica_average_mi_dev(ctx, d_mi, n, n, d_avg, d_full, nullptr);
+  if (s != CMX_OK) return s;
+  if ((s = cmx_mica_zscore_null_dev(ctx, which, d_mi, n, n, d_avg, d_full, d_key, d_ns, d_nk, nullptr)) != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(null_stat, d_ns, sizeof(double) * np, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(null_key, d_nk, sizeof(double) * np, hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ clustering
 static cmx_status check_cluster(cmx_ctx* ctx, int dist_kind, int linkage, size_t n) {
   if (dist_kind < CMX_DIST_CORRELATION || dist_kind > CMX_DIST_EUCLIDIAN) return fail(ctx, CMX_ERR_INVALID, "unknown clustering distance");

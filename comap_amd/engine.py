@@ -42,6 +42,7 @@ EXPORTS = [
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
+    "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
 ]
 # clustering.distance / clustering.method options of the reference (CoMap/CoMap.cpp:402-428, :460-472)
@@ -51,6 +52,7 @@ DIST_BY_NAME = {"cor": DIST_CORRELATION, "Correlation": DIST_CORRELATION, "comp"
                 "Compensation": DIST_COMPENSATION, "euclidian": DIST_EUCLIDIAN, "Euclidian": DIST_EUCLIDIAN}
 LINK_BY_NAME = {"complete": LINK_COMPLETE, "single": LINK_SINGLE, "average": LINK_AVERAGE}
 CLUSTER_MAX_SITES = 5000
+MICA_MI, MICA_MIP, MICA_MIC = range(3)      # null.method_zscore.stat (Mica.cpp:551-559)
 
 
 class CmxError(RuntimeError):
@@ -323,6 +325,23 @@ class Engine:
                                            _vp(a1), _sz(n1), _vp(a2), _sz(0 if a2 is None else a2.shape[1]), _vp(i1),
                                            _vp(i2), _sz(len(i1)), _vp(mi), _vp(hj)))
         return dict(mi=mi, hjoint=hj)
+
+    # -- Mica after the all-pairs matrix
+    def mica_average_mi(self, mi):
+        """-> (averageMI [n], fullAverageMI) (Mica.cpp:346-363); mi: [n, n], upper triangle read"""
+        m = _f64(mi)
+        n = m.shape[0]
+        avg, full = np.zeros(n), np.zeros(1)
+        self._check(self._lib.cmx_mica_average_mi(self._ctx, _vp(m), _sz(n), _vp(avg), _vp(full)))
+        return avg, float(full[0])
+
+    def mica_zscore_null(self, which, mi, key):
+        """null.method = z-score (Mica.cpp:549-607) -> (null_stat, null_key) [n(n-1)/2]; which: MICA_MI / MIP / MIC"""
+        m, k = _f64(mi), _f64(key)
+        n = m.shape[0]
+        ns, nk = np.zeros(n * (n - 1) // 2), np.zeros(n * (n - 1) // 2)
+        self._check(self._lib.cmx_mica_zscore_null(self._ctx, int(which), _vp(m), _sz(n), _vp(k), _vp(ns), _vp(nk)))
+        return ns, nk
 
     # -- clustering analysis
     def hclust(self, dist, linkage):

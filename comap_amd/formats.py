@@ -173,6 +173,30 @@ def write_null(out, stat, rcmin, prmin, nmin):
             fh.close()
 
 
+# --------------------------------------------------------------------------------------------------------- Mica
+def write_mica(out, coords, res):
+    """Mica's output.file (CoMap/Mica.cpp:634-690).  res: comap_amd.mica.analysis(...)."""
+    n = len(coords)
+    mi, hj, h, avg, full = res["mi"], res["hjoint"], res["entropy"], res["average_mi"], res["full_average_mi"]
+    norms, pv = res.get("norms"), res.get("pvalue")
+    fh, close = _open(out, "w")
+    try:
+        fh.write("Group\tMI\tAPC\tRCW\tHjoint\tHmin" + ("\tNmin" if norms is not None else "") +
+                 ("\tBs.p.value\tBs.nb" if pv is not None else "") + "\n")
+        for i in range(n - 1):
+            for j in range(i + 1, n):
+                f = ["[%d;%d]" % (int(coords[i]), int(coords[j])), fmt(mi[i, j]), fmt(avg[i] * avg[j] / full),
+                     fmt(avg[i] * avg[j] / 2.0), fmt(hj[i, j]), fmt(min(h[i], h[j]))]
+                if norms is not None:
+                    f.append(fmt(min(norms[i], norms[j])))
+                if pv is not None:
+                    f += ["NA", "0"] if math.isnan(pv[i, j]) else [fmt(pv[i, j]), str(int(res["nsim"][i, j]))]
+                fh.write("\t".join(f) + "\n")
+    finally:
+        if close:
+            fh.close()
+
+
 # --------------------------------------------------------------------------------------------------------- clustering
 def write_groups(out, groups, coords, is_constant, dmax, stat, nmin):
     """clustering.output.groups.file: the DataTable of CoMap/CoMap.cpp:493-548 (no row names, tab separated).

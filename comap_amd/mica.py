@@ -8,6 +8,7 @@
 
 Site indices come from the engine's counter-based generator scheme (Philox keyed by seed), not from Bio++'s global
 generator: null distributions agree with the reference in distribution, not draw for draw.
+  zscore_null / analysis  <- null.method = z-score, CoMap/Mica.cpp:549-607, and the output table of :634-690
 The permutation test (miTest, Mica.cpp:93-118) is sequential per pair and is not offered."""
 import numpy as np
 
@@ -42,3 +43,25 @@ def parametric_null(engine, seed, nrep_cpu=10, nrep_ram=100, nalpha=20):
         mi.append(r["mi"])
         hj.append(r["hjoint"])
     return dict(mi=np.concatenate(mi), hjoint=np.concatenate(hj))
+
+
+def analysis(engine, aln, nalpha=20, masks=None, norms=None, null=None, nclasses=10):
+    """The table Mica writes (Mica.cpp:634-690) as dense arrays: MI, Hjoint per pair, entropy / averageMI per column,
+    fullAverageMI, and -- if `null` = (null_stat, null_key) is given -- Bs.p.value / Bs.nb per pair, binned on the
+    model norms when given (withModel) and on min entropy otherwise (Mica.cpp:383-386, 672).  All numbers come from the
+    device entry points; comap_amd.formats.write_mica turns the result into the reference's text."""
+    r = engine.mi_columns(aln, None, nalpha, masks)
+    avg, full = engine.mica_average_mi(r["mi"])
+    out = dict(mi=r["mi"], hjoint=r["hjoint"], entropy=r["h1"], average_mi=avg, full_average_mi=full,
+               norms=None if norms is None else np.asarray(norms, dtype=np.float64))
+    if null is not None:
+        key = out["entropy"] if norms is None else out["norms"]
+        out["pvalue"], out["nsim"] = engine.intra_pvalues(r["mi"], key, nclasses, null[0], null[1])
+    return out
+
+
+def zscore_null(engine, mi, entropy, which="MIp", norms=None):
+    """-> (null_stat, null_key): every pair of the data set as one draw of the null (Mica.cpp:565-603)."""
+    from .engine import MICA_MI, MICA_MIP, MICA_MIC
+    kind = {"MI": MICA_MI, "MIp": MICA_MIP, "MIc": MICA_MIC}[which]
+    return engine.mica_zscore_null(kind, mi, entropy if norms is None else norms)

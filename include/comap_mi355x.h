@@ -207,6 +207,25 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
                         size_t n1, const uint8_t* aln2, size_t n2, const int64_t* idx1, const int64_t* idx2,
                         size_t npairs, double* mi, double* hjoint);
 
+/* ---- Mica, after the all-pairs matrix (intra, n columns, upper triangle j > i is what is read):
+ * cmx_mica_average_mi: averageMI[i] = sum_{j != i} MI(i,j) / (n-1) and fullAverageMI = mean(averageMI)
+ * (CoMap/Mica.cpp:346-363); the APC and RCW columns of the output are averageMI[i]*averageMI[j]/fullAverageMI and
+ * averageMI[i]*averageMI[j]/2 (Mica.cpp:656-657).
+ * cmx_mica_zscore_null: null.method = z-score (Mica.cpp:549-607): every pair of the data set is one draw; `which`
+ * selects null.method_zscore.stat (MI, MIp = MI - APC, MIc = MI / RCW); key = entropy per column, or the norms when a
+ * model is used (Mica.cpp:573-601).  Outputs [n(n-1)/2] in the reference's (i, j) order: the statistic and
+ * min(key[i], key[j]).  p-values (Mica.cpp:671-683) then come from cmx_intra_pvalues(_dev) with stat = the MI
+ * matrix and norms = key: same Domain(0, max(key), null.nb_rate_classes) binning, same count, same "NA". */
+enum { CMX_MICA_MI = 0, CMX_MICA_MIP = 1, CMX_MICA_MIC = 2 };
+cmx_status cmx_mica_average_mi_dev(cmx_ctx* ctx, const double* d_mi, size_t n, size_t ldo, double* d_average,
+                                   double* d_full_average, void* stream);
+cmx_status cmx_mica_average_mi(cmx_ctx* ctx, const double* mi, size_t n, double* average, double* full_average);
+cmx_status cmx_mica_zscore_null_dev(cmx_ctx* ctx, int which, const double* d_mi, size_t n, size_t ldo,
+                                    const double* d_average, const double* d_full_average, const double* d_key,
+                                    double* d_null_stat, double* d_null_key, void* stream);
+cmx_status cmx_mica_zscore_null(cmx_ctx* ctx, int which, const double* mi, size_t n, const double* key,
+                                double* null_stat, double* null_key);
+
 /* ---- clustering analysis (CoMap/CoMap.cpp:395-560; null: ClusterTools::computeGlobalDistanceDistribution,
  * CoMap/ClusterTools.cpp:200-294).  Distances of CoMap.cpp:402-428: 1 - correlation (StatisticBasedDistance(cor, 1.),
  * Distance.h:321-336), 1 - compensation (CompensationDistance, Distance.h:376-385), Euclidian (Distance.h:161-181).

@@ -201,3 +201,28 @@ def mi_columns(aln1, aln2, A, masks=None):
     lib().orc_mi_columns(T, A, _p(masks, ctypes.c_uint32), ctypes.c_long(N1), _p(aln1, ctypes.c_uint8),
                          ctypes.c_long(N2), _p(aln2, ctypes.c_uint8), _p(mi, D), _p(hj, D), _p(h1, D), _p(h2, D))
     return dict(mi=mi, hjoint=hj, h1=h1, h2=h2)
+
+
+def mica_average_mi(mi):
+    """averageMI / fullAverageMI of CoMap/Mica.cpp:346-363 (mi: [n, n], upper triangle used)."""
+    m = np.triu(np.asarray(mi, dtype=np.float64), 1)
+    m = m + m.T
+    n = m.shape[0]
+    avg = np.array([(m[i, :i].sum() + m[i, i + 1:].sum()) / (n - 1) for i in range(n)])
+    return avg, float(avg.mean())
+
+
+def mica_zscore_null(which, mi, key):
+    """null.method = z-score, CoMap/Mica.cpp:565-603: (statistic, min key) of every pair i < j in row order;
+    which: 0 MI, 1 MIp = MI - APC, 2 MIc = MI / RCW."""
+    mi = np.asarray(mi, dtype=np.float64)
+    avg, full = mica_average_mi(mi)
+    iu = np.triu_indices(mi.shape[0], 1)
+    v = mi[iu].copy()
+    if which == 1:
+        v = v - avg[iu[0]] * avg[iu[1]] / full
+    elif which == 2:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = v / (avg[iu[0]] * avg[iu[1]] / 2.0)
+    key = np.asarray(key, dtype=np.float64)
+    return v, np.minimum(key[iu[0]], key[iu[1]])

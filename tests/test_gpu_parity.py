@@ -439,6 +439,47 @@ def test_mica_bootstrap_nulls_match_oracle():
         rel_close(pn["hjoint"][rep * 50:(rep + 1) * 50], np.diag(o["hjoint"]), 1e-6, 1e-12)
 
 
+@pytest.mark.parametrize("with_model", [False, True])
+def test_mica_zscore_null_and_output_table(with_model):
+    """null.method = z-score (Mica.cpp:549-607) and the rows of Mica's output file (:634-690): average MI, APC, RCW,
+    Hmin / Nmin, Bs.p.value, against the oracle's column MI and p-value restatement"""
+    from comap_amd import formats, mica
+    rng = np.random.default_rng(21)
+    T, n, ncls = 40, 37, 4
+    base = rng.integers(0, 20, size=(T, 1))
+    aln = np.where(rng.random((T, n)) < 0.5, base, rng.integers(0, 20, size=(T, n))).astype(np.uint8)
+    aln[:, 5] = 3                                            # a constant column: entropy 0, MI 0
+    eng = engine.Engine()
+    o = oracle.mi_columns(aln, aln, 20)
+    norms = rng.uniform(0.0, 3.0, size=n) if with_model else None
+    key = norms if with_model else o["h1"]
+    r0 = mica.analysis(eng, aln, norms=norms)
+    avg, full = oracle.mica_average_mi(o["mi"])
+    rel_close(r0["average_mi"], avg, 1e-6, 1e-12)
+    assert abs(r0["full_average_mi"] - full) <= 1e-6 * full
+    for which, name in enumerate(("MI", "MIp", "MIc")):
+        ns, nk = mica.zscore_null(eng, r0["mi"], r0["entropy"], name, norms=norms)
+        os_, ok = oracle.mica_zscore_null(which, o["mi"], key)
+        assert ns.shape == (n * (n - 1) // 2,)
+        iu0 = np.triu_indices(n, 1)
+        fin = np.isfinite(os_) & (iu0[0] != 5) & (iu0[1] != 5)   # MIc divides by the constant column's zero average MI
+        rel_close(ns[fin], os_[fin], 1e-6, 1e-12)
+        rel_close(nk, ok, 1e-6, 0.0)
+    ns, nk = mica.zscore_null(eng, r0["mi"], r0["entropy"], "MI", norms=norms)
+    res = mica.analysis(eng, aln, norms=norms, null=(ns, nk), nclasses=ncls)
+    po, no = oracle.intra_pvalues(res["mi"], key if with_model else res["entropy"], ncls, ns, nk)
+    iu = np.triu_indices(n, 1)
+    assert np.array_equal(res["nsim"][iu], no[iu])
+    assert np.array_equal(res["pvalue"][iu], po[iu], equal_nan=True)
+    txt = formats.to_text(formats.write_mica, np.arange(1, n + 1), res)
+    lines = txt.split("\n")
+    assert lines[0] == "Group\tMI\tAPC\tRCW\tHjoint\tHmin" + ("\tNmin" if with_model else "") + "\tBs.p.value\tBs.nb"
+    assert len(lines) == n * (n - 1) // 2 + 2 and lines[1].startswith("[1;2]\t")
+    f = lines[1].split("\t")
+    assert f[2] == formats.fmt(r0["average_mi"][0] * r0["average_mi"][1] / r0["full_average_mi"])
+    assert f[3] == formats.fmt(r0["average_mi"][0] * r0["average_mi"][1] / 2.0)
+
+
 def test_mi_columns_matches_oracle_with_ambiguity():
     rng = np.random.default_rng(3)
     T, n1, n2 = 40, 37, 21
