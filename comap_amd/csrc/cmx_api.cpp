@@ -881,6 +881,193 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
 }
 
 
+// ------------------------------------------------------------------------------------------------ groups of sites
+cmx_status cmx_group_stats_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts, size_t n, size_t ldc,
+                               const int64_t* d_offsets, const int32_t* d_sites, size_t ngroups, double* d_out, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
+  if (!d_counts || n == 0 || ldc < n || !d_offsets || !d_sites || !d_out) return fail(ctx, CMX_ERR_INVALID, "cmx_group_stats: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  const double* d_mean = nullptr;
+  if ((s = stat_mean_vectors(ctx, kind, params, &d_mean)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_group_stats(kind, param, ctx->hm.B, ctx->hm.K, d_counts, ldc, d_offsets, d_sites, ngroups, d_out, d_mean,
+                                  (hipStream_t)stream));
+  return CMX_OK;
+}
+
+static cmx_status check_groups(cmx_ctx* ctx, const int64_t* offsets, const int32_t* sites, size_t ngroups, size_t n) {
+  if (offsets[0] != 0) return fail(ctx, CMX_ERR_INVALID, "groups: offsets[0] must be 0");
+  for (size_t g = 0; g < ngroups; ++g)
+    if (offsets[g + 1] < offsets[g]) return fail(ctx, CMX_ERR_INVALID, "groups: offsets must not decrease");
+  if (sites)
+    for (int64_t q = 0; q < offsets[ngroups]; ++q)
+      if (sites[q] < 0 || (size_t)sites[q] >= n) return fail(ctx, CMX_ERR_INVALID, "groups: site index out of range");
+  return CMX_OK;
+}
+
+cmx_status cmx_group_stats(cmx_ctx* ctx, int kind, const double* params, const double* counts, size_t n, const int64_t* offsets,
+                           const int32_t* sites, size_t ngroups, double* out) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!counts || n == 0 || !offsets || !sites || !out) return fail(ctx, CMX_ERR_INVALID, "cmx_group_stats: bad arguments");
+  if (ngroups == 0) return CMX_OK;
+  if ((s = check_groups(ctx, offsets, sites, ngroups, n)) != CMX_OK) return s;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t BK = (size_t)ctx->hm.B * ctx->hm.K;
+  std::vector<double> bm;
+  to_branch_major(counts, n, BK, &bm);
+  TmpDev tmp;
+  double *d_c, *d_out;
+  int64_t* d_off;
+  int32_t* d_sites;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_c, sizeof(double) * bm.size()));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_out, sizeof(double) * ngroups));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_off, sizeof(int64_t) * (ngroups + 1)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_sites, sizeof(int32_t) * (size_t)offsets[ngroups]));
+  HIP_TRY(ctx, hipMemcpy(d_c, bm.data(), sizeof(double) * bm.size(), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_off, offsets, sizeof(int64_t) * (ngroups + 1), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_sites, sites, sizeof(int32_t) * (size_t)offsets[ngroups], hipMemcpyHostToDevice));
+  if ((s = cmx_group_stats_dev(ctx, kind, params, d_c, n, n, d_off, d_sites, ngroups, d_out, nullptr)) != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, d_out, sizeof(double) * ngroups, hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+namespace {
+// The bookkeeping of CandidateGroupSet (CoMap/CoETools.h:139-300, CoETools.cpp:900-1038) on norms alone: which
+// simulated site goes to which candidate site, and which pseudo-groups are thereby completed.  Whether a completed
+// pseudo-group also counts for n1 needs its statistic -- evaluated afterwards for the whole batch on the device.
+struct CandidateCursor {
+  size_t G = 0;
+  const int64_t* off = nullptr;
+  const double *lo = nullptr, *hi = nullptr;
+  const uint8_t* usable = nullptr;
+  uint32_t min_sim = 0, completed = 0, n_usable = 0, trials = 0;
+  size_t gpos = 0, spos = 0;                       // the reference's groupPos_ / sitePos_ (kept across batches)
+  std::vector<uint32_t> n2;
+  std::vector<std::vector<int32_t>> waiting;       // per candidate site: simulated sites not yet used, oldest first
+  std::vector<size_t> head;                        // per candidate site: first unused entry of `waiting`
+  std::vector<int64_t> pg_off;                     // completed pseudo-groups of the current batch
+  std::vector<int32_t> pg_sites, pg_group;
+
+  size_t gsize(size_t g) const { return (size_t)(off[g + 1] - off[g]); }
+  bool open(size_t g) const { return n2[g] < min_sim && usable[g]; }
+  // nextCandidateSite: step to the next site of the current group (or the next group), then skip groups that are
+  // complete or not analysable.  false: no group is left (the reference throws)
+  bool advance() {
+    if (n2[gpos] < min_sim && ++spos >= gsize(gpos)) { gpos = (gpos + 1) % G; spos = 0; }
+    if (!open(gpos)) {
+      const size_t start = gpos;
+      do {
+        gpos = (gpos + 1) % G;
+        if (gpos == start) return false;
+      } while (!open(gpos));
+      spos = 0;
+    }
+    return true;
+  }
+  // addSimulatedSite: true if the group now has one simulated site for each of its members
+  bool give(size_t g, size_t sidx, int32_t sim) {
+    waiting[off[g] + sidx].push_back(sim);
+    for (size_t q = off[g]; q < (size_t)off[g + 1]; ++q)
+      if (head[q] >= waiting[q].size()) return false;
+    for (size_t q = off[g]; q < (size_t)off[g + 1]; ++q) pg_sites.push_back(waiting[q][head[q]++]);
+    pg_off.push_back((int64_t)pg_sites.size());
+    pg_group.push_back((int32_t)g);
+    if (++n2[g] == min_sim) ++completed;
+    return true;
+  }
+  // analyseSimulations: 1 more batches needed, 0 done, -1 cursor error
+  int batch(const double* norms, size_t nsim) {
+    pg_off.assign(1, 0); pg_sites.clear(); pg_group.clear();
+    bool more = true, nothing = true;
+    for (size_t i = 0; more && i < nsim; ++i) {
+      bool first = true, hit = false;
+      size_t g0 = 0, s0 = 0;
+      while (more && !hit) {
+        if (!advance()) return -1;
+        if (first) { g0 = gpos; s0 = spos; first = false; }
+        else if (gpos == g0 && spos == s0) break;              // went round the whole set: this site fits nowhere
+        const size_t q = off[gpos] + spos;
+        hit = norms[i] >= lo[q] && norms[i] <= hi[q];
+        if (hit) {
+          if (give(gpos, spos, (int32_t)i)) nothing = false;
+          if (completed == n_usable) more = false;
+        }
+      }
+    }
+    if (nothing) ++trials;
+    for (size_t q = 0; q < waiting.size(); ++q) { waiting[q].clear(); head[q] = 0; }   // resetSimulations
+    return more ? 1 : 0;
+  }
+};
+}  // namespace
+
+cmx_status cmx_candidate_groups(cmx_ctx* ctx, int kind, const double* params, size_t ngroups, const int64_t* offsets,
+                                const double* norm_lo, const double* norm_hi, const uint8_t* analysable,
+                                const double* observed, uint32_t min_sim, size_t rep_ram, uint32_t max_trials,
+                                uint64_t max_batches, uint64_t seed, uint32_t* n1, uint32_t* n2, uint32_t* trials,
+                                uint64_t* batches) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
+  if (ngroups == 0 || !offsets || !norm_lo || !norm_hi || !analysable || !observed || min_sim == 0 || rep_ram == 0 || !n1 || !n2)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_candidate_groups: bad arguments");
+  if ((s = check_groups(ctx, offsets, nullptr, ngroups, 0)) != CMX_OK) return s;
+  CandidateCursor cur;
+  cur.G = ngroups; cur.off = offsets; cur.lo = norm_lo; cur.hi = norm_hi; cur.usable = analysable; cur.min_sim = min_sim;
+  cur.n2.assign(ngroups, 0);
+  cur.waiting.resize((size_t)offsets[ngroups]);
+  cur.head.assign((size_t)offsets[ngroups], 0);
+  for (size_t g = 0; g < ngroups; ++g) {
+    if (analysable[g] && cur.gsize(g) == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_candidate_groups: an analysable group is empty");
+    if (analysable[g]) ++cur.n_usable;
+  }
+  if (cur.n_usable == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_candidate_groups: no analysable group");
+  std::fill(n1, n1 + ngroups, 0u);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const HostModel& h = ctx->hm;
+  const size_t BK = (size_t)h.B * h.K, N = rep_ram;
+  uint8_t *d_aln, *d_states;
+  int32_t *d_cls, *d_pgs;
+  int64_t* d_pgo;
+  double *d_cnt, *d_norm, *d_st;
+  if ((s = scratch(ctx, "cg_aln", (size_t)h.T * N, (void**)&d_aln)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cg_states", (size_t)h.nn * N, (void**)&d_states)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cg_cls", sizeof(int32_t) * N, (void**)&d_cls)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cg_cnt", sizeof(double) * BK * N, (void**)&d_cnt)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cg_norm", sizeof(double) * N, (void**)&d_norm)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cg_pgs", sizeof(int32_t) * N, (void**)&d_pgs)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cg_pgo", sizeof(int64_t) * (N + 1), (void**)&d_pgo)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "cg_stat", sizeof(double) * N, (void**)&d_st)) != CMX_OK) return s;
+  std::vector<double> norms(N), stats(N);
+  uint64_t nb = 0;
+  int more = 1;
+  while (more == 1 && cur.trials < max_trials && (max_batches == 0 || nb < max_batches)) {
+    HIP_TRY(ctx, launch_simulate(ctx->dm, seed, nb * (uint64_t)N, N, d_aln, N, d_cls, d_states, nullptr));
+    if ((s = cmx_map_sites_dev(ctx, d_aln, N, N, nullptr, d_cnt, N, nullptr, nullptr, nullptr, d_norm, nullptr)) != CMX_OK) return s;
+    HIP_TRY(ctx, hipMemcpy(norms.data(), d_norm, sizeof(double) * N, hipMemcpyDeviceToHost));
+    ++nb;
+    more = cur.batch(norms.data(), N);
+    if (more < 0) return fail(ctx, CMX_ERR_INVALID, "cmx_candidate_groups: candidate cursor found no open group");
+    const size_t npg = cur.pg_group.size();
+    if (npg) {
+      HIP_TRY(ctx, hipMemcpy(d_pgo, cur.pg_off.data(), sizeof(int64_t) * (npg + 1), hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_pgs, cur.pg_sites.data(), sizeof(int32_t) * cur.pg_sites.size(), hipMemcpyHostToDevice));
+      if ((s = cmx_group_stats_dev(ctx, kind, params, d_cnt, N, N, d_pgo, d_pgs, npg, d_st, nullptr)) != CMX_OK) return s;
+      HIP_TRY(ctx, hipMemcpy(stats.data(), d_st, sizeof(double) * npg, hipMemcpyDeviceToHost));
+      for (size_t q = 0; q < npg; ++q)
+        if (stats[q] >= observed[cur.pg_group[q]]) ++n1[cur.pg_group[q]];
+    }
+  }
+  std::copy(cur.n2.begin(), cur.n2.end(), n2);
+  if (trials) *trials = cur.trials;
+  if (batches) *batches = nb;
+  return CMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Mica post-processing
 cmx_status cmx_mica_average_mi_dev(cmx_ctx* ctx, const double* d_mi, size_t n, size_t ldo, double* d_average,
                                    double* d_full_average, void* stream) {

@@ -115,6 +115,8 @@ hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* 
                             size_t n, const int32_t* rc1, const int32_t* rc2, const double* pr1, const double* pr2,
                             const double* nm1, const double* nm2, double* stat, int32_t* rcmin, double* prmin, double* nmin,
                             const double* d_mean, hipStream_t stream);
+hipError_t launch_group_stats(int kind, double param, int B, int K, const double* d_counts, size_t ld, const int64_t* d_offsets,
+                              const int32_t* d_sites, size_t ngroups, double* d_out, const double* d_mean, hipStream_t stream);
 // Mica post-processing (cmx_mica_post.hip)
 hipError_t launch_mica_average(const double* d_mi, size_t n, size_t ld, double* d_avg, double* d_full, hipStream_t stream);
 hipError_t launch_mica_zscore(int which, const double* d_mi, size_t n, size_t ld, const double* d_avg, const double* d_full,

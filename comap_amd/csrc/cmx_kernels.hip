@@ -1221,6 +1221,65 @@ hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* 
   return hipGetLastError();
 }
 
+// Statistic of a group of sites, Statistic::getValueForGroup: the smallest pairwise value over the group
+// (AbstractMinimumStatistic, CoMap/Statistics.h:121-133) or, for Compensation, the closed form of Statistics.h:267-294.
+// One wave per group; group g owns sites[offsets[g] .. offsets[g+1]) (columns of the branch-major counts).
+__global__ __launch_bounds__(kWave) void group_stat_kernel(int kind, double param, int B, int K, const double* __restrict__ counts,
+                                                          size_t ld, const int64_t* __restrict__ offsets,
+                                                          const int32_t* __restrict__ sites, double* __restrict__ out,
+                                                          const double* __restrict__ mv) {
+  const size_t g = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int32_t* mem = sites + offsets[g];
+  const int m = (int)(offsets[g + 1] - offsets[g]);
+  if (kind == CMX_STAT_COMPENSATION) {
+    double sumnorms = 0.0, sq2 = 0.0;
+    for (int j = 0; j < m; ++j) {
+      double q = 0.0;
+      for (int b = lane; b < B; b += kWave) {
+        double t = 0.0;
+        for (int k = 0; k < K; ++k) t += counts[((size_t)b * K + k) * ld + mem[j]];
+        q += t * t;
+      }
+      for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
+      sumnorms += sqrt(q);
+    }
+    for (int b = lane; b < B; b += kWave) {
+      double t = 0.0;
+      for (int j = 0; j < m; ++j)
+        for (int k = 0; k < K; ++k) t += counts[((size_t)b * K + k) * ld + mem[j]];
+      sq2 += t * t;
+    }
+    for (int off = 32; off; off >>= 1) sq2 += __shfl_xor(sq2, off);
+    if (lane == 0) out[g] = 1.0 - sqrt(sq2) / sumnorms;
+    return;
+  }
+  // pairs (i, j), j < i, in the reference's order; "val < mini" with a NaN val never wins, so NaN pairs are skipped
+  double best = __builtin_inf();
+  const int npairs = m * (m - 1) / 2;
+  for (int p = lane; p < npairs; p += kWave) {
+    int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)p)) / 2.0);
+    while (i * (i - 1) / 2 > p) --i;
+    while ((i + 1) * i / 2 <= p) ++i;
+    const int j = p - i * (i - 1) / 2;
+    const double v = pair_stat_strided(kind, param, B, K, counts + mem[i], ld, counts + mem[j], ld, mv);
+    if (v < best) best = v;
+  }
+  for (int off = 32; off; off >>= 1) {
+    const double o = __shfl_xor(best, off);
+    if (o < best) best = o;
+  }
+  if (lane == 0) out[g] = best;
+}
+
+hipError_t launch_group_stats(int kind, double param, int B, int K, const double* d_counts, size_t ld, const int64_t* d_offsets,
+                              const int32_t* d_sites, size_t ngroups, double* d_out, const double* d_mean, hipStream_t stream) {
+  if (ngroups == 0) return hipSuccess;
+  hipLaunchKernelGGL(group_stat_kernel, dim3((unsigned)ngroups), dim3(kWave), 0, stream, kind, param, B, K, d_counts, ld,
+                     d_offsets, d_sites, d_out, d_mean);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ stand-alone simulator
 __global__ void simulate_kernel(const DevModel m, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln, size_t ld,
                                 int32_t* classes, uint8_t* states) {

@@ -43,6 +43,7 @@ EXPORTS = [
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
     "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
+    "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
 ]
 # clustering.distance / clustering.method options of the reference (CoMap/CoMap.cpp:402-428, :460-472)
@@ -325,6 +326,44 @@ class Engine:
                                            _vp(a1), _sz(n1), _vp(a2), _sz(0 if a2 is None else a2.shape[1]), _vp(i1),
                                            _vp(i2), _sz(len(i1)), _vp(mi), _vp(hj)))
         return dict(mi=mi, hjoint=hj)
+
+    # -- groups of sites / candidate-group test
+    @staticmethod
+    def _flatten_groups(groups):
+        off = np.zeros(len(groups) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(g) for g in groups])
+        flat = np.array([x for g in groups for x in g], dtype=np.int32)
+        return off, flat
+
+    def group_stats(self, kind, counts, groups, threshold=0.99, mean_vectors=None):
+        """Statistic::getValueForGroup for each list of site indices in `groups` (Statistics.h:121-133, :267-294)"""
+        c = _f64(counts)
+        off, flat = self._flatten_groups(groups)
+        out = np.zeros(len(groups))
+        params = _stat_params(kind, threshold, mean_vectors)
+        self._check(self._lib.cmx_group_stats(self._ctx, int(kind), _vp(params), _vp(c), _sz(c.shape[0]), _vp(off), _vp(flat),
+                                              _sz(len(groups)), _vp(out)))
+        return out
+
+    def candidate_groups(self, kind, norm_windows, analysable, observed, min_sim, rep_ram, max_trials, seed, max_batches=0,
+                         threshold=0.99, mean_vectors=None):
+        """CoETools::computePValuesForCandidateGroups.  norm_windows: per group a list of (lo, hi) per candidate site.
+        -> dict(n1, n2, pvalue, trials, batches)"""
+        off = np.zeros(len(norm_windows) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(g) for g in norm_windows])
+        lo = _f64([w[0] for g in norm_windows for w in g])
+        hi = _f64([w[1] for g in norm_windows for w in g])
+        G = len(norm_windows)
+        ok = np.ascontiguousarray(analysable, dtype=np.uint8)
+        obs = _f64(observed)
+        n1, n2 = np.zeros(G, dtype=np.uint32), np.zeros(G, dtype=np.uint32)
+        trials, batches = ctypes.c_uint32(0), ctypes.c_uint64(0)
+        params = _stat_params(kind, threshold, mean_vectors)
+        self._check(self._lib.cmx_candidate_groups(self._ctx, int(kind), _vp(params), _sz(G), _vp(off), _vp(lo), _vp(hi), _vp(ok),
+                                                   _vp(obs), ctypes.c_uint32(min_sim), _sz(rep_ram), ctypes.c_uint32(max_trials),
+                                                   ctypes.c_uint64(max_batches), ctypes.c_uint64(seed), _vp(n1), _vp(n2),
+                                                   ctypes.byref(trials), ctypes.byref(batches)))
+        return dict(n1=n1, n2=n2, pvalue=(n1 + 1.0) / (n2 + 1.0), trials=trials.value, batches=batches.value)
 
     # -- Mica after the all-pairs matrix
     def mica_average_mi(self, mi):

@@ -226,6 +226,29 @@ cmx_status cmx_mica_zscore_null_dev(cmx_ctx* ctx, int which, const double* d_mi,
 cmx_status cmx_mica_zscore_null(cmx_ctx* ctx, int which, const double* mi, size_t n, const double* key,
                                 double* null_stat, double* null_key);
 
+/* ---- groups of sites.  Statistic::getValueForGroup (CoMap/Statistics.h:121-133: the smallest pairwise value; :267-294:
+ * Compensation's closed form) of ngroups groups; group g = sites[offsets[g] .. offsets[g+1]) (indices into the
+ * mapping).  This is CandidateGroup::computeStatisticValue (CoMap/CoETools.h:106-117). */
+cmx_status cmx_group_stats_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts, size_t n, size_t ldc,
+                               const int64_t* d_offsets, const int32_t* d_sites, size_t ngroups, double* d_out,
+                               void* stream);
+cmx_status cmx_group_stats(cmx_ctx* ctx, int kind, const double* params, const double* counts, size_t n,
+                           const int64_t* offsets, const int32_t* sites, size_t ngroups, double* out);
+/* Candidate-group test: CoETools::computePValuesForCandidateGroups + CandidateGroupSet::analyseSimulations
+ * (CoMap/CoETools.cpp:1042-1087, :950-1038, cursor :900-947).  Batches of rep_ram sites are simulated and mapped on the
+ * device; their norms drive the reference's greedy assembly of pseudo-groups (a simulated site is given to the next
+ * candidate site, in cursor order, whose norm window [norm_lo, norm_hi] contains its norm -- windows from
+ * CandidateGroup::computeNormRanges, CoETools.h:118-128); the statistic of every completed pseudo-group is evaluated on
+ * the device and counted in n1 when >= observed[g] (n2 counts the pseudo-groups).  Stops when every analysable group
+ * has min_sim pseudo-groups, after max_trials batches that completed nothing (candidates.nb_max_trials), or after
+ * max_batches batches (0 = no limit; a safety valve the reference does not have).  p-value of group g =
+ * (n1[g] + 1) / (n2[g] + 1) (CoETools.h:235-238).  Batch t simulates sites t*rep_ram .. of the counter RNG. */
+cmx_status cmx_candidate_groups(cmx_ctx* ctx, int kind, const double* params, size_t ngroups, const int64_t* offsets,
+                                const double* norm_lo, const double* norm_hi, const uint8_t* analysable,
+                                const double* observed, uint32_t min_sim, size_t rep_ram, uint32_t max_trials,
+                                uint64_t max_batches, uint64_t seed, uint32_t* n1, uint32_t* n2, uint32_t* trials,
+                                uint64_t* batches);
+
 /* ---- clustering analysis (CoMap/CoMap.cpp:395-560; null: ClusterTools::computeGlobalDistanceDistribution,
  * CoMap/ClusterTools.cpp:200-294).  Distances of CoMap.cpp:402-428: 1 - correlation (StatisticBasedDistance(cor, 1.),
  * Distance.h:321-336), 1 - compensation (CompensationDistance, Distance.h:376-385), Euclidian (Distance.h:161-181).

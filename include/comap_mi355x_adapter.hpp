@@ -449,10 +449,110 @@ class CoETools {
     }
     return rows;
   }
+
+  // CoETools.cpp:1042-1087 (defined after CandidateGroupSet below).  seed replaces the global RandomTools state;
+  // repRAM = candidates.null.nb_rep_RAM, maxTrials = candidates.nb_max_trials.
+  static void computePValuesForCandidateGroups(class CandidateGroupSet& candidates, const Engine& eng, uint64_t seed,
+                                               unsigned int repRAM, unsigned int maxTrials);
 };
 
 // ------------------------------------------------------------------------------------------------ text outputs
 // The files either side of the path, written with default ostream formatting exactly as the reference does.
+// ------------------------------------------------------------------------------------------------ candidate groups
+// CoMap/CoETools.h:71-137: a candidate site is a position of the mapping with the norm window its simulated stand-ins
+// must fall into; a candidate group carries its observed statistic.
+class CandidateSite {
+ public:
+  explicit CandidateSite(size_t index) : index_(index) {}
+  void setNormRange(double min, double max) { normMin_ = min; normMax_ = max; }
+  bool checkNorm(double norm) const { return norm >= normMin_ && norm <= normMax_; }
+  size_t getIndex() const { return index_; }
+  double getNormMin() const { return normMin_; }
+  double getNormMax() const { return normMax_; }
+
+ private:
+  size_t index_;
+  double normMin_ = 0, normMax_ = 0;
+};
+
+class CandidateGroup {
+ public:
+  double getStatisticValue() const { return statistic_; }
+  void setStatisticValue(double v) { statistic_ = v; }
+  // Statistic::getValueForGroup on the device (CoETools.h:106-117)
+  void computeStatisticValue(const Engine& eng, const Statistic& stat, const ProbabilisticSubstitutionMapping& mapping) {
+    if (!analysable_) throw Exception("CandidateGroup::computeStatisticValue. Group is not analysable.");
+    if (sites_.empty()) throw Exception("CandidateGroup::computeStatisticValue. Group is empty!");
+    std::vector<int32_t> idx(sites_.size());
+    for (size_t i = 0; i < sites_.size(); ++i) idx[i] = static_cast<int32_t>(sites_[i].getIndex());
+    const int64_t off[2] = {0, static_cast<int64_t>(idx.size())};
+    eng.check(cmx_group_stats(eng.ctx(), stat.kind(), stat.params(), mapping.data(), mapping.getNumberOfSites(), off, idx.data(), 1,
+                              &statistic_));
+  }
+  // CoETools.h:118-128
+  void computeNormRanges(double omega, const ProbabilisticSubstitutionMapping& mapping) {
+    if (!analysable_) throw Exception("CandidateGroup::computeNormRanges. Group is not analyzable.");
+    if (sites_.empty()) throw Exception("CandidateGroup::computeNormRanges. Group is empty!");
+    const Vdouble norms = AnalysisTools::computeNorms(mapping);
+    for (CandidateSite& s : sites_) s.setNormRange(norms[s.getIndex()] - omega, norms[s.getIndex()] + omega);
+  }
+  void setAnalysable(bool yn) { analysable_ = yn; }
+  bool isAnalysable() const { return analysable_; }
+  size_t size() const { return sites_.size(); }
+  const CandidateSite& operator[](size_t i) const { return sites_[i]; }
+  CandidateSite& operator[](size_t i) { return sites_[i]; }
+  void addSite(const CandidateSite& cs) { sites_.push_back(cs); }
+
+ private:
+  std::vector<CandidateSite> sites_;
+  double statistic_ = 0;
+  bool analysable_ = true;
+};
+
+// CoETools.h:139-300.  The simulation bookkeeping lives behind cmx_candidate_groups; this class holds the candidates
+// and, afterwards, the counts.
+class CandidateGroupSet {
+ public:
+  CandidateGroupSet(const Statistic* statistic, unsigned int minSim) : statistic_(statistic), minSim_(minSim) {}
+  void addCandidate(const CandidateGroup& g) { candidates_.push_back(g); n1_.push_back(0); n2_.push_back(0); }
+  double getPValueForGroup(size_t g) const { return (static_cast<double>(n1_[g]) + 1.) / (static_cast<double>(n2_[g]) + 1.); }
+  double getN1ForGroup(size_t g) const { return n1_[g]; }
+  double getN2ForGroup(size_t g) const { return n2_[g]; }
+  size_t size() const { return candidates_.size(); }
+  const CandidateGroup& operator[](size_t g) const { return candidates_[g]; }
+  unsigned int getNumberOfTrials() const { return nbTrials_; }
+  uint64_t getNumberOfBatches() const { return nbBatches_; }
+
+ private:
+  friend class CoETools;
+  const Statistic* statistic_;
+  unsigned int minSim_;
+  std::vector<CandidateGroup> candidates_;
+  std::vector<uint32_t> n1_, n2_;
+  unsigned int nbTrials_ = 0;
+  uint64_t nbBatches_ = 0;
+};
+
+inline void CoETools::computePValuesForCandidateGroups(CandidateGroupSet& candidates, const Engine& eng, uint64_t seed,
+                                                       unsigned int repRAM, unsigned int maxTrials) {
+  const size_t G = candidates.size();
+  std::vector<int64_t> off(G + 1, 0);
+  Vdouble lo, hi, observed(G);
+  std::vector<uint8_t> ok(G);
+  for (size_t g = 0; g < G; ++g) {
+    const CandidateGroup& c = candidates[g];
+    for (size_t i = 0; i < c.size(); ++i) { lo.push_back(c[i].getNormMin()); hi.push_back(c[i].getNormMax()); }
+    off[g + 1] = static_cast<int64_t>(lo.size());
+    observed[g] = c.getStatisticValue();
+    ok[g] = c.isAnalysable() ? 1 : 0;
+  }
+  uint32_t trials = 0;
+  eng.check(cmx_candidate_groups(eng.ctx(), candidates.statistic_->kind(), candidates.statistic_->params(), G, off.data(),
+                                 lo.data(), hi.data(), ok.data(), observed.data(), candidates.minSim_, repRAM, maxTrials, 0, seed,
+                                 candidates.n1_.data(), candidates.n2_.data(), &trials, &candidates.nbBatches_));
+  candidates.nbTrials_ = trials;
+}
+
 // ------------------------------------------------------------------------------------------------ clustering
 // bpp::HierarchicalClustering's method names as CoMap.cpp:460-472 passes them
 struct HierarchicalClustering {

@@ -4,6 +4,7 @@
 //   adapter_main groups <tree.bin>                   -> ClusterTools::getGroups + io::writeGroups to stdout (host only);
 //      tree.bin: int32 n, maxGroupSize; int32 merge[2(n-1)]; f64 dmax, stat, nmin [n-1]; int32 coords[n], isConstant[n]
 //   adapter_main clusternull <input.bin> cor|euclidian <method> <nsites> <nrep> <maxsize>   -> null groups file (GPU)
+//   adapter_main candidates <input.bin> <omega> <minSim> <repRAM> <maxTrials> <seed>   -> candidate-group test (GPU)
 //   adapter_main vec <input.bin>                     -> cmx::io::writeToStream of a mapping to stdout (host only);
 //      input.bin: int32 N, B; int32 coords[N]; f64 blen[B]; f64 counts[N*B] (site-major)
 // input.bin (little endian): int32 nn, T, S, C, N, repCPU, repRAM, nclasses; uint64 seed;
@@ -112,6 +113,45 @@ int main(int argc, char** argv) {
         cmx::ClusterTools::computeGlobalDistanceDistribution(
             eng, cmx::StatisticBasedDistance(std::make_shared<cmx::CorrelationStatistic>(), 1.), method, seed, nsites, nrep,
             maxSize, &std::cout);
+      return 0;
+    }
+    if (argc == 8 && std::strcmp(argv[1], "candidates") == 0) {   // GPU: <input.bin of "run"> omega minSim repRAM maxTrials seed2
+      std::ifstream in(argv[2], std::ios::binary);
+      int32_t h[8];
+      uint64_t seed;
+      rd(in, h, 8);
+      rd(in, &seed, 1);
+      const int nn = h[0], T = h[1], S = h[2], C = h[3], N = h[4];
+      cmx::TreeArrays t;
+      cmx::ModelArrays m;
+      t.parent.resize(nn); t.branchLengths.resize(nn); t.leafOfTaxon.resize(T);
+      rd(in, t.parent.data(), nn); rd(in, t.branchLengths.data(), nn); rd(in, t.leafOfTaxon.data(), T);
+      m.nbStates = S;
+      m.generator.resize(S * S); m.frequencies.resize(S); m.rates.resize(C); m.rateProbabilities.resize(C);
+      rd(in, m.generator.data(), S * S); rd(in, m.frequencies.data(), S); rd(in, m.rates.data(), C);
+      rd(in, m.rateProbabilities.data(), C);
+      std::vector<uint8_t> aln(static_cast<size_t>(T) * N);
+      rd(in, aln.data(), aln.size());
+      cmx::Engine eng(t, m, 0);
+      auto mapping = cmx::CoETools::getVectors(eng, aln.data(), N);
+      cmx::CorrelationStatistic stat;
+      cmx::CandidateGroupSet set(&stat, static_cast<unsigned>(std::atoi(argv[4])));
+      // groups: sites (3g, 3g+1, 3g+2) for g = 0..3, the last one flagged not analysable
+      for (int g = 0; g < 4; ++g) {
+        cmx::CandidateGroup c;
+        for (int k = 0; k < 3; ++k) c.addSite(cmx::CandidateSite(static_cast<size_t>(3 * g + k)));
+        c.computeNormRanges(std::atof(argv[3]), *mapping);
+        c.computeStatisticValue(eng, stat, *mapping);
+        if (g == 3) c.setAnalysable(false);
+        set.addCandidate(c);
+      }
+      cmx::CoETools::computePValuesForCandidateGroups(set, eng, std::strtoull(argv[7], nullptr, 10),
+                                                      static_cast<unsigned>(std::atoi(argv[5])), static_cast<unsigned>(std::atoi(argv[6])));
+      std::cout.precision(17);
+      for (size_t g = 0; g < set.size(); ++g)
+        std::cout << set[g].getStatisticValue() << " " << set.getN1ForGroup(g) << " " << set.getN2ForGroup(g) << " "
+                  << set.getPValueForGroup(g) << "\n";
+      std::cout << set.getNumberOfTrials() << " " << set.getNumberOfBatches() << "\n";
       return 0;
     }
     if (argc == 3 && std::strcmp(argv[1], "vec") == 0) {
