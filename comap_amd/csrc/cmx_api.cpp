@@ -1029,7 +1029,12 @@ cmx_status cmx_candidate_groups(cmx_ctx* ctx, int kind, const double* params, si
   std::fill(n1, n1 + ngroups, 0u);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const HostModel& h = ctx->hm;
-  const size_t BK = (size_t)h.B * h.K, N = rep_ram;
+  // The device works ahead of the cursor: a round simulates and maps several batches in one launch, the cursor then
+  // consumes them batch by batch exactly as the reference would (batches it does not get to are discarded), and the
+  // statistics of all pseudo-groups of the round are evaluated in one launch.
+  const size_t BK = (size_t)h.B * h.K;
+  const size_t round_batches = std::max<size_t>(1, std::min<size_t>(32, 32768 / rep_ram));
+  const size_t N = round_batches * rep_ram;
   uint8_t *d_aln, *d_states;
   int32_t *d_cls, *d_pgs;
   int64_t* d_pgo;
@@ -1043,23 +1048,34 @@ cmx_status cmx_candidate_groups(cmx_ctx* ctx, int kind, const double* params, si
   if ((s = scratch(ctx, "cg_pgo", sizeof(int64_t) * (N + 1), (void**)&d_pgo)) != CMX_OK) return s;
   if ((s = scratch(ctx, "cg_stat", sizeof(double) * N, (void**)&d_st)) != CMX_OK) return s;
   std::vector<double> norms(N), stats(N);
+  std::vector<int64_t> r_off;
+  std::vector<int32_t> r_sites, r_group;
   uint64_t nb = 0;
   int more = 1;
-  while (more == 1 && cur.trials < max_trials && (max_batches == 0 || nb < max_batches)) {
-    HIP_TRY(ctx, launch_simulate(ctx->dm, seed, nb * (uint64_t)N, N, d_aln, N, d_cls, d_states, nullptr));
+  auto go_on = [&]() { return more == 1 && cur.trials < max_trials && (max_batches == 0 || nb < max_batches); };
+  while (go_on()) {
+    HIP_TRY(ctx, launch_simulate(ctx->dm, seed, nb * (uint64_t)rep_ram, N, d_aln, N, d_cls, d_states, nullptr));
     if ((s = cmx_map_sites_dev(ctx, d_aln, N, N, nullptr, d_cnt, N, nullptr, nullptr, nullptr, d_norm, nullptr)) != CMX_OK) return s;
     HIP_TRY(ctx, hipMemcpy(norms.data(), d_norm, sizeof(double) * N, hipMemcpyDeviceToHost));
-    ++nb;
-    more = cur.batch(norms.data(), N);
-    if (more < 0) return fail(ctx, CMX_ERR_INVALID, "cmx_candidate_groups: candidate cursor found no open group");
-    const size_t npg = cur.pg_group.size();
+    r_off.assign(1, 0); r_sites.clear(); r_group.clear();
+    for (size_t t = 0; t < round_batches && go_on(); ++t) {
+      ++nb;
+      more = cur.batch(norms.data() + t * rep_ram, rep_ram);
+      if (more < 0) return fail(ctx, CMX_ERR_INVALID, "cmx_candidate_groups: candidate cursor found no open group");
+      for (size_t q = 0; q < cur.pg_group.size(); ++q) {
+        for (int64_t e = cur.pg_off[q]; e < cur.pg_off[q + 1]; ++e) r_sites.push_back((int32_t)(t * rep_ram) + cur.pg_sites[e]);
+        r_off.push_back((int64_t)r_sites.size());
+        r_group.push_back(cur.pg_group[q]);
+      }
+    }
+    const size_t npg = r_group.size();
     if (npg) {
-      HIP_TRY(ctx, hipMemcpy(d_pgo, cur.pg_off.data(), sizeof(int64_t) * (npg + 1), hipMemcpyHostToDevice));
-      HIP_TRY(ctx, hipMemcpy(d_pgs, cur.pg_sites.data(), sizeof(int32_t) * cur.pg_sites.size(), hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_pgo, r_off.data(), sizeof(int64_t) * (npg + 1), hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_pgs, r_sites.data(), sizeof(int32_t) * r_sites.size(), hipMemcpyHostToDevice));
       if ((s = cmx_group_stats_dev(ctx, kind, params, d_cnt, N, N, d_pgo, d_pgs, npg, d_st, nullptr)) != CMX_OK) return s;
       HIP_TRY(ctx, hipMemcpy(stats.data(), d_st, sizeof(double) * npg, hipMemcpyDeviceToHost));
       for (size_t q = 0; q < npg; ++q)
-        if (stats[q] >= observed[cur.pg_group[q]]) ++n1[cur.pg_group[q]];
+        if (stats[q] >= observed[r_group[q]]) ++n1[r_group[q]];
     }
   }
   std::copy(cur.n2.begin(), cur.n2.end(), n2);
