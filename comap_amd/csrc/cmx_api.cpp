@@ -290,16 +290,21 @@ cmx_status cmx_synchronize(cmx_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------------------------------ mapping
-cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
-                             double* d_counts, size_t ldc, double* d_logL, double* d_post_rate, int32_t* d_rate_class,
-                             double* d_norm, void* stream) {
+// full_grid: use the whole-chip workspace of the null launches instead of the quarter-chip slice reserved for
+// observed alignments (which exists so that a caller can overlap the observed mapping with cmx_null_intra_dev on a
+// second stream).  Only the engine's own simulate -> map pipelines (inter null, clustering null, candidate groups)
+// ask for it: they are blocking calls on the null stream and map hundreds of thousands of simulated sites.
+static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
+                                 double* d_counts, size_t ldc, double* d_logL, double* d_post_rate, int32_t* d_rate_class,
+                                 double* d_norm, void* stream, bool full_grid) {
   cmx_status s = need_model(ctx);
   if (s != CMX_OK) return s;
   if (!d_aln || nsites == 0 || ld < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: bad alignment arguments");
   if (d_counts && ldc < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: ldc < nsites");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MapArgs a{};
-  a.m = ctx->dm; a.ws = ctx->ws_obs;
+  a.m = ctx->dm; a.ws = full_grid ? ctx->ws : ctx->ws_obs;
+  const int max_blocks = full_grid ? ctx->grid_blocks : ctx->obs_blocks;
   a.aln = d_aln; a.ld = ld; a.nsites = nsites;
   // ambiguity ids S .. S+max_ambig(S)-1: rebuild the extra rows of the leaf operators when the table changes
   if (d_masks || ctx->leaf_rows_custom) {
@@ -310,7 +315,7 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
   a.norm = d_norm;
   const size_t ks = (size_t)map_sites_per_wave(ctx->hm.dS);
   const size_t nblocks = (nsites + ks - 1) / ks;
-  const size_t obs_waves = (size_t)ctx->obs_blocks * kWavesPerBlock;
+  const size_t obs_waves = (size_t)max_blocks * kWavesPerBlock;
   if (nblocks * (size_t)ctx->hm.dC <= obs_waves && ctx->hm.dC > 1) {
     // small alignment: one (site block, class) per wave, classes summed by a second kernel (same arithmetic order)
     const size_t ntasks = nblocks * (size_t)ctx->hm.dC, BK = (size_t)ctx->hm.B * ctx->hm.K;
@@ -322,9 +327,15 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
     return CMX_OK;
   }
   const size_t blocks_needed = (nblocks + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int grid = (int)std::min<size_t>(blocks_needed, (size_t)ctx->obs_blocks);
+  const int grid = (int)std::min<size_t>(blocks_needed, (size_t)max_blocks);
   HIP_TRY(ctx, launch_map(a, kModeObserved, grid, (hipStream_t)stream));
   return CMX_OK;
+}
+
+cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
+                             double* d_counts, size_t ldc, double* d_logL, double* d_post_rate, int32_t* d_rate_class,
+                             double* d_norm, void* stream) {
+  return map_sites_impl(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_logL, d_post_rate, d_rate_class, d_norm, stream, false);
 }
 
 cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t ld, const uint32_t* masks,
@@ -584,7 +595,7 @@ cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const doub
       const uint64_t g0 = ((uint64_t)(rep_begin + r) * 2 + h) * (uint64_t)rep_ram;
       HIP_TRY(ctx1, launch_simulate(c->dm, seed, g0, rep_ram, d_aln + r * rep_ram, n, d_cls, d_st, st));
     }
-    s = cmx_map_sites_dev(c, d_aln, n, n, nullptr, cnt[h], n, nullptr, pr[h], rc[h], nm[h], stream);
+    s = map_sites_impl(c, d_aln, n, n, nullptr, cnt[h], n, nullptr, pr[h], rc[h], nm[h], stream, true);
     if (s != CMX_OK) { if (c != ctx1) ctx1->err = c->err; return s; }
   }
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
@@ -1055,7 +1066,7 @@ cmx_status cmx_candidate_groups(cmx_ctx* ctx, int kind, const double* params, si
   auto go_on = [&]() { return more == 1 && cur.trials < max_trials && (max_batches == 0 || nb < max_batches); };
   while (go_on()) {
     HIP_TRY(ctx, launch_simulate(ctx->dm, seed, nb * (uint64_t)rep_ram, N, d_aln, N, d_cls, d_states, nullptr));
-    if ((s = cmx_map_sites_dev(ctx, d_aln, N, N, nullptr, d_cnt, N, nullptr, nullptr, nullptr, d_norm, nullptr)) != CMX_OK) return s;
+    if ((s = map_sites_impl(ctx, d_aln, N, N, nullptr, d_cnt, N, nullptr, nullptr, nullptr, d_norm, nullptr, true)) != CMX_OK) return s;
     HIP_TRY(ctx, hipMemcpy(norms.data(), d_norm, sizeof(double) * N, hipMemcpyDeviceToHost));
     r_off.assign(1, 0); r_sites.clear(); r_group.clear();
     for (size_t t = 0; t < round_batches && go_on(); ++t) {
@@ -1318,7 +1329,7 @@ cmx_status cmx_cluster_null(cmx_ctx* ctx, int dist_kind, int linkage, uint64_t s
   for (size_t r0 = 0; r0 < nrep; r0 += R) {
     const size_t rb = std::min(R, nrep - r0), nb = rb * n;
     HIP_TRY(ctx, launch_simulate(ctx->dm, seed, (uint64_t)(rep_begin + r0) * n, nb, d_aln, nb, d_cls, d_states, nullptr));
-    if ((s = cmx_map_sites_dev(ctx, d_aln, nb, nb, nullptr, d_cnt, nb, nullptr, nullptr, nullptr, d_norm, nullptr)) != CMX_OK) return s;
+    if ((s = map_sites_impl(ctx, d_aln, nb, nb, nullptr, d_cnt, nb, nullptr, nullptr, nullptr, d_norm, nullptr, true)) != CMX_OK) return s;
     if ((s = cluster_batch_dev(ctx, dist_kind, linkage, d_cnt, nb, n, rb, d_norm, nullptr, d_mg, d_dm, d_sz, d_st, d_nmn, nullptr)) != CMX_OK)
       return s;
     HIP_TRY(ctx, hipDeviceSynchronize());
