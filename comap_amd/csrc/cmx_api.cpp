@@ -1016,6 +1016,49 @@ struct CandidateCursor {
 };
 }  // namespace
 
+// host-side only (no GPU): run the candidate cursor over caller-supplied norms, batch by batch, and list the
+// pseudo-groups it assembles.  For tests of the bookkeeping.
+cmx_status cmx_debug_candidate_cursor(size_t ngroups, const int64_t* offsets, const double* norm_lo, const double* norm_hi,
+                                      const uint8_t* analysable, uint32_t min_sim, const double* norms, size_t rep_ram,
+                                      size_t nbatches, uint32_t max_trials, uint32_t* n2, uint32_t* trials,
+                                      uint64_t* batches_used, int32_t* pg_group, int32_t* pg_batch, int64_t* pg_offsets,
+                                      int32_t* pg_sites, size_t cap_groups, size_t cap_sites, size_t* npg) {
+  if (ngroups == 0 || !offsets || !norm_lo || !norm_hi || !analysable || min_sim == 0 || !norms || rep_ram == 0 || !n2 || !npg)
+    return CMX_ERR_INVALID;
+  CandidateCursor cur;
+  cur.G = ngroups; cur.off = offsets; cur.lo = norm_lo; cur.hi = norm_hi; cur.usable = analysable; cur.min_sim = min_sim;
+  cur.n2.assign(ngroups, 0);
+  cur.waiting.resize((size_t)offsets[ngroups]);
+  cur.head.assign((size_t)offsets[ngroups], 0);
+  for (size_t g = 0; g < ngroups; ++g)
+    if (analysable[g]) { if (cur.gsize(g) == 0) return CMX_ERR_INVALID; ++cur.n_usable; }
+  if (cur.n_usable == 0) return CMX_ERR_INVALID;
+  size_t ng = 0, ns = 0;
+  uint64_t nb = 0;
+  int more = 1;
+  if (pg_offsets && cap_groups) pg_offsets[0] = 0;
+  while (more == 1 && cur.trials < max_trials && nb < nbatches) {
+    more = cur.batch(norms + nb * rep_ram, rep_ram);
+    if (more < 0) return CMX_ERR_INVALID;
+    for (size_t q = 0; q < cur.pg_group.size(); ++q, ++ng) {
+      const size_t m = (size_t)(cur.pg_off[q + 1] - cur.pg_off[q]);
+      if (ng < cap_groups && ns + m <= cap_sites) {
+        pg_group[ng] = cur.pg_group[q];
+        pg_batch[ng] = (int32_t)nb;
+        for (size_t e = 0; e < m; ++e) pg_sites[ns + e] = cur.pg_sites[cur.pg_off[q] + e];
+        pg_offsets[ng + 1] = (int64_t)(ns + m);
+      }
+      ns += m;
+    }
+    ++nb;
+  }
+  std::copy(cur.n2.begin(), cur.n2.end(), n2);
+  if (trials) *trials = cur.trials;
+  if (batches_used) *batches_used = nb;
+  *npg = ng;
+  return CMX_OK;
+}
+
 cmx_status cmx_candidate_groups(cmx_ctx* ctx, int kind, const double* params, size_t ngroups, const int64_t* offsets,
                                 const double* norm_lo, const double* norm_hi, const uint8_t* analysable,
                                 const double* observed, uint32_t min_sim, size_t rep_ram, uint32_t max_trials,

@@ -43,7 +43,7 @@ EXPORTS = [
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
     "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
-    "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups",
+    "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups", "cmx_debug_candidate_cursor",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
 ]
 # clustering.distance / clustering.method options of the reference (CoMap/CoMap.cpp:402-428, :460-472)
@@ -151,6 +151,33 @@ def debug_traversal(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
         raise CmxError(st, lib.cmx_last_error(None).decode())
     return dict(nrec=nrec[: n1.value].reshape(-1, 16).copy(), ldsched=ld[: n2.value].copy(), msched=ms[: n3.value].copy(),
                 slot=slot)
+
+
+def debug_candidate_cursor(norm_windows, analysable, min_sim, norms, max_trials):
+    """Host-side run of the candidate cursor (no GPU).  norms: [nbatches, rep_ram].
+    -> dict(n2, trials, batches, pseudo_groups=[(group, batch, [sites])])"""
+    lib = load_library()
+    off = np.zeros(len(norm_windows) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(g) for g in norm_windows])
+    lo = _f64([w[0] for g in norm_windows for w in g])
+    hi = _f64([w[1] for g in norm_windows for w in g])
+    ok = np.ascontiguousarray(analysable, dtype=np.uint8)
+    nm = _f64(norms)
+    nb, rr = nm.shape
+    G = len(norm_windows)
+    n2 = np.zeros(G, dtype=np.uint32)
+    cap = nb * rr
+    pg_group, pg_batch = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+    pg_off, pg_sites = np.zeros(cap + 1, dtype=np.int64), np.zeros(cap, dtype=np.int32)
+    trials, used, npg = ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_size_t(0)
+    st = lib.cmx_debug_candidate_cursor(_sz(G), _vp(off), _vp(lo), _vp(hi), _vp(ok), ctypes.c_uint32(min_sim), _vp(nm), _sz(rr),
+                                        _sz(nb), ctypes.c_uint32(max_trials), _vp(n2), ctypes.byref(trials), ctypes.byref(used),
+                                        _vp(pg_group), _vp(pg_batch), _vp(pg_off), _vp(pg_sites), _sz(cap), _sz(cap),
+                                        ctypes.byref(npg))
+    if st != 0:
+        raise CmxError(st, "cmx_debug_candidate_cursor: bad arguments")
+    pgs = [(int(pg_group[q]), int(pg_batch[q]), [int(x) for x in pg_sites[pg_off[q]:pg_off[q + 1]]]) for q in range(npg.value)]
+    return dict(n2=n2, trials=trials.value, batches=used.value, pseudo_groups=pgs)
 
 
 class Engine:

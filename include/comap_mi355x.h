@@ -248,6 +248,14 @@ cmx_status cmx_candidate_groups(cmx_ctx* ctx, int kind, const double* params, si
                                 const double* observed, uint32_t min_sim, size_t rep_ram, uint32_t max_trials,
                                 uint64_t max_batches, uint64_t seed, uint32_t* n1, uint32_t* n2, uint32_t* trials,
                                 uint64_t* batches);
+/* host-side only (no GPU needed): the cursor of cmx_candidate_groups run over caller-supplied norms
+ * [nbatches][rep_ram]; lists the pseudo-groups it assembles (candidate group, batch, stand-in sites within the batch;
+ * pg_offsets has cap_groups + 1 entries).  *npg receives their number even beyond the capacities. */
+cmx_status cmx_debug_candidate_cursor(size_t ngroups, const int64_t* offsets, const double* norm_lo, const double* norm_hi,
+                                      const uint8_t* analysable, uint32_t min_sim, const double* norms, size_t rep_ram,
+                                      size_t nbatches, uint32_t max_trials, uint32_t* n2, uint32_t* trials,
+                                      uint64_t* batches_used, int32_t* pg_group, int32_t* pg_batch, int64_t* pg_offsets,
+                                      int32_t* pg_sites, size_t cap_groups, size_t cap_sites, size_t* npg);
 
 /* ---- clustering analysis (CoMap/CoMap.cpp:395-560; null: ClusterTools::computeGlobalDistanceDistribution,
  * CoMap/ClusterTools.cpp:200-294).  Distances of CoMap.cpp:402-428: 1 - correlation (StatisticBasedDistance(cor, 1.),
