@@ -1204,6 +1204,69 @@ cmx_status cmx_mica_zscore_null(cmx_ctx* ctx, int which, const double* mi, size_
   return CMX_OK;
 }
 
+cmx_status cmx_mica_permutation_test_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* d_aln, size_t n, size_t ld,
+                                         uint32_t max_perm, uint64_t seed, size_t pair_begin, size_t pair_end,
+                                         double* d_pvalue, int32_t* d_nperm, void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (nalpha != 4 && nalpha != 20) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: alphabet size must be 4 or 20");
+  if (ntaxa < 2 || ntaxa > mica_perm_max_taxa())
+    return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: 2 <= ntaxa <= " + std::to_string(mica_perm_max_taxa()));
+  if (!d_aln || n < 2 || ld < n || max_perm == 0 || pair_end <= pair_begin || pair_end > n * (n - 1) / 2 || !d_pvalue || !d_nperm)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_mica_permutation_test: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  uint16_t* d_cnt;
+  int* d_bad;
+  long long* d_dF;
+  cmx_status s;
+  if ((s = scratch(ctx, "perm_cnt", sizeof(uint16_t) * n * nalpha, (void**)&d_cnt)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "perm_bad", sizeof(int), (void**)&d_bad)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "perm_dF", sizeof(long long) * ntaxa, (void**)&d_dF)) != CMX_OK) return s;
+  // F[c] = round(c ln c * 2^40); the kernel accumulates F[c+1] - F[c] per increment of a joint count
+  std::vector<long long> dF(ntaxa);
+  long long prev = 0;
+  for (int c = 1; c <= ntaxa; ++c) {
+    const long long f = std::llround((double)c * std::log((double)c) * 1099511627776.0);
+    dF[c - 1] = f - prev;
+    prev = f;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d_dF, dF.data(), sizeof(long long) * ntaxa, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), st));
+  HIP_TRY(ctx, launch_mica_colcount(d_aln, ntaxa, n, ld, nalpha, d_cnt, d_bad, st));
+  int bad = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (bad) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: the alignment has gaps or ambiguity codes "
+                                                 "(only fully resolved columns; use the bootstrap or z-score nulls)");
+  int cus = 0;
+  HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+  HIP_TRY(ctx, launch_mica_perm(d_aln, ntaxa, n, ld, nalpha, d_cnt, d_dF, max_perm, seed, pair_begin, pair_end, d_pvalue, d_nperm,
+                                cus, st));
+  return CMX_OK;
+}
+
+cmx_status cmx_mica_permutation_test(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* aln, size_t n, uint32_t max_perm,
+                                     uint64_t seed, double* pvalue, int32_t* nperm) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!aln || n < 2 || ntaxa < 2 || !pvalue || !nperm) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_permutation_test: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t np = n * (n - 1) / 2;
+  TmpDev tmp;
+  uint8_t* d_aln;
+  double* d_pv;
+  int32_t* d_np;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_aln, (size_t)ntaxa * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_pv, sizeof(double) * np));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_np, sizeof(int32_t) * np));
+  HIP_TRY(ctx, hipMemcpy(d_aln, aln, (size_t)ntaxa * n, hipMemcpyHostToDevice));
+  cmx_status s = cmx_mica_permutation_test_dev(ctx, nalpha, ntaxa, d_aln, n, n, max_perm, seed, 0, np, d_pv, d_np, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(pvalue, d_pv, sizeof(double) * np, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(nperm, d_np, sizeof(int32_t) * np, hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ clustering
 static cmx_status check_cluster(cmx_ctx* ctx, int dist_kind, int linkage, size_t n) {
   if (dist_kind < CMX_DIST_CORRELATION || dist_kind > CMX_DIST_EUCLIDIAN) return fail(ctx, CMX_ERR_INVALID, "unknown clustering distance");

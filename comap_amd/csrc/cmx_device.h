@@ -121,6 +121,11 @@ hipError_t launch_group_stats(int kind, double param, int B, int K, const double
 hipError_t launch_mica_average(const double* d_mi, size_t n, size_t ld, double* d_avg, double* d_full, hipStream_t stream);
 hipError_t launch_mica_zscore(int which, const double* d_mi, size_t n, size_t ld, const double* d_avg, const double* d_full,
                               const double* d_key, double* d_stat, double* d_outkey, hipStream_t stream);
+int mica_perm_max_taxa();
+hipError_t launch_mica_colcount(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, uint16_t* d_cnt, int* d_bad, hipStream_t stream);
+hipError_t launch_mica_perm(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, const uint16_t* d_colcnt, const long long* d_dF,
+                            uint32_t max_perm, uint64_t seed, size_t pair_begin, size_t pair_end, double* d_pvalue, int32_t* d_nperm,
+                            int cu_count, hipStream_t stream);
 // clustering (cmx_cluster.hip)
 size_t hclust_lds_bytes(int n);
 size_t cluster_props_lds_bytes(int n);

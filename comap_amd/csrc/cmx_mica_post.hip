@@ -3,6 +3,8 @@
 // data set itself into one draw of the null distribution.  Bandwidth-bound passes over the n x n matrix.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "cmx_device.h"
 
 namespace cmx {
@@ -58,6 +60,154 @@ __global__ __launch_bounds__(256) void mica_zscore_kernel(int which, const doubl
   out_key[p] = fmin(key[i], key[j]);
 }
 
+
+// ------------------------------------------------------------------------------------------------ permutation test
+// miTest (CoMap/Mica.cpp:93-118): MI of the pair against MI after shuffling the columns, until 5 shuffles reach the
+// observed value or max_perm were done.  What the device does with it:
+//  * shuffling both columns or one is the same distribution of joint tables; H1 and H2 do not change under a shuffle,
+//    so "rep >= mi" is "sum_xy f(c_xy) of the shuffle >= the observed one", f(c) = c ln c.  That sum is kept in fixed
+//    point (F[c] = round(c ln c * 2^40), int64), so it is exact and order-free: tables with the same counts tie
+//    exactly, on any device and in the CPU restatement (the reference's own floating-point sums decide such ties by
+//    rounding noise);
+//  * one wave per pair, one LANE per permutation: 64 shuffles of the same pair run side by side, each lane with its
+//    own copy of column j in LDS (forward Fisher-Yates from the counter RNG: Philox4x32-10, key = seed, counter =
+//    (pair, pair >> 32, permutation, 'P' << 24 | position / 4)) and a 20-counter histogram for the current state of
+//    column i -- positions are taken in the order of column i's states, so only the counts of the current state are
+//    live, and the sum is accumulated from the increments (F[c+1] - F[c]), no pass over the A x A table;
+//  * the sequential stopping rule is applied to the 64 results in order (ballot + popcount).
+// Only fully resolved columns (no gaps / ambiguity codes); T <= kPermMaxTaxa.
+constexpr int kPermMaxTaxa = 2047;
+
+__device__ __forceinline__ void philox4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void mica_colcount_kernel(const uint8_t* __restrict__ aln, int T, size_t n, size_t ld, int A,
+                                                            uint16_t* __restrict__ cnt /*[n][A]*/, int* __restrict__ bad) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint16_t c[20];
+  for (int x = 0; x < A; ++x) c[x] = 0;
+  for (int t = 0; t < T; ++t) {
+    const int v = aln[(size_t)t * ld + i];
+    if (v >= A) { *bad = 1; continue; }
+    for (int x = 0; x < A; ++x) c[x] += (v == x) ? 1 : 0;
+  }
+  for (int x = 0; x < A; ++x) cnt[i * A + x] = c[x];
+}
+
+struct PermArgs {
+  const uint8_t* aln; int T; size_t n, ld; int A;
+  const uint16_t* colcnt;
+  const long long* dF;       // [T]: F[c+1] - F[c]
+  uint32_t max_perm; uint64_t seed;
+  size_t pair_begin, pair_end;   // pairs in row-major (i < j) order
+  double* pvalue; int32_t* nperm;   // indexed by pair - pair_begin
+  int qstride, cstride;      // bytes per lane of the private column copy / counters
+  int wave_bytes;
+};
+
+__global__ void mica_perm_kernel(PermArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t perm_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int T = a.T, A = a.A;
+  long long* dF = reinterpret_cast<long long*>(perm_smem);                       // [T] block-shared
+  uint8_t* wbase = perm_smem + (size_t)T * 8 + (size_t)wave * a.wave_bytes;
+  uint32_t* joint = reinterpret_cast<uint32_t*>(wbase);                          // [A*A] observed table
+  uint16_t* seg = reinterpret_cast<uint16_t*>(wbase + A * A * 4);                // [A] end position of state x in column i's order
+  uint8_t* qbase = wbase + A * A * 4 + 64;                                       // [T] column j
+  uint8_t* q = qbase + ((T + 3) & ~3) + (size_t)lane * a.qstride;               // private copy
+  uint16_t* cnt = reinterpret_cast<uint16_t*>(qbase + ((T + 3) & ~3) + (size_t)64 * a.qstride + (size_t)lane * a.cstride);
+  for (int c = threadIdx.x; c < T; c += blockDim.x) dF[c] = a.dF[c];
+  __syncthreads();
+  const size_t n = a.n;
+  for (size_t p = a.pair_begin + (size_t)blockIdx.x * nwaves + wave; p < a.pair_end; p += (size_t)gridDim.x * nwaves) {
+    // (i, j) of pair p in row-major order: p = i*n - i(i+1)/2 + (j - i - 1)
+    size_t i = (size_t)((2.0 * n - 1.0 - sqrt((2.0 * n - 1.0) * (2.0 * n - 1.0) - 8.0 * (double)p)) / 2.0);
+    while (i > 0 && i * n - i * (i + 1) / 2 > p) --i;
+    while ((i + 1) * n - (i + 1) * (i + 2) / 2 <= p) ++i;
+    const size_t j = p - (i * n - i * (i + 1) / 2) + i + 1;
+    // column setup (wave-cooperative)
+    for (int e = lane; e < A * A; e += 64) joint[e] = 0;
+    int nz_i = 0, nz_j = 0;
+    if (lane == 0) {
+      int run = 0;
+      for (int x = 0; x < A; ++x) {
+        const int ci = a.colcnt[i * A + x], cj = a.colcnt[j * A + x];
+        nz_i += ci > 0; nz_j += cj > 0;
+        run += ci;
+        seg[x] = (uint16_t)run;
+      }
+    }
+    nz_i = __shfl(nz_i, 0); nz_j = __shfl(nz_j, 0);
+    for (int t = lane; t < T; t += 64) qbase[t] = a.aln[(size_t)t * a.ld + j];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (nz_i <= 1 || nz_j <= 1) {     // SiteTools::isConstant(site, ignoreUnknown = true), Mica.cpp:100-104
+      if (lane == 0) { a.pvalue[p - a.pair_begin] = 1.0; a.nperm[p - a.pair_begin] = 0; }
+      continue;
+    }
+    long long sobs = 0;
+    for (int t = lane; t < T; t += 64) {
+      const int x = a.aln[(size_t)t * a.ld + i], y = qbase[t];
+      const uint32_t old = atomicAdd(&joint[x * A + y], 1u);
+      sobs += dF[old];
+    }
+    for (int off = 32; off; off >>= 1) sobs += __shfl_xor(sobs, off);
+    uint32_t done = 0, count = 0;
+    bool stop = false;
+    while (!stop && done < a.max_perm) {
+      const uint32_t k = done + (uint32_t)lane;
+      for (int t = 0; t < T; t += 4) *reinterpret_cast<uint32_t*>(q + t) = *reinterpret_cast<const uint32_t*>(qbase + t);
+      long long s = 0;
+      int x = -1, send = 0;
+      uint32_t r[4] = {0, 0, 0, 0};
+      for (int t = 0; t < T; ++t) {
+        while (t >= send) {            // next state of column i that occurs (wave-uniform)
+          ++x;
+          send = seg[x];
+          for (int y = 0; y < A; y += 2) *reinterpret_cast<uint32_t*>(cnt + y) = 0;
+        }
+        if ((t & 3) == 0) philox4(a.seed, (uint32_t)p, (uint32_t)((uint64_t)p >> 32), k, 0x50000000u | (uint32_t)(t >> 2), r);
+        const int jj = t + (int)__umulhi(r[t & 3], (uint32_t)(T - t));
+        const uint8_t vj = q[jj], vt = q[t];
+        q[jj] = vt;                    // q[t] itself is not read again
+        const int c = cnt[vj];
+        s += dF[c];
+        cnt[vj] = (uint16_t)(c + 1);
+      }
+      const bool hit = k < a.max_perm && s >= sobs;
+      const unsigned long long m = __ballot(hit);
+      const uint32_t avail = min(64u, a.max_perm - done);
+      const int need = 5 - (int)count;
+      if (__popcll(m) >= need) {       // the need-th hit ends the loop: find its position
+        unsigned long long mm = m;
+        for (int z = 1; z < need; ++z) mm &= mm - 1;
+        const int pos = __ffsll((long long)mm) - 1;
+        done += (uint32_t)pos + 1;
+        count = 5;
+        stop = true;
+      } else {
+        count += (uint32_t)__popcll(m);
+        done += avail;
+      }
+    }
+    if (lane == 0) {
+      a.pvalue[p - a.pair_begin] = (double)(count + 1) / (double)(done + 1);
+      a.nperm[p - a.pair_begin] = (int32_t)done;
+    }
+  }
+}
+
 }  // namespace
 
 hipError_t launch_mica_average(const double* d_mi, size_t n, size_t ld, double* d_avg, double* d_full, hipStream_t stream) {
@@ -73,4 +223,36 @@ hipError_t launch_mica_zscore(int which, const double* d_mi, size_t n, size_t ld
   return hipGetLastError();
 }
 
+}  // namespace cmx
+
+namespace cmx {
+int mica_perm_max_taxa() { return kPermMaxTaxa; }
+
+hipError_t launch_mica_colcount(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, uint16_t* d_cnt, int* d_bad, hipStream_t stream) {
+  hipLaunchKernelGGL(mica_colcount_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_aln, T, n, ld, A, d_cnt, d_bad);
+  return hipGetLastError();
+}
+
+hipError_t launch_mica_perm(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, const uint16_t* d_colcnt, const long long* d_dF,
+                            uint32_t max_perm, uint64_t seed, size_t pair_begin, size_t pair_end, double* d_pvalue, int32_t* d_nperm,
+                            int cu_count, hipStream_t stream) {
+  PermArgs a{};
+  a.aln = d_aln; a.T = T; a.n = n; a.ld = ld; a.A = A; a.colcnt = d_colcnt; a.dF = d_dF; a.max_perm = max_perm; a.seed = seed;
+  a.pair_begin = pair_begin; a.pair_end = pair_end; a.pvalue = d_pvalue; a.nperm = d_nperm;
+  int sd = (T + 3) / 4; if (sd % 2 == 0) ++sd;
+  a.qstride = 4 * sd;
+  int cd = (A * 2 + 3) / 4; if (cd % 2 == 0) ++cd;
+  a.cstride = 4 * cd;
+  a.wave_bytes = (A * A * 4 + 64 + ((T + 3) & ~3) + 64 * a.qstride + 64 * a.cstride + 15) & ~15;
+  const int budget = 150 * 1024 - T * 8;
+  const int waves = std::max(1, std::min(4, budget / a.wave_bytes));
+  const size_t lds = (size_t)T * 8 + (size_t)waves * a.wave_bytes;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mica_perm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const size_t npairs = pair_end - pair_begin;
+  const size_t per_cu = std::max<size_t>(1, (160 * 1024) / lds);
+  const unsigned grid = (unsigned)std::min<size_t>((npairs + waves - 1) / waves, (size_t)cu_count * per_cu);
+  hipLaunchKernelGGL(mica_perm_kernel, dim3(grid), dim3(64 * waves), lds, stream, a);
+  return hipGetLastError();
+}
 }  // namespace cmx

@@ -178,17 +178,19 @@ def write_mica(out, coords, res):
     """Mica's output.file (CoMap/Mica.cpp:634-690).  res: comap_amd.mica.analysis(...)."""
     n = len(coords)
     mi, hj, h, avg, full = res["mi"], res["hjoint"], res["entropy"], res["average_mi"], res["full_average_mi"]
-    norms, pv = res.get("norms"), res.get("pvalue")
+    norms, pv, pp = res.get("norms"), res.get("pvalue"), res.get("perm_pvalue")
     fh, close = _open(out, "w")
     try:
         fh.write("Group\tMI\tAPC\tRCW\tHjoint\tHmin" + ("\tNmin" if norms is not None else "") +
-                 ("\tBs.p.value\tBs.nb" if pv is not None else "") + "\n")
+                 ("\tPerm.p.value\tPerm.nb" if pp is not None else "") + ("\tBs.p.value\tBs.nb" if pv is not None else "") + "\n")
         for i in range(n - 1):
             for j in range(i + 1, n):
                 f = ["[%d;%d]" % (int(coords[i]), int(coords[j])), fmt(mi[i, j]), fmt(avg[i] * avg[j] / full),
                      fmt(avg[i] * avg[j] / 2.0), fmt(hj[i, j]), fmt(min(h[i], h[j]))]
                 if norms is not None:
                     f.append(fmt(min(norms[i], norms[j])))
+                if pp is not None:
+                    f += [fmt(pp[i, j]), str(int(res["perm_nb"][i, j]))]
                 if pv is not None:
                     f += ["NA", "0"] if math.isnan(pv[i, j]) else [fmt(pv[i, j]), str(int(res["nsim"][i, j]))]
                 fh.write("\t".join(f) + "\n")

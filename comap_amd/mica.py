@@ -9,7 +9,7 @@
 Site indices come from the engine's counter-based generator scheme (Philox keyed by seed), not from Bio++'s global
 generator: null distributions agree with the reference in distribution, not draw for draw.
   zscore_null / analysis  <- null.method = z-score, CoMap/Mica.cpp:549-607, and the output table of :634-690
-The permutation test (miTest, Mica.cpp:93-118) is sequential per pair and is not offered."""
+  permutation_test        <- null.method = permutations, miTest CoMap/Mica.cpp:93-118 (fully resolved columns only)"""
 import numpy as np
 
 
@@ -45,7 +45,17 @@ def parametric_null(engine, seed, nrep_cpu=10, nrep_ram=100, nalpha=20):
     return dict(mi=np.concatenate(mi), hjoint=np.concatenate(hj))
 
 
-def analysis(engine, aln, nalpha=20, masks=None, norms=None, null=None, nclasses=10):
+def permutation_test(engine, aln, max_perm=1000, seed=0, nalpha=20):
+    """-> dense (pvalue [n, n], nperm [n, n]) filled for j > i: Perm.p.value / Perm.nb of Mica.cpp:667-668"""
+    n = aln.shape[1]
+    pv, npm = engine.mica_permutation_test(aln, max_perm, seed, nalpha)
+    iu = np.triu_indices(n, 1)
+    P, N = np.full((n, n), np.nan), np.zeros((n, n), dtype=np.int32)
+    P[iu], N[iu] = pv, npm
+    return P, N
+
+
+def analysis(engine, aln, nalpha=20, masks=None, norms=None, null=None, nclasses=10, permutations=None):
     """The table Mica writes (Mica.cpp:634-690) as dense arrays: MI, Hjoint per pair, entropy / averageMI per column,
     fullAverageMI, and -- if `null` = (null_stat, null_key) is given -- Bs.p.value / Bs.nb per pair, binned on the
     model norms when given (withModel) and on min entropy otherwise (Mica.cpp:383-386, 672).  All numbers come from the
@@ -57,6 +67,8 @@ def analysis(engine, aln, nalpha=20, masks=None, norms=None, null=None, nclasses
     if null is not None:
         key = out["entropy"] if norms is None else out["norms"]
         out["pvalue"], out["nsim"] = engine.intra_pvalues(r["mi"], key, nclasses, null[0], null[1])
+    if permutations is not None:          # (max_perm, seed)
+        out["perm_pvalue"], out["perm_nb"] = permutation_test(engine, aln, permutations[0], permutations[1], nalpha)
     return out
 
 

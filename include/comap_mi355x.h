@@ -257,6 +257,19 @@ cmx_status cmx_debug_candidate_cursor(size_t ngroups, const int64_t* offsets, co
                                       uint64_t* batches_used, int32_t* pg_group, int32_t* pg_batch, int64_t* pg_offsets,
                                       int32_t* pg_sites, size_t cap_groups, size_t cap_sites, size_t* npg);
 
+/* Mica's permutation test, null.method = permutations: miTest (CoMap/Mica.cpp:93-118) for the pairs
+ * [pair_begin, pair_end) of the row-major (i < j) order: columns are shuffled until 5 shuffles reach the observed MI or
+ * max_perm (null.max_number_of_permutations) were done; pvalue = (count + 1) / (nperm + 1); pairs with a constant
+ * column get pvalue 1, nperm 0.  "MI of the shuffle >= MI" is decided on sum c ln c of the joint table in 2^-40 fixed
+ * point (exact, order-free).  Shuffles come from the counter RNG (seed, pair, permutation, position), so
+ * results do not depend on how pairs are sharded.  Only fully resolved alignments (every code < nalpha), ntaxa <= 2047:
+ * CMX_ERR_UNSUPPORTED otherwise. */
+cmx_status cmx_mica_permutation_test_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* d_aln, size_t n, size_t ld,
+                                         uint32_t max_perm, uint64_t seed, size_t pair_begin, size_t pair_end,
+                                         double* d_pvalue, int32_t* d_nperm, void* stream);
+cmx_status cmx_mica_permutation_test(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* aln, size_t n, uint32_t max_perm,
+                                     uint64_t seed, double* pvalue /*[n(n-1)/2]*/, int32_t* nperm);
+
 /* ---- clustering analysis (CoMap/CoMap.cpp:395-560; null: ClusterTools::computeGlobalDistanceDistribution,
  * CoMap/ClusterTools.cpp:200-294).  Distances of CoMap.cpp:402-428: 1 - correlation (StatisticBasedDistance(cor, 1.),
  * Distance.h:321-336), 1 - compensation (CompensationDistance, Distance.h:376-385), Euclidian (Distance.h:161-181).

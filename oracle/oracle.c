@@ -646,3 +646,61 @@ void orc_mi_columns(int T, int A, const uint32_t* masks, long N1, const uint8_t*
     }
   free(p12);
 }
+
+
+/* ------------------------------------------------------------------ Mica permutation test
+ * miTest (CoMap/Mica.cpp:93-118) for the column pairs [pair_begin, pair_end) of the row-major (i < j) order, fully
+ * resolved columns only.  PARITY UNPINNED (no reference output; Bio++'s Site::shuffle draws from a global generator).
+ * This build's scheme, shared with the product: only column j is shuffled (same distribution of joint tables), by a
+ * forward Fisher-Yates over the positions 0..T-1 with jj = t + mulhi32(r, T - t), r = word (t & 3) of Philox4x32-10
+ * (key = seed, counter = (pair, pair >> 32, permutation, 'P' << 24 | t >> 2)); position t carries column i's states in
+ * sorted order; "MI of the shuffle >= MI" is decided on sum_xy F[c_xy], F[c] = round(c ln c * 2^40) in int64. */
+int orc_mica_permutation_test(const uint8_t* aln, int T, long n, int A, uint32_t max_perm, uint64_t seed, long pair_begin,
+                              long pair_end, double* pvalue, int32_t* nperm) {
+  long long* F = (long long*)calloc((size_t)T + 1, sizeof(long long));
+  uint8_t* q = (uint8_t*)malloc((size_t)T);
+  uint8_t* xs = (uint8_t*)malloc((size_t)T);
+  int* joint = (int*)malloc(sizeof(int) * (size_t)A * A);
+  for (int c = 1; c <= T; c++) F[c] = llround((double)c * log((double)c) * 1099511627776.0);
+  long p = 0;
+  for (long i = 0; i < n - 1; i++)
+    for (long j = i + 1; j < n; j++, p++) {
+      if (p < pair_begin || p >= pair_end) continue;
+      int ci[32] = {0}, cj[32] = {0}, nzi = 0, nzj = 0;
+      for (int t = 0; t < T; t++) {
+        if (aln[(size_t)t * n + i] >= A || aln[(size_t)t * n + j] >= A) { free(F); free(q); free(xs); free(joint); return -2; }
+        ci[aln[(size_t)t * n + i]]++;
+        cj[aln[(size_t)t * n + j]]++;
+      }
+      for (int x = 0; x < A; x++) { nzi += ci[x] > 0; nzj += cj[x] > 0; }
+      if (nzi <= 1 || nzj <= 1) { pvalue[p - pair_begin] = 1.0; nperm[p - pair_begin] = 0; continue; }
+      memset(joint, 0, sizeof(int) * (size_t)A * A);
+      for (int t = 0; t < T; t++) joint[aln[(size_t)t * n + i] * A + aln[(size_t)t * n + j]]++;
+      long long sobs = 0;
+      for (int e = 0; e < A * A; e++) sobs += F[joint[e]];
+      { int t = 0; for (int x = 0; x < A; x++) for (int c = 0; c < ci[x]; c++) xs[t++] = (uint8_t)x; }
+      uint32_t k = 0, count = 0;
+      for (; count < 5 && k < max_perm; k++) {
+        for (int t = 0; t < T; t++) q[t] = aln[(size_t)t * n + j];
+        memset(joint, 0, sizeof(int) * (size_t)A * A);
+        uint32_t r[4] = {0, 0, 0, 0};
+        for (int t = 0; t < T; t++) {
+          if ((t & 3) == 0)
+            philox4x32_10((uint32_t)p, (uint32_t)((uint64_t)p >> 32), k, 0x50000000u | (uint32_t)(t >> 2), (uint32_t)seed,
+                          (uint32_t)(seed >> 32), r);
+          const int jj = t + (int)(((uint64_t)r[t & 3] * (uint32_t)(T - t)) >> 32);
+          const uint8_t vj = q[jj];
+          q[jj] = q[t];
+          q[t] = vj;
+          joint[xs[t] * A + vj]++;
+        }
+        long long s = 0;
+        for (int e = 0; e < A * A; e++) s += F[joint[e]];
+        if (s >= sobs) count++;
+      }
+      pvalue[p - pair_begin] = (double)(count + 1) / (double)(k + 1);
+      nperm[p - pair_begin] = (int32_t)k;
+    }
+  free(F); free(q); free(xs); free(joint);
+  return 0;
+}

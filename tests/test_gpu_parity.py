@@ -500,3 +500,39 @@ def test_mi_columns_matches_oracle_with_ambiguity():
     oi = oracle.mi_columns(a2, a2, 20, masks)
     iu = np.triu_indices(n2, 1)
     rel_close(gi["mi"][iu], oi["mi"][iu], 1e-6, 1e-12)
+
+
+@pytest.mark.parametrize("A,T,n,max_perm", [(20, 30, 14, 200), (4, 64, 9, 1000), (20, 65, 7, 64), (20, 257, 6, 130), (4, 7, 5, 63)])
+def test_mica_permutation_test_matches_oracle(A, T, n, max_perm):
+    """miTest (Mica.cpp:93-118): p-value and number of permutations per pair, bit for bit (counter RNG + fixed-point
+    comparison), across batch boundaries of 64 permutations and for constant columns"""
+    rng = np.random.default_rng(A * 1000 + T)
+    base = rng.integers(0, A, size=(T, 1))
+    aln = np.where(rng.random((T, n)) < 0.55, base, rng.integers(0, A, size=(T, n))).astype(np.uint8)
+    aln[:, 2] = 1                                        # constant column: p = 1, 0 permutations
+    eng = engine.Engine()
+    pv, npm = eng.mica_permutation_test(aln, max_perm, 99, nalpha=A)
+    po, no = oracle.mica_permutation_test(aln, A, max_perm, 99)
+    assert np.array_equal(npm, no) and np.array_equal(pv, po)
+    iu = np.triu_indices(n, 1)
+    const = (iu[0] == 2) | (iu[1] == 2)
+    assert np.all(npm[const] == 0) and np.all(pv[const] == 1.0)
+    assert np.all(npm[~const] >= 5) and np.all(npm <= max_perm)
+    stopped = npm < max_perm
+    assert np.allclose(pv[stopped & ~const], 6.0 / (npm[stopped & ~const] + 1.0))
+
+
+def test_mica_permutation_test_is_calibrated_and_rejects_gaps():
+    """independent columns: p-values roughly uniform; coupled columns: small p; gaps are refused, not guessed"""
+    rng = np.random.default_rng(1)
+    T, n = 100, 40
+    aln = rng.integers(0, 4, size=(T, n)).astype(np.uint8)
+    aln[:, 1] = (aln[:, 0] + (rng.random(T) < 0.15)) % 4     # column 1 follows column 0
+    eng = engine.Engine()
+    pv, npm = eng.mica_permutation_test(aln, 1000, 3, nalpha=4)
+    assert pv[0] < 0.01 and npm[0] == 1000                   # pair (0, 1)
+    rest = pv[n - 1:]                                        # pairs not involving column 0... (row 0 is the first n-1 pairs)
+    assert 0.3 < np.median(rest) < 0.8 and (rest < 0.05).mean() < 0.12
+    aln[3, 5] = 4
+    with pytest.raises(engine.CmxError, match="gaps or ambiguity"):
+        eng.mica_permutation_test(aln, 100, 3, nalpha=4)
