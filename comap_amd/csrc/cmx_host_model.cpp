@@ -352,14 +352,15 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   *code = CMX_ERR_INVALID;
   if (!model || !tree) return "model and tree are required";
   const int S = model->nstates, C = model->nclasses;
-  const int K = model->Bk ? model->ntypes : 1;
+  const int K = (model->nmodels > 0 ? model->Bks : model->Bk) ? model->ntypes : 1;
   if (S != 4 && S != 20) {
     *code = CMX_ERR_UNSUPPORTED;
     return "nstates must be 4 (nucleotides) or 20 (proteins); got " + std::to_string(S);
   }
   if (C < 1 || C > 64) return "nclasses out of range";
   if (K < 1 || K > 64) return "ntypes out of range";
-  if (!model->Q || !model->pi || !model->rates || !model->probs) return "Q, pi, rates and probs are required";
+  if (!model->rates || !model->probs) return "rates and probs are required";
+  if (model->nmodels <= 0 && (!model->Q || !model->pi)) return "Q, pi, rates and probs are required";
   const int nn = tree->nnodes, T = tree->ntaxa;
   if (nn < 3 || T < 2 || !tree->parent || !tree->blen || !tree->leaf_of_taxon) return "tree is incomplete";
   if (nn > 65535) return "tree too large";
@@ -407,7 +408,15 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
     if (!bad.empty()) return bad;
   }
   // ---- model checks
-  hm->pi.assign(model->pi, model->pi + S);
+  const bool nh = model->nmodels > 0;
+  const int NM = nh ? model->nmodels : 1;
+  if (nh && (!model->Qs || !model->pis || !model->model_of_branch || !model->root_freqs))
+    return "non-homogeneous model: Qs, pis, model_of_branch and root_freqs are required";
+  if (!nh && (model->Qs || model->pis || model->Bks || model->model_of_branch || model->root_freqs))
+    return "non-homogeneous fields are set but nmodels is 0";
+  // frequencies at the root: the stationary ones, or the model set's root frequency set
+  const double* rootf = nh ? model->root_freqs : model->pi;
+  hm->pi.assign(rootf, rootf + S);
   hm->rates.assign(model->rates, model->rates + C);
   hm->probs.assign(model->probs, model->probs + C);
   double spi = 0, spr = 0;
@@ -416,45 +425,65 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   if (std::fabs(spi - 1.0) > 1e-6 || std::fabs(spr - 1.0) > 1e-6) return "pi and probs must sum to one";
   for (double v : hm->rates) if (!(v >= 0) || !std::isfinite(v)) return "rates must be finite and >= 0";
   const size_t S2 = (size_t)S * S;
-  Mat Q(model->Q, model->Q + S2);
-  for (int x = 0; x < S; ++x) {
-    double rs = 0;
-    for (int y = 0; y < S; ++y) {
-      rs += Q[(size_t)x * S + y];
-      const double a = hm->pi[x] * Q[(size_t)x * S + y], b = hm->pi[y] * Q[(size_t)y * S + x];
-      if (std::fabs(a - b) > 1e-9 * (std::fabs(a) + std::fabs(b) + 1e-300) + 1e-14)
-        return "Q must be reversible with respect to pi (pi_x Q_xy == pi_y Q_yx)";
+  std::vector<int> model_of(hm->B, 0);
+  if (nh)
+    for (int b = 0; b < hm->B; ++b) {
+      model_of[b] = model->model_of_branch[b];
+      if (model_of[b] < 0 || model_of[b] >= NM) return "model_of_branch: generator index out of range";
     }
-    if (std::fabs(rs) > 1e-9) return "rows of Q must sum to zero";
-  }
-  std::vector<Mat> Bk(K);
-  for (int k = 0; k < K; ++k) {
-    if (model->Bk) Bk[k].assign(model->Bk + k * S2, model->Bk + (k + 1) * S2);
-    else { Bk[k] = Q; for (int x = 0; x < S; ++x) Bk[k][(size_t)x * S + x] = 0.0; }
-  }
-  // ---- eigen-decomposition through the symmetrised generator
-  Mat A(S2), U;
-  std::vector<double> lam;
-  for (int x = 0; x < S; ++x)
-    for (int y = 0; y < S; ++y) A[(size_t)x * S + y] = std::sqrt(hm->pi[x]) * Q[(size_t)x * S + y] / std::sqrt(hm->pi[y]);
-  for (int x = 0; x < S; ++x)
-    for (int y = x + 1; y < S; ++y) A[(size_t)x * S + y] = A[(size_t)y * S + x] = 0.5 * (A[(size_t)x * S + y] + A[(size_t)y * S + x]);
-  jacobi(S, A, &U, &lam);
-  Mat V(S2), Vi(S2);
-  for (int x = 0; x < S; ++x)
-    for (int j = 0; j < S; ++j) {
-      V[(size_t)x * S + j] = U[(size_t)x * S + j] / std::sqrt(hm->pi[x]);
-      Vi[(size_t)j * S + x] = U[(size_t)x * S + j] * std::sqrt(hm->pi[x]);
+  // ---- per generator: checks and eigen-decomposition through the symmetrised generator
+  struct Eig { Mat V, Vi; std::vector<double> lam; std::vector<Mat> W; };
+  std::vector<Eig> eig(NM);
+  for (int m = 0; m < NM; ++m) {
+    const double* Qp = nh ? model->Qs + (size_t)m * S2 : model->Q;
+    const double* pip = nh ? model->pis + (size_t)m * S : model->pi;
+    const double* Bp = nh ? (model->Bks ? model->Bks + (size_t)m * K * S2 : nullptr) : model->Bk;
+    Mat Q(Qp, Qp + S2);
+    double sp = 0;
+    for (int x = 0; x < S; ++x) { if (!(pip[x] > 0)) return "pi must be positive"; sp += pip[x]; }
+    if (std::fabs(sp - 1.0) > 1e-6) return "pi and probs must sum to one";
+    for (int x = 0; x < S; ++x) {
+      double rs = 0;
+      for (int y = 0; y < S; ++y) {
+        rs += Q[(size_t)x * S + y];
+        const double a = pip[x] * Q[(size_t)x * S + y], b = pip[y] * Q[(size_t)y * S + x];
+        if (std::fabs(a - b) > 1e-9 * (std::fabs(a) + std::fabs(b) + 1e-300) + 1e-14)
+          return "Q must be reversible with respect to pi (pi_x Q_xy == pi_y Q_yx)";
+      }
+      if (std::fabs(rs) > 1e-9) return "rows of Q must sum to zero";
     }
-  std::vector<Mat> W(K);  // Vinv B_k V
-  for (int k = 0; k < K; ++k) W[k] = matmul(S, matmul(S, Vi, Bk[k]), V);
-  // ---- per (class, branch) matrices
+    std::vector<Mat> Bk(K);
+    for (int k = 0; k < K; ++k) {
+      if (Bp) Bk[k].assign(Bp + k * S2, Bp + (k + 1) * S2);
+      else { Bk[k] = Q; for (int x = 0; x < S; ++x) Bk[k][(size_t)x * S + x] = 0.0; }
+    }
+    Mat A(S2), U;
+    for (int x = 0; x < S; ++x)
+      for (int y = 0; y < S; ++y) A[(size_t)x * S + y] = std::sqrt(pip[x]) * Q[(size_t)x * S + y] / std::sqrt(pip[y]);
+    for (int x = 0; x < S; ++x)
+      for (int y = x + 1; y < S; ++y) A[(size_t)x * S + y] = A[(size_t)y * S + x] = 0.5 * (A[(size_t)x * S + y] + A[(size_t)y * S + x]);
+    Eig& e = eig[m];
+    jacobi(S, A, &U, &e.lam);
+    e.V.resize(S2); e.Vi.resize(S2);
+    for (int x = 0; x < S; ++x)
+      for (int j = 0; j < S; ++j) {
+        e.V[(size_t)x * S + j] = U[(size_t)x * S + j] / std::sqrt(pip[x]);
+        e.Vi[(size_t)j * S + x] = U[(size_t)x * S + j] * std::sqrt(pip[x]);
+      }
+    e.W.resize(K);   // Vinv B_k V
+    for (int k = 0; k < K; ++k) e.W[k] = matmul(S, matmul(S, e.Vi, Bk[k]), e.V);
+  }
+  // ---- per (class, branch) matrices, each branch with its own generator
   const int B = hm->B;
   hm->P.assign((size_t)C * B * S2, 0.0);
   hm->PN.assign((size_t)C * B * K * S2, 0.0);
   Mat E(S2), Phi(S2);
   for (int c = 0; c < C; ++c)
     for (int b = 0; b < B; ++b) {
+      const Eig& e = eig[model_of[b]];
+      const Mat &V = e.V, &Vi = e.Vi;
+      const std::vector<double>& lam = e.lam;
+      const std::vector<Mat>& W = e.W;
       const double t = hm->blen[b] * hm->rates[c];
       double* P = &hm->P[((size_t)c * B + b) * S2];
       for (int x = 0; x < S; ++x)

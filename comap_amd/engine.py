@@ -68,7 +68,9 @@ class _Model(ctypes.Structure):
     _fields_ = [("nstates", ctypes.c_int32), ("nclasses", ctypes.c_int32), ("ntypes", ctypes.c_int32),
                 ("Q", ctypes.c_void_p), ("pi", ctypes.c_void_p), ("rates", ctypes.c_void_p),
                 ("probs", ctypes.c_void_p), ("Bk", ctypes.c_void_p), ("count_method", ctypes.c_int32),
-                ("clamp_negative", ctypes.c_int32), ("naive_weights", ctypes.c_void_p)]
+                ("clamp_negative", ctypes.c_int32), ("naive_weights", ctypes.c_void_p),
+                ("nmodels", ctypes.c_int32), ("Qs", ctypes.c_void_p), ("pis", ctypes.c_void_p), ("Bks", ctypes.c_void_p),
+                ("model_of_branch", ctypes.c_void_p), ("root_freqs", ctypes.c_void_p)]
 
 
 class _Tree(ctypes.Structure):
@@ -184,7 +186,10 @@ class Engine:
     """One context per GPU (cmx_ctx).  tree/model given as plain arrays (see include/comap_mi355x.h)."""
 
     def __init__(self, parent=None, blen=None, leaf_of_taxon=None, Q=None, pi=None, rates=None, probs=None, Bk=None,
-                 count_method=COUNT_EXPECTED, clamp_negative=True, naive_weights=None, device=0):
+                 count_method=COUNT_EXPECTED, clamp_negative=True, naive_weights=None, device=0, model_of_branch=None,
+                 root_freqs=None):
+        """Non-homogeneous model set (CoETools.cpp:126-206): Q [M, S, S], pi [M, S], Bk [M, K, S, S] or None,
+        model_of_branch [nnodes], root_freqs [S]."""
         self._lib = load_library()
         self._ctx = ctypes.c_void_p(None)
         self.device = device
@@ -197,10 +202,20 @@ class Engine:
                           _f64(probs), None if Bk is None else _f64(Bk),
                           None if naive_weights is None else _f64(naive_weights)]
             p, bl, lot, Qa, pia, ra, pr, Bka, nw = self._keep
-            S, C = len(pia), len(ra)
-            K = 1 if Bka is None else Bka.reshape(-1, S, S).shape[0]
-            model = _Model(S, C, K, _vp(Qa), _vp(pia), _vp(ra), _vp(pr), _vp(Bka), int(count_method),
-                           int(bool(clamp_negative)), _vp(nw))
+            C = len(ra)
+            if model_of_branch is None:
+                S = len(pia)
+                K = 1 if Bka is None else Bka.reshape(-1, S, S).shape[0]
+                model = _Model(S, C, K, _vp(Qa), _vp(pia), _vp(ra), _vp(pr), _vp(Bka), int(count_method),
+                               int(bool(clamp_negative)), _vp(nw))
+            else:
+                M, S = pia.shape
+                K = 1 if Bka is None else Bka.reshape(M, -1, S, S).shape[1]
+                mob = np.ascontiguousarray(model_of_branch, dtype=np.int32)
+                rf = _f64(root_freqs)
+                self._keep += [mob, rf]
+                model = _Model(S, C, K, _vp(None), _vp(None), _vp(ra), _vp(pr), _vp(None), int(count_method),
+                               int(bool(clamp_negative)), _vp(nw), M, _vp(Qa), _vp(pia), _vp(Bka), _vp(mob), _vp(rf))
             tree = _Tree(len(p), _vp(p), _vp(bl), len(lot), _vp(lot))
             st = self._lib.cmx_ctx_create(ctypes.byref(model), ctypes.byref(tree), int(device), ctypes.byref(self._ctx))
             self.S, self.C, self.K, self.B, self.T = S, C, K, len(p) - 1, len(lot)

@@ -75,6 +75,15 @@ typedef struct {
   int32_t count_method;        /* cmx_count_method */
   int32_t clamp_negative;      /* 1: clamp negative conditional counts to 0 (Bio++ rule for unweighted counts) */
   const double* naive_weights; /* [S*S] for CMX_COUNT_NAIVE, NULL => 1 */
+  /* Non-homogeneous models (nonhomogeneous = one_per_branch | general, CoMap/CoETools.cpp:126-206:
+   * DRNonHomogeneousTreeLikelihood over a SubstitutionModelSet): nmodels > 0 gives every branch its own generator.
+   * Leave all six fields zero for the homogeneous case above (zero-initialise the struct). */
+  int32_t nmodels;                /* number of generators in the set */
+  const double* Qs;               /* [nmodels][S*S], each reversible w.r.t. its row of pis */
+  const double* pis;              /* [nmodels][S] equilibrium frequencies of each generator */
+  const double* Bks;              /* [nmodels][K][S*S] registers per generator; NULL => K = 1, unweighted total */
+  const int32_t* model_of_branch; /* [nnodes] generator of the branch above each node (root entry ignored) */
+  const double* root_freqs;       /* [S] frequencies at the root (the model set's root frequency set) */
 } cmx_model;
 
 typedef struct {

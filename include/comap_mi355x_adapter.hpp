@@ -97,6 +97,11 @@ struct ModelArrays {
   std::vector<double> rates, rateProbabilities;
   std::vector<double> registers;    // K * S * S: Q o register_k o weights; empty => unweighted total count
   int nbTypes = 1;
+  // non-homogeneous model set (leave empty for a homogeneous model): generators [M][S*S], their equilibrium
+  // frequencies [M][S], registers [M][K][S*S] (optional), the generator of the branch above each node [nnodes] =
+  // SubstitutionModelSet::getModelIndexForNode, and the root frequency set [S]
+  std::vector<double> generators, generatorFrequencies, generatorRegisters, rootFrequencies;
+  std::vector<int32_t> modelOfBranch;
   bool naive = false;               // nijt = Naive
   std::vector<double> naiveWeights;
   bool clampNegative = true;        // unweighted counts (Bio++ clamps negative round-off)
@@ -106,7 +111,7 @@ struct ModelArrays {
 class Engine {
  public:
   Engine(const TreeArrays& t, const ModelArrays& m, int device = 0) : S_(m.nbStates) {
-    cmx_model cm;
+    cmx_model cm{};   // zero: homogeneous unless the non-homogeneous fields are filled below
     cm.nstates = m.nbStates;
     cm.nclasses = static_cast<int32_t>(m.rates.size());
     cm.ntypes = m.registers.empty() ? 1 : m.nbTypes;
@@ -118,6 +123,15 @@ class Engine {
     cm.count_method = m.naive ? CMX_COUNT_NAIVE : CMX_COUNT_EXPECTED;
     cm.clamp_negative = m.clampNegative ? 1 : 0;
     cm.naive_weights = m.naiveWeights.empty() ? nullptr : m.naiveWeights.data();
+    if (!m.modelOfBranch.empty()) {   // SubstitutionModelSet: one generator per branch (CoETools.cpp:126-206)
+      cm.nmodels = static_cast<int32_t>(m.generators.size() / (static_cast<size_t>(m.nbStates) * m.nbStates));
+      cm.Qs = m.generators.data();
+      cm.pis = m.generatorFrequencies.data();
+      cm.Bks = m.generatorRegisters.empty() ? nullptr : m.generatorRegisters.data();
+      cm.model_of_branch = m.modelOfBranch.data();
+      cm.root_freqs = m.rootFrequencies.data();
+      cm.ntypes = m.generatorRegisters.empty() ? 1 : m.nbTypes;
+    }
     cmx_tree ct;
     ct.nnodes = static_cast<int32_t>(t.parent.size());
     ct.parent = t.parent.data();

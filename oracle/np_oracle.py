@@ -189,11 +189,21 @@ def leaf_partials(codes, masks, S):
 
 
 def map_sites(parent, blen, leaf_of_taxon, aln, masks, Q, pi, rates, probs, Bk_list, method="unif",
-              nonneg=None, naive_W=None):
+              nonneg=None, naive_W=None, model_of_branch=None, root_freqs=None):
     """DR likelihood + computeSubstitutionVectors(average=yes, joint=yes).
 
     aln: [T, N] uint8 codes (taxon-major).  Returns dict(counts[N,B,K], logL[N], post_rate[N],
-    rate_class[N], norm[N])."""
+    rate_class[N], norm[N]).
+    Non-homogeneous model set (DRNonHomogeneousTreeLikelihood, CoMap/CoETools.cpp:126-206): Q, pi and Bk_list are lists
+    with one entry per generator, model_of_branch[n] names the generator of the branch above node n, root_freqs the
+    frequencies at the root (the tree is used as rooted)."""
+    if model_of_branch is not None:
+        Qs, pis, Bks = [np.asarray(q) for q in Q], [np.asarray(p) for p in pi], Bk_list
+        mob = np.asarray(model_of_branch)
+        pi = np.asarray(root_freqs, dtype=np.float64)
+    else:
+        Qs, pis, Bks = [np.asarray(Q)], [np.asarray(pi)], [Bk_list]
+        mob = np.zeros(len(parent), dtype=np.int64)
     parent = np.asarray(parent)
     nn = len(parent)
     root = nn - 1
@@ -201,9 +211,9 @@ def map_sites(parent, blen, leaf_of_taxon, aln, masks, Q, pi, rates, probs, Bk_l
     T, N = aln.shape
     S = len(pi)
     C = len(rates)
-    K = len(Bk_list) if method != "naive" else 1
+    K = len(Bks[0]) if method != "naive" else 1
     ch = children_lists(parent)
-    lam, V, Vinv = eigen_reversible(Q, pi)
+    eig = [eigen_reversible(q, p) for q, p in zip(Qs, pis)]
     taxon_of_leaf = {int(n): t for t, n in enumerate(leaf_of_taxon)}
 
     D = [None] * nn          # D[n]: [C, N, S]
@@ -211,7 +221,7 @@ def map_sites(parent, blen, leaf_of_taxon, aln, masks, Q, pi, rates, probs, Bk_l
     P = np.zeros((nn, C, S, S))
     for e in range(B):
         for c in range(C):
-            P[e, c] = transition_matrix(lam, V, Vinv, blen[e] * rates[c])
+            P[e, c] = transition_matrix(*eig[mob[e]], blen[e] * rates[c])
     for n in range(nn):
         if not ch[n]:
             lp = leaf_partials(aln[taxon_of_leaf[n]], masks, S)
@@ -250,9 +260,9 @@ def map_sites(parent, blen, leaf_of_taxon, aln, masks, Q, pi, rates, probs, Bk_l
                         np.fill_diagonal(Nm, 0.0)
                     else:
                         if method == "unif":
-                            J = count_matrix_uniformization(Q, Bk_list[k], t)
+                            J = count_matrix_uniformization(Qs[mob[n]], Bks[mob[n]][k], t)
                         else:
-                            J = count_matrix_decomposition(lam, V, Vinv, Bk_list[k], t)
+                            J = count_matrix_decomposition(*eig[mob[n]], Bks[mob[n]][k], t)
                         Nm = conditional_counts(J, P[n, c], nonneg if nonneg is not None else True)
                     JJ = P[n, c] * Nm
                     tot += probs[c] * np.einsum("nx,xy,ny->n", U[c], JJ, D[n][c])

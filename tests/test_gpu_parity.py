@@ -536,3 +536,70 @@ def test_mica_permutation_test_is_calibrated_and_rejects_gaps():
     aln[3, 5] = 4
     with pytest.raises(engine.CmxError, match="gaps or ambiguity"):
         eng.mica_permutation_test(aln, 100, 3, nalpha=4)
+
+
+def _nh_case(nstates, seed):
+    """a rooted tree with three generators spread over its branches (nonhomogeneous = general, CoETools.cpp:184-200)"""
+    from oracle import np_oracle as npo
+    rng = np.random.default_rng(seed)
+    parent, blen, lot = synthetic.random_tree(9, seed)
+    mk = synthetic.protein_model if nstates == 20 else synthetic.dna_model
+    base = mk(0.6, 4 if nstates == 4 else 3)      # 4 classes: the class-fused nucleotide layout
+    Qs, pis = [], []
+    for m in range(3):
+        pi = rng.dirichlet(np.full(nstates, 8.0))
+        R = np.asarray(base["Q"]) / np.asarray(base["pi"])[None, :]      # exchangeabilities of the base generator
+        R = (R + R.T) / 2
+        Q = R * pi[None, :]
+        np.fill_diagonal(Q, 0.0)
+        np.fill_diagonal(Q, -Q.sum(axis=1))
+        Q /= -(pi * np.diag(Q)).sum()
+        Qs.append(Q)
+        pis.append(pi)
+    mob = rng.integers(0, 3, size=len(parent))
+    root = rng.dirichlet(np.full(nstates, 5.0))
+    Bks = [[npo.rate_matrix_register(q)] for q in Qs]
+    return dict(parent=parent, blen=blen, lot=lot, Qs=np.array(Qs), pis=np.array(pis), mob=mob, root=root, Bks=Bks,
+                rates=base["rates"], probs=base["probs"])
+
+
+@pytest.mark.parametrize("nstates", [20, 4])
+def test_non_homogeneous_model_set(nstates):
+    """one generator per branch + root frequency set (DRNonHomogeneousTreeLikelihood, CoETools.cpp:126-206): mapping
+    against the numpy restatement; the simulator against the transition matrices it should draw from"""
+    from oracle import np_oracle as npo
+    c = _nh_case(nstates, 17 + nstates)
+    rng = np.random.default_rng(3)
+    N = 70
+    aln = rng.integers(0, nstates, size=(len(c["lot"]), N)).astype(np.uint8)
+    eng = engine.Engine(c["parent"], c["blen"], c["lot"], c["Qs"], c["pis"], c["rates"], c["probs"], model_of_branch=c["mob"],
+                        root_freqs=c["root"])
+    r = eng.map_sites(aln)
+    o = npo.map_sites(c["parent"], c["blen"], c["lot"], aln, oracle.default_masks(nstates), list(c["Qs"]), list(c["pis"]),
+                      np.asarray(c["rates"]), np.asarray(c["probs"]), c["Bks"], model_of_branch=c["mob"], root_freqs=c["root"])
+    rel_close(r["counts"], o["counts"], 1e-6, 1e-12)
+    rel_close(r["logL"], o["logL"], 1e-6, 0.0)
+    rel_close(r["post_rate"], o["post_rate"], 1e-6, 0.0)
+    assert np.array_equal(r["rate_class"], o["rate_class"])
+    # the same data under the homogeneous model of generator 0 must differ: the set is really used
+    hom = engine.Engine(c["parent"], c["blen"], c["lot"], c["Qs"][0], c["pis"][0], c["rates"], c["probs"]).map_sites(aln)
+    assert np.abs(hom["logL"] - r["logL"]).max() > 1e-3
+    # transition matrices per branch come from the branch's generator
+    P = eng.transition_matrices()
+    for b in (0, 3, len(c["parent"]) - 2):
+        lam, V, Vi = npo.eigen_reversible(c["Qs"][c["mob"][b]], c["pis"][c["mob"][b]])
+        rel_close(P[1, b], npo.transition_matrix(lam, V, Vi, c["blen"][b] * c["rates"][1]), 1e-9, 1e-13)
+    # simulator: root states follow the root frequency set
+    sim, _ = eng.simulate(5, 0, 40000)
+    assert sim.shape == (len(c["lot"]), 40000) and sim.max() < nstates
+    null = eng.null_intra(engine.STAT_CORRELATION, 5, 0, 2, 64)
+    assert np.isfinite(null["stat"]).all()
+
+
+def test_non_homogeneous_argument_errors():
+    c = _nh_case(4, 1)
+    bad = c["mob"].copy()
+    bad[2] = 7
+    with pytest.raises(engine.CmxError, match="out of range"):
+        engine.Engine(c["parent"], c["blen"], c["lot"], c["Qs"], c["pis"], c["rates"], c["probs"], model_of_branch=bad,
+                      root_freqs=c["root"])
