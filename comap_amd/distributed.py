@@ -35,3 +35,22 @@ def gather_null(local_stat, local_nmin, nrep, rep_ram, group=None):
     stat = torch.cat([recv[r, 0, : sizes[r]] for r in range(world)]).to(dev)
     nmin = torch.cat([recv[r, 1, : sizes[r]] for r in range(world)]).to(dev)
     return stat, nmin
+
+
+def gather_shards(local, nitems, group=None):
+    """All-gather of per-item rows computed for the contiguous shard replicate_shard(rank, world, nitems): the
+    clustering null shards its replicates this way (ClusterTools.cpp:221 loop, independent iterations) and Mica's
+    permutation test its column pairs (Mica.cpp:642-648 loop).  local: tensor [items_of_this_rank, ...]; returns
+    [nitems, ...] in item order.  One collective; shards may differ by one item."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [e - b for b, e in (replicate_shard(r, world, nitems) for r in range(world))]
+    mx = max(sizes)
+    dev = local.device
+    xdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+    send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=xdev)
+    send[: local.shape[0]] = local
+    recv = torch.empty((world,) + tuple(send.shape), dtype=local.dtype, device=xdev)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    return torch.cat([recv[r, : sizes[r]] for r in range(world)]).to(dev)

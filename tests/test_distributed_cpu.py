@@ -59,3 +59,38 @@ def test_two_rank_gloo_null_matches_single_process(nrep):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_stat and ok_nmin and n == nrep * 10
+
+
+def _worker_shards(rank, world, port, nitems, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from comap_amd.distributed import gather_shards, replicate_shard
+    import oracle
+    rng = np.random.default_rng(0)
+    aln = rng.integers(0, 4, size=(20, 7)).astype(np.uint8)
+    b, e = replicate_shard(rank, world, nitems)
+    pv, npm = oracle.mica_permutation_test(aln, 4, 50, 11, b, e)          # this rank's pairs of Mica's permutation test
+    loc = torch.stack([torch.from_numpy(pv), torch.from_numpy(npm.astype(np.float64))], dim=1)
+    full = gather_shards(loc, nitems)
+    if rank == 0:
+        pv0, npm0 = oracle.mica_permutation_test(aln, 4, 50, 11)
+        q.put((np.array_equal(full[:, 0].numpy(), pv0), np.array_equal(full[:, 1].numpy(), npm0.astype(np.float64))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_pair_shards_match_single_process():
+    """pairs of Mica's permutation test sharded over two ranks (uneven: 21 pairs) and gathered in pair order"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_shards, args=(r, 2, port, 21, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok_pv, ok_n = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok_pv and ok_n
