@@ -4,6 +4,7 @@ import csv, glob, json, os, sys
 root = sys.argv[1]
 out = {"kernels": {}}
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = n.split("(")[0]
     return n.replace("void ", "").strip()[-70:]
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
