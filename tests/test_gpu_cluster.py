@@ -189,3 +189,27 @@ def test_cpp_cluster_null_writes_the_same_table_as_python(tmp_path):
                              capture_output=True, text=True, check=True).stdout
         exp = formats.to_text(formats.write_cluster_null, eng.cluster_null(dist, oc.LINK_AVERAGE, seed, 0, nrep, nsites), maxsize)
         assert got == exp and got.count("\n") > nrep
+
+
+def test_cluster_sites_at_the_size_limit():
+    """n = CMX_CLUSTER_MAX_SITES: the per-matrix state (100 KB) and the group-property state (160 KB) still fit LDS;
+    dendrogram against scipy, group properties against their definitions"""
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import squareform
+    n = engine.CLUSTER_MAX_SITES
+    parent, blen, lot = synthetic.random_tree(6, 2)
+    mdl = synthetic.dna_model(1.0, 1)
+    eng = engine.Engine(parent, blen, lot, mdl["Q"], mdl["pi"], mdl["rates"], mdl["probs"])
+    rng = np.random.default_rng(8)
+    counts = rng.random((n, eng.B, 1))
+    g = eng.cluster_sites(oc.DIST_EUCLIDIAN, oc.LINK_AVERAGE, counts)
+    d = g["dist"]
+    ref = np.sqrt(((counts[:50, None, :, 0] - counts[None, :50, :, 0]) ** 2).sum(-1))
+    assert np.allclose(d[:50, :50], ref, rtol=1e-9, atol=1e-12)
+    Z = linkage(squareform(d, checks=False), "average")
+    assert np.allclose(np.sort(g["dmax"]), Z[:, 2], rtol=1e-10, atol=0)
+    assert g["size"][-1] == n and np.array_equal(g["stat"], g["dmax"])
+    norm = np.sqrt((counts.sum(2) ** 2).sum(1))
+    assert np.isclose(g["nmin"][-1], norm.min(), rtol=1e-12)
+    for m, mem in oc.groups(g["merge"], max_group_size=3)[:200]:
+        assert np.isclose(g["nmin"][m], norm[mem].min(), rtol=1e-12)

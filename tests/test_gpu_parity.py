@@ -603,3 +603,17 @@ def test_non_homogeneous_argument_errors():
     with pytest.raises(engine.CmxError, match="out of range"):
         engine.Engine(c["parent"], c["blen"], c["lot"], c["Qs"], c["pis"], c["rates"], c["probs"], model_of_branch=bad,
                       root_freqs=c["root"])
+
+
+def test_mica_permutation_test_many_taxa():
+    """T = 1025 and T = 2047 (the limit): one wave per workgroup, the private column copies fill the LDS"""
+    rng = np.random.default_rng(12)
+    eng = engine.Engine()
+    for T in (1025, 2047):
+        aln = rng.integers(0, 4, size=(T, 4)).astype(np.uint8)
+        aln[:, 1] = np.where(rng.random(T) < 0.9, aln[:, 0], aln[:, 1])
+        pv, npm = eng.mica_permutation_test(aln, 70, 5, nalpha=4)
+        po, no = oracle.mica_permutation_test(aln, 4, 70, 5)
+        assert np.array_equal(npm, no) and np.array_equal(pv, po)
+    with pytest.raises(engine.CmxError, match="ntaxa"):
+        eng.mica_permutation_test(rng.integers(0, 4, size=(2048, 3)).astype(np.uint8), 10, 1, nalpha=4)
