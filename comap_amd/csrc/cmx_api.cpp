@@ -1327,15 +1327,17 @@ static cmx_status cluster_batch_dev(cmx_ctx* ctx, int dist_kind, int linkage, co
   if ((s = scratch(ctx, "cl_D", sizeof(double) * batch * n * n, (void**)&D)) != CMX_OK) return s;
   const int stat_kind = dist_kind == CMX_DIST_CORRELATION ? CMX_STAT_CORRELATION
                         : dist_kind == CMX_DIST_COMPENSATION ? CMX_STAT_COMPENSATION : CMX_STAT_EUCLIDIAN_DISTANCE;
-  {  // one operand preparation over all batch * n sites, one Gram launch with a replicate per grid.z slice
-    const size_t N = batch * n, ldx = (N + 15) / 16 * 16;
+  {  // one operand preparation over all batch * n sites (an operand block per replicate), one Gram launch with a
+     // replicate per grid.z slice
+    const size_t N = batch * n, ldx = (n + 15) / 16 * 16;
     const int Bp = (h.B + 3) / 4 * 4;
     double *X, *sv, *rv;
-    if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx, (void**)&X)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx * batch, (void**)&X)) != CMX_OK) return s;
     if ((s = scratch(ctx, "pair_s1", sizeof(double) * N, (void**)&sv)) != CMX_OK) return s;
     if ((s = scratch(ctx, "pair_r1", sizeof(double) * N, (void**)&rv)) != CMX_OK) return s;
-    HIP_TRY(ctx, launch_pair_prep(stat_kind, 0.0, d_counts, N, ldc, h.B, h.K, X, ldx, Bp, sv, rv, nullptr, st));
-    HIP_TRY(ctx, launch_pair_gram(stat_kind, h.B, Bp, X, sv, rv, n, ldx, X, sv, rv, n, ldx, 1, D, n, st, batch, n, n * n));
+    HIP_TRY(ctx, launch_pair_prep(stat_kind, 0.0, d_counts, N, ldc, h.B, h.K, X, ldx, Bp, sv, rv, nullptr, st, n));
+    HIP_TRY(ctx, launch_pair_gram(stat_kind, h.B, Bp, X, sv, rv, n, ldx, X, sv, rv, n, ldx, 2 /* upper triangle only */, D, n, st,
+                                  batch, n, n * n, (size_t)Bp * ldx));
   }
   HIP_TRY(ctx, launch_dist_finish(dist_kind, D, n, n, n * n, batch, st));
   if (d_dist_out) HIP_TRY(ctx, hipMemcpyAsync(d_dist_out, D, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));

@@ -140,11 +140,11 @@ hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t
                            int32_t* d_classes, uint8_t* d_states /*[nn][ld]*/, hipStream_t stream);
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,
                             double* d_X, size_t ldx, int Bp, double* d_s, double* d_r, const double* d_mvec,
-                            hipStream_t stream);
+                            hipStream_t stream, size_t blk = 0);
 hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const double* d_s1, const double* d_r1,
                             size_t n1, size_t ldx1, const double* d_X2, const double* d_s2, const double* d_r2,
                             size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream,
-                            size_t nblk = 1, size_t zsite = 0, size_t zout = 0);
+                            size_t nblk = 1, size_t zsite = 0, size_t zout = 0, size_t zx = 0);
 hipError_t launch_max_reduce(const double* d_x, size_t n, double* d_out, hipStream_t stream);
 hipError_t launch_null_classify(const double* d_stat, const double* d_nmin, size_t nnull, const double* d_maxnorm,
                                 int nclasses, uint32_t* d_cls, uint32_t* d_hist, hipStream_t stream);

@@ -1313,9 +1313,13 @@ hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t
 //   2: X = [total >= 1];  5: X = [total >= threshold], r = sum X, s = NaN flag when a total leaves [0, 10000)
 __global__ void pair_prep_kernel(int kind, double param, const double* __restrict__ counts, size_t n, size_t ldc, int B,
                                  int K, double* __restrict__ X, size_t ldx, int Bp, double* __restrict__ sv,
-                                 double* __restrict__ rv, const double* __restrict__ mvec /* [B] or null */) {
+                                 double* __restrict__ rv, const double* __restrict__ mvec /* [B] or null */, size_t blk) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  // blk > 0: the sites are `blk`-site blocks side by side (replicates of the clustering null); every block gets its own
+  // [Bp][ldx] operand so that a block's rows stay ldx * 8 bytes apart (not the whole batch's row length: 128 rows
+  // 4 MB apart thrash the TLB and land on one L2 channel)
+  if (blk) X += (i / blk) * ((size_t)Bp * ldx) - (i / blk) * blk;
   double mean = 0.0;
   if (kind == 0 || kind == 4) {   // (CorrectedCorrelation arrives as kind 0 with its mean vector in mvec)
     for (int b = 0; b < B; ++b) mean += counts[(size_t)b * K * ldc + i] - (mvec ? mvec[b] : 0.0);
@@ -1348,25 +1352,32 @@ __global__ void pair_prep_kernel(int kind, double param, const double* __restric
 
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,
                             double* d_X, size_t ldx, int Bp, double* d_s, double* d_r, const double* d_mvec,
-                            hipStream_t stream) {
+                            hipStream_t stream, size_t blk) {
   const int block = 256;
   hipLaunchKernelGGL(pair_prep_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, stream, kind, param,
-                     d_counts, n, ldc, B, K, d_X, ldx, Bp, d_s, d_r, d_mvec);
+                     d_counts, n, ldc, B, K, d_X, ldx, Bp, d_s, d_r, d_mvec, blk);
   return hipGetLastError();
 }
 
-__device__ __forceinline__ double pair_epilogue(int kind, int B, double g, double si, double sj, double ri, double rj) {
+// the factor of a statistic that depends on one site only (fi, fj of pair_epilogue)
+__device__ __forceinline__ double pair_site_factor(int kind, int B, double s) {
+  if (kind == 0) return sqrt(s / (B - 1));
+  if (kind == 3 || kind == 1) return sqrt(s);
+  return 0.0;
+}
+__device__ __forceinline__ double pair_epilogue(int kind, int B, double g, double si, double sj, double ri, double rj, double fi,
+                                                double fj) {
   switch (kind) {
     case 0: {
       const double cov = g / (B - 1);
-      return cov / (sqrt(si / (B - 1)) * sqrt(sj / (B - 1)));
+      return cov / (fi * fj);
     }
     case 4: return g / (B - 1);
-    case 3: return g / (sqrt(si) * sqrt(sj));
+    case 3: return g / (fi * fj);
     case 1: {
       double s3 = si + sj + 2.0 * g;
       if (s3 < 0.0) s3 = 0.0;
-      return 1.0 - sqrt(s3) / (sqrt(si) + sqrt(sj));
+      return 1.0 - sqrt(s3) / (fi + fj);
     }
     case 2: return g;
     case 5: {
@@ -1387,20 +1398,25 @@ __device__ __forceinline__ double pair_epilogue(int kind, int B, double g, doubl
 // One wave computes a 64x64 tile of G = X1^T-rows . X2-rows on v_mfma_f64_16x16x4_f64 (A[i][k]: lane = i + 16k,
 // C[row = (lane>>4) + 4r][col = lane & 15]); operands come straight from L2 (X is a few MB), prefetched one k-step
 // ahead; 16 MFMAs per 8 operand loads.
-__global__ __launch_bounds__(kWave) void pair_gram_kernel(int kind, int B, int Bp, const double* __restrict__ X1,
+// Four tiles (four waves) per workgroup: single-wave workgroups made the launch dispatch-bound (262 144 of them for a
+// batch of 256 matrices of 2 000 sites ran at 0.1-0.5 resident waves per SIMD, profiles/r01_cluster_null_pmc_summary.json).
+__global__ __launch_bounds__(4 * kWave) void pair_gram_kernel(int kind, int B, int Bp, const double* __restrict__ X1,
                                                          const double* __restrict__ s1, const double* __restrict__ r1,
                                                          size_t n1, size_t ldx1, const double* __restrict__ X2,
                                                          const double* __restrict__ s2, const double* __restrict__ r2,
                                                          size_t n2, size_t ldx2, int intra, double* __restrict__ out,
-                                                         size_t ldo, size_t zsite, size_t zout) {
-  // blockIdx.z: independent blocks of sites side by side in the same operand arrays (clustering null: one per replicate)
-  X1 += blockIdx.z * zsite; s1 += blockIdx.z * zsite; r1 += blockIdx.z * zsite;
-  X2 += blockIdx.z * zsite; s2 += blockIdx.z * zsite; r2 += blockIdx.z * zsite;
+                                                         size_t ldo, size_t zsite, size_t zout, size_t zx) {
+  // blockIdx.z: independent blocks of sites (clustering null: one per replicate): per-site vectors side by side
+  // (zsite apart), operands zx apart
+  X1 += blockIdx.z * zx; s1 += blockIdx.z * zsite; r1 += blockIdx.z * zsite;
+  X2 += blockIdx.z * zx; s2 += blockIdx.z * zsite; r2 += blockIdx.z * zsite;
   out += blockIdx.z * zout;
-  const int lane = threadIdx.x;
-  const size_t ti = blockIdx.y, tj = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const size_t ti = blockIdx.y, tj = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const size_t i0 = ti * 64, j0 = tj * 64;
+  if (j0 >= n2) return;
   const double nanv = __builtin_nan("");
+  if (intra == 2 && tj < ti) return;   // the caller fills the lower triangle itself (clustering: mirrored distances)
   if (intra && tj < ti) {  // strictly below the diagonal: NaN fill (reference loop is j > i, CoETools.cpp:680)
     for (int r = 0; r < 64; ++r) {
       const size_t i = i0 + r, j = j0 + lane;
@@ -1441,34 +1457,48 @@ __global__ __launch_bounds__(kWave) void pair_gram_kernel(int kind, int B, int B
 #pragma unroll
     for (int t = 0; t < 4; ++t) { a[t] = an[t]; b[t] = bn[t]; }
   }
+  // Epilogue: the per-site factors of the statistic (a square root and a division each) are computed once per row
+  // and column of the tile, not once per pair -- the same operations on the same operands, so the values do not
+  // change, but 64 pairs per lane no longer repeat them (they were three quarters of the kernel's instructions).
+  double sjv[4], rjv[4], fj[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const size_t j = j0 + 16 * q + li;
-    const double sj = s2[j < n2 ? j : n2 - 1], rj = r2[j < n2 ? j : n2 - 1];
+    sjv[q] = s2[j < n2 ? j : n2 - 1];
+    rjv[q] = r2[j < n2 ? j : n2 - 1];
+    fj[q] = pair_site_factor(kind, B, sjv[q]);
+  }
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t i = i0 + 16 * p + lk + 4 * r;
-        if (i < n1 && j < n2) {
-          double v = pair_epilogue(kind, B, acc[p][q][r], s1[i], sj, r1[i], rj);
+    for (int r = 0; r < 4; ++r) {
+      const size_t i = i0 + 16 * p + lk + 4 * r;
+      if (i >= n1) continue;
+      const double si = s1[i], ri = r1[i];
+      const double fi = pair_site_factor(kind, B, si);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t j = j0 + 16 * q + li;
+        if (j < n2) {
+          double v = pair_epilogue(kind, B, acc[p][q][r], si, sjv[q], ri, rjv[q], fi, fj[q]);
           if (intra && j <= i) v = nanv;
           out[i * ldo + j] = v;
         }
       }
-  }
+    }
 }
 
 // EuclidianDistance (CoMap/Distance.h:157-171): sqrt(sum_b (tot2_b - tot1_b)^2) over the per-branch totals.  Computed from
 // the differences themselves, not from the Gram matrix: ||a||^2 + ||b||^2 - 2 a.b loses all digits for near-identical
 // vectors.  X = the totals operand of pair_prep_kernel (kind 1), [Bp][ldx]; one thread per pair, row i broadcast.
-__global__ __launch_bounds__(64) void pair_euclid_kernel(int B, const double* __restrict__ X1, size_t n1, size_t ldx1,
+__global__ __launch_bounds__(256) void pair_euclid_kernel(int B, const double* __restrict__ X1, size_t n1, size_t ldx1,
                                                          const double* __restrict__ X2, size_t n2, size_t ldx2, int intra,
-                                                         double* __restrict__ out, size_t ldo, size_t zsite,
+                                                         double* __restrict__ out, size_t ldo, size_t zx,
                                                          size_t zout) {
-  X1 += blockIdx.z * zsite; X2 += blockIdx.z * zsite; out += blockIdx.z * zout;
-  const size_t i = blockIdx.y, j = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (j >= n2) return;
+  X1 += blockIdx.z * zx; X2 += blockIdx.z * zx; out += blockIdx.z * zout;
+  const size_t i = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6), j = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  if (i >= n1 || j >= n2) return;   // four rows (four waves) per workgroup
+  if (intra == 2 && j <= i) return;  // lower triangle left to the caller
   double d = 0.0;
   for (int b = 0; b < B; ++b) {
     const double t = X2[(size_t)b * ldx2 + j] - X1[(size_t)b * ldx1 + i];
@@ -1481,18 +1511,18 @@ __global__ __launch_bounds__(64) void pair_euclid_kernel(int B, const double* __
 hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const double* d_s1, const double* d_r1,
                             size_t n1, size_t ldx1, const double* d_X2, const double* d_s2, const double* d_r2,
                             size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream,
-                            size_t nblk, size_t zsite, size_t zout) {
+                            size_t nblk, size_t zsite, size_t zout, size_t zx) {
   for (size_t z0 = 0; z0 < nblk; z0 += 65535) {     // grid.z limit
     const unsigned gz = (unsigned)std::min<size_t>(65535, nblk - z0);
-    const size_t so = z0 * zsite;
+    const size_t so = z0 * zsite, xo = z0 * zx;
     double* out = d_out + z0 * zout;
     if (kind == CMX_STAT_EUCLIDIAN_DISTANCE) {
-      hipLaunchKernelGGL(pair_euclid_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)n1, gz), dim3(64), 0, stream, B,
-                         d_X1 + so, n1, ldx1, d_X2 + so, n2, ldx2, intra, out, ldo, zsite, zout);
+      hipLaunchKernelGGL(pair_euclid_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 3) / 4), gz), dim3(256), 0, stream, B,
+                         d_X1 + xo, n1, ldx1, d_X2 + xo, n2, ldx2, intra, out, ldo, zx, zout);
     } else {
-      dim3 grid((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 63) / 64), gz);
-      hipLaunchKernelGGL(pair_gram_kernel, grid, dim3(kWave), 0, stream, kind, B, Bp, d_X1 + so, d_s1 + so, d_r1 + so, n1,
-                         ldx1, d_X2 + so, d_s2 + so, d_r2 + so, n2, ldx2, intra, out, ldo, zsite, zout);
+      dim3 grid((unsigned)((n2 + 255) / 256), (unsigned)((n1 + 63) / 64), gz);
+      hipLaunchKernelGGL(pair_gram_kernel, grid, dim3(4 * kWave), 0, stream, kind, B, Bp, d_X1 + xo, d_s1 + so, d_r1 + so, n1,
+                         ldx1, d_X2 + xo, d_s2 + so, d_r2 + so, n2, ldx2, intra, out, ldo, zsite, zout, zx);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
