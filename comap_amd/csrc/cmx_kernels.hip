@@ -1488,6 +1488,7 @@ __global__ __launch_bounds__(4 * kWave) void pair_gram_kernel(int kind, int B, i
     }
 }
 
+constexpr int kEuclidRows = 8;
 // EuclidianDistance (CoMap/Distance.h:157-171): sqrt(sum_b (tot2_b - tot1_b)^2) over the per-branch totals.  Computed from
 // the differences themselves, not from the Gram matrix: ||a||^2 + ||b||^2 - 2 a.b loses all digits for near-identical
 // vectors.  X = the totals operand of pair_prep_kernel (kind 1), [Bp][ldx]; one thread per pair, row i broadcast.
@@ -1495,16 +1496,33 @@ __global__ __launch_bounds__(256) void pair_euclid_kernel(int B, const double* _
                                                          const double* __restrict__ X2, size_t n2, size_t ldx2, int intra,
                                                          double* __restrict__ out, size_t ldo, size_t zx,
                                                          size_t zout) {
+  // one wave = kEuclidRows rows x 64 columns: the column operand is loaded once per branch and used for all rows, the
+  // row operands are wave-uniform (scalar loads); per pair the arithmetic is the same chain of FMAs in branch order
   X1 += blockIdx.z * zx; X2 += blockIdx.z * zx; out += blockIdx.z * zout;
-  const size_t i = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6), j = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  if (i >= n1 || j >= n2) return;   // four rows (four waves) per workgroup
-  if (intra == 2 && j <= i) return;  // lower triangle left to the caller
-  double d = 0.0;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t i0 = ((size_t)blockIdx.y * 4 + wave) * kEuclidRows, j = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  if (i0 >= n1) return;
+  if (intra == 2 && (size_t)blockIdx.x * 64 + 63 <= i0) return;   // whole tile in the lower triangle: left to the caller
+  const size_t jc = j < n2 ? j : n2 - 1;
+  double d[kEuclidRows];
+#pragma unroll
+  for (int r = 0; r < kEuclidRows; ++r) d[r] = 0.0;
   for (int b = 0; b < B; ++b) {
-    const double t = X2[(size_t)b * ldx2 + j] - X1[(size_t)b * ldx1 + i];
-    d = __builtin_fma(t, t, d);
+    const double t2 = X2[(size_t)b * ldx2 + jc];
+    const double* row = X1 + (size_t)b * ldx1 + i0;
+#pragma unroll
+    for (int r = 0; r < kEuclidRows; ++r) {
+      const double t = t2 - row[i0 + r < n1 ? r : 0];
+      d[r] = __builtin_fma(t, t, d[r]);
+    }
   }
-  out[i * ldo + j] = (!intra || j > i) ? sqrt(d) : __builtin_nan("");
+  if (j >= n2) return;
+#pragma unroll
+  for (int r = 0; r < kEuclidRows; ++r) {
+    const size_t i = i0 + r;
+    if (i >= n1 || (intra == 2 && j <= i)) continue;
+    out[i * ldo + j] = (!intra || j > i) ? sqrt(d[r]) : __builtin_nan("");
+  }
 }
 
 // nblk > 1: nblk independent site blocks of n1 (= n2) sites, block z at site offset z * zsite, output at z * zout
@@ -1517,7 +1535,7 @@ hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const d
     const size_t so = z0 * zsite, xo = z0 * zx;
     double* out = d_out + z0 * zout;
     if (kind == CMX_STAT_EUCLIDIAN_DISTANCE) {
-      hipLaunchKernelGGL(pair_euclid_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 3) / 4), gz), dim3(256), 0, stream, B,
+      hipLaunchKernelGGL(pair_euclid_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 4 * kEuclidRows - 1) / (4 * kEuclidRows)), gz), dim3(256), 0, stream, B,
                          d_X1 + xo, n1, ldx1, d_X2 + xo, n2, ldx2, intra, out, ldo, zx, zout);
     } else {
       dim3 grid((unsigned)((n2 + 255) / 256), (unsigned)((n1 + 63) / 64), gz);
