@@ -34,6 +34,7 @@ class CandidateGroupSet:
         self.simulations = [[[] for _ in g] for g in windows]
         self.n1 = [0] * len(windows)
         self.n2 = [0] * len(windows)
+        self.near_ties = [0] * len(windows)
         self.nb_completed = 0
         self.nb_analysable = sum(1 for a in analysable if a)
         self.nb_trials = 0
@@ -71,8 +72,11 @@ class CandidateGroupSet:
             return False
         vectors = [q.pop(0) for q in group]
         self.n2[g] += 1
-        if group_stat(self.kind, vectors, self.params) >= self.observed[g]:
+        st = group_stat(self.kind, vectors, self.params)
+        if st >= self.observed[g]:
             self.n1[g] += 1
+        if abs(st - self.observed[g]) <= 1e-6 * max(1.0, abs(self.observed[g])):
+            self.near_ties[g] += 1       # decided by the last bits: implementations may legitimately differ here
         if self.n2[g] == self.min_sim:
             self.nb_completed += 1
         return True
@@ -110,4 +114,4 @@ def candidate_groups(model, kind, windows, analysable, observed, min_sim, rep_ra
         mp = oracle.map_sites(model, aln)
         nb += 1
         test = cs.analyse_simulations(mp["counts"], mp["norm"]) and cs.nb_trials < max_trials
-    return dict(n1=np.array(cs.n1), n2=np.array(cs.n2), trials=cs.nb_trials, batches=nb)
+    return dict(n1=np.array(cs.n1), n2=np.array(cs.n2), trials=cs.nb_trials, batches=nb, near_ties=np.array(cs.near_ties))

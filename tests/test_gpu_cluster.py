@@ -213,3 +213,25 @@ def test_cluster_sites_at_the_size_limit():
     assert np.isclose(g["nmin"][-1], norm.min(), rtol=1e-12)
     for m, mem in oc.groups(g["merge"], max_group_size=3)[:200]:
         assert np.isclose(g["nmin"][m], norm[mem].min(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_cluster_configurations_against_oracle(seed):
+    """seeded sweep: alphabet, taxa, number of sites (2 ..), distance, linkage, weighted counts"""
+    rng = np.random.default_rng(900 + seed)
+    nstates = 20 if rng.random() < 0.6 else 4
+    dist = int(rng.integers(0, 3))
+    link = int(rng.integers(0, 3))
+    om, eng = _setup(nstates, int(rng.integers(8, 16)) if nstates == 20 else 18, 40 + seed, Bk=dist == oc.DIST_COMPENSATION)
+    n = int(rng.integers(2, 90))
+    aln, _ = oracle.simulate(om, 77 + seed, 0, n)
+    if np.unique(aln, axis=1).shape[1] != n:
+        pytest.skip("simulated columns not distinct for this seed")
+    counts = oracle.map_sites(om, aln)["counts"]
+    g = eng.cluster_sites(dist, link, counts)
+    d = oc.distance_matrix(dist, counts)
+    merge, dmax, size = oc.hclust(d, link)
+    assert np.array_equal(g["merge"], merge) and np.array_equal(g["size"], size)
+    assert np.allclose(g["dmax"], dmax, rtol=1e-6, atol=1e-12)
+    stat, nmin = oc.group_properties(dist, merge, dmax, counts)
+    assert np.allclose(g["stat"], stat, rtol=1e-6, atol=1e-9) and np.allclose(g["nmin"], nmin, rtol=1e-6, atol=0)
