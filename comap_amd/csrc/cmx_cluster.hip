@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <type_traits>
 #include <cmath>
 
 #include "cmx_device.h"
@@ -165,7 +166,9 @@ __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(
 constexpr int kStale = -2;   // nn[r]: minimum unknown, rmin[r] is a lower bound
 constexpr int kNone = -1;    // nn[r]: no live column right of the diagonal
 
-template <int LINK>
+// PER = columns of a row per thread (compile-time, so the per-thread row slices live in registers without predicated
+// dead iterations): the launcher picks the smallest instantiated value >= ceil(n / kHcThreads)
+template <int LINK, int PER>
 __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
   extern __shared__ double hc_smem[];
   const int n = a.n;
@@ -182,7 +185,6 @@ __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
   const size_t ld = a.ld;
   const size_t ob = (size_t)blockIdx.x * (size_t)(n - 1);
   const int nseg = (n + kHcSeg - 1) / kHcSeg;
-  const int per = (n + kHcThreads - 1) / kHcThreads;   // columns of a row per thread
   const unsigned ld32 = (unsigned)ld;                  // n <= CMX_CLUSTER_MAX_SITES: element offsets fit 32 bits
   for (int r = tid; r < n; r += kHcThreads) {
     rmin[r] = a.grmin[(size_t)blockIdx.x * n + r];
@@ -198,8 +200,11 @@ __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
     for (;;) {
       double bv = INFINITY;
       int br = INT_MAX;
-      for (int r = tid; r < n; r += kHcThreads)
-        if (cid[r] >= 0 && nn[r] != kNone && key_less(rmin[r], r, bv, br)) { bv = rmin[r]; br = r; }
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {      // merged-away rows carry nn = kNone
+        const int r = tid + t * kHcThreads;
+        if (r < n && nn[r] != kNone && key_less(rmin[r], r, bv, br)) { bv = rmin[r]; br = r; }
+      }
       wave_argmin(bv, br);
       if (lane == 0) { pv[0][wave] = bv; pi[0][wave] = br; }
       __syncthreads();   // full: the matrix stores of the previous step are complete before anyone loads from it
@@ -246,15 +251,15 @@ __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
     // step are issued before the first store (the compiler cannot prove the stores do not alias the next loads)
     double cv = INFINITY;
     int cc = INT_MAX;
-    double xi[kHcMaxPerThread], xj[kHcMaxPerThread];
+    double xi[PER], xj[PER];
     const double* rowi = D + (size_t)i * ld;
     const double* rowj = D + (size_t)j * ld;
     double* coli = D + i;
 #pragma unroll
-    for (int t = 0; t < kHcMaxPerThread; ++t) {
+    for (int t = 0; t < PER; ++t) {
       const int k = tid + t * kHcThreads;
-      const bool on = t < per && k < n && k != i && k != j && cid[k < n ? k : 0] >= 0;
-      if (t < per) {
+      const bool on = k < n && k != i && k != j && cid[k < n ? k : 0] >= 0;
+      {
 #if HC_ABLATE < 3
         xi[t] = on ? rowi[k] : 0.0;
         xj[t] = on ? rowj[k] : 0.0;
@@ -265,9 +270,9 @@ __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
       }
     }
 #pragma unroll
-    for (int t = 0; t < kHcMaxPerThread; ++t) {
+    for (int t = 0; t < PER; ++t) {
       const int k = tid + t * kHcThreads;
-      if (t >= per || k >= n || k == i || k == j || cid[k] < 0) continue;
+      if (k >= n || k == i || k == j || cid[k] < 0) continue;
       const double nw = linkage_update<LINK>(xi[t], xj[t], ni, nj);
 #if HC_ABLATE < 2
       D[(size_t)i * ld + k] = nw;
@@ -307,6 +312,7 @@ __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
       csz[i] = sz;
       cid[i] = n + step;
       cid[j] = -1;
+      nn[j] = kNone;
     }
     barrier_lds();
   }
@@ -400,10 +406,19 @@ hipError_t launch_hclust(int linkage, double* d_D, size_t n, size_t ld, size_t m
     hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kHcThreads), lds, stream, a);
     return hipGetLastError();
   };
+  const int per = (int)((n + kHcThreads - 1) / kHcThreads);
+  auto pick = [&](auto link) -> hipError_t {
+    constexpr int L = decltype(link)::value;
+    if (per <= 1) return go(hclust_kernel<L, 1>);
+    if (per <= 2) return go(hclust_kernel<L, 2>);
+    if (per <= 4) return go(hclust_kernel<L, 4>);
+    if (per <= 6) return go(hclust_kernel<L, 6>);
+    return go(hclust_kernel<L, kHcMaxPerThread>);
+  };
   switch (linkage) {
-    case CMX_LINK_COMPLETE: return go(hclust_kernel<CMX_LINK_COMPLETE>);
-    case CMX_LINK_SINGLE: return go(hclust_kernel<CMX_LINK_SINGLE>);
-    case CMX_LINK_AVERAGE: return go(hclust_kernel<CMX_LINK_AVERAGE>);
+    case CMX_LINK_COMPLETE: return pick(std::integral_constant<int, CMX_LINK_COMPLETE>());
+    case CMX_LINK_SINGLE: return pick(std::integral_constant<int, CMX_LINK_SINGLE>());
+    case CMX_LINK_AVERAGE: return pick(std::integral_constant<int, CMX_LINK_AVERAGE>());
   }
   return hipErrorInvalidValue;
 }
