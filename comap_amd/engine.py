@@ -56,6 +56,16 @@ CLUSTER_MAX_SITES = 5000
 MICA_MI, MICA_MIP, MICA_MIC = range(3)      # null.method_zscore.stat (Mica.cpp:551-559)
 
 
+def label_substitution_weights(nstates):
+    """nijt = Label (bpp::LabelSubstitutionCount, doc/comap.texi nijt option; SURVEY 8 row a3): every ordered pair of
+    distinct states carries its own label 1 .. S(S-1), numbered row by row; the "count" of a branch is then the
+    label of the substitution when there is exactly one.  It is the Naive count with these weights:
+    Engine(..., count_method=COUNT_NAIVE, naive_weights=label_substitution_weights(S))."""
+    W = np.zeros((nstates, nstates))
+    W[~np.eye(nstates, dtype=bool)] = np.arange(1, nstates * (nstates - 1) + 1)
+    return W
+
+
 class CmxError(RuntimeError):
     """Raised for any non-zero cmx_status (the reference throws bpp::Exception)."""
 

@@ -617,3 +617,13 @@ def test_mica_permutation_test_many_taxa():
         assert np.array_equal(npm, no) and np.array_equal(pv, po)
     with pytest.raises(engine.CmxError, match="ntaxa"):
         eng.mica_permutation_test(rng.integers(0, 4, size=(2048, 3)).astype(np.uint8), 10, 1, nalpha=4)
+
+
+def test_label_substitution_count_is_the_naive_count_with_label_weights():
+    """nijt = Label: N(x, y) = label of (x, y), 1 .. S(S-1) row by row, through the naive path"""
+    case = make_case(8, 60, 4, 23)
+    W = engine.label_substitution_weights(4)
+    assert W[0, 1] == 1 and W[0, 3] == 3 and W[1, 0] == 4 and W[3, 2] == 12 and np.all(np.diag(W) == 0)
+    r = _engine(case, count_method=engine.COUNT_NAIVE, naive_weights=W).map_sites(case["aln"])
+    o = oracle.map_sites(_omodel(case, method=oracle.METHOD_NAIVE, naive_W=W), case["aln"])
+    rel_close(r["counts"], o["counts"], 1e-6, 1e-12)
