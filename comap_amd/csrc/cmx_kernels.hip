@@ -1943,6 +1943,12 @@ __global__ void mica_ftable_kernel(int T, double* __restrict__ f, int* __restric
 // (four waves per SIMD) and one workgroup's barriers and table epilogue overlap the other's MFMAs.  The 12 operand tiles
 // of a k-step (64 lanes x 16 B each) go through LDS once per workgroup.
 constexpr int kMicaTileI = 8, kMicaTileJ = 4;
+template <int CTRL>
+__device__ __forceinline__ double mica_dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
                                                            const uint8_t* __restrict__ flag1, const double* __restrict__ S1,
                                                            const int8_t* __restrict__ H2, size_t n2,
@@ -2012,6 +2018,10 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const 
     buf ^= 1;
   }
   const double lnT = log((double)T), invT = 1.0 / (double)T;
+  // sum_ab f(c_ab) of the wave's four pairs: 16 table lookups per lane and pair, then ONE reduce-scatter for all four
+  // (lane bits 5 and 4 with v_permlane32/16_swap: row r of 16 lanes ends up with pair r; bits 3..0 with DPP row
+  // rotations) instead of four butterfly reductions through ds_bpermute
+  double ps[4];
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -2019,15 +2029,26 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const 
       double s = 0.0;
 #pragma unroll
       for (int v = 0; v < 16; ++v) s += ftab[acc[ii][jj][v]];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      const size_t i = i0 + 2 * wi + ii, j = j0 + 2 * wj + jj;
-      if (lane == 0 && i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
-        const bool valid = !intra || j > i;
-        mi[i * ldo + j] = valid ? lnT + (s - S1[i] - S2[j]) * invT : __builtin_nan("");
-        hj[i * ldo + j] = valid ? lnT - s * invT : __builtin_nan("");
-      }
+      ps[2 * ii + jj] = s;
     }
+  swap32(ps[0], ps[2]);
+  swap32(ps[1], ps[3]);
+  double k0 = ps[0] + ps[2], k1 = ps[1] + ps[3];
+  swap16(k0, k1);
+  double s = k0 + k1;
+  s += mica_dpp_f64<0x128>(s);   // row_ror:8
+  s += mica_dpp_f64<0x124>(s);   // row_ror:4
+  s += mica_dpp_f64<0x122>(s);   // row_ror:2
+  s += mica_dpp_f64<0x121>(s);   // row_ror:1
+  {
+    const int r = lane >> 4;
+    const size_t i = i0 + 2 * wi + (r >> 1), j = j0 + 2 * wj + (r & 1);
+    if ((lane & 15) == 0 && i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
+      const bool valid = !intra || j > i;
+      mi[i * ldo + j] = valid ? lnT + (s - S1[i] - S2[j]) * invT : __builtin_nan("");
+      hj[i * ldo + j] = valid ? lnT - s * invT : __builtin_nan("");
+    }
+  }
 }
 
 template <int A>
