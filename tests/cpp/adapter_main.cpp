@@ -3,6 +3,7 @@
 //   adapter_main run <input.bin> <output.bin>        -> getVectors + computeIntraStats with null on the GPU
 //   adapter_main groups <tree.bin>                   -> ClusterTools::getGroups + io::writeGroups to stdout (host only);
 //      tree.bin: int32 n, maxGroupSize; int32 merge[2(n-1)]; f64 dmax, stat, nmin [n-1]; int32 coords[n], isConstant[n]
+//   adapter_main cluster <input.bin> <method> <maxsize>   -> ClusterTools::cluster + getGroups + writeGroups of the observed data (GPU)
 //   adapter_main clusternull <input.bin> cor|euclidian <method> <nsites> <nrep> <maxsize>   -> null groups file (GPU)
 //   adapter_main candidates <input.bin> <omega> <minSim> <repRAM> <maxTrials> <seed>   -> candidate-group test (GPU)
 //   adapter_main vec <input.bin>                     -> cmx::io::writeToStream of a mapping to stdout (host only);
@@ -87,6 +88,34 @@ int main(int argc, char** argv) {
       std::vector<bool> isConst(n);
       for (size_t i = 0; i < n; ++i) { names[i] = std::to_string(coords[i]); isConst[i] = isc[i] != 0; }
       cmx::io::writeGroups(cmx::ClusterTools::getGroups(t), names, isConst, maxSize, std::cout);
+      return 0;
+    }
+    if (argc == 5 && std::strcmp(argv[1], "cluster") == 0) {   // GPU: <input.bin of "run"> <method> <maxsize>: observed clustering
+      std::ifstream in(argv[2], std::ios::binary);
+      int32_t h[8];
+      uint64_t seed;
+      rd(in, h, 8);
+      rd(in, &seed, 1);
+      const int nn = h[0], T = h[1], S = h[2], C = h[3], N = h[4];
+      cmx::TreeArrays t;
+      cmx::ModelArrays m;
+      t.parent.resize(nn); t.branchLengths.resize(nn); t.leafOfTaxon.resize(T);
+      rd(in, t.parent.data(), nn); rd(in, t.branchLengths.data(), nn); rd(in, t.leafOfTaxon.data(), T);
+      m.nbStates = S;
+      m.generator.resize(S * S); m.frequencies.resize(S); m.rates.resize(C); m.rateProbabilities.resize(C);
+      rd(in, m.generator.data(), S * S); rd(in, m.frequencies.data(), S); rd(in, m.rates.data(), C);
+      rd(in, m.rateProbabilities.data(), C);
+      std::vector<uint8_t> aln(static_cast<size_t>(T) * N);
+      rd(in, aln.data(), aln.size());
+      cmx::Engine eng(t, m, 0);
+      auto mapping = cmx::CoETools::getVectors(eng, aln.data(), N);
+      cmx::StatisticBasedDistance dist(std::make_shared<cmx::CorrelationStatistic>(), 1.);
+      cmx::ClusteringTree tree = cmx::ClusterTools::cluster(eng, dist, std::atoi(argv[3]), *mapping, true);
+      std::vector<std::string> names(N);
+      std::vector<bool> isConst(N, false);
+      for (int i = 0; i < N; ++i) names[i] = std::to_string(10 + i);
+      cmx::io::writeGroups(cmx::ClusterTools::getGroups(tree), names, isConst, static_cast<size_t>(std::atoi(argv[4])), std::cout);
+      std::cout << tree.distances[1] << " " << tree.distances[static_cast<size_t>(N) * 2 + 1] << "\n";
       return 0;
     }
     if (argc == 8 && std::strcmp(argv[1], "clusternull") == 0) {   // GPU: <input.bin of "run"> dist method nsites nrep maxsize

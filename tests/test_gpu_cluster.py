@@ -235,3 +235,33 @@ def test_random_cluster_configurations_against_oracle(seed):
     assert np.allclose(g["dmax"], dmax, rtol=1e-6, atol=1e-12)
     stat, nmin = oc.group_properties(dist, merge, dmax, counts)
     assert np.allclose(g["stat"], stat, rtol=1e-6, atol=1e-9) and np.allclose(g["nmin"], nmin, rtol=1e-6, atol=0)
+
+
+def test_cpp_observed_clustering_matches_python(tmp_path):
+    """cmx::ClusterTools::cluster + getGroups + io::writeGroups (C++ mirror of CoMap.cpp:432-548) == the ctypes path"""
+    import os
+    import struct
+    import subprocess
+    from comap_amd import cluster as pc, formats
+    from conftest import make_case
+    from test_adapter_cpp import EXE, ROOT
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+                           "-L", os.path.dirname(engine.LIB_PATH), "-lcomap_mi355x",
+                           "-Wl,-rpath," + os.path.dirname(engine.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    case = make_case(10, 55, 20, 7)
+    nn, T, S, C, N = len(case["parent"]), len(case["lot"]), 20, 4, 55
+    inp = tmp_path / "in.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<8i", nn, T, S, C, N, 1, 1, 1) + struct.pack("<Q", 1))
+        f.write(case["parent"].astype(np.int32).tobytes() + case["blen"].tobytes() + case["lot"].astype(np.int32).tobytes())
+        f.write(case["Q"].tobytes() + case["pi"].tobytes() + case["rates"].tobytes() + case["probs"].tobytes())
+        f.write(np.ascontiguousarray(case["aln"]).tobytes())
+    got = subprocess.run([EXE, "cluster", str(inp), str(oc.LINK_COMPLETE), "6"], capture_output=True, text=True, check=True).stdout
+    eng = engine.Engine(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    mp = eng.map_sites(case["aln"])
+    g = eng.cluster_sites(oc.DIST_CORRELATION, oc.LINK_COMPLETE, mp["counts"])
+    exp = formats.to_text(formats.write_groups, pc.get_groups(g["merge"], 6), 10 + np.arange(N), np.zeros(N), g["dmax"], g["stat"],
+                          g["nmin"])
+    exp += formats.fmt(g["dist"][0, 1]) + " " + formats.fmt(g["dist"][2, 1]) + "\n"
+    assert got == exp
