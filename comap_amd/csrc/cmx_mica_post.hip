@@ -114,32 +114,53 @@ struct PermArgs {
   double* pvalue; int32_t* nperm;   // indexed by pair - pair_begin
   int qstride, cstride;      // bytes per lane of the private column copy / counters
   int wave_bytes;
+  uint32_t first;            // shuffles already done by the opening pass (0 if it was skipped)
 };
 
+// G = column pairs per wave.  G = 4 is the opening pass: four pairs, 16 shuffles each -- half of all pairs between
+// unrelated columns collect their 5 hits within the first 16 shuffles, and a whole wave per pair would run 64.  A pair
+// that is not decided yet leaves nperm = -1 - hits; the G = 1 pass (one pair per wave, 64 shuffles per round) picks
+// those up at shuffle 16.  Shuffle k of a pair is the same in either pass: the result does not depend on the split.
+constexpr int kPermFirst = 16;
+template <int G>
 __global__ void mica_perm_kernel(PermArgs a) {
+  constexpr int LPG = 64 / G;                                                     // lanes (= shuffles per round) per pair
   extern __shared__ __attribute__((aligned(16))) uint8_t perm_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int T = a.T, A = a.A;
+  const int grp = lane / LPG, gl = lane % LPG;
+  const int T = a.T, A = a.A, Tr = (T + 3) & ~3;
   long long* dF = reinterpret_cast<long long*>(perm_smem);                       // [T] block-shared
   uint8_t* wbase = perm_smem + (size_t)T * 8 + (size_t)wave * a.wave_bytes;
-  uint32_t* joint = reinterpret_cast<uint32_t*>(wbase);                          // [A*A] observed table
-  uint16_t* seg = reinterpret_cast<uint16_t*>(wbase + A * A * 4);                // [A] end position of state x in column i's order
-  uint8_t* qbase = wbase + A * A * 4 + 64;                                       // [T] column j
-  uint8_t* q = qbase + ((T + 3) & ~3) + (size_t)lane * a.qstride;               // private copy
-  uint16_t* cnt = reinterpret_cast<uint16_t*>(qbase + ((T + 3) & ~3) + (size_t)64 * a.qstride + (size_t)lane * a.cstride);
+  const int gbytes = A * A * 4 + 64 + Tr;                                         // per pair: joint | seg | column j
+  uint32_t* joint = reinterpret_cast<uint32_t*>(wbase + (size_t)grp * gbytes);   // [A*A] observed table
+  uint16_t* seg = reinterpret_cast<uint16_t*>(wbase + (size_t)grp * gbytes + A * A * 4);   // [A] end of state x in column i's order
+  uint8_t* qbase = wbase + (size_t)grp * gbytes + A * A * 4 + 64;                // [T] column j
+  uint8_t* priv = wbase + (size_t)G * gbytes;
+  uint8_t* q = priv + (size_t)lane * a.qstride;                                  // private copy
+  uint16_t* cnt = reinterpret_cast<uint16_t*>(priv + (size_t)64 * a.qstride + (size_t)lane * a.cstride);
   for (int c = threadIdx.x; c < T; c += blockDim.x) dF[c] = a.dF[c];
   __syncthreads();
   const size_t n = a.n;
-  for (size_t p = a.pair_begin + (size_t)blockIdx.x * nwaves + wave; p < a.pair_end; p += (size_t)gridDim.x * nwaves) {
+  for (size_t pb = a.pair_begin + ((size_t)blockIdx.x * nwaves + wave) * G; pb < a.pair_end; pb += (size_t)gridDim.x * nwaves * G) {
+    const bool exists = pb + grp < a.pair_end;
+    const size_t p = exists ? pb + grp : a.pair_end - 1;
+    uint32_t done = 0, count = 0;
+    bool open = exists;
+    if (G == 1) {                      // second pass: only what the opening pass left undecided
+      const int st = a.nperm[p - a.pair_begin];
+      if (st >= 0) continue;
+      count = (uint32_t)(-1 - st);
+      done = a.first;
+    }
     // (i, j) of pair p in row-major order: p = i*n - i(i+1)/2 + (j - i - 1)
     size_t i = (size_t)((2.0 * n - 1.0 - sqrt((2.0 * n - 1.0) * (2.0 * n - 1.0) - 8.0 * (double)p)) / 2.0);
     while (i > 0 && i * n - i * (i + 1) / 2 > p) --i;
     while ((i + 1) * n - (i + 1) * (i + 2) / 2 <= p) ++i;
     const size_t j = p - (i * n - i * (i + 1) / 2) + i + 1;
-    // column setup (wave-cooperative)
-    for (int e = lane; e < A * A; e += 64) joint[e] = 0;
+    // column setup (cooperative within the pair's lanes)
+    for (int e = gl; e < A * A; e += LPG) joint[e] = 0;
     int nz_i = 0, nz_j = 0;
-    if (lane == 0) {
+    if (gl == 0) {
       int run = 0;
       for (int x = 0; x < A; ++x) {
         const int ci = a.colcnt[i * A + x], cj = a.colcnt[j * A + x];
@@ -148,31 +169,31 @@ __global__ void mica_perm_kernel(PermArgs a) {
         seg[x] = (uint16_t)run;
       }
     }
-    nz_i = __shfl(nz_i, 0); nz_j = __shfl(nz_j, 0);
-    for (int t = lane; t < T; t += 64) qbase[t] = a.aln[(size_t)t * a.ld + j];
+    nz_i = __shfl(nz_i, grp * LPG); nz_j = __shfl(nz_j, grp * LPG);
+    for (int t = gl; t < T; t += LPG) qbase[t] = a.aln[(size_t)t * a.ld + j];
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     if (nz_i <= 1 || nz_j <= 1) {     // SiteTools::isConstant(site, ignoreUnknown = true), Mica.cpp:100-104
-      if (lane == 0) { a.pvalue[p - a.pair_begin] = 1.0; a.nperm[p - a.pair_begin] = 0; }
-      continue;
+      if (open && gl == 0) { a.pvalue[p - a.pair_begin] = 1.0; a.nperm[p - a.pair_begin] = 0; }
+      open = false;
+      if (G == 1) continue;
     }
     long long sobs = 0;
-    for (int t = lane; t < T; t += 64) {
+    for (int t = gl; t < T; t += LPG) {
       const int x = a.aln[(size_t)t * a.ld + i], y = qbase[t];
       const uint32_t old = atomicAdd(&joint[x * A + y], 1u);
       sobs += dF[old];
     }
-    for (int off = 32; off; off >>= 1) sobs += __shfl_xor(sobs, off);
-    uint32_t done = 0, count = 0;
+    for (int off = LPG / 2; off; off >>= 1) sobs += __shfl_xor(sobs, off);
     bool stop = false;
-    while (!stop && done < a.max_perm) {
-      const uint32_t k = done + (uint32_t)lane;
+    do {
+      const uint32_t k = done + (uint32_t)gl;
       for (int t = 0; t < T; t += 4) *reinterpret_cast<uint32_t*>(q + t) = *reinterpret_cast<const uint32_t*>(qbase + t);
       long long s = 0;
       int x = -1, send = 0;
       uint32_t r[4] = {0, 0, 0, 0};
       for (int t = 0; t < T; ++t) {
-        while (t >= send) {            // next state of column i that occurs (wave-uniform)
+        while (t >= send) {            // next state of column i that occurs (uniform within the pair's lanes)
           ++x;
           send = seg[x];
           for (int y = 0; y < A; y += 2) *reinterpret_cast<uint32_t*>(cnt + y) = 0;
@@ -186,8 +207,9 @@ __global__ void mica_perm_kernel(PermArgs a) {
         cnt[vj] = (uint16_t)(c + 1);
       }
       const bool hit = k < a.max_perm && s >= sobs;
-      const unsigned long long m = __ballot(hit);
-      const uint32_t avail = min(64u, a.max_perm - done);
+      const unsigned long long mw = __ballot(hit);
+      const unsigned long long m = G == 1 ? mw : (mw >> (grp * LPG)) & ((1ull << LPG) - 1ull);
+      const uint32_t avail = min((uint32_t)LPG, a.max_perm - done);
       const int need = 5 - (int)count;
       if (__popcll(m) >= need) {       // the need-th hit ends the loop: find its position
         unsigned long long mm = m;
@@ -200,10 +222,14 @@ __global__ void mica_perm_kernel(PermArgs a) {
         count += (uint32_t)__popcll(m);
         done += avail;
       }
-    }
-    if (lane == 0) {
-      a.pvalue[p - a.pair_begin] = (double)(count + 1) / (double)(done + 1);
-      a.nperm[p - a.pair_begin] = (int32_t)done;
+    } while (G == 1 && !stop && done < a.max_perm);
+    if (open && gl == 0) {
+      if (stop || done >= a.max_perm) {
+        a.pvalue[p - a.pair_begin] = (double)(count + 1) / (double)(done + 1);
+        a.nperm[p - a.pair_begin] = (int32_t)done;
+      } else {
+        a.nperm[p - a.pair_begin] = -1 - (int32_t)count;   // undecided after kPermFirst shuffles
+      }
     }
   }
 }
@@ -243,16 +269,31 @@ hipError_t launch_mica_perm(const uint8_t* d_aln, int T, size_t n, size_t ld, in
   a.qstride = 4 * sd;
   int cd = (A * 2 + 3) / 4; if (cd % 2 == 0) ++cd;
   a.cstride = 4 * cd;
-  a.wave_bytes = (A * A * 4 + 64 + ((T + 3) & ~3) + 64 * a.qstride + 64 * a.cstride + 15) & ~15;
-  const int budget = 150 * 1024 - T * 8;
-  const int waves = std::max(1, std::min(4, budget / a.wave_bytes));
-  const size_t lds = (size_t)T * 8 + (size_t)waves * a.wave_bytes;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mica_perm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
   const size_t npairs = pair_end - pair_begin;
-  const size_t per_cu = std::max<size_t>(1, (160 * 1024) / lds);
-  const unsigned grid = (unsigned)std::min<size_t>((npairs + waves - 1) / waves, (size_t)cu_count * per_cu);
-  hipLaunchKernelGGL(mica_perm_kernel, dim3(grid), dim3(64 * waves), lds, stream, a);
-  return hipGetLastError();
+  auto go = [&](auto kern, int G) -> hipError_t {
+    a.wave_bytes = (G * (A * A * 4 + 64 + ((T + 3) & ~3)) + 64 * a.qstride + 64 * a.cstride + 15) & ~15;
+    const int budget = 150 * 1024 - T * 8;
+    const int waves = std::max(1, std::min(4, budget / a.wave_bytes));
+    const size_t lds = (size_t)T * 8 + (size_t)waves * a.wave_bytes;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const size_t per_cu = std::max<size_t>(1, (160 * 1024) / lds);
+    const size_t units = (npairs + G - 1) / G;
+    const unsigned grid = (unsigned)std::min<size_t>((units + waves - 1) / waves, (size_t)cu_count * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), lds, stream, a);
+    return hipGetLastError();
+  };
+  // opening pass (four pairs per wave, 16 shuffles each) if its four column copies fit the LDS, then one pair per wave
+  // for what is still undecided
+  const size_t lds4 = (size_t)T * 8 + (((size_t)4 * (A * A * 4 + 64 + ((T + 3) & ~3)) + 64 * a.qstride + 64 * a.cstride + 15) & ~(size_t)15);
+  hipError_t e;
+  if (lds4 <= 160 * 1024) {
+    a.first = kPermFirst;
+    if ((e = go(mica_perm_kernel<4>, 4)) != hipSuccess) return e;
+  } else {
+    a.first = 0;
+    if ((e = hipMemsetAsync(d_nperm, 0xFF, sizeof(int32_t) * npairs, stream)) != hipSuccess) return e;   // -1: undecided, no hits
+  }
+  return go(mica_perm_kernel<1>, 1);
 }
 }  // namespace cmx

@@ -19,11 +19,12 @@ ap.add_argument("--n", type=int, default=2000)
 ap.add_argument("--taxa", type=int, default=256)
 ap.add_argument("--alpha", type=int, default=20)
 ap.add_argument("--max-perm", type=int, default=1000)
+ap.add_argument("--shared", type=float, default=0.3, help="fraction of each column copied from a common ancestor column (0: independent columns)")
 a = ap.parse_args()
 rng = np.random.default_rng(20260103)
 T, A, n = a.taxa, a.alpha, a.n
 base = rng.integers(0, A, size=(T, 1))
-aln = np.where(rng.random((T, n)) < 0.3, base, rng.integers(0, A, size=(T, n))).astype(np.uint8)
+aln = np.where(rng.random((T, n)) < a.shared, base, rng.integers(0, A, size=(T, n))).astype(np.uint8)
 d = torch.from_numpy(aln).cuda()
 npairs = n * (n - 1) // 2
 pv = torch.empty(npairs, dtype=torch.float64, device="cuda")
