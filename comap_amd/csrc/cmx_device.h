@@ -163,7 +163,8 @@ hipError_t launch_mi_pairs(int A, int T, const uint32_t* d_masks, const uint8_t*
 // scratch of the MFMA Mica path (all device pointers; H1 null = LDS-table kernel only)
 struct MicaWork {
   int8_t *H1, *H2;         // one-hot [n][32][Tp] int8
-  uint8_t *flag1, *flag2;  // [n] column has ambiguous symbols
+  uint8_t *flag1, *flag2;  // [n] column has ambiguous symbols other than "unknown" (-> LDS-table kernel)
+  uint8_t *gap1, *gap2;    // [n] column has unknowns (gap / X / N: compatible with every state; handled on the matrix cores)
   double *S1, *S2;         // [n] sum_a f(count_a)
   double* ftab;            // [T + 1] c ln c
   int* anyflag;            // some column of either alignment has ambiguous symbols

@@ -1901,22 +1901,31 @@ typedef int cmx_i4 __attribute__((ext_vector_type(4)));
 typedef int cmx_i16v __attribute__((ext_vector_type(16)));
 constexpr int kMicaK = 32;   // taxa per MFMA step (v_mfma_i32_32x32x32_i8)
 
-// one block per column: one-hot rows H[col][a][t] (a < 32, t < Tp, zero padded), flag = column has a code >= A,
-// S[col] = sum_a f(count_a)
-__global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, const uint8_t* __restrict__ aln, size_t ld,
+// one block per column: one-hot rows H[col][a][t] (a < 32, t < Tp, zero padded).  A symbol compatible with EVERY state
+// (gap, X, N: mask = all ones) becomes pseudo-state A -- row A of the one-hot matrix -- and the column is marked in
+// gap[]: its pairs stay on the matrix cores and the epilogue spreads the pseudo-state's counts (weight 1/A per state,
+// the fractional counts of SiteTools::getCounts(.., resolveUnknowns = true)).  Any other ambiguity code sets flag[]
+// (pairs of that column go to the LDS-table kernel).  S[col] = sum_a f(count_a) with the fractional counts.
+__global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, const uint32_t* __restrict__ masks,
+                                                          const uint8_t* __restrict__ aln, size_t ld,
                                                           int8_t* __restrict__ H, uint8_t* __restrict__ flag,
-                                                          double* __restrict__ S, int* __restrict__ anyflag) {
-  __shared__ int cnt[32];
+                                                          uint8_t* __restrict__ gap, double* __restrict__ S,
+                                                          int* __restrict__ anyflag) {
+  __shared__ int cnt[33];
   __shared__ int amb;
   const size_t i = blockIdx.x;
-  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+  const uint32_t full = (1u << A) - 1u;
+  if (threadIdx.x < 33) cnt[threadIdx.x] = 0;
   if (threadIdx.x == 0) amb = 0;
   __syncthreads();
   for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
-    const unsigned c = t < T ? aln[(size_t)t * ld + i] : 255u;
+    unsigned c = t < T ? aln[(size_t)t * ld + i] : 255u;
     if (t < T) {
-      if (c < (unsigned)A) atomicAdd(&cnt[c], 1);
-      else amb = 1;
+      if (c >= (unsigned)A) {
+        if ((masks[c] & full) == full) c = (unsigned)A;     // unknown: pseudo-state
+        else { amb = 1; c = 255u; }
+      }
+      if (c <= (unsigned)A) atomicAdd(&cnt[c], 1);
     }
 #pragma unroll
     for (int a = 0; a < 32; ++a) H[(i * 32 + a) * (size_t)Tp + t] = (int8_t)((c == (unsigned)a) ? 1 : 0);
@@ -1924,10 +1933,14 @@ __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, 
   __syncthreads();
   if (threadIdx.x == 0) {
     double s = 0.0;
-    for (int a = 0; a < A; ++a)
-      if (cnt[a] > 1) s += (double)cnt[a] * log((double)cnt[a]);
+    const double g = (double)cnt[A] / (double)A;
+    for (int a = 0; a < A; ++a) {
+      const double c = (double)cnt[a] + g;
+      if (c > 0.0) s += c * log(c);
+    }
     S[i] = s;
     flag[i] = (uint8_t)amb;
+    gap[i] = (uint8_t)(cnt[A] > 0 ? 1 : 0);
     if (amb) atomicOr(anyflag, 1);
   }
 }
@@ -1949,10 +1962,12 @@ __device__ __forceinline__ double mica_dpp_f64(double v) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
-                                                           const uint8_t* __restrict__ flag1, const double* __restrict__ S1,
+__global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int A, int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
+                                                           const uint8_t* __restrict__ flag1, const uint8_t* __restrict__ gap1,
+                                                           const double* __restrict__ S1,
                                                            const int8_t* __restrict__ H2, size_t n2,
-                                                           const uint8_t* __restrict__ flag2, const double* __restrict__ S2,
+                                                           const uint8_t* __restrict__ flag2, const uint8_t* __restrict__ gap2,
+                                                           const double* __restrict__ S2,
                                                            const double* __restrict__ ftab_g, int intra,
                                                            double* __restrict__ mi, double* __restrict__ hj, size_t ldo) {
   extern __shared__ __attribute__((aligned(16))) uint8_t mica_smem[];
@@ -1972,6 +1987,12 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const 
     }
     return;
   }
+  // does any column of this tile carry unknowns?  (independent loads, issued here so that the main loop hides them)
+  unsigned gapbits = 0;
+#pragma unroll
+  for (int c = 0; c < kMicaTileI; ++c) gapbits |= gap1[i0 + c < n1 ? i0 + c : n1 - 1];
+#pragma unroll
+  for (int c = 0; c < kMicaTileJ; ++c) gapbits |= gap2[j0 + c < n2 ? j0 + c : n2 - 1];
   // loader role of this thread: 12 operand tiles x 64 lanes = 768 slots of 16 bytes, threads 0..383 take two each
   // (operand tile q = slot / 64: q < 8 column i0 + q of H1, else column j0 + q - 8 of H2; a lane's 16 bytes are row
   // (lane % 32), taxa group (lane / 32) of the one-hot matrix)
@@ -2040,6 +2061,44 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const 
   s += mica_dpp_f64<0x124>(s);   // row_ror:4
   s += mica_dpp_f64<0x122>(s);   // row_ror:2
   s += mica_dpp_f64<0x121>(s);   // row_ror:1
+  const bool blockgap = gapbits != 0;
+  // Pairs with unknowns (pseudo-state A): the integer table N (states + pseudo-state, from the same accumulators) is
+  // expanded into the fractional counts c_ab = N_ab + (N_aA + N_Ab) / A + N_AA / A^2 and f is evaluated with a
+  // logarithm per cell.  v_mfma_i32_32x32x32_i8 leaves D[row][col] in register v of lane l with
+  // row = 8 (v / 4) + 4 (l / 32) + v % 4, col = l % 32.
+  {
+    if (blockgap) {
+      __syncthreads();                                  // the operand buffers are free now: reuse them as count tables
+      int* tile = reinterpret_cast<int*>(ops) + w * 448;   // (A + 1)^2 <= 441 ints per wave
+      const int A1 = A + 1;
+      const double invA = 1.0 / (double)A;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = r >> 1, jj = r & 1;
+        const size_t i = i0 + 2 * wi + ii, j = j0 + 2 * wj + jj;
+        if (!(gap1[i < n1 ? i : n1 - 1] || gap2[j < n2 ? j : n2 - 1])) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = 8 * (v / 4) + 4 * (lane / 32) + v % 4, col = lane % 32;
+          if (row <= A && col <= A) tile[row * A1 + col] = acc[ii][jj][v];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const double gam = (double)tile[A * A1 + A] * invA * invA;
+        double sg = 0.0;
+        for (int e = lane; e < A * A; e += 64) {
+          const int x = e / A, y = e % A;
+          const double c = (double)tile[x * A1 + y] + ((double)tile[x * A1 + A] + (double)tile[A * A1 + y]) * invA + gam;
+          if (c > 0.0) sg += c * log(c);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, 64);
+        if ((lane >> 4) == r) s = sg;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
   {
     const int r = lane >> 4;
     const size_t i = i0 + 2 * wi + (r >> 1), j = j0 + 2 * wj + (r & 1);
@@ -2087,14 +2146,16 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
   if (work && work->H1) {
     const int Tp = work->Tp;
     hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)(T / 256 + 1)), dim3(256), 0, stream, T, work->ftab, work->anyflag);
-    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_aln1, ld1, work->H1, work->flag1, work->S1, work->anyflag);
+    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, work->H1, work->flag1,
+                       work->gap1, work->S1, work->anyflag);
     if (!intra)
-      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_aln2, ld2, work->H2, work->flag2, work->S2, work->anyflag);
+      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln2, ld2, work->H2,
+                         work->flag2, work->gap2, work->S2, work->anyflag);
     dim3 g2((unsigned)((n2 + kMicaTileJ - 1) / kMicaTileJ), (unsigned)((n1 + kMicaTileI - 1) / kMicaTileI));
     const size_t lds2 = (((size_t)(T + 1) * 8 + 15) & ~(size_t)15) + 2 * (kMicaTileI + kMicaTileJ) * 64 * sizeof(cmx_i4);
-    hipLaunchKernelGGL(mica_mfma_kernel, g2, dim3(512), lds2, stream, T, Tp, work->H1, n1,
-                       work->flag1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
-                       intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
+    hipLaunchKernelGGL(mica_mfma_kernel, g2, dim3(512), lds2, stream, A, T, Tp, work->H1, n1,
+                       work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
+                       intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
     f1 = work->flag1;
     f2 = intra ? work->flag1 : work->flag2;
   }

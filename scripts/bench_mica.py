@@ -20,12 +20,18 @@ ap.add_argument("--n2", type=int, default=5000)
 ap.add_argument("--taxa", type=int, default=256)
 ap.add_argument("--alpha", type=int, default=20)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--gap-columns", type=float, default=0.0, help="fraction of columns that carry gaps (code = alpha), 5 %% of their rows")
 a = ap.parse_args()
 rng = np.random.default_rng(20260103)
 T, A = a.taxa, a.alpha
 base = rng.integers(0, A, size=(T, 1))
 a1 = np.where(rng.random((T, a.n1)) < 0.6, base, rng.integers(0, A, size=(T, a.n1))).astype(np.uint8)
 a2 = np.where(rng.random((T, a.n2)) < 0.4, base, rng.integers(0, A, size=(T, a.n2))).astype(np.uint8)
+if a.gap_columns > 0:
+    for arr in (a1, a2):
+        cols = rng.random(arr.shape[1]) < a.gap_columns
+        mask = (rng.random(arr.shape) < 0.05) & cols[None, :]
+        arr[mask] = A
 dev = torch.device("cuda:0")
 d1, d2 = torch.from_numpy(a1).to(dev), torch.from_numpy(a2).to(dev)
 mi = torch.empty((a.n1, a.n2), dtype=torch.float64, device=dev)

@@ -627,3 +627,39 @@ def test_label_substitution_count_is_the_naive_count_with_label_weights():
     r = _engine(case, count_method=engine.COUNT_NAIVE, naive_weights=W).map_sites(case["aln"])
     o = oracle.map_sites(_omodel(case, method=oracle.METHOD_NAIVE, naive_W=W), case["aln"])
     rel_close(r["counts"], o["counts"], 1e-6, 1e-12)
+
+
+@pytest.mark.parametrize("A,T", [(20, 96), (4, 77), (20, 256)])
+def test_mi_columns_with_gaps_everywhere(A, T):
+    """unknowns (gap / X / N: compatible with every state) stay on the matrix cores as pseudo-state A and are spread
+    over the states in the epilogue (weight 1/A); partial ambiguity codes still go to the LDS-table kernel.  Gaps in
+    both columns of a pair, gap-only rows, intra and cross layouts, tile overhangs"""
+    rng = np.random.default_rng(A + T)
+    n1, n2 = 23, 18
+    a1 = rng.integers(0, A, size=(T, n1)).astype(np.uint8)
+    a2 = rng.integers(0, max(2, A // 2), size=(T, n2)).astype(np.uint8)
+    a1[rng.random(a1.shape) < 0.15] = A          # unknown, default mask = every state
+    a2[rng.random(a2.shape) < 0.30] = A + 3      # another unknown code
+    a2[:, 1] = A                                 # a column of gaps only
+    a1[:, 2] = np.where(rng.random(T) < 0.5, a1[:, 2], A)
+    masks = oracle.default_masks(A)
+    eng = engine.Engine()
+    g = eng.mi_columns(a1, a2, A)
+    o = oracle.mi_columns(a1, a2, A)
+    rel_close(g["mi"], o["mi"], 1e-6, 1e-10)
+    rel_close(g["hjoint"], o["hjoint"], 1e-6, 1e-10)
+    gi = eng.mi_columns(a1, None, A)
+    oi = oracle.mi_columns(a1, a1, A)
+    iu = np.triu_indices(n1, 1)
+    rel_close(gi["mi"][iu], oi["mi"][iu], 1e-6, 1e-10)
+    rel_close(gi["hjoint"][iu], oi["hjoint"][iu], 1e-6, 1e-10)
+    # a partial ambiguity code (two states) next to the gaps: that column takes the LDS-table kernel, the rest does not change
+    m2 = masks.copy()
+    m2[A + 1] = 0b11
+    a3 = a1.copy()
+    a3[rng.integers(0, T, 5), 4] = A + 1
+    g3 = eng.mi_columns(a3, a2, A, masks=m2[: A + 4])
+    o3 = oracle.mi_columns(a3, a2, A, m2)
+    rel_close(g3["mi"], o3["mi"], 1e-6, 1e-10)
+    keep = np.arange(n1) != 4
+    assert np.array_equal(g3["mi"][keep], g["mi"][keep])
