@@ -202,7 +202,11 @@ cmx_status cmx_intra_rows(cmx_ctx* ctx, int kind, const double* params, const do
                           const cmx_pair_filters* filters, cmx_pair_row* rows, size_t capacity, uint64_t* count);
 
 /* ---- Mica: mutual information between alignment columns over taxa (Mica.cpp:93-95, 349-361, 646-660).
- * aln2 == NULL: intra.  Outputs dense [n1][n2] (mi, hjoint) and per-column entropies; nalpha = alphabet size. */
+ * aln2 == NULL: intra (filled for j > i, NaN elsewhere).  Outputs dense [n1][n2] (mi, hjoint) and per-column entropies;
+ * nalpha = alphabet size.  Alignment codes >= nalpha index `masks` (bit a set = compatible with state a; masks == NULL:
+ * every such code is an unknown): SiteTools::*(.., resolveUnknowns = true) spreads such a symbol evenly over its
+ * compatible states.  Unknowns (gap, X, N: all states) cost nothing extra; a column with a partial ambiguity code sends
+ * its pairs through a slower kernel. */
 cmx_status cmx_mi_columns(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks,
                           const uint8_t* aln1, size_t n1, const uint8_t* aln2, size_t n2, double* mi,
                           double* hjoint, double* h1, double* h2);
