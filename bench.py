@@ -5,14 +5,22 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic input (DESIGN.md section "Measurement"):
-  map the observed alignment -> parametric-bootstrap null for this rank's replicates (simulate, re-map twice,
-  score) -> [N > 1: one RCCL all-gather of the null] -> all-pairs statistic on MFMA -> p-values.
-Metric (BASELINE.json): site-pair coevolution statistics/s incl. null sims = (observed pairs + null pairs of all
-ranks) / time, inputs resident in HBM.  Default workload = BASELINE configs[1] alignment (2 000 sites x 64 taxa
-protein, JTT92+G4, correlation) with configs[2]'s null sharded as 125 replicates x 2 000 per GPU (weak scaling:
-8 GPUs = the 1 000 replicates of configs[2]).
+  map the observed alignment  ||  parametric-bootstrap null for this rank's replicates (simulate, re-map twice, score)
+  -> [N > 1: one RCCL all-gather of the null] -> all-pairs statistic on MFMA + p-values for this rank's row block
+Metric (BASELINE.json): site-pair coevolution statistics/s incl. null sims = (observed pairs + null pairs) / time,
+inputs resident in HBM when the timed region starts.
+
+Default workload = the configuration the metric is quoted on (BASELINE.json north_star): 10 000-column x 64-taxa
+protein alignment, JTT92+G4, correlation, 1 000 null replicates x 10 000 sites.  With N GPUs the SAME 1 000
+replicates are sharded over the ranks (strong scaling) and the observed all-pairs stage is split in row blocks.
+Next to the headline the JSON line carries: `roofline` (dominant kernel, HIP events on its stream), `cpu_baseline`
+(oracle on the host cores, 1 thread as the reference runs + all cores), `host_to_host` (same step with the alignment
+coming from and the statistics / p-values going to host memory: BASELINE.md section 3's counting rule) and
+`mica_cfg5` (BASELINE configs[4], the Mica column-MI kernel with its own roofline and CPU figure).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -24,19 +32,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: ntaxa, nsites, nstates, tree seed, statistic, replicates per GPU, rep_ram, norm classes
-    "cfg3": dict(ntaxa=64, nsites=2000, nstates=20, seed=20260101, statistic="Correlation", rep_per_gpu=125,
-                 rep_ram=2000, nclasses=10,
-                 desc="2000x64 protein JTT92+G4(a=0.5), correlation, null 125 rep/GPU x 2000 (cfg3 sharded)"),
-    "target": dict(ntaxa=64, nsites=10000, nstates=20, seed=20260101, statistic="Correlation", rep_per_gpu=1000,
-                   rep_ram=10000, nclasses=10,
-                   desc="north-star target: 10000x64 protein, correlation, 1000 null replicates x 10000 per GPU"),
-    "cfg4": dict(ntaxa=256, nsites=10000, nstates=4, seed=20260102, statistic="Compensation", rep_per_gpu=12,
-                 rep_ram=10000, nclasses=10,
+    # name: ntaxa, nsites, nstates, tree seed, statistic, total null replicates at N GPUs, rep_ram, norm classes
+    "target": dict(ntaxa=64, nsites=10000, nstates=20, seed=20260101, statistic="Correlation", nrep=lambda n: 1000,
+                   rep_ram=10000, nclasses=10, scaling="strong",
+                   desc="north-star target: 10000x64 protein JTT92+G4(a=0.5), correlation, 1000 null replicates x 10000"),
+    "cfg3": dict(ntaxa=64, nsites=2000, nstates=20, seed=20260101, statistic="Correlation", nrep=lambda n: 125 * n,
+                 rep_ram=2000, nclasses=10, scaling="weak",
+                 desc="2000x64 protein JTT92+G4(a=0.5), correlation, null 125 rep/GPU x 2000 (configs[2] at 8 GPUs)"),
+    "cfg4": dict(ntaxa=256, nsites=10000, nstates=4, seed=20260102, statistic="Compensation", nrep=lambda n: 12 * n,
+                 rep_ram=10000, nclasses=10, scaling="weak",
                  desc="10000x256 DNA GTR+G4, compensation (W=idx[y]-idx[x]), null 12 rep/GPU x 10000"),
 }
-FP64_PEAK_TFLOPS = 78.6  # MI355X public spec, vector == matrix fp64 (the microarch guide has no fp64 row);
-# measured here (scripts/ubench_f64.hip): v_mfma_f64_16x16x4 72-75, v_fma_f64 55-59 TFLOP/s
+FP64_PEAK_TFLOPS = 78.6   # MI355X public spec, vector == matrix fp64 (the microarch guide has no fp64 row);
+# measured here (scripts/ubench_f64.hip): v_mfma_f64_16x16x4 72-75, v_mfma_f64_4x4x4_4b 65-68, v_fma_f64 55-59 TFLOP/s
+INT8_PEAK_TOPS = 5000.0   # guide, Matrix cores: I8 = 2x the BF16 rate per clock, BF16 ~2.5 PF dense
 
 
 def build_inputs(w):
@@ -59,14 +68,25 @@ def flops_per_site(B, C, S, K, nn, ni_nonroot, nleaves):
     return algorithmic, executed
 
 
-def cpu_baseline(w, parent, blen, lot, mdl, Bk, clamp, n_gpu_units, world):
-    """Oracle (CPU restatement, single thread, reference loop structure) on a bounded sample, extrapolated to the
-    benchmark's unit mix.  kind = "port": the reference itself cannot be built here (Bio++ absent)."""
+def kernel_source_sha():
+    """sha of the device sources: a PMC traffic figure in profiles/ is attached only when it was taken on this code"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "comap_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "comap_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(w, parent, blen, lot, mdl, Bk, clamp, nrep_total):
+    """Oracle (CPU restatement, reference loop structure) on a bounded sample, extrapolated to the step's unit mix.
+    kind = "port": the reference itself cannot be built here (Bio++ absent).  The headline figure is ONE thread, as the
+    reference runs; `all_cores` repeats the dominant stage (the null) with one replicate range per host thread."""
+    import concurrent.futures as cf
     import oracle
     kind = {"Correlation": 0, "Compensation": 1}[w["statistic"]]
     om = oracle.Model(parent, blen, lot, mdl["Q"], mdl["pi"], mdl["rates"], mdl["probs"], Bk=Bk, nonneg=clamp)
     n_obs = min(w["nsites"], 2000)
-    nrep_s, ram_s = 16, min(w["rep_ram"], 2000)   # ~64 000 sites re-mapped: 10-30 s of host work
+    nrep_s, ram_s = 16, min(w["rep_ram"], 2000)   # 64 000 sites re-mapped: 10-15 s on one core
     aln, _ = oracle.simulate(om, w["seed"] + 1, 0, n_obs)
     t0 = time.perf_counter()
     m = oracle.map_sites(om, aln)
@@ -80,26 +100,92 @@ def cpu_baseline(w, parent, blen, lot, mdl, Bk, clamp, n_gpu_units, world):
     t0 = time.perf_counter()
     oracle.intra_pvalues(st, m["norm"], w["nclasses"], nl["stat"], nl["nmin"])
     t_pv = time.perf_counter() - t0
-    # extrapolate the sample to one benchmark step of ONE rank's share (CPU has no ranks: total work / 1 thread)
     scale_obs = w["nsites"] / n_obs
     pairs_obs = w["nsites"] * (w["nsites"] - 1) / 2
-    null_pairs_total = world * w["rep_per_gpu"] * w["rep_ram"]
-    t_full = (t_map * scale_obs + t_pairs * scale_obs ** 2 + t_null * null_pairs_total / (nrep_s * ram_s)
-              + t_pv * scale_obs ** 2 * null_pairs_total / (nrep_s * ram_s))   # linear-scan p-values scale with nsim
-    value = (pairs_obs + null_pairs_total) / t_full
+    null_pairs_total = nrep_total * w["rep_ram"]
+    null_scale = null_pairs_total / (nrep_s * ram_s)
+
+    def full_time(t_null_sample, div=1.0):
+        return (t_map * scale_obs / div + t_pairs * scale_obs ** 2 / div + t_null_sample * null_scale
+                + t_pv * scale_obs ** 2 * null_scale / div)   # linear-scan p-values scale with nsim
+    t_full = full_time(t_null)
+    # all host cores: the replicate loop (AnalysisTools.cpp:587) split over threads (the C oracle is re-entrant and
+    # ctypes releases the GIL); the observed stages are divided by the thread count as perfectly parallel loops
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nthr = max(1, min(cores, 64))
+    nrep_mt = max(nrep_s, 2 * nthr)
+    bounds = np.linspace(0, nrep_mt, nthr + 1).astype(int)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(lambda i: oracle.null_intra(om, kind, 1, int(bounds[i]), int(bounds[i + 1]), ram_s), range(nthr)))
+    t_null_mt = (time.perf_counter() - t0) * nrep_s / nrep_mt
+    t_full_mt = full_time(t_null_mt, div=nthr)
+    unit = "site-pair statistics/s"
     sample = (f"oracle/oracle.c -O2, 1 thread: map {n_obs} sites {t_map:.2f}s, {n_obs * (n_obs - 1) // 2} pair stats "
               f"{t_pairs:.2f}s, null {nrep_s} rep x {ram_s} (={2 * nrep_s * ram_s} sites re-mapped) {t_null:.2f}s, "
               f"linear-scan p-values {t_pv:.2f}s; extrapolated to the step's unit mix ({t_full:.0f}s of CPU work)")
-    return dict(value=value, unit="site-pair statistics/s", cores=1, kind="port", sample=sample)
+    return dict(value=(pairs_obs + null_pairs_total) / t_full, unit=unit, cores=1, kind="port", sample=sample,
+                all_cores=dict(value=(pairs_obs + null_pairs_total) / t_full_mt, unit=unit, cores=nthr,
+                               sample=f"null {nrep_mt} rep x {ram_s} over {nthr} threads (one replicate range each) "
+                                      f"{t_null_mt * nrep_mt / nrep_s:.2f}s; observed stages / {nthr}; extrapolated "
+                                      f"({t_full_mt:.0f}s)"))
+
+
+def mica_leg(dev, steps):
+    """BASELINE configs[4] on this GPU: Mica column MI of 5000 + 5000 columns, 256 taxa, protein alphabet, all 25e6 cross
+    pairs (Mica.cpp:349-361, 646-689), inputs resident in HBM.  Own roofline (one-hot Gram, 2 A^2 T int8 ops per pair)
+    and own CPU figure (oracle's SiteTools restatement on a 300 x 300 column sample)."""
+    import torch
+    from comap_amd import engine as E
+    rng = np.random.default_rng(20260103)
+    T, A, n1, n2 = 256, 20, 5000, 5000
+    base = rng.integers(0, A, size=(T, 1))
+    a1 = np.where(rng.random((T, n1)) < 0.6, base, rng.integers(0, A, size=(T, n1))).astype(np.uint8)
+    a2 = np.where(rng.random((T, n2)) < 0.4, base, rng.integers(0, A, size=(T, n2))).astype(np.uint8)
+    d1, d2 = torch.from_numpy(a1).to(dev), torch.from_numpy(a2).to(dev)
+    mi = torch.empty((n1, n2), dtype=torch.float64, device=dev)
+    hj = torch.empty_like(mi)
+    h1 = torch.empty(n1, dtype=torch.float64, device=dev)
+    h2 = torch.empty(n2, dtype=torch.float64, device=dev)
+    eng = E.Engine(device=dev.index)
+    eng.mi_columns_dev(d1, mi, hj, d2, A, None, h1, h2)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        eng.mi_columns_dev(d1, mi, hj, d2, A, None, h1, h2)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    pairs = n1 * n2
+    ident = float((mi - (h1[:, None] + h2[None, :] - hj)).abs().max())
+    import oracle
+    ns = 300
+    t0 = time.perf_counter()
+    o = oracle.mi_columns(a1[:, :ns], a2[:, :ns], A)
+    t_cpu = time.perf_counter() - t0
+    err = float(np.max(np.abs(o["mi"] - mi[:ns, :ns].cpu().numpy())))
+    tops = pairs * 2.0 * A * A * T / (ms * 1e-3) / 1e12
+    eng.close()
+    return dict(workload="cfg5: Mica MI, 5000 + 5000 columns x 256 taxa, protein alphabet, all 25e6 cross pairs",
+                value=pairs / (ms * 1e-3), unit="column-pair MI/s", ms_per_step=ms, steps=steps, dtype="i8",
+                roofline=dict(bound="mfma", kernel="mica_mfma_kernel (+ one-hot / epilogue)", achieved=tops,
+                              peak=INT8_PEAK_TOPS, unit="TOP/s", frac=tops / INT8_PEAK_TOPS, traffic=None,
+                              ops_per_pair_algorithmic=2.0 * A * A * T),
+                cpu_baseline=dict(value=ns * ns / t_cpu, unit="column-pair MI/s", cores=1, kind="port",
+                                  sample=f"oracle/oracle.c orc_mi_columns on {ns} x {ns} columns: {t_cpu:.2f}s"),
+                max_identity_residual=ident, max_abs_diff_vs_oracle_sample=err)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mica", action="store_true")
+    ap.add_argument("--no-host", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -140,24 +226,24 @@ def main():
     ana = IntraAnalysis(eng, d_aln, w["statistic"], w["nclasses"])
     from comap_amd.distributed import gather_null, replicate_shard
     ram = w["rep_ram"]
-    nrep_total = w["rep_per_gpu"] * world                  # weak scaling: fixed replicates per GPU
+    nrep_total = w["nrep"](world)
     rep_begin, rep_end = replicate_shard(rank, world, nrep_total)
     n_local = (rep_end - rep_begin) * ram
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     side = torch.cuda.Stream(device=dev)   # observed-alignment mapping overlaps the null kernel (independent work)
-    main = torch.cuda.current_stream()
+    main_s = torch.cuda.current_stream()
 
-    def step(i, timed):
-        side.wait_stream(main)
+    def step(i, timed, aln=None):
+        side.wait_stream(main_s)
         with torch.cuda.stream(side):
-            ana.get_vectors()
+            ana.get_vectors(aln)
         if timed:
             ev[i][0].record()
         nb = ana.null_distribution(w["seed"] + 7, rep_begin, rep_end, ram)
         if timed:
             ev[i][1].record()
-        main.wait_stream(side)
+        main_s.wait_stream(side)
         # the path's one exchange: every rank needs the merged null before p-values (one RCCL all-gather)
         ns, nm = gather_null(nb["stat"], nb["nmin"], nrep_total, ram)
         ana.compute_intra_stats(ns, nm)
@@ -194,32 +280,66 @@ def main():
     alg, exe = flops_per_site(eng.B, eng.C, eng.S, eng.K, nn, ni_nonroot, nleaves)
     sites_per_launch = 2 * n_local
     achieved = sites_per_launch * alg / (null_ms * 1e-3) / 1e12
+    ach_exe = sites_per_launch * exe / (null_ms * 1e-3) / 1e12
+    # `achieved` / `frac` follow SURVEY 8(d): ALGORITHMIC flops (7 B C S^2 per site, leaf edges counted as dense
+    # products) / time / peak.  `frac_executed` counts only the matrix products the kernel issues (leaf edges are row
+    # gathers, sibling messages are stored instead of recomputed): the matrix pipe's duty, always lower.
     roofline = dict(bound="mfma", kernel=f"map_kernel<{eng.S},null>", achieved=achieved, peak=FP64_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
                     launch_ms=null_ms, sites_per_launch=sites_per_launch, flops_per_site_algorithmic=alg,
-                    flops_per_site_executed=exe,
-                    achieved_executed=sites_per_launch * exe / (null_ms * 1e-3) / 1e12)
-    traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if os.path.exists(traffic_file):
+                    flops_per_site_executed=exe, achieved_executed=ach_exe, frac_executed=ach_exe / FP64_PEAK_TFLOPS)
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
         try:
-            roofline["traffic"] = json.load(open(traffic_file)).get(args.workload)
+            t = json.load(open(tf))
+            if t.get("kernel_source_sha") == kernel_source_sha() and args.workload in t:
+                roofline["traffic"] = t[args.workload]
+                roofline["traffic_source"] = os.path.relpath(tf, ROOT)
+                break
         except Exception:
             pass
 
     out = dict(metric="site-pair coevolution statistics/s (incl. null sims)", value=value,
                unit="site-pair statistics/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
+               ms_per_step=ms_per_step, higher_is_better=True, scaling=w["scaling"], vs_baseline=None, dtype="f64",
                data="synthetic",
                config=dict(workload=f"{args.workload}: {w['desc']}", observed_pairs=pairs_obs,
-                           null_pairs_per_gpu=n_local, sites_mapped_per_step_per_gpu=w["nsites"] + 2 * n_local,
-                           parallelism=f"null replicates sharded x{world}, one RCCL all-gather" if world > 1 else "single GPU",
+                           null_pairs_total=nrep_total * ram, null_pairs_this_gpu=n_local,
+                           sites_mapped_per_step_this_gpu=w["nsites"] + 2 * n_local,
+                           parallelism=(f"null replicates sharded x{world}, one RCCL all-gather" if world > 1 else "single GPU"),
                            cu_count=info["cu_count"], mapping_waves=info["waves"]),
                roofline=roofline)
+
+    # same step, host memory to host memory (BASELINE.md section 3 counting rule; never `value`): the alignment is
+    # uploaded inside the timed region and statistic / p-value / Nsim of every pair end in (pinned) host memory
+    if not args.no_host and world == 1:
+        h_aln = torch.from_numpy(aln_h).pin_memory()
+        d_in = torch.empty_like(d_aln)
+        hs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (ana.stat, ana.pvalue, ana.nsim)]
+        reps = max(1, min(args.steps, 2))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            d_in.copy_(h_aln, non_blocking=True)
+            step(0, False, d_in)
+            for h, t in zip(hs, (ana.stat, ana.pvalue, ana.nsim)):
+                h.copy_(t, non_blocking=True)
+            torch.cuda.synchronize()
+        th = (time.perf_counter() - t0) / reps
+        out["host_to_host"] = dict(value=units_per_step / th, unit="site-pair statistics/s", ms_per_step=1e3 * th,
+                                   h2d_bytes=int(h_aln.numel()), d2h_bytes=int(sum(h.numel() * h.element_size() for h in hs)),
+                                   note="alignment H2D + dense statistic / p-value / Nsim D2H (pinned) inside the timed region")
+        del hs, h_aln, d_in
+
     if rank == 0:
         if args.no_cpu_baseline or world > 1:   # CPU baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = None
         else:
-            out["cpu_baseline"] = cpu_baseline(w, parent, blen, lot, mdl, Bk, clamp, units_per_step, world)
+            out["cpu_baseline"] = cpu_baseline(w, parent, blen, lot, mdl, Bk, clamp, nrep_total)
+    if world == 1 and not args.no_mica:
+        del ana
+        torch.cuda.empty_cache()
+        out["mica_cfg5"] = mica_leg(dev, max(3, args.steps))
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

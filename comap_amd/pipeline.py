@@ -32,8 +32,8 @@ class IntraAnalysis:
         self.nsim = torch.empty((self.n, self.n), dtype=torch.int32, device=dev)
         self._null = {}
 
-    def get_vectors(self):
-        self.eng.map_sites_dev(self.aln, self.counts, self.logL, self.post_rate, self.rate_class, self.norm)
+    def get_vectors(self, aln=None):
+        self.eng.map_sites_dev(self.aln if aln is None else aln, self.counts, self.logL, self.post_rate, self.rate_class, self.norm)
         return self.counts
 
     def compute_norms(self):
