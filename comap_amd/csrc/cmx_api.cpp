@@ -158,16 +158,16 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     if (!ctx->has_model) return CMX_OK;
     const HostModel& h = ctx->hm;
     DevModel& d = ctx->dm;
-    d.S = h.dS; d.C = h.dC; d.S0 = h.S; d.C0 = h.C; d.fuse = h.fuse; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.NV = h.NV; d.root = h.root;
+    d.S = h.dS; d.C = h.dC; d.S0 = h.S; d.C0 = h.C; d.fuse = h.fuse; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.NIW = h.NIW; d.NV = h.NV; d.root = h.root;
 #define UP(field) if ((s = upload(ctx, h.field, &d.field)) != CMX_OK) return s
-    UP(int_post); UP(first_child); UP(next_sib); UP(taxon_of); UP(slot); UP(parent);
+    UP(taxon_of); UP(parent);
     {
       const double* mat = nullptr;
       if ((s = upload(ctx, h.MAT, &mat)) != CMX_OK) return s;
       d.MAT = const_cast<double*>(mat);
     }
     d.MC = h.MC;
-    {  // device copy of the op stream: operator indices premultiplied to element offsets, and the first two entries
+    {  // device copy of the operator stream: operator indices premultiplied to element offsets, and the first two entries
        // repeated after the last one so that "the entry two ops ahead" never needs a wrap test
       std::vector<int> ms(h.msched);
       const int unit = mat_unit(h.dS);
@@ -177,10 +177,9 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       const int* dms = nullptr;
       if ((s = upload(ctx, ms, &dms)) != CMX_OK) return s;
       d.msched = dms;
+      d.nmv = (int)(h.msched.size() / 2);
     }
     UP(nrec);
-    d.nmv = (int)(h.msched.size() / 2);
-    UP(CP); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
     {  // two zero entries (not prefetchable) after the last load: the kernel reads one entry ahead without a bounds test
       std::vector<int> ld(h.ldsched);
       ld.push_back(0);
@@ -189,8 +188,8 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       if ((s = upload(ctx, ld, &dld)) != CMX_OK) return s;
       d.ldsched = dld;
     }
+    UP(CP); UP(CPG); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
 #undef UP
-    d.nloads = (int)h.ldsched.size();
     // ambiguity rows of the leaf operators: default "every state compatible" until a call brings a mask table
     HIP_TRY(ctx, launch_extend_leaf_rows(d, nullptr, nullptr));
     HIP_TRY(ctx, hipDeviceSynchronize());
@@ -204,7 +203,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
     auto alloc_ws = [&](Workspace* ws, size_t w, size_t* bytes) -> cmx_status {
       const size_t ks = (size_t)map_sites_per_wave(h.dS);   // sites per mapping wave
-      const size_t bD = w * h.NI * h.dS * ks * sizeof(double);
+      const size_t bD = w * h.NIW * h.dS * ks * sizeof(double);
       const size_t bC = w * 2 * h.B * h.K * ks * sizeof(double);
       const size_t bP = w * h.dC * h.B * h.K * ks * sizeof(double);
       const size_t bS = w * h.nn * ks, bA = w * h.T * ks;
@@ -260,9 +259,9 @@ cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P) {
   return CMX_OK;
 }
 
-cmx_status cmx_debug_traversal(const cmx_model* model, const cmx_tree* tree, int32_t* nrec, size_t nrec_cap,
-                               size_t* nrec_n, int32_t* ldsched, size_t ld_cap, size_t* ld_n, int32_t* msched,
-                               size_t m_cap, size_t* m_n, int32_t* slot_of_node) {
+cmx_status cmx_debug_walk(const cmx_model* model, const cmx_tree* tree, int32_t* nrec, size_t nrec_cap, size_t* nrec_n,
+                          int32_t* ldsched, size_t ld_cap, size_t* ld_n, int32_t* msched, size_t m_cap, size_t* m_n,
+                          int32_t* slot_of_node, uint64_t* stats /*[4]: loads, stores, products, leaf ops per pass*/) {
   HostModel hm;
   int code = CMX_OK;
   const std::string msg = build_host_model(model, tree, &hm, &code);
@@ -271,7 +270,7 @@ cmx_status cmx_debug_traversal(const cmx_model* model, const cmx_tree* tree, int
     return (cmx_status)code;
   }
   if (hm.nrec.size() > nrec_cap || hm.ldsched.size() > ld_cap || hm.msched.size() > m_cap) {
-    g_create_error = "cmx_debug_traversal: buffers too small";
+    g_create_error = "cmx_debug_walk: buffers too small";
     return CMX_ERR_INVALID;
   }
   std::memcpy(nrec, hm.nrec.data(), hm.nrec.size() * sizeof(int32_t));
@@ -279,6 +278,7 @@ cmx_status cmx_debug_traversal(const cmx_model* model, const cmx_tree* tree, int
   std::memcpy(msched, hm.msched.data(), hm.msched.size() * sizeof(int32_t));
   *nrec_n = hm.nrec.size(); *ld_n = hm.ldsched.size(); *m_n = hm.msched.size();
   if (slot_of_node) std::memcpy(slot_of_node, hm.slot.data(), hm.slot.size() * sizeof(int32_t));
+  if (stats) { stats[0] = hm.n_loads; stats[1] = hm.n_stores; stats[2] = hm.n_products; stats[3] = hm.n_leaf_ops; }
   return CMX_OK;
 }
 

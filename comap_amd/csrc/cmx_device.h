@@ -30,41 +30,37 @@ constexpr int map_waves_per_simd(int S) { return S == 4 ? CMX_WAVES_PER_SIMD_S4 
 
 // Device-resident model + tree program.  All pointers are device pointers.
 struct DevModel {
-  int S, C, K, nn, B, T, NI, NV, root;  // NI internal nodes (slots), NV of them visited by the traversal
+  int S, C, K, nn, B, T, NI, NIW, NV, root;  // NI internal nodes (operator slots), NIW workspace slots (+ pseudo nodes), NV visited nodes
   // S, C are the DEVICE view: with fuse > 1 (nucleotides, >= 4 rate classes) S = S0 * fuse concatenated per-class states
   // and C = ceil(C0 / fuse) passes; S0, C0 are the model's own state and class counts (simulator, rates, probs, pi)
   int S0, C0, fuse;
-  // tree program (wave-uniform, read through the scalar cache)
-  const int* int_post;     // [NI]  internal nodes in post-order, root last
-  const int* first_child;  // [nn]
-  const int* next_sib;     // [nn]
+  // tree (wave-uniform, read through the scalar cache; simulator only)
   const int* taxon_of;     // [nn]  alignment row of a leaf, -1 for internal nodes
-  const int* slot;         // [nn]  internal nodes: 0..NI-1 (root = NI-1); leaves: -1
   const int* parent;       // [nn]
   // matrices, [C][MC][mat_unit(S)]: per class a block of packed P | packed (P o N^k) | leaf P^T | leaf (P o N^k)^T
   // (cmx_host_model.cpp); a matrix use DMAs mat_unit(S)*8 bytes from MAT + (class*MC + index)*mat_unit(S) into LDS
   double* MAT;
   int MC;
-  // matrix uses of one class pass in program order: pairs (matrix index in the class block, taxon or -1)
-  const int* msched;
+  // tree walk of one rate-class pass (cmx_walk.h; built and checked by cmx_host_model.cpp)
+  const int* nrec;         // [NV][16] per-visited-node records
+  const int* msched;       // operator uses in program order: pairs (element offset in the class block, taxon or -1),
+                           // followed by copies of its first two pairs (the op two ahead is read without a wrap test)
   int nmv;                 // number of pairs
-  const int* nrec;         // [NV][16] per-visited-node records (enum REC_* in cmx_kernels.hip)
-  // simulator: running sums of the rows of P, [C][nn][S(x)][S]
+  const int* ldsched;      // [nloads + 2] workspace loads: bit 31 prefetchable, bit 30 array (0 M, 1 U), low 24 bits slot
+  // simulator: running sums of the rows of P, [C][nn][S(x)][S], and a 32-entry guide table per row (see draw_guided)
   const double* CP;
+  const uint8_t* CPG;      // [C][nn][S(x)][32]
   const double* pi;        // [S]
   const double* rates;     // [C]
   const double* probs;     // [C]
   const double* cum_pi;    // [S]
   const double* cum_probs; // [C]
-  // workspace-load schedule of one rate-class pass (see CMX_POP in cmx_kernels.hip)
-  const int* ldsched;      // [nloads] bit31 prefetchable, bit30 array (0 D, 1 U), low 24 bits slot
-  int nloads;
 };
 
 // Per-wave workspace strides (in elements); every wave owns one slice of each array.
 struct Workspace {
-  double* D;        // [waves][NI][S][64]   inside (post-order) conditional likelihoods of internal nodes
-  double* U;        // [waves][NI][S][64]   outside messages arriving at internal nodes
+  double* D;        // [waves][NIW][S][64]  messages M_n = P_n D_n of internal nodes (inside pass)
+  double* U;        // [waves][NIW][S][64]  outside messages arriving at internal nodes
   double* cnt;      // [waves][2][B*K][64]  final counts of the wave's sites (two batches for the null)
   double* part;     // [waves][C][B*K][64]  per-class joint counts, summed in class order at the end
   uint8_t* st;      // [waves][nn][64]      simulated states

@@ -1,8 +1,10 @@
 // Host-side model preparation (see cmx_host_model.h).  Plain C++17, no device code.
 #include "cmx_host_model.h"
 #include "cmx_device.h"
+#include "cmx_walk.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 
@@ -69,282 +71,286 @@ void pack_blocks(int S, const double* M, double* out) {
 
 }  // namespace
 
-// Builds the traversal of one rate-class pass: the per-node records the kernel walks, and -- by simulating exactly
-// the kernel's control flow (map_sites_wave in cmx_kernels.hip) -- the order of its workspace loads (ldsched, with
-// prefetchability) and of its matrix products (msched).
-//
-// Bytes are ~10x dearer than flops in this kernel (a 10 KiB workspace vector costs a wave ~5 us of its HBM share, a
-// 20x20 product ~1 us), so the traversal avoids workspace traffic wherever a vector can stay in registers or be
-// rebuilt from leaves:
-//   * "inlined cherries": an internal node whose two children are leaves (and whose parent is binary) is never
-//     visited on its own.  Its inside vector is rebuilt from two leaf gathers where needed, and the counts of its
-//     two leaf branches are taken right where its outside message is produced -- no store, no load for either.
-//   * a binary node's child Y = its largest-id child that is a visited node: Y is visited right before (inside
-//     pass) / right after (outside pass) its parent, so its vectors are handed over in registers both ways.
-void build_load_schedule(HostModel* hm) {
-  const int NI = hm->NI, root = hm->root, K = hm->K, nn = hm->nn;
-  auto internal = [&](int n) { return hm->taxon_of[n] < 0; };
-  auto kids = [&](int n) { std::vector<int> v; for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e]) v.push_back(e); return v; };
-  std::vector<char> inlined(nn, 0);
+// ------------------------------------------------------------------------------------------------ tree program
+// The walk of a rate-class pass is written once (cmx_walk.h).  Here: the per-node records it reads, the Recorder
+// backend that lists its operators and workspace loads in program order (what the device follows), and the Numeric
+// backend + direct computation that check the whole thing before a context is accepted.
+void build_records(HostModel* hm) {
+  const int root = hm->root, nn = hm->nn;
+  // ---- binary device tree: nodes 0 .. nn-1 are the tree's own, nn .. are pseudo nodes (zero-length branches) that
+  // split a node with k > 2 children c1 .. ck into ((..((c1, c2), c3) ..), ck)
+  std::vector<std::array<int, 2>> ch(nn, {-1, -1});
+  auto kids0 = [&](int n) { std::vector<int> v; for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e]) v.push_back(e); return v; };
   for (int n = 0; n < nn; ++n) {
-    if (!internal(n) || n == root) continue;
-    const std::vector<int> c = kids(n);
-    if (c.size() == 2 && !internal(c[0]) && !internal(c[1]) && kids(hm->parent[n]).size() == 2) inlined[n] = 1;
+    if (hm->taxon_of[n] >= 0) continue;
+    const std::vector<int> c = kids0(n);
+    int left = c[0];
+    for (size_t i = 1; i + 1 < c.size(); ++i) {
+      ch.push_back({left, c[i]});
+      left = (int)ch.size() - 1;
+    }
+    ch[n] = {left, c.back()};
   }
-  auto kind = [&](int e) { return !internal(e) ? 0 : (inlined[e] ? 2 : 1); };
-  std::vector<int> visited;
-  for (int idx = 0; idx < NI; ++idx) if (!inlined[hm->int_post[idx]]) visited.push_back(hm->int_post[idx]);
+  const int nd = (int)ch.size();
+  auto is_leaf = [&](int n) { return n < nn && hm->taxon_of[n] >= 0; };
+  auto pseudo = [&](int n) { return n >= nn; };
+  // workspace slots: the tree's internal nodes keep their operator slot, pseudo nodes follow
+  std::vector<int> wslot(nd, -1);
+  for (int n = 0; n < nn; ++n) wslot[n] = hm->slot[n];
+  for (int n = nn; n < nd; ++n) wslot[n] = hm->NI + (n - nn);
+  hm->NIW = hm->NI + (nd - nn);
+  // inlined cherries: a (real, non-root) internal node with two leaf children is never visited
+  std::vector<char> inlined(nd, 0);
+  for (int n = 0; n < nn; ++n)
+    if (!is_leaf(n) && n != root && is_leaf(ch[n][0]) && is_leaf(ch[n][1])) inlined[n] = 1;
+  auto kind = [&](int e) { return is_leaf(e) ? (int)KIND_LEAF : (inlined[e] ? (int)KIND_CHERRY : (int)KIND_STORED); };
+  // post-order of the visited nodes (explicit stack: caterpillar trees are deep)
+  std::vector<int> visited, parent_d(nd, -1);
+  {
+    std::vector<std::pair<int, int>> st;
+    st.push_back({root, 0});
+    while (!st.empty()) {
+      auto& top = st.back();
+      const int n = top.first;
+      if (is_leaf(n) || inlined[n]) { st.pop_back(); continue; }
+      if (top.second < 2) {
+        const int e = ch[n][top.second++];
+        parent_d[e] = n;
+        st.push_back({e, 0});
+      } else {
+        visited.push_back(n);
+        st.pop_back();
+      }
+    }
+  }
   const int NV = (int)visited.size();
   hm->NV = NV;
   hm->nrec.assign((size_t)NV * 16, -1);
-  // child descriptor, 5 ints: kind, node (= branch), slot (stored) / taxon (leaf), and for an inlined cherry its two
-  // leaf nodes (their taxa are named by the op stream)
-  auto fill_child = [&](int* r, int e) {
-    r[0] = kind(e); r[1] = e;
-    r[2] = internal(e) ? hm->slot[e] : hm->taxon_of[e];
-    if (kind(e) == 2) {
-      const std::vector<int> c = kids(e);
-      r[3] = c[0]; r[4] = c[1];
-    }
+  auto fill_child = [&](int* d, int e) {
+    d[CH_KIND] = kind(e); d[CH_NODE] = pseudo(e) ? -1 : e; d[CH_SLOT] = is_leaf(e) ? -1 : wslot[e];
+    d[CH_L1] = d[CH_L2] = -1;
+    if (kind(e) == KIND_CHERRY) { d[CH_L1] = ch[e][0]; d[CH_L2] = ch[e][1]; }
   };
-  std::vector<int> Xof(nn, -1), Yof(nn, -1);
   for (int v = 0; v < NV; ++v) {
     const int n = visited[v];
     int* r = &hm->nrec[(size_t)v * 16];
-    const std::vector<int> c = kids(n);
-    r[0] = n; r[1] = hm->slot[n]; r[2] = (int)c.size(); r[3] = 0; r[14] = -1;
-    if (c.size() == 2) {
-      int y = (kind(c[1]) == 1) ? c[1] : ((kind(c[0]) == 1) ? c[0] : c[1]);
-      int x = (y == c[1]) ? c[0] : c[1];
-      Xof[n] = x; Yof[n] = y;
-      fill_child(r + 4, x);
-      fill_child(r + 9, y);
-      if (kind(y) == 1) r[3] |= 2;   // Y's vectors are handed over in registers
-    } else {
-      const int last = c.back();
-      if (kind(last) == 1) r[14] = last;   // general node: its last child is the node finished right before it
+    r[REC_NODE] = pseudo(n) ? -1 : n; r[REC_SLOT] = wslot[n]; r[2] = 2; r[REC_FLAGS] = 0;
+    if (n == root) r[REC_FLAGS] |= FLAG_ROOT;
+    if (pseudo(n)) r[REC_FLAGS] |= FLAG_PSEUDO;
+    // the child visited right before n (inside pass) = right after n (outside pass): its vectors stay in registers
+    int a = ch[n][0], b = ch[n][1];
+    if (v > 0 && parent_d[visited[v - 1]] == n) {
+      if (visited[v - 1] == a) std::swap(a, b);
+      r[REC_FLAGS] |= FLAG_HAND;
     }
-  }
-  // ---- simulate the kernel
-  struct Ev { int arr, slot; long t, src_store; };
-  std::vector<Ev> pops;
-  std::vector<long> storeD(NI, -1), storeU(NI, -1);
-  long t = 0;
-  hm->stores_D = hm->stores_U = 0;
-  auto pop = [&](int arr, int slot) { pops.push_back({arr, slot, t++, arr ? storeU[slot] : storeD[slot]}); };
-  hm->msched.clear();
-  // op stream: one (matrix index within a class block, taxon or -1) pair per matrix use, in kernel program order.
-  // Class block layout (HostModel::MAT): P[slot] | J[slot*K+k] | leaf P^T[taxon] | leaf J^T[k*T+taxon]
-  const int T = hm->T;
-  auto op = [&](int mat, int tx) { hm->msched.push_back(mat); hm->msched.push_back(tx); };
-  auto mvP = [&](int slot) { op(slot, -1); };
-  auto mvJ = [&](int slot) { for (int k = 0; k < K; ++k) op(NI + slot * K + k, -1); };
-  auto leafP = [&](int tx) { op(NI + NI * K + tx, tx); };
-  auto leafJ = [&](int tx) { for (int k = 0; k < K; ++k) op(NI + NI * K + T + k * T + tx, tx); };
-  auto txof = [&](int e) { return hm->taxon_of[e]; };
-  auto cherry_leaves = [&](int e) { const std::vector<int> c = kids(e); leafP(txof(c[0])); leafP(txof(c[1])); };
-  auto cherry_counts = [&](int e) {
-    const std::vector<int> c = kids(e);
-    leafP(txof(c[1])); leafJ(txof(c[0])); leafP(txof(c[0])); leafJ(txof(c[1]));
-  };
-  // inside vector of child edge e into registers (CMX_GET_D)
-  auto getD = [&](int e) { if (kind(e) == 1) pop(0, hm->slot[e]); else cherry_leaves(e); };
-  // inside pass
-  for (int v = 0; v < NV; ++v) {
-    const int n = visited[v];
-    const std::vector<int> c = kids(n);
-    if (c.size() == 2) {
-      const int x = Xof[n], y = Yof[n];
-      if (kind(y) == 1) mvP(hm->slot[y]);                       // carried
-      auto edge = [&](int e) {
-        if (kind(e) == 0) leafP(txof(e));
-        else { getD(e); mvP(hm->slot[e]); }
-      };
-      edge(x);
-      if (kind(y) != 1) edge(y);
-    } else {
-      const int carry = hm->nrec[(size_t)v * 16 + 14];
-      if (carry >= 0) mvP(hm->slot[carry]);
-      for (int e : c) {
-        if (!internal(e)) leafP(txof(e));
-        else if (e != carry) { pop(0, hm->slot[e]); mvP(hm->slot[e]); }
-      }
-    }
-    if (n != root) { storeD[hm->slot[n]] = t++; hm->stores_D++; }
-  }
-  // outside pass
-  std::vector<char> up_in_acc(nn, 0);
-  for (int v = NV - 1; v >= 0; --v) {
-    const int f = visited[v];
-    if (f != root) {
-      if (up_in_acc[f]) hm->nrec[(size_t)v * 16 + 3] |= 4;
-      else pop(1, hm->slot[f]);
-    }
-    const std::vector<int> c = kids(f);
-    if (c.size() == 2) {
-      const int x = Xof[f], y = Yof[f];
-      if (kind(y) == 0) leafP(txof(y)); else { getD(y); mvP(hm->slot[y]); }
-      if (kind(x) == 0) { leafJ(txof(x)); leafP(txof(x)); }
-      else {
-        getD(x); mvJ(hm->slot[x]); mvP(hm->slot[x]); mvP(hm->slot[x]);
-        if (kind(x) == 1) { storeU[hm->slot[x]] = t++; hm->stores_U++; } else cherry_counts(x);
-      }
-      if (kind(y) == 0) leafJ(txof(y));
-      else {
-        getD(y); mvJ(hm->slot[y]); mvP(hm->slot[y]);
-        if (kind(y) == 1) up_in_acc[y] = 1; else cherry_counts(y);
-      }
-    } else {
-      for (int n : c) {
-        for (int sb : c) {
-          if (sb == n) continue;
-          if (!internal(sb)) leafP(txof(sb)); else { pop(0, hm->slot[sb]); mvP(hm->slot[sb]); }
-        }
-        if (!internal(n)) leafJ(txof(n));
-        else { pop(0, hm->slot[n]); mvJ(hm->slot[n]); mvP(hm->slot[n]); storeU[hm->slot[n]] = t++; hm->stores_U++; }
-      }
-    }
-  }
-  hm->ldsched.clear();
-  hm->loads_D = hm->loads_U = 0;
-  for (size_t j = 0; j < pops.size(); ++j) {
-    const Ev& e = pops[j];
-    unsigned w = (unsigned)e.slot | (e.arr ? 0x40000000u : 0u);
-    // prefetchable: its producer store is issued before the previous pop (where the prefetch is issued)
-    if (j > 0 && e.src_store >= 0 && e.src_store < pops[j - 1].t) w |= 0x80000000u;
-    hm->ldsched.push_back((int)w);
-    if (e.arr) hm->loads_U++; else hm->loads_D++;
+    if (v + 1 < NV && parent_d[n] == visited[v + 1]) r[REC_FLAGS] |= FLAG_U_HANDED;
+    fill_child(r + REC_A, a);
+    fill_child(r + REC_B, b);
   }
 }
 
-// Host-side dry run of map_sites_wave's control flow, driven by the SAME records and schedules the kernel reads:
-// every index is bounds-checked, every workspace load must name the vector the code needs and must have been stored
-// before, every matrix product must find its matrix next in msched.  A mismatch here would be an out-of-bounds or
-// stale access on the GPU, so a context is refused instead (cmx_ctx_create).
-std::string verify_traversal(const HostModel& hm) {
-  const int NI = hm.NI, NV = hm.NV, K = hm.K, T = hm.T, nn = hm.nn, root = hm.root;
-  if ((int)hm.nrec.size() != NV * 16) return "nrec size";
-  size_t fi = 0, mi = 0;
-  std::vector<char> haveD(NI, 0), haveU(NI, 0), counted((size_t)hm.B * K, 0);
+namespace {
+// ---- Recorder: the operator stream (matrix index in a class block, taxon or -1) and the workspace loads of a pass
+struct Recorder {
+  HostModel* hm;
+  long t = 0;
+  std::vector<long> store_time[2];
+  struct Ld { int arr, slot; long t, src; };
+  std::vector<Ld> loads;
+  explicit Recorder(HostModel* h) : hm(h) { store_time[0].assign(h->NIW, -1); store_time[1].assign(h->NIW, -1); }
+  // matrix indices inside a class block (HostModel::MAT): P[slot] | J[slot*K+k] | leaf P^T[taxon] | leaf J^T[k*T+taxon]
+  int mat_internal(int node, int which) const { return which < 0 ? hm->slot[node] : hm->NI + hm->slot[node] * hm->K + which; }
+  int mat_leaf(int leaf, int which) const {
+    const int tx = hm->taxon_of[leaf];
+    return which < 0 ? hm->NI + hm->NI * hm->K + tx : hm->NI + hm->NI * hm->K + hm->T + which * hm->T + tx;
+  }
+  void op(int mat, int tx) { hm->msched.push_back(mat); hm->msched.push_back(tx); ++t; }
+  void rec(int v, int (&r)[16]) const { for (int i = 0; i < 16; ++i) r[i] = hm->nrec[(size_t)v * 16 + i]; }
+  template <int D> void lset(int leaf, int which) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); hm->n_leaf_ops++; }
+  template <int S, int D> void lmul(int leaf, int which) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); hm->n_leaf_ops++; }
+  template <int S> void ldot(int leaf, int which, int) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); hm->n_leaf_ops++; }
+  template <int S, int D, bool TR> void mv(int node, int which) { op(mat_internal(node, which), -1); hm->n_products++; }
+  template <int D> void load(int arr, int slot) { loads.push_back({arr, slot, t++, store_time[arr][slot]}); hm->n_loads++; }
+  template <int S> void store(int arr, int slot) { store_time[arr][slot] = t++; hm->n_stores++; }
+  template <int D, int S> void mov() {}
+  template <int D, int S> void mul() {}
+  void mulup() {}
+  template <int D> void setpi() {}
+  template <int S> void rootl() {}
+  void dot3(int) {}
+  template <int R> void kill() {}
+};
+
+// ---- Numeric: the pass in plain doubles for one site, operators read from HostModel::MAT in their device layouts
+// and selected by the recorded stream exactly as the device selects them; every register starts as NaN.
+struct Numeric {
+  const HostModel& hm;
+  int dS, NB;
+  size_t MU;
+  const double* blk;
+  std::vector<int> code;                   // symbol per taxon
+  std::vector<double> R[4], ws[2], cnt, Lg;
+  std::vector<char> counted;
+  size_t mi = 0, fi = 0;
   std::string err;
-  auto fail = [&](const std::string& m) { if (err.empty()) err = "traversal self-check failed: " + m; };
-  auto pop = [&](int arr, int slot) {
-    if (fi >= hm.ldsched.size()) return fail("more workspace loads than scheduled");
-    const int e = hm.ldsched[fi++];
-    if ((((unsigned)e >> 30) & 1) != (unsigned)arr || (e & 0xffffff) != slot) return fail("load " + std::to_string(fi - 1) + " names the wrong vector");
-    if (slot < 0 || slot >= NI) return fail("slot out of range");
-    if (!(arr ? haveU[slot] : haveD[slot])) return fail("load of a vector that was never stored");
-  };
-  const int MC = NI + NI * K + T + K * T;  // matrices per class block
-  auto opchk = [&](int want_mat, int want_tx, const char* what) {
-    if (2 * mi + 1 >= hm.msched.size()) return fail(std::string("more matrix uses than scheduled (") + what + ")");
+  explicit Numeric(const HostModel& h) : hm(h), dS(h.dS), NB(h.dS / 4), MU((size_t)mat_unit(h.dS)), blk(h.MAT.data()) {
+    const double nan = std::nan("");
+    for (auto& r : R) r.assign(dS, nan);
+    ws[0].assign((size_t)h.NIW * dS, nan);
+    ws[1].assign((size_t)h.NIW * dS, nan);
+    cnt.assign((size_t)h.B * h.K, nan);
+    counted.assign((size_t)h.B * h.K, 0);
+    Lg.assign(h.fuse, nan);
+    code.resize(h.T);
+    for (int t = 0; t < h.T; ++t) {      // splitmix-style hash of the taxon index: no global RNG state
+      uint64_t z = 0x9E3779B97F4A7C15ull * (uint64_t)(t + 1);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      code[t] = (int)(z % (uint64_t)h.S);
+    }
+  }
+  void fail(const std::string& m) { if (err.empty()) err = "tree-walk self-check failed: " + m; }
+  void rec(int v, int (&r)[16]) const { for (int i = 0; i < 16; ++i) r[i] = hm.nrec[(size_t)v * 16 + i]; }
+  // the operator the stream stages for this op; `want` = what the walk asked for
+  int staged(int want_mat, int want_tx) {
+    if (2 * mi + 1 >= hm.msched.size()) { fail("more operator uses than the stream holds"); return -1; }
     const int mat = hm.msched[2 * mi], tx = hm.msched[2 * mi + 1];
     ++mi;
-    if (mat < 0 || mat >= MC) return fail("matrix index out of range");
-    if (mat != want_mat || tx != want_tx) return fail("op " + std::to_string(mi - 1) + " (" + what + ") finds the wrong matrix staged");
-  };
-  auto mv = [&](bool isJ, int idx) {
-    if (isJ ? (idx < 0 || idx >= NI * K) : (idx < 0 || idx >= NI)) return fail("matrix index out of range");
-    opchk(isJ ? NI + idx : idx, -1, isJ ? "count product" : "product");
-  };
-  auto leaf = [&](int tx) {  // leaf edge, transition matrix
-    if (tx < 0 || tx >= T) return fail("taxon out of range");
-    opchk(NI + NI * K + tx, tx, "leaf P");
-  };
-  auto leafJ = [&](int tx) {
-    if (tx < 0 || tx >= T) return fail("taxon out of range");
-    for (int k = 0; k < K; ++k) opchk(NI + NI * K + T + k * T + tx, tx, "leaf J");
-  };
-  auto count = [&](int node) {
-    if (node < 0 || node >= nn - 1) return fail("branch out of range");
-    for (int k = 0; k < K; ++k) { if (counted[(size_t)node * K + k]) fail("branch counted twice"); counted[(size_t)node * K + k] = 1; }
-  };
-  auto tx_of = [&](int node) { return (node >= 0 && node < nn) ? hm.taxon_of[node] : -1; };  // leaf node -> taxon
-  auto getD = [&](const int* ch) {
-    if (ch[0] == 1) pop(0, ch[2]);
-    else if (ch[0] == 2) { leaf(tx_of(ch[3])); leaf(tx_of(ch[4])); }
-    else fail("bad child kind");
-  };
-  auto cherry_counts = [&](const int* ch) {
-    leaf(tx_of(ch[4])); leafJ(tx_of(ch[3])); count(ch[3]); leaf(tx_of(ch[3])); leafJ(tx_of(ch[4])); count(ch[4]);
-  };
-  auto kids = [&](int n) { std::vector<int> v; for (int e = hm.first_child[n]; e >= 0; e = hm.next_sib[e]) v.push_back(e); return v; };
-  bool acc_is_D_of_prev = false;
-  int prev_node = -1;
-  // inside pass
-  for (int idx = 0; idx < NV && err.empty(); ++idx) {
-    const int* r = &hm.nrec[(size_t)idx * 16];
-    const int n = r[0];
-    if (n < 0 || n >= nn || r[1] != hm.slot[n]) return "traversal self-check failed: bad node record";
-    if (r[2] == 2) {
-      const int* X = r + 4; const int* Y = r + 9;
-      if (r[3] & 2) {
-        if (!acc_is_D_of_prev || prev_node != Y[1] || Y[0] != 1) fail("Y is not the node finished last");
-        mv(false, Y[2]);
-      }
-      if (X[0] == 0) leaf(X[2]); else { getD(X); mv(false, X[2]); }
-      if (!(r[3] & 2)) { if (Y[0] == 0) leaf(Y[2]); else { if (Y[0] != 2) fail("stored Y not handed over"); getD(Y); mv(false, Y[2]); } }
-    } else {
-      const int carry = r[14];
-      if (carry >= 0) { if (!acc_is_D_of_prev || prev_node != carry) fail("general carry"); mv(false, hm.slot[carry]); }
-      for (int e : kids(n)) {
-        if (hm.taxon_of[e] >= 0) leaf(hm.taxon_of[e]);
-        else if (e != carry) { pop(0, hm.slot[e]); mv(false, hm.slot[e]); }
-      }
-    }
-    if (n != root) haveD[r[1]] = 1;
-    acc_is_D_of_prev = true;
-    prev_node = n;
+    if (mat < 0 || mat >= hm.MC) { fail("operator index out of range"); return -1; }
+    if (mat != want_mat || tx != want_tx) { fail("op " + std::to_string(mi - 1) + " finds the wrong operator staged"); return -1; }
+    return mat;
   }
-  // outside pass
-  int up_node_in_acc = -1;
-  for (int idx = NV - 1; idx >= 0 && err.empty(); --idx) {
-    const int* r = &hm.nrec[(size_t)idx * 16];
-    const int f = r[0];
-    if (f != root) {
-      if (r[3] & 4) { if (up_node_in_acc != f) fail("outside message not in registers"); }
-      else pop(1, r[1]);
+  int leaf_mat(int leaf, int which) {
+    if (leaf < 0 || leaf >= hm.nn || hm.taxon_of[leaf] < 0) { fail("leaf op on a non-leaf"); return -1; }
+    const int tx = hm.taxon_of[leaf];
+    return staged(which < 0 ? hm.NI + hm.NI * hm.K + tx : hm.NI + hm.NI * hm.K + hm.T + which * hm.T + tx, tx);
+  }
+  double leafrow(int mat, int leaf, int X) const { return blk[(size_t)mat * MU + (size_t)code[hm.taxon_of[leaf]] * dS + (X % 4) * NB + X / 4]; }
+  double packed(int mat, int r, int c) const { return blk[(size_t)mat * MU + ((size_t)(r / 4) * NB + c / 4) * 16 + (r % 4) * 4 + c % 4]; }
+  void count_row(int row, double v) {
+    if (row < 0 || row >= hm.B * hm.K) return fail("count row out of range");
+    if (counted[row]) return fail("branch counted twice");
+    counted[row] = 1;
+    cnt[row] = v;
+  }
+  template <int D> void lset(int leaf, int which) {
+    const int mat = leaf_mat(leaf, which);
+    if (mat < 0) return;
+    for (int x = 0; x < dS; ++x) R[D][x] = leafrow(mat, leaf, x);
+  }
+  template <int S, int D> void lmul(int leaf, int which) {
+    const int mat = leaf_mat(leaf, which);
+    if (mat < 0) return;
+    for (int x = 0; x < dS; ++x) R[D][x] = R[S][x] * leafrow(mat, leaf, x);
+  }
+  template <int S> void ldot(int leaf, int which, int row) {
+    const int mat = leaf_mat(leaf, which);
+    if (mat < 0) return;
+    double s = 0;
+    for (int x = 0; x < dS; ++x) s += R[S][x] * leafrow(mat, leaf, x);
+    count_row(row, s);
+  }
+  template <int S, int D, bool TR> void mv(int node, int which) {
+    if (node < 0 || node >= hm.nn || hm.slot[node] < 0) return fail("product on a leaf or pseudo branch");
+    const int mat = staged(which < 0 ? hm.slot[node] : hm.NI + hm.slot[node] * hm.K + which, -1);
+    if (mat < 0) return;
+    std::vector<double> out(dS, 0.0);
+    for (int r = 0; r < dS; ++r)
+      for (int c = 0; c < dS; ++c) out[r] += (TR ? packed(mat, c, r) : packed(mat, r, c)) * R[S][c];
+    R[D] = out;
+  }
+  template <int D> void load(int arr, int slot) {
+    if (slot < 0 || slot >= hm.NIW) return fail("workspace slot out of range");
+    if (fi >= hm.ldsched.size()) return fail("more workspace loads than scheduled");
+    const int w = hm.ldsched[fi++];
+    if (((w >> 30) & 1) != arr || (w & 0xffffff) != slot) return fail("load " + std::to_string(fi - 1) + " names the wrong vector");
+    R[D].assign(&ws[arr][(size_t)slot * dS], &ws[arr][(size_t)slot * dS] + dS);
+  }
+  template <int S> void store(int arr, int slot) {
+    if (slot < 0 || slot >= hm.NIW) return fail("workspace slot out of range");
+    std::copy(R[S].begin(), R[S].end(), &ws[arr][(size_t)slot * dS]);
+  }
+  template <int D, int S> void mov() { R[D] = R[S]; }
+  template <int D, int S> void mul() { for (int x = 0; x < dS; ++x) R[D][x] *= R[S][x]; }
+  void mulup() { for (int x = 0; x < dS; ++x) { R[1][x] *= R[3][x]; R[2][x] *= R[3][x]; } }
+  template <int D> void setpi() { for (int x = 0; x < dS; ++x) R[D][x] = hm.pi[x % hm.S]; }
+  template <int S> void rootl() {
+    for (int g = 0; g < hm.fuse; ++g) { double s = 0; for (int x = 0; x < hm.S; ++x) s += hm.pi[x] * R[S][g * hm.S + x]; Lg[g] = s; }
+  }
+  void dot3(int row) { double s = 0; for (int x = 0; x < dS; ++x) s += R[3][x] * R[1][x] * R[2][x]; count_row(row, s); }
+  template <int Rg> void kill() { R[Rg].assign(dS, std::nan("")); }   // a killed register must not be read again
+};
+}  // namespace
+
+// records -> operator stream + load schedule (with prefetchability) by a dry run of the walk
+void record_walk(HostModel* hm) {
+  hm->msched.clear();
+  hm->ldsched.clear();
+  hm->n_loads = hm->n_stores = hm->n_products = hm->n_leaf_ops = 0;
+  Recorder rc(hm);
+  walk_pass(rc, hm->NV, hm->K);
+  for (size_t j = 0; j < rc.loads.size(); ++j) {
+    const Recorder::Ld& e = rc.loads[j];
+    unsigned w = (unsigned)e.slot | (e.arr ? 0x40000000u : 0u);
+    // prefetchable: its producer store is issued before the previous load (where the prefetch is issued)
+    if (j > 0 && e.src >= 0 && e.src < rc.loads[j - 1].t) w |= 0x80000000u;
+    hm->ldsched.push_back((int)w);
+  }
+}
+
+// Runs the walk numerically for one random site of device class 0 and compares site likelihood and all joint counts
+// with a direct pruning computation from the row-major hm.P / hm.PN.  Empty string when they agree.
+std::string verify_walk(const HostModel& hm) {
+  const int S = hm.S, F = hm.fuse, K = hm.K, nn = hm.nn, B = hm.B, root = hm.root;
+  const size_t S2 = (size_t)S * S;
+  if ((int)hm.nrec.size() != hm.NV * 16) return "tree-walk self-check failed: record table size";
+  Numeric nm(hm);
+  walk_pass(nm, hm.NV, K);
+  if (!nm.err.empty()) return nm.err;
+  if (2 * nm.mi != hm.msched.size()) return "tree-walk self-check failed: unused operators in the stream";
+  if (nm.fi != hm.ldsched.size()) return "tree-walk self-check failed: unused workspace loads in the schedule";
+  const std::vector<int>& code = nm.code;
+  std::vector<double> ref((size_t)B * K, 0.0), Lref(F, 0.0);
+  auto kids = [&](int n) { std::vector<int> v; for (int e = hm.first_child[n]; e >= 0; e = hm.next_sib[e]) v.push_back(e); return v; };
+  for (int g = 0; g < F && g < hm.C; ++g) {   // true classes g of device class 0
+    std::vector<double> D((size_t)nn * S), M((size_t)nn * S), U((size_t)nn * S), Up((size_t)nn * S);
+    for (int n = 0; n < nn; ++n) {
+      double* Dn = &D[(size_t)n * S];
+      if (hm.taxon_of[n] >= 0) for (int x = 0; x < S; ++x) Dn[x] = x == code[hm.taxon_of[n]] ? 1.0 : 0.0;
+      else { for (int x = 0; x < S; ++x) Dn[x] = 1.0; for (int e : kids(n)) for (int x = 0; x < S; ++x) Dn[x] *= M[(size_t)e * S + x]; }
+      if (n != root) {
+        const double* P = &hm.P[((size_t)g * B + n) * S2];
+        for (int x = 0; x < S; ++x) { double s = 0; for (int z = 0; z < S; ++z) s += P[(size_t)x * S + z] * Dn[z]; M[(size_t)n * S + x] = s; }
+      }
     }
-    up_node_in_acc = -1;
-    if (r[2] == 2) {
-      const int* X = r + 4; const int* Y = r + 9;
-      if (Y[0] == 0) leaf(Y[2]); else { getD(Y); mv(false, Y[2]); }
-      if (X[0] == 0) { leafJ(X[2]); count(X[1]); leaf(X[2]); }
-      else {
-        getD(X);
-        for (int k = 0; k < K; ++k) mv(true, X[2] * K + k);
-        count(X[1]);
-        mv(false, X[2]); mv(false, X[2]);
-        if (X[0] == 1) haveU[X[2]] = 1; else cherry_counts(X);
-      }
-      if (Y[0] == 0) { leafJ(Y[2]); count(Y[1]); }
-      else {
-        getD(Y);
-        for (int k = 0; k < K; ++k) mv(true, Y[2] * K + k);
-        count(Y[1]);
-        mv(false, Y[2]);
-        if (Y[0] == 1) up_node_in_acc = Y[1]; else cherry_counts(Y);
-      }
-    } else {
+    for (int x = 0; x < S; ++x) { Lref[g] += hm.pi[x] * D[(size_t)root * S + x]; Up[(size_t)root * S + x] = hm.pi[x]; }
+    const double wgt = F > 1 ? hm.probs[g] : 1.0;   // fused: class probabilities are folded into the count operators
+    for (int f = nn - 1; f >= 0; --f) {
+      if (hm.taxon_of[f] >= 0) continue;
       const std::vector<int> c = kids(f);
       for (int n : c) {
-        for (int sb : c)
-          if (sb != n) { if (hm.taxon_of[sb] >= 0) leaf(hm.taxon_of[sb]); else { pop(0, hm.slot[sb]); mv(false, hm.slot[sb]); } }
-        if (hm.taxon_of[n] >= 0) { leafJ(hm.taxon_of[n]); count(n); }
-        else {
-          pop(0, hm.slot[n]);
-          for (int k = 0; k < K; ++k) mv(true, hm.slot[n] * K + k);
-          count(n);
-          mv(false, hm.slot[n]);
-          haveU[hm.slot[n]] = 1;
+        double* Un = &U[(size_t)n * S];
+        for (int x = 0; x < S; ++x) Un[x] = Up[(size_t)f * S + x];
+        for (int m : c) if (m != n) for (int x = 0; x < S; ++x) Un[x] *= M[(size_t)m * S + x];
+        for (int k = 0; k < K; ++k) {
+          const double* PN = &hm.PN[(((size_t)g * B + n) * K + k) * S2];
+          double tot = 0;
+          for (int x = 0; x < S; ++x) { double s = 0; for (int y = 0; y < S; ++y) s += PN[(size_t)x * S + y] * D[(size_t)n * S + y]; tot += Un[x] * s; }
+          ref[(size_t)n * K + k] += wgt * tot;
+        }
+        if (hm.taxon_of[n] < 0) {
+          const double* P = &hm.P[((size_t)g * B + n) * S2];
+          for (int z = 0; z < S; ++z) { double s = 0; for (int x = 0; x < S; ++x) s += P[(size_t)x * S + z] * Un[x]; Up[(size_t)n * S + z] = s; }
         }
       }
     }
   }
-  if (!err.empty()) return err;
-  if (fi != hm.ldsched.size()) return "traversal self-check failed: unused workspace loads in the schedule";
-  if (2 * mi != hm.msched.size()) return "traversal self-check failed: unused matrix uses in the schedule";
-  for (char c : counted) if (!c) return "traversal self-check failed: a branch is never counted";
+  auto close = [](double a, double b) { return std::fabs(a - b) <= 1e-9 * (std::fabs(a) + std::fabs(b)) + 1e-290; };
+  for (int g = 0; g < F && g < hm.C; ++g)
+    if (!close(nm.Lg[g], Lref[g])) return "tree-walk self-check failed: site likelihood differs from the direct computation";
+  for (size_t r = 0; r < ref.size(); ++r) {
+    if (!nm.counted[r]) return "tree-walk self-check failed: a branch is never counted";
+    if (!close(nm.cnt[r], ref[r])) return "tree-walk self-check failed: joint count of branch " + std::to_string(r / K) + " differs from the direct computation";
+  }
   return std::string();
 }
 
@@ -402,11 +408,8 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   }
   if (nchild[nn - 1] < 2) return "the root needs at least two children";
   hm->NI = (int)hm->int_post.size();
-  build_load_schedule(hm);
-  {
-    const std::string bad = verify_traversal(*hm);
-    if (!bad.empty()) return bad;
-  }
+  build_records(hm);
+  record_walk(hm);
   // ---- model checks
   const bool nh = model->nmodels > 0;
   const int NM = nh ? model->nmodels : 1;
@@ -583,6 +586,21 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
         }
       }
     }
+  }
+  // guide table of the simulator's inverse-CDF search: entry k of a row = the number of leading running sums that are
+  // <= k/32, i.e. where the linear scan "index = #{j < S-1 : u >= cum[j]}" may start for any u in [k/32, (k+1)/32)
+  hm->CPG.assign((size_t)C * nn * S * 32, 0);
+  for (size_t r = 0; r < (size_t)C * nn * S; ++r) {
+    const double* cum = &hm->CP[r * S];
+    for (int k = 0; k < 32; ++k) {
+      int st = 0;
+      while (st < S - 1 && cum[st] <= k / 32.0) ++st;
+      hm->CPG[r * 32 + k] = (uint8_t)st;
+    }
+  }
+  {
+    const std::string bad = verify_walk(*hm);
+    if (!bad.empty()) return bad;
   }
   hm->cum_pi.resize(S);
   hm->cum_probs.resize(C);

@@ -13,7 +13,7 @@
 namespace cmx {
 
 struct HostModel {
-  int S = 0, C = 0, K = 0, nn = 0, B = 0, T = 0, NI = 0, NV = 0, root = 0;  // NV = visited (non-inlined) internal nodes
+  int S = 0, C = 0, K = 0, nn = 0, B = 0, T = 0, NI = 0, root = 0;
   // Device view.  Nucleotide models with >= 4 rate classes are mapped `fuse` classes at a time: the per-class 4-vectors
   // of a site are concatenated into one dS = 4*fuse vector and the per-class operators become the diagonal blocks of
   // one dS x dS operator (class probabilities folded into the count operators), so that one pass of the 20-state
@@ -26,16 +26,22 @@ struct HostModel {
   std::vector<double> MAT;  // [C][MC][S*S]     device matrices: packed P | packed PN | leaf P^T | leaf PN^T (cmx_host_model.cpp)
   int MC = 0;               // matrices per (device) class block = NI + NI*K + T + K*T
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
-  std::vector<int> ldsched; // workspace-load schedule of one class pass (DevModel::ldsched)
-  std::vector<int> msched;  // matrix uses of one class pass in program order: (matrix index, taxon or -1) pairs
-  std::vector<int> nrec;    // [NV][16] per-visited-node records (DevModel::nrec)
-  size_t loads_D = 0, loads_U = 0, stores_D = 0, stores_U = 0;  // per class pass, for traffic accounting
+  std::vector<uint8_t> CPG; // [C][nn][S][32]   guide table of the simulator's inverse-CDF search (cmx_kernels.hip: draw_guided)
+  int NV = 0;               // visited nodes of the binary device tree (internal, not inlined; pseudo nodes included)
+  int NIW = 0;              // workspace slots: NI + pseudo nodes of split multifurcations
+  std::vector<int> nrec;    // [NV][16] per-visited-node records (cmx_walk.h)
+  std::vector<int> msched;  // operator uses of one class pass in program order: (matrix index, taxon or -1) pairs
+  std::vector<int> ldsched; // workspace loads of one class pass: bit 31 prefetchable, bit 30 array, low 24 bits slot
+  // per class pass, for traffic / flop accounting
+  size_t n_loads = 0, n_stores = 0, n_products = 0, n_leaf_ops = 0;
 };
 
-// Mirrors the loop nest of map_sites_wave (cmx_kernels.hip) and lists its workspace loads in program order.
-void build_load_schedule(HostModel* hm);
-
-std::string verify_traversal(const HostModel& hm);
+// The walk of a rate-class pass lives in cmx_walk.h.  build_records: the per-node records it reads; record_walk: the
+// operator stream and load schedule the device follows (a dry run of the walk); verify_walk: the walk run numerically
+// on the host from the device layouts against a direct pruning computation (empty string when they agree).
+void build_records(HostModel* hm);
+void record_walk(HostModel* hm);
+std::string verify_walk(const HostModel& hm);
 
 // returns empty string on success, otherwise the error message (status in *code)
 std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostModel* out, int* code);

@@ -18,13 +18,14 @@
 //   AnalysisTools::getNullDistributionIntraDR (CoMap/AnalysisTools.cpp:587-653).
 // pair_gram_kernel: all-pairs statistic as X.X^T on v_mfma_f64_16x16x4_f64 with per-statistic epilogues
 //   (CoMap/Statistics.h:164-329; loops CoMap/CoETools.cpp:672-692, 786-810).
-// mica_mfma_kernel: column mutual information as a one-hot Gram on v_mfma_f32_32x32x16_f16 (CoMap/Mica.cpp:349-361).
+// mica_mfma_kernel: column mutual information as a one-hot Gram on v_mfma_i32_32x32x32_i8 (CoMap/Mica.cpp:349-361).
 #include <algorithm>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
 #include "cmx_device.h"
+#include "cmx_walk.h"
 
 namespace cmx {
 
@@ -355,6 +356,14 @@ __device__ __forceinline__ int draw_index(double u, CumPtr cum, int n) {
   for (int j = 0; j < n - 1; ++j) idx += (u >= cum[j]) ? 1 : 0;
   return idx;
 }
+// the same index (#{ j < n-1 : u >= cum[j] }, cum non-decreasing) found from a guide table: entry k = the number of
+// leading running sums that are <= k/32, so the scan for a u in [k/32, (k+1)/32) starts there -- one or two reads of the
+// lane's own row instead of n - 1 (the rows are lane-divergent 160-byte gathers: the simulator's whole cost)
+__device__ __forceinline__ int draw_guided(double u, const double* __restrict__ cum, const uint8_t* __restrict__ guide, int n) {
+  int idx = guide[(int)(u * 32.0)];
+  while (idx < n - 1 && u >= cum[idx]) ++idx;
+  return idx;
+}
 
 // ------------------------------------------------------------------------------------------------ mapping core
 extern __shared__ __attribute__((aligned(16))) uint8_t cmx_smem[];
@@ -364,42 +373,21 @@ extern __shared__ __attribute__((aligned(16))) uint8_t cmx_smem[];
 // queue every dependent tree-walk step behind the HBM prefetches outstanding on vmcnt.
 typedef const int __attribute__((address_space(4)))* cmx_cint;
 typedef const double __attribute__((address_space(4)))* cmx_cdbl;
-// schedule words feed vector address arithmetic, where hipcc would pick a VECTOR load for them (and then wait
-// vmcnt(0), draining the prefetches in flight): force the scalar path.
-__device__ __forceinline__ int sload_i32(cmx_cint p) {
-  int v;
-  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-  return v;
-}
-
-__device__ __forceinline__ void sload_i32x2(cmx_cint p, int& a, int& b) {
-  typedef int cmx_i2 __attribute__((ext_vector_type(2)));
-  cmx_i2 v;
-  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-  a = v[0];
-  b = v[1];
-}
-
-// per-visited-node record (host-built, cmx_host_model.cpp build_load_schedule): 16 ints, one scalar load
+// per-visited-node record of the tree walk (cmx_walk.h): 16 ints, one scalar load
 typedef int cmx_i16 __attribute__((ext_vector_type(16)));
-enum { REC_N = 0, REC_SLOT = 1, REC_NCH = 2, REC_FLAGS = 3, REC_X = 4 /* ints 4..8 */, REC_Y = 9 /* ints 9..13 */,
-       REC_GCARRY = 14 };
-enum { CH_KIND = 0, CH_NODE = 1, CH_ID = 2, CH_L1 = 3, CH_L2 = 4 };  // child descriptor (L1 / L2: leaves of an inlined cherry)
-enum { FLAG_Y_IN_REGS = 2, FLAG_UP_IN_ACC = 4 };
 __device__ __forceinline__ void sload_rec(cmx_cint p, cmx_i16& r) {
   asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
 }
 
 struct ConstModel {
-  cmx_cint int_post, first_child, next_sib, taxon_of, slot, parent, ldsched, msched, nrec;
+  cmx_cint taxon_of, parent, nrec, msched, ldsched;
   cmx_cdbl pi, rates, probs, cum_pi, cum_probs;
   __device__ __forceinline__ explicit ConstModel(const DevModel& m)
-      : int_post((cmx_cint)m.int_post), first_child((cmx_cint)m.first_child), next_sib((cmx_cint)m.next_sib),
-        taxon_of((cmx_cint)m.taxon_of), slot((cmx_cint)m.slot), parent((cmx_cint)m.parent),
-        ldsched((cmx_cint)m.ldsched), msched((cmx_cint)m.msched), nrec((cmx_cint)m.nrec), pi((cmx_cdbl)m.pi), rates((cmx_cdbl)m.rates),
+      : taxon_of((cmx_cint)m.taxon_of), parent((cmx_cint)m.parent), nrec((cmx_cint)m.nrec),
+        msched((cmx_cint)m.msched), ldsched((cmx_cint)m.ldsched), pi((cmx_cdbl)m.pi), rates((cmx_cdbl)m.rates),
         probs((cmx_cdbl)m.probs), cum_pi((cmx_cdbl)m.cum_pi), cum_probs((cmx_cdbl)m.cum_probs) {}
 };
-// Op-stream bookkeeping of a wave (wave-uniform, lives across site blocks).  vs counts the VMEM instructions this
+// Operator-stream bookkeeping of a wave (wave-uniform, lives across site blocks).  vs counts the VMEM instructions this
 // code issued and knows about (DMA rows, vector stores); an asynchronous transfer remembers vs right after its issue,
 // and "wait for X" is s_waitcnt vmcnt(vs - X_seq): VMEM completes in order, so the instructions issued after X may stay
 // in flight.  Instructions that are not counted only make the wait stricter.
@@ -411,62 +399,226 @@ struct ConstModel {
 #define CMX_TIC() do {} while (0)
 #define CMX_TOC(slot) do {} while (0)
 #endif
-enum { TM_OPWAIT = 0, TM_POPWAIT = 1, TM_MV = 2, TM_LEAF = 3, TM_SLOAD = 4, TM_STORE = 5, TM_PASS = 6, TM_SIM = 7, TM_OPB = 8, TM_POP = 9, TM_N = 10 };
+enum { TM_OPWAIT = 0, TM_POPWAIT = 1, TM_MV = 2, TM_LEAF = 3, TM_LOAD = 4, TM_STORE = 5, TM_PASS = 6, TM_SIM = 7, TM_OPB = 8, TM_EPI = 9, TM_N = 10 };
 struct OpState {
 #ifdef CMX_TIMING
   long long tm[TM_N];
   long long tn[TM_N];
 #endif
   int pre_mat, pre_tx;  // op-stream entry of the NEXT op, loaded one op early (its latency hides behind the current op)
-  unsigned par;      // stage buffer / code slot of the current op
+  unsigned par;      // stage buffer / code slot of the current operator op
   unsigned vs;       // counted VMEM instructions issued so far
-  unsigned cur_seq;  // vs right after the current op's operator (and symbols) were requested
+  unsigned cur_seq;  // vs right after the current operator op's operator (and symbols) were requested
 };
 
-// Workspace vector loads follow a host-built schedule (m.ldsched, one entry per load in program order):
-// bit 30 = array (0: inside D, 1: outside U), low 24 bits = slot.
-#define CMX_SCHED_ADDR(e) (((e) & 0x40000000) ? wsU : wsD) + (size_t)((e) & 0x00ffffff) * VL * kWave + 2 * lane
-// pop: take the vector prefetched into LDS (or load it now), then start the LDS-DMA of the next schedule entry if
-// the host marked it prefetchable (bit 31: its producing store precedes this point).  The DMA needs no VGPRs and
-// overlaps the ops that follow; lgkmcnt(0) orders the next DMA behind the LDS read.
-#define CMX_POP(dst)                                                        \
-  do {                                                                      \
-    if (!pend) { /* not prefetchable (its store is too recent): request it now, through the same LDS path -- a plain  \
-                    global load here would be a compiler-visible VMEM load whose pending destination registers make   \
-                    hipcc put conservative vmcnt waits (draining the DMAs in flight) into every following op */       \
-      prefetch_vec_lds<VL>(CMX_SCHED_ADDR(ld_cur), pfl);                    \
-      os.vs += VL / 2;                                                      \
-      pf_seq = os.vs;                                                       \
-    }                                                                       \
-    { CMX_TIC(); wait_vm<S, VL>((int)(os.vs - pf_seq)); CMX_TOC(TM_POPWAIT); } \
-    read_vec_lds<VL>(pfl, lane, dst);                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
-    ++fi;                                                                   \
-    ld_cur = ld_next;                 /* entry fi, loaded one pop early */  \
-    ld_next = cm.ldsched[fi + 1];     /* the schedule ends with two zero entries: no bounds test */ \
-    pend = ld_cur < 0;                                                      \
-    if (pend) {                                                             \
-      prefetch_vec_lds<VL>(CMX_SCHED_ADDR(ld_cur), pfl);                    \
-      os.vs += VL / 2;                                                      \
-      pf_seq = os.vs;                                                       \
-    }                                                                       \
-  } while (0)
-#define CMX_STORE(ptr, v)     \
-  do {                        \
-    { CMX_TIC(); store_vec<VL>(ptr, v); CMX_TOC(TM_STORE); } \
-    os.vs += VL / 2;           \
-  } while (0)
-
-// Maps the 64 sites of this wave (symbol of taxon t at gcodes[t * gstride], per lane) for all rate classes.
-// Classes [c_begin, c_end) are processed; c_after is the class of the first pass that follows this call (its first
-// operator is requested by the last op here).  With finalize, on return cnt[(b*K+k)*64 + lane] holds the final counts
-// n(b, site, k) and the scalars are per lane; without (class-split observed mode) only part[] and L_out = sum of
-// p_c L_c over the processed classes are produced.
-// part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
-// The loop nest below is mirrored statement for statement by build_load_schedule() / verify_traversal() in
-// cmx_host_model.cpp: the op stream decides WHICH operator every CMX_MV / CMX_LEAF applies.
+// Device backend of the tree walk (cmx_walk.h): registers R0..R3 are S-vectors of the wave's sites in the matrix-core
+// layout.  The walk names what it wants; the operator stream (m.msched) and the load schedule (m.ldsched) -- recorded
+// from the same walk on the host and checked numerically there -- say where it is.
 template <int S, int FUSE, int NG>
-__device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsD, double* __restrict__ wsU,
+struct DevWalk {
+  static constexpr int VL = S / 4 * NG, kSites = 16 * NG;
+  double R0[VL], R1[VL], R2[VL], R3[VL];
+  OpState& os;
+  const ConstModel& cm;
+  const double* pi;            // root frequencies (vector loads: lane-dependent index)
+  int nmv;
+  const double *mat_c, *mat_after;
+  double *wsM, *wsU, *pcnt;
+  const uint8_t* gcodes;
+  size_t gstride;
+  uint8_t *pfl, *stage, *cslot;
+  uint32_t lds_stage, lds_codes;
+  int lane, c, c_end;
+  double pc;
+  double Lg[FUSE];
+  int mi, fi, ld_cur, ld_next;
+  bool pend;
+  unsigned pf_seq;
+
+  __device__ __forceinline__ DevWalk(OpState& os_, const ConstModel& cm_) : os(os_), cm(cm_) {}
+
+  template <int I>
+  __device__ __forceinline__ double (&reg())[VL] {
+    if constexpr (I == 0) return R0;
+    else if constexpr (I == 1) return R1;
+    else if constexpr (I == 2) return R2;
+    else return R3;
+  }
+  __device__ __forceinline__ void begin_pass() {
+    mi = 0;
+    fi = 0;
+    ld_cur = cm.ldsched[0];
+    ld_next = cm.ldsched[1];
+    pend = false;
+    pf_seq = 0;
+#pragma unroll
+    for (int g = 0; g < FUSE; ++g) Lg[g] = 0.0;
+  }
+  __device__ __forceinline__ void rec(int v, int (&r)[16]) const {
+    cmx_i16 q;
+    sload_rec(cm.nrec + v * 16, q);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = q[i];
+  }
+  // tells the compiler a register's old value is dead here (defines it without an instruction)
+  template <int R>
+  __device__ __forceinline__ void kill() {
+#pragma unroll
+    for (int i = 0; i < VL; ++i) asm volatile("" : "=v"(reg<R>()[i]));
+  }
+  // One operator op: request the operator (and symbols) of the NEXT op of the stream -- entry mi + 1, or entry 0 of the
+  // next class / next site block -- into the other buffer, then wait for this op's operator.  Returns its buffer.
+  __device__ __forceinline__ const uint8_t* op_begin(unsigned& nseq) {
+    const bool more = (mi + 1 < nmv);
+    const int emat = os.pre_mat, etx = os.pre_tx;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads of the other buffer are done
+    mat_dma_l<S>((more ? mat_c : mat_after) + emat /* element offset, premultiplied on the host */,
+                 lds_stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane);
+    unsigned issued = MatStage<S>::ROWS;
+    if (etx >= 0 && (more || c + 1 < c_end)) {
+      code_dma_l(gcodes + (size_t)etx * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);
+      issued += 1;
+    }
+    {  // entry two ops ahead; the stream carries its first two entries again after the last (no wrap test)
+      const int i2 = more ? mi + 2 : 1;
+      os.pre_mat = cm.msched[2 * i2];
+      os.pre_tx = cm.msched[2 * i2 + 1];
+    }
+    { CMX_TIC(); if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S, VL>((int)(os.vs - os.cur_seq + issued)); CMX_TOC(TM_OPWAIT); }
+    os.vs += issued;
+    nseq = os.vs;
+    return stage + os.par * MatStage<S>::BYTES;
+  }
+  __device__ __forceinline__ void op_end(unsigned nseq) {
+    os.par ^= 1u;
+    os.cur_seq = nseq;
+    ++mi;
+  }
+  template <int SRC, int DST, bool TR>
+  __device__ __forceinline__ void mv(int, int) {
+    unsigned nseq;
+    const uint8_t* buf = op_begin(nseq);
+    { CMX_TIC(); matvec_stage<S, TR, NG>(buf, lane, reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1])); CMX_TOC(TM_MV); }
+    op_end(nseq);
+  }
+  template <int MODE, int SRC, int DST>
+  __device__ __forceinline__ double leaf(void) {
+    unsigned nseq;
+    const uint8_t* buf = op_begin(nseq);
+    CMX_TIC();
+    const double tot = leaf_apply<S, MODE, NG>(buf, cslot + os.par * kCodeSlotBytes + 4 * (lane & 15), lane, reg<SRC>(), reg<DST>());
+    asm volatile("" :: "v"(tot), "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1]));
+    CMX_TOC(TM_LEAF);
+    op_end(nseq);
+    return tot;
+  }
+  template <int D> __device__ __forceinline__ void lset(int, int) { (void)leaf<LEAF_SET, D, D>(); }
+  template <int SRC, int D> __device__ __forceinline__ void lmul(int, int) { (void)leaf<LEAF_MUL, SRC, D>(); }
+  template <int SRC> __device__ __forceinline__ void ldot(int, int, int row) {
+    const double tot = leaf<LEAF_DOT, SRC, SRC>();
+    pcnt[(size_t)row * kSites] = pc * tot;
+  }
+  __device__ __forceinline__ const double* ws_addr(int w) const {
+    return ((w & 0x40000000) ? wsU : wsM) + (size_t)(w & 0x00ffffff) * VL * kWave + 2 * lane;
+  }
+  // workspace vector -> register: take the vector prefetched into LDS (or request it now, through the same LDS path -- a
+  // plain global load here would be a compiler-visible VMEM load whose pending destination registers make hipcc put
+  // conservative vmcnt waits, draining the DMAs in flight, into every following op), then start the LDS-DMA of the next
+  // schedule entry if the host marked it prefetchable (bit 31: its producing store precedes this point).  The DMA needs
+  // no VGPRs and overlaps the ops that follow; lgkmcnt(0) orders it behind the LDS read.
+  template <int D>
+  __device__ __forceinline__ void load(int, int) {
+    CMX_TIC();
+    if (!pend) {
+      prefetch_vec_lds<VL>(ws_addr(ld_cur), pfl);
+      os.vs += VL / 2;
+      pf_seq = os.vs;
+    }
+    wait_vm<S, VL>((int)(os.vs - pf_seq));
+    read_vec_lds<VL>(pfl, lane, reg<D>());
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ++fi;
+    ld_cur = ld_next;                 // entry fi, loaded one load early
+    ld_next = cm.ldsched[fi + 1];     // the schedule ends with two zero entries: no bounds test
+    pend = ld_cur < 0;
+    if (pend) {
+      prefetch_vec_lds<VL>(ws_addr(ld_cur), pfl);
+      os.vs += VL / 2;
+      pf_seq = os.vs;
+    }
+    CMX_TOC(TM_LOAD);
+  }
+  template <int SRC>
+  __device__ __forceinline__ void store(int arr, int slot) {
+    CMX_TIC();
+    store_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * lane, reg<SRC>());
+    os.vs += VL / 2;
+    CMX_TOC(TM_STORE);
+  }
+  template <int D, int SRC> __device__ __forceinline__ void mov() {
+#pragma unroll
+    for (int x = 0; x < VL; ++x) reg<D>()[x] = reg<SRC>()[x];
+  }
+  template <int D, int SRC> __device__ __forceinline__ void mul() {
+#pragma unroll
+    for (int x = 0; x < VL; ++x) reg<D>()[x] *= reg<SRC>()[x];
+  }
+  __device__ __forceinline__ void mulup() {
+#pragma unroll
+    for (int x = 0; x < VL; ++x) { R1[x] *= R3[x]; R2[x] *= R3[x]; }
+  }
+  template <int D> __device__ __forceinline__ void setpi() {
+#pragma unroll
+    for (int sb = 0; sb < S / 4; ++sb) {
+      const double pv = pi[(4 * sb + (lane >> 4)) % (S / FUSE)];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) reg<D>()[sb * NG + g] = pv;
+    }
+  }
+  template <int SRC> __device__ __forceinline__ void rootl() {
+    // lane l holds state 4 sb + (l >> 4) of its four sites: weight it with that state's frequency
+    if constexpr (FUSE == 1) {
+      double p_[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) p_[g] = 0.0;
+#pragma unroll
+      for (int sb = 0; sb < S / 4; ++sb) {
+        const double pv = pi[4 * sb + (lane >> 4)];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) p_[g] = __builtin_fma(pv, reg<SRC>()[sb * NG + g], p_[g]);
+      }
+      Lg[0] = reduce_sites<NG>(p_);
+    } else {   // one 4-state tile per fused class
+      const double pv = pi[lane >> 4];
+#pragma unroll
+      for (int sb = 0; sb < FUSE; ++sb) {
+        double p_[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) p_[g] = pv * reg<SRC>()[sb * NG + g];
+        Lg[sb] = reduce_sites<NG>(p_);
+      }
+    }
+  }
+  __device__ __forceinline__ void dot3(int row) {
+    double p_[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) p_[g] = 0.0;
+#pragma unroll
+    for (int sb = 0; sb < S / 4; ++sb)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) p_[g] = __builtin_fma(R3[sb * NG + g] * R1[sb * NG + g], R2[sb * NG + g], p_[g]);
+    pcnt[(size_t)row * kSites] = pc * reduce_sites<NG>(p_);
+  }
+};
+
+// Maps the 64 sites of this wave (symbol of taxon t at gcodes[t * gstride], per lane) for all rate classes: one walk of
+// the tree (cmx_walk.h) per class.  Classes [c_begin, c_end) are processed; c_after is the class of the first pass that
+// follows this call (its first operator is requested by the last operator op here).  With finalize, on return
+// cnt[(b*K+k)*64 + lane] holds the final counts n(b, site, k) and the scalars are per lane; without (class-split
+// observed mode) only part[] and L_out = sum of p_c L_c over the processed classes are produced.
+// part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
+template <int S, int FUSE, int NG>
+__device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsM, double* __restrict__ wsU,
                                                double* __restrict__ part, double* __restrict__ cnt, int lds_off,
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
                                                OpState& os, double& L_out, double& pr_out, int& rc_out,
@@ -478,218 +630,45 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   // site of this lane inside the wave's block for per-site scalars and arrays: NG = 4: the lane itself; NG = 2: lanes
   // l and l ^ 16 both carry site 16 (l >> 5) + (l & 15) and do the per-site work redundantly (identical values)
   const int sidx = NG == 4 ? lane : (((lane >> 5) << 4) | (lane & 15));
-  uint8_t* pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, VL*64*8 bytes
-  uint8_t* stage = pfl + VL * kWave * 8;                               // two operator buffers
-  uint8_t* cslot = stage + 2 * MatStage<S>::BYTES;                     // two symbol slots
-  const uint32_t lds_stage = lds_addr(stage), lds_codes = lds_addr(cslot);   // wave-uniform LDS byte addresses (SGPRs)
-  const int C = m.C, K = m.K, root = m.root;
+  const int C = m.C, K = m.K;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
+  DevWalk<S, FUSE, NG> be(os, cm);
+  be.pi = m.pi;
+  be.nmv = m.nmv;
+  be.wsM = wsM;
+  be.wsU = wsU;
+  be.gcodes = gcodes;
+  be.gstride = gstride;
+  be.pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, VL*64*8 bytes
+  be.stage = be.pfl + VL * kWave * 8;                            // two operator buffers
+  be.cslot = be.stage + 2 * MatStage<S>::BYTES;                  // two symbol slots
+  be.lds_stage = lds_addr(be.stage);                             // wave-uniform LDS byte addresses (SGPRs)
+  be.lds_codes = lds_addr(be.cslot);
+  be.lane = lane;
+  be.c_end = c_end;
   {  // symbols of op 0 if it is a leaf op (the previous site block could not request them).  Everything this wave
      // wrote before (simulated symbols) is in L2 first; the request is not counted, so drain it here.
-    int mat0, tx0;
-    sload_i32x2(cm.msched, mat0, tx0);
+    const int tx0 = cm.msched[1];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tx0 >= 0) {
-      code_dma(gcodes + (size_t)tx0 * gstride, cslot + os.par * kCodeSlotBytes);
+      code_dma(gcodes + (size_t)tx0 * gstride, be.cslot + os.par * kCodeSlotBytes);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
-// One op: request the operator (and symbols) of the NEXT op of the stream -- entry mi + 1, or entry 0 of the next
-// class / next site block -- into the other buffer, then wait for this op's operator.
-#ifdef CMX_TIMING
-#define CMX_TIC2() const long long tic2_ = (long long)__builtin_readcyclecounter()
-#define CMX_TOC2(slot) os.tm[slot] += (long long)__builtin_readcyclecounter() - tic2_; os.tn[slot] += 1
-#else
-#define CMX_TIC2() do {} while (0)
-#define CMX_TOC2(slot) do {} while (0)
-#endif
-#define CMX_OP_BEGIN()                                                                                   \
-  CMX_TIC2();                                                                                            \
-  const bool more_ = (mi + 1 < m.nmv);                                                                   \
-  const int cn_ = more_ ? c : ((c + 1 < c_end) ? c + 1 : c_after);                                        \
-  const int emat_ = os.pre_mat, etx_ = os.pre_tx;                                                        \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the LDS reads of the other buffer are done */    \
-  (void)cn_;                                                                                             \
-  mat_dma_l<S>((more_ ? mat_c : mat_after) + emat_ /* element offset, premultiplied on the host */,      \
-               lds_stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane);                                    \
-  unsigned issued_ = MatStage<S>::ROWS;                                                                  \
-  if (etx_ >= 0 && (more_ || c + 1 < c_end)) {                                                           \
-    code_dma_l(gcodes + (size_t)etx_ * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);             \
-    issued_ += 1;                                                                                        \
-  }                                                                                                      \
-  { /* entry two ops ahead; the stream carries its first two entries again after the last (no wrap test) */ \
-    const int i2_ = more_ ? mi + 2 : 1;                                                                  \
-    os.pre_mat = cm.msched[2 * i2_];                                                                     \
-    os.pre_tx = cm.msched[2 * i2_ + 1];                                                                  \
-  }                                                                                                      \
-  { CMX_TIC(); if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S, VL>((int)(os.vs - os.cur_seq + issued_)); CMX_TOC(TM_OPWAIT); } \
-  os.vs += issued_;                                                                                      \
-  const unsigned nseq_ = os.vs;                                                                          \
-  const uint8_t* buf_ = stage + os.par * MatStage<S>::BYTES;                                             \
-  CMX_TOC2(TM_OPB)
-#define CMX_OP_END()   \
-  os.par ^= 1u;        \
-  os.cur_seq = nseq_;  \
-  ++mi
-#define CMX_MV(TR, in, out)                     \
-  do {                                          \
-    CMX_OP_BEGIN();                             \
-    { CMX_TIC(); matvec_stage<S, TR, NG>(buf_, lane, in, out); asm volatile("" :: "v"(out[0]), "v"(out[VL - 1])); CMX_TOC(TM_MV); } \
-    CMX_OP_END();                               \
-  } while (0)
-// leaf edge the op stream names (P or P o N^k of a taxon, transposed): out = message, out = message o in, tot = <in, message>
-#define CMX_LEAF_OP(MODE_, in, out, tot)                                                     \
-  do {                                                                                       \
-    CMX_OP_BEGIN();                                                                          \
-    CMX_TIC();                                                                               \
-    tot = leaf_apply<S, MODE_, NG>(buf_, cslot + os.par * kCodeSlotBytes + 4 * (lane & 15), lane, in, out); \
-    asm volatile("" :: "v"(tot), "v"(out[0]), "v"(out[VL - 1]));                              \
-    CMX_TOC(TM_LEAF);                                                                        \
-    CMX_OP_END();                                                                            \
-  } while (0)
-#define CMX_LEAF(out)          do { double z_; CMX_LEAF_OP(LEAF_SET, out, out, z_); (void)z_; } while (0)
-#define CMX_LEAF_MUL(in, out)  do { double z_; CMX_LEAF_OP(LEAF_MUL, in, out, z_); (void)z_; } while (0)
-#define CMX_LEAF_DOT(in, tot)  CMX_LEAF_OP(LEAF_DOT, in, in, tot)
-// tells the compiler a vector is dead here (defines it without an instruction): the four S-vectors are loop-carried
-// variables and would otherwise count as live on paths whose successors never read them
-#define CMX_KILL(v) \
-  do { _Pragma("unroll") for (int i_ = 0; i_ < VL; ++i_) asm volatile("" : "=v"(v[i_])); } while (0)
-#define CMX_DOT(x_, y_, out)                                                          \
-  do {                                                                                \
-    double p_[NG];                                                                    \
-    _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) p_[g_] = 0.0;                   \
-    _Pragma("unroll") for (int sb_ = 0; sb_ < S / 4; ++sb_)                           \
-      _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_)                               \
-        p_[g_] = __builtin_fma(x_[sb_ * NG + g_], y_[sb_ * NG + g_], p_[g_]);         \
-    out = reduce_sites<NG>(p_);                                                       \
-  } while (0)
   for (int c = c_begin; c < c_end; ++c) {
     CMX_TIC();
     // operators of this class and of the class of the pass that follows (its first operator is requested by our last op)
-    const double* mat_c = m.MAT + (size_t)c * m.MC * MatStage<S>::UNIT;
-    const double* mat_after = m.MAT + (size_t)((c + 1 < c_end) ? c + 1 : c_after) * m.MC * MatStage<S>::UNIT;
+    be.mat_c = m.MAT + (size_t)c * m.MC * MatStage<S>::UNIT;
+    be.mat_after = m.MAT + (size_t)((c + 1 < c_end) ? c + 1 : c_after) * m.MC * MatStage<S>::UNIT;
     const double pc = FUSE > 1 ? 1.0 : cm.probs[c];  // fused: the class probabilities are folded into the count operators
-    double Lg[FUSE];   // site likelihood per fused class at the root
-    double* pcnt = part + (size_t)c * m.B * K * kSites + sidx;
-    double d[VL], t[VL];  // popped vector / matvec result
-    int fi = 0;         // next schedule entry
-    int ld_cur = cm.ldsched[0], ld_next = cm.ldsched[1];   // its word and the following one
-    int mi = 0;         // matrix products done in this class pass
-    bool pend = false;  // the LDS prefetch buffer holds entry fi
-    unsigned pf_seq = 0;  // os.vs right after that prefetch was issued
-    double acc[VL], u[VL];
-    double Lc = 0.0;
-// inside vector of a child edge into `d`: kind 1 = stored (pop), kind 2 = inlined cherry (two leaf ops)
-#define CMX_GET_D(r_, off_)                                    \
-  do {                                                         \
-    if ((r_)[(off_) + CH_KIND] == 1) {                         \
-      CMX_POP(d);                                              \
-    } else {                                                   \
-      CMX_LEAF(d);                                             \
-      CMX_LEAF_MUL(d, d);                                      \
-    }                                                          \
-  } while (0)
-// counts of the two leaf branches of an inlined cherry whose outside message is `up`; t1_ is a scratch vector
-#define CMX_CHERRY_COUNTS(r_, off_, up, t1_)                                             \
-  do {                                                                                   \
-    CMX_LEAF_MUL(up, t1_);                       /* up o (P of leaf 2) */                \
-    for (int k = 0; k < K; ++k) {                                                        \
-      double tot_;                                                                       \
-      CMX_LEAF_DOT(t1_, tot_);                   /* . (P o N^k of leaf 1) */             \
-      pcnt[((size_t)(r_)[(off_) + CH_L1] * K + k) * kSites] = pc * tot_;                  \
-    }                                                                                    \
-    CMX_LEAF_MUL(up, t1_);                       /* up o (P of leaf 1) */                \
-    for (int k = 0; k < K; ++k) {                                                        \
-      double tot_;                                                                       \
-      CMX_LEAF_DOT(t1_, tot_);                   /* . (P o N^k of leaf 2) */             \
-      pcnt[((size_t)(r_)[(off_) + CH_L2] * K + k) * kSites] = pc * tot_;                  \
-    }                                                                                    \
-  } while (0)
-    // ---------------- inside (post-order) pass over the visited nodes.  acc leaves each iteration holding D of the
-    // node just finished; it is the Y child of the next node whenever FLAG_Y_IN_REGS is set there.
-    for (int idx = 0; idx < m.NV; ++idx) {
-      cmx_i16 r;
-      sload_rec(cm.nrec + idx * 16, r);
-      const int n = r[REC_N];
-      if (r[REC_NCH] == 2) {
-        // child Y arrives in acc when it was the node finished last (its message goes to t), child X never does
-        const bool yreg = (r[REC_FLAGS] & FLAG_Y_IN_REGS) != 0;
-        if (yreg) CMX_MV(false, acc, t);
-        if (r[REC_X + CH_KIND] == 0) {
-          if (yreg) CMX_LEAF_MUL(t, acc); else CMX_LEAF(acc);
-        } else {
-          CMX_GET_D(r, REC_X);
-          CMX_MV(false, d, acc);
-          if (yreg) {
-#pragma unroll
-            for (int x = 0; x < VL; ++x) acc[x] *= t[x];
-          }
-        }
-        if (!yreg) {
-          if (r[REC_Y + CH_KIND] == 0) {
-            CMX_LEAF_MUL(acc, acc);
-          } else {  // inlined cherry (a stored Y is always handed over)
-            CMX_GET_D(r, REC_Y);
-            CMX_MV(false, d, t);
-#pragma unroll
-            for (int x = 0; x < VL; ++x) acc[x] *= t[x];
-          }
-        }
-      } else {
-        const int carry = r[REC_GCARRY];
-        if (carry >= 0) {
-          CMX_MV(false, acc, t);
-#pragma unroll
-          for (int x = 0; x < VL; ++x) acc[x] = t[x];
-        } else {
-#pragma unroll
-          for (int x = 0; x < VL; ++x) acc[x] = 1.0;
-        }
-        for (int e = cm.first_child[n]; e >= 0; e = cm.next_sib[e]) {
-          if (cm.taxon_of[e] >= 0) {
-            CMX_LEAF_MUL(acc, acc);
-          } else {
-            if (e == carry) continue;
-            CMX_POP(d);
-            CMX_MV(false, d, t);
-#pragma unroll
-            for (int x = 0; x < VL; ++x) acc[x] *= t[x];
-          }
-        }
-      }
-      if (n != root) {
-        CMX_STORE(wsD + (size_t)r[REC_SLOT] * VL * kWave + 2 * lane, acc);
-      } else {
-        // lane l holds state 4 sb + (l >> 4) of its four sites: weight it with that state's frequency
-        if constexpr (FUSE == 1) {
-          double p_[NG];
-#pragma unroll
-          for (int g = 0; g < NG; ++g) p_[g] = 0.0;
-#pragma unroll
-          for (int sb = 0; sb < S / 4; ++sb) {
-            const double pv = m.pi[4 * sb + (lane >> 4)];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) p_[g] = __builtin_fma(pv, acc[sb * NG + g], p_[g]);
-          }
-          Lg[0] = reduce_sites<NG>(p_);
-        } else {   // one 4-state tile per fused class
-          const double pv = m.pi[lane >> 4];
-#pragma unroll
-          for (int sb = 0; sb < FUSE; ++sb) {
-            double p_[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) p_[g] = pv * acc[sb * NG + g];
-            Lg[sb] = reduce_sites<NG>(p_);
-          }
-        }
-        Lc = Lg[0];
-      }
-      CMX_KILL(d);
-      CMX_KILL(t);
-    }
-    CMX_KILL(acc);
+    be.pc = pc;
+    be.c = c;
+    be.pcnt = part + (size_t)c * m.B * K * kSites + sidx;
+    be.begin_pass();
+    walk_pass(be, m.NV, K);
     if constexpr (FUSE == 1) {
+      const double Lc = be.Lg[0];
       Lsum += pc * Lc;
       prsum += cm.rates[c] * pc * Lc;
       if (pc * Lc > best) { best = pc * Lc; bestc = c; }  // first maximum wins (getRateClassWithMaxPostProbPerSite)
@@ -699,143 +678,14 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         const int cc = c * FUSE + g;
         if (cc < m.C0) {
           const double pg = cm.probs[cc];
-          Lsum += pg * Lg[g];
-          prsum += cm.rates[cc] * pg * Lg[g];
-          if (pg * Lg[g] > best) { best = pg * Lg[g]; bestc = cc; }
+          Lsum += pg * be.Lg[g];
+          prsum += cm.rates[cc] * pg * be.Lg[g];
+          if (pg * be.Lg[g] > best) { best = pg * be.Lg[g]; bestc = cc; }
         }
       }
-    }
-    // ---------------- outside (pre-order) pass + joint counts.  acc carries the outside message Up_f.
-    for (int idx = m.NV - 1; idx >= 0; --idx) {
-      cmx_i16 r;
-      sload_rec(cm.nrec + idx * 16, r);
-      const int f = r[REC_N];
-      if (f == root) {
-#pragma unroll
-        for (int sb = 0; sb < S / 4; ++sb) {
-          const double pv = m.pi[(4 * sb + (lane >> 4)) % (S / FUSE)];
-#pragma unroll
-          for (int g = 0; g < NG; ++g) acc[sb * NG + g] = pv;
-        }
-      } else if (!(r[REC_FLAGS] & FLAG_UP_IN_ACC)) {  // otherwise Up_f was left in acc by the parent
-        CMX_POP(acc);
-      }
-      if (r[REC_NCH] == 2) {
-        const int kx = r[REC_X + CH_KIND], ky = r[REC_Y + CH_KIND];
-        // ---- message of Y -> U_X = Up_f o M_Y
-        if (ky == 0) {
-          CMX_LEAF_MUL(acc, u);
-        } else {
-          CMX_GET_D(r, REC_Y);
-          CMX_MV(false, d, t);
-#pragma unroll
-          for (int x = 0; x < VL; ++x) u[x] = acc[x] * t[x];
-        }
-        // ---- X: counts of its branch, its message -> U_Y, its outside message
-        if (kx == 0) {
-          for (int k = 0; k < K; ++k) {
-            double tot;
-            CMX_LEAF_DOT(u, tot);
-            pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kSites] = pc * tot;
-          }
-          CMX_LEAF_MUL(acc, t);                        // U_Y = Up_f o M_X
-        } else {
-          CMX_GET_D(r, REC_X);
-          for (int k = 0; k <= K; ++k) {               // K count operators, then P itself (one product site)
-            CMX_MV(false, d, t);
-            if (k < K) {
-              double tot;
-              CMX_DOT(u, t, tot);
-              pcnt[((size_t)r[REC_X + CH_NODE] * K + k) * kSites] = pc * tot;
-            }
-          }
-#pragma unroll
-          for (int x = 0; x < VL; ++x) t[x] *= acc[x];  // U_Y
-          CMX_MV(true, u, d);                          // Up_X
-          if (kx == 1) {
-            CMX_STORE(wsU + (size_t)r[REC_X + CH_ID] * VL * kWave + 2 * lane, d);
-          } else {
-            CMX_CHERRY_COUNTS(r, REC_X, d, acc);       // Up_f is dead here
-          }
-        }
-        // ---- Y: counts of its branch, its outside message (t = U_Y)
-        if (ky == 0) {
-          for (int k = 0; k < K; ++k) {
-            double tot;
-            CMX_LEAF_DOT(t, tot);
-            pcnt[((size_t)r[REC_Y + CH_NODE] * K + k) * kSites] = pc * tot;
-          }
-          CMX_KILL(acc);
-        } else {
-          CMX_GET_D(r, REC_Y);
-          for (int k = 0; k < K; ++k) {
-            CMX_MV(false, d, u);
-            double tot;
-            CMX_DOT(t, u, tot);
-            pcnt[((size_t)r[REC_Y + CH_NODE] * K + k) * kSites] = pc * tot;
-          }
-          CMX_MV(true, t, acc);                        // Up_Y: handed to the next visited node when Y is stored
-          if (ky != 1) {
-            CMX_CHERRY_COUNTS(r, REC_Y, acc, u);
-            CMX_KILL(acc);
-          }
-        }
-      } else {
-        // ---- general node (root trifurcation, multifurcations): every sibling message recomputed per child
-        const int ca = cm.first_child[f];
-        for (int n = ca; n >= 0; n = cm.next_sib[n]) {
-#pragma unroll
-          for (int x = 0; x < VL; ++x) u[x] = acc[x];
-          for (int sb = ca; sb >= 0; sb = cm.next_sib[sb]) {
-            if (sb == n) continue;
-            if (cm.taxon_of[sb] >= 0) {
-              CMX_LEAF_MUL(u, u);
-            } else {
-              CMX_POP(d);
-              CMX_MV(false, d, t);
-#pragma unroll
-              for (int x = 0; x < VL; ++x) u[x] *= t[x];
-            }
-          }
-          if (cm.taxon_of[n] >= 0) {
-            for (int k = 0; k < K; ++k) {
-              double tot;
-              CMX_LEAF_DOT(u, tot);
-              pcnt[((size_t)n * K + k) * kSites] = pc * tot;
-            }
-          } else {
-            const int sl = cm.slot[n];
-            CMX_POP(d);
-            for (int k = 0; k < K; ++k) {
-              CMX_MV(false, d, t);
-              double tot;
-              CMX_DOT(u, t, tot);
-              pcnt[((size_t)n * K + k) * kSites] = pc * tot;
-            }
-            CMX_MV(true, u, t);
-            CMX_STORE(wsU + (size_t)sl * VL * kWave + 2 * lane, t);
-          }
-        }
-        CMX_KILL(acc);
-      }
-      CMX_KILL(d);
-      CMX_KILL(t);
-      CMX_KILL(u);
     }
     CMX_TOC(TM_PASS);
   }
-#undef CMX_GET_D
-#undef CMX_CHERRY_COUNTS
-#undef CMX_LEAF
-#undef CMX_LEAF_MUL
-#undef CMX_LEAF_DOT
-#undef CMX_LEAF_OP
-#undef CMX_MV
-#undef CMX_OP_BEGIN
-#undef CMX_OP_END
-#undef CMX_STORE
-#undef CMX_DOT
-#undef CMX_KILL
   if (!finalize) {   // class-split mode: the pass's sums, its best class and that class's weight
     L_out = Lsum;
     pr_out = prsum;
@@ -846,6 +696,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   // ---------------- sum the classes in class order, divide by the site likelihood, norm (computeNormForSite)
   // Rows r = b*K + k are taken eight at a time so that eight independent loads are in flight per class; the sums run
   // in the same order as a plain (b, k, c) loop nest.
+  CMX_TIC();
   double nrm = 0.0, tot = 0.0;
   const int BK = m.B * K;
   int kk = 0;  // r % K
@@ -872,6 +723,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       }
     }
   }
+  CMX_TOC(TM_EPI);
   L_out = Lsum;
   pr_out = prsum / Lsum;
   rc_out = bestc;
@@ -966,8 +818,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   const int sidx = NG == 4 ? lane : (((lane >> 5) << 4) | (lane & 15));   // site of this lane in the wave's block
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * kWavesPerBlock;
-  double* wsD = a.ws.D + (size_t)wave * m.NI * VL * kWave;
-  double* wsU = a.ws.U + (size_t)wave * m.NI * VL * kWave;
+  double* wsD = a.ws.D + (size_t)wave * m.NIW * VL * kWave;
+  double* wsU = a.ws.U + (size_t)wave * m.NIW * VL * kWave;
   double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kSites;
   double* cnt1 = cnt0 + (size_t)m.B * m.K * kSites;
   double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kSites;
@@ -982,17 +834,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
 #endif
   os.par = 0;
   {
-    int mat0, tx0;
-    sload_i32x2(cm.msched, mat0, tx0);
     const int c0 = (MODE == kModeObservedSplit) ? wave % m.C : 0;   // class of this wave's first pass
-    mat_dma<S>(m.MAT + (size_t)c0 * m.MC * MatStage<S>::UNIT + mat0, cmx_smem + lds_off + VL * kWave * 8, lane);
+    mat_dma<S>(m.MAT + (size_t)c0 * m.MC * MatStage<S>::UNIT + cm.msched[0], cmx_smem + lds_off + VL * kWave * 8, lane);
   }
   os.vs = MatStage<S>::ROWS;
   os.cur_seq = os.vs;
-  {
-    os.pre_mat = cm.msched[2];   // entry 1 (the stream is padded with copies of its first entries)
-    os.pre_tx = cm.msched[3];
-  }
+  os.pre_mat = cm.msched[2];   // entry 1 (the stream is padded with copies of its first entries)
+  os.pre_tx = cm.msched[3];
   if (MODE == kModeObservedSplit) {
     const size_t ntasks = nblocks * (size_t)m.C, BK = (size_t)m.B * m.K;
     for (size_t task = wave; task < ntasks; task += nwaves) {
@@ -1045,6 +893,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
           uint8_t* al = a.ws.aln + (size_t)wave * m.T * kSites + sidx;
           gbase = al;
           gstride = kSites;
+          CMX_TIC();
           const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
           const int S0 = S / FUSE;
           const int c = draw_index(philox_uniform(a.seed, g, 0), cm.cum_probs, m.C0);
@@ -1058,11 +907,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
             const int pn = cm.parent[node];
             const int x = st_lds ? stl[(size_t)pn * kSites] : stg[(size_t)pn * kSites];
             const double u = philox_uniform(a.seed, g, 2u + (uint32_t)node);
-            const int y = draw_index(u, m.CP + (((size_t)c * m.nn + node) * S0 + x) * S0, S0);
+            const size_t row = ((size_t)c * m.nn + node) * S0 + x;
+            const int y = draw_guided(u, m.CP + row * S0, m.CPG + row * 32, S0);
             if (st_lds) stl[(size_t)node * kSites] = (uint8_t)y; else stg[(size_t)node * kSites] = (uint8_t)y;
             const int tx = cm.taxon_of[node];
             if (tx >= 0) al[(size_t)tx * kSites] = (uint8_t)y;
           }
+          CMX_TOC(TM_SIM);
         }
         double L, pr, nrm;
         int rc;
@@ -1083,9 +934,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
 #ifdef CMX_TIMING
   if (MODE == kModeNull && lane == 0 && (wave == 0 || wave == 777)) {
     const long long tot_ = (long long)__builtin_readcyclecounter() - tk0_;
-    printf("wave %d total %lld | opwait %lld/%lld popwait %lld/%lld mv %lld/%lld leaf %lld/%lld sload %lld/%lld store %lld/%lld pass %lld/%lld opbegin %lld/%lld pop %lld/%lld\n",
+    printf("wave %d total %lld | opwait %lld/%lld loadwait %lld/%lld mv %lld/%lld leaf %lld/%lld load %lld/%lld store %lld/%lld pass %lld/%lld sim %lld/%lld epi %lld/%lld\n",
            wave, tot_, os.tm[0], os.tn[0], os.tm[1], os.tn[1], os.tm[2], os.tn[2], os.tm[3], os.tn[3], os.tm[4], os.tn[4],
-           os.tm[5], os.tn[5], os.tm[6], os.tn[6], os.tm[8], os.tn[8], os.tm[9], os.tn[9]);
+           os.tm[5], os.tn[5], os.tm[6], os.tn[6], os.tm[7], os.tn[7], os.tm[9], os.tn[9]);
   }
 #endif
 }
@@ -1102,12 +953,10 @@ hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t s
   if ((int)lds > lim) return hipErrorInvalidValue;
 #define CMX_LAUNCH(S_, MODE_, F_)                                                                             \
   do {                                                                                                        \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<S_, MODE_, F_>),                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lim);                             \
-      attr_set = true;                                                                                        \
-    }                                                                                                         \
+    /* per launch: the attribute belongs to the current device (a process may hold contexts on several) */    \
+    const hipError_t ea_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<S_, MODE_, F_>),     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);              \
+    if (ea_ != hipSuccess) return ea_;                                                                        \
     hipLaunchKernelGGL((map_kernel<S_, MODE_, F_>), grid, block, lds, stream, a);                             \
   } while (0)
 #define CMX_LAUNCH_MODES(S_, F_)                                            \
@@ -1116,11 +965,16 @@ hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t s
     else if (mode == kModeObservedSplit) CMX_LAUNCH(S_, kModeObservedSplit, F_); \
     else CMX_LAUNCH(S_, kModeNull, F_);                                     \
   } while (0)
+#ifdef CMX_PROBE   // register-allocation experiments: one instantiation only (make probe)
+  if (a.m.S == 20 && a.m.fuse == 1) CMX_LAUNCH(20, kModeNull, 1);
+  else return hipErrorInvalidValue;
+#else
   if (a.m.S == 20 && a.m.fuse == 1) CMX_LAUNCH_MODES(20, 1);
   else if (a.m.S == 20 && a.m.fuse == 5) CMX_LAUNCH_MODES(20, 5);
   else if (a.m.S == 16 && a.m.fuse == 4) CMX_LAUNCH_MODES(16, 4);
   else if (a.m.S == 4 && a.m.fuse == 1) CMX_LAUNCH_MODES(4, 1);
   else return hipErrorInvalidValue;
+#endif
 #undef CMX_LAUNCH_MODES
 #undef CMX_LAUNCH
   return hipGetLastError();
@@ -1292,7 +1146,8 @@ __global__ void simulate_kernel(const DevModel m, uint64_t seed, uint64_t g0, si
   states[(size_t)m.root * ld + j] = (uint8_t)draw_index(philox_uniform(seed, g, 1), m.cum_pi, S);
   for (int node = m.nn - 2; node >= 0; --node) {
     const int x = states[(size_t)m.parent[node] * ld + j];
-    const int y = draw_index(philox_uniform(seed, g, 2u + (uint32_t)node), m.CP + (((size_t)c * m.nn + node) * S + x) * S, S);
+    const size_t row = ((size_t)c * m.nn + node) * S + x;
+    const int y = draw_guided(philox_uniform(seed, g, 2u + (uint32_t)node), m.CP + row * S, m.CPG + row * 32, S);
     states[(size_t)node * ld + j] = (uint8_t)y;
     const int tx = m.taxon_of[node];
     if (tx >= 0) aln[(size_t)tx * ld + j] = (uint8_t)y;

@@ -38,7 +38,7 @@ COUNT_EXPECTED, COUNT_NAIVE = 0, 1
 
 EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
-    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_traversal", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate",
+    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
@@ -142,8 +142,9 @@ def _sz(x):
     return ctypes.c_size_t(int(x))
 
 
-def debug_traversal(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
-    """Host-side compilation of the tree into the kernel's traversal (no GPU): dict(nrec[NV,16], ldsched, msched, slot)."""
+def debug_walk(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
+    """Host-side compilation of the tree into what the mapping kernel's walk reads (no GPU): dict(nrec[NV,16], ldsched,
+    msched[nops,2], slot[nnodes], loads, stores, products, leaf_ops) -- counts are per rate-class pass."""
     lib = load_library()
     keep = [np.ascontiguousarray(parent, dtype=np.int32), _f64(blen), np.ascontiguousarray(leaf_of_taxon, dtype=np.int32),
             _f64(Q), _f64(pi), _f64(rates), _f64(probs), None if Bk is None else _f64(Bk)]
@@ -156,13 +157,15 @@ def debug_traversal(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
     cap = 64 * nn * max(K, 1) + 64
     nrec, ld, ms = (np.zeros(cap, dtype=np.int32) for _ in range(3))
     slot = np.zeros(nn, dtype=np.int32)
+    stats = np.zeros(4, dtype=np.uint64)
     n1, n2, n3 = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
-    st = lib.cmx_debug_traversal(ctypes.byref(model), ctypes.byref(tree), _vp(nrec), _sz(cap), ctypes.byref(n1), _vp(ld),
-                                 _sz(cap), ctypes.byref(n2), _vp(ms), _sz(cap), ctypes.byref(n3), _vp(slot))
+    st = lib.cmx_debug_walk(ctypes.byref(model), ctypes.byref(tree), _vp(nrec), _sz(cap), ctypes.byref(n1), _vp(ld),
+                            _sz(cap), ctypes.byref(n2), _vp(ms), _sz(cap), ctypes.byref(n3), _vp(slot), _vp(stats))
     if st != 0:
         raise CmxError(st, lib.cmx_last_error(None).decode())
-    return dict(nrec=nrec[: n1.value].reshape(-1, 16).copy(), ldsched=ld[: n2.value].copy(), msched=ms[: n3.value].copy(),
-                slot=slot)
+    return dict(nrec=nrec[: n1.value].reshape(-1, 16).copy(), ldsched=ld[: n2.value].copy(),
+                msched=ms[: n3.value].reshape(-1, 2).copy(), slot=slot, loads=int(stats[0]), stores=int(stats[1]),
+                products=int(stats[2]), leaf_ops=int(stats[3]))
 
 
 def debug_candidate_cursor(norm_windows, analysable, min_sim, norms, max_trials):

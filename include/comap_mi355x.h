@@ -108,12 +108,15 @@ cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info);
 /* transition probabilities the engine uses, for inspection/tests: P[C][B][S][S] (row x -> column y) */
 cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P);
 cmx_status cmx_synchronize(cmx_ctx* ctx);
-/* host-side only (no GPU needed): compile the tree into the traversal the mapping kernel walks and copy it out for
- * inspection/tests.  nrec: [nvisited][16] node records; ldsched: workspace loads; msched: matrix products of one
- * rate-class pass.  Each *_cap is the capacity (in int32) of the caller's buffer; sizes are returned in *_n. */
-cmx_status cmx_debug_traversal(const cmx_model* model, const cmx_tree* tree, int32_t* nrec, size_t nrec_cap,
-                               size_t* nrec_n, int32_t* ldsched, size_t ld_cap, size_t* ld_n, int32_t* msched,
-                               size_t m_cap, size_t* m_n, int32_t* slot_of_node /*[nnodes]*/);
+/* host-side only (no GPU needed): compile the tree into what the mapping kernel's walk of a rate-class pass reads
+ * (comap_amd/csrc/cmx_walk.h) and copy it out for inspection/tests.  nrec: [nvisited][16] node records; ldsched:
+ * workspace loads; msched: operator uses, pairs (matrix index in a class block, taxon or -1), in program order.  The walk
+ * has already passed the engine's self-check (run numerically on the host against a direct pruning computation).
+ * Each *_cap is the capacity (in int32) of the caller's buffer; sizes are returned in *_n. */
+cmx_status cmx_debug_walk(const cmx_model* model, const cmx_tree* tree, int32_t* nrec, size_t nrec_cap, size_t* nrec_n,
+                          int32_t* ldsched, size_t ld_cap, size_t* ld_n, int32_t* msched, size_t m_cap, size_t* m_n,
+                          int32_t* slot_of_node /*[nnodes] or NULL*/,
+                          uint64_t* stats /*[4] or NULL: workspace loads, stores, matrix products, leaf ops per pass*/);
 
 /* ---- substitution mapping: replaces DRHomogeneousTreeLikelihood::initialize + getLogLikelihoodPerSite /
  * getPosteriorRatePerSite / getRateClassWithMaxPostProbPerSite + computeSubstitutionVectors + computeNormForSite

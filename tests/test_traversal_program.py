@@ -1,7 +1,8 @@
-"""Host logic without a GPU: the tree program the mapping kernel executes (records, op stream, workspace-load schedule)
-is compiled and self-checked by cmx_debug_traversal for many tree shapes -- binary, caterpillar, star, random
-multifurcations.  The self-check (verify_traversal, cmx_host_model.cpp) dry-runs the kernel's control flow against the
-tree: every load must name a vector stored before, every op must find its operator, every branch is counted once."""
+"""Host logic without a GPU: what the mapping kernel's tree walk reads (node records, operator stream, workspace-load
+schedule) is compiled and self-checked by cmx_debug_walk for many tree shapes -- binary, caterpillar, star, random
+multifurcations.  The self-check (verify_walk, cmx_host_model.cpp) runs the SAME walk (cmx_walk.h) numerically on the
+host, from the device matrix layouts and through the recorded operator stream, and compares site likelihood and every
+joint count with a direct pruning computation on the original (not binarised) tree."""
 import numpy as np
 import pytest
 
@@ -57,20 +58,25 @@ def _random_multifurcating(ntaxa, seed):
 def test_binary_trees_compile(ntaxa):
     Q, pi, rates, probs = _model()
     parent, blen, lot = sy.random_tree(ntaxa, 1000 + ntaxa)
-    d = engine.debug_traversal(parent, blen, lot, Q, pi, rates, probs)
+    d = engine.debug_walk(parent, blen, lot, Q, pi, rates, probs)
     nn = len(parent)
     ninternal = nn - ntaxa
-    assert d["nrec"].shape[1] == 16 and 1 <= d["nrec"].shape[0] <= ninternal
-    ops = d["msched"].reshape(-1, 2)
+    # a trifurcating root is split by one pseudo node
+    assert d["nrec"].shape[1] == 16 and 1 <= d["nrec"].shape[0] <= ninternal + 1
+    ops = d["msched"]
     assert ((ops[:, 1] >= -1) & (ops[:, 1] < ntaxa)).all()
     leaf_ops = ops[ops[:, 1] >= 0]
     assert set(leaf_ops[:, 1]) == set(range(ntaxa))            # every leaf edge is applied
     # per class pass: every leaf needs its transition operator on the way down and up, and its count operator once
-    assert len(leaf_ops) >= 3 * ntaxa
-    # every stored vector is loaded at least once; at most four times (children of the multifurcating root)
+    assert len(leaf_ops) >= 3 * ntaxa and len(leaf_ops) == d["leaf_ops"]
+    # message scheme: one product per internal branch on the way up, two (count + transposed) on the way down; an
+    # inlined cherry's message is rebuilt once more
+    assert d["products"] <= 4 * (ninternal - 1)
+    # every stored vector is loaded; a message at most twice (by its parent in either pass), an outside message once
     if len(d["ldsched"]):
         slots, counts = np.unique(d["ldsched"] & 0x40ffffff, return_counts=True)
-        assert counts.max() <= 4
+        assert counts.max() <= 2
+        assert d["loads"] == len(d["ldsched"])
 
 
 def test_caterpillar_and_star():
@@ -101,11 +107,11 @@ def test_caterpillar_and_star():
     parent[cur] = root
     assert idx == root
     blen = np.full(2 * n - 2, 0.05)
-    engine.debug_traversal(parent, blen, lot, Q, pi, rates, probs)
-    # star tree: all leaves on the root
+    engine.debug_walk(parent, blen, lot, Q, pi, rates, probs)
+    # star tree: all leaves on the root -> a chain of n - 2 pseudo nodes under a binary root, no operator for any of them
     parent = np.array([n] * n + [-1], dtype=np.int32)
-    d = engine.debug_traversal(parent, np.full(n + 1, 0.1), np.arange(n, dtype=np.int32), Q, pi, rates, probs)
-    assert d["nrec"].shape[0] == 1 and len(d["ldsched"]) == 0
+    d = engine.debug_walk(parent, np.full(n + 1, 0.1), np.arange(n, dtype=np.int32), Q, pi, rates, probs)
+    assert d["nrec"].shape[0] == n - 1 and d["products"] == 0
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -113,8 +119,8 @@ def test_random_multifurcating_trees_compile(seed):
     Q, pi, rates, probs = _model()
     ntaxa = int(np.random.default_rng(seed).integers(4, 70))
     parent, blen, lot = _random_multifurcating(ntaxa, seed)
-    d = engine.debug_traversal(parent, blen, lot, Q, pi, rates, probs)
-    ops = d["msched"].reshape(-1, 2)
+    d = engine.debug_walk(parent, blen, lot, Q, pi, rates, probs)
+    ops = d["msched"]
     assert set(ops[ops[:, 1] >= 0][:, 1]) == set(range(ntaxa))
 
 
@@ -126,6 +132,6 @@ def test_malformed_trees_are_rejected():
     bad2 = parent.copy()
     bad2[2] = 1                          # parent id below the child id: not post-order
     with pytest.raises(engine.CmxError):
-        engine.debug_traversal(bad2, blen, lot, Q, pi, rates, probs)
+        engine.debug_walk(bad2, blen, lot, Q, pi, rates, probs)
     with pytest.raises(engine.CmxError):
-        engine.debug_traversal(parent, -blen, lot, Q, pi, rates, probs)
+        engine.debug_walk(parent, -blen, lot, Q, pi, rates, probs)
