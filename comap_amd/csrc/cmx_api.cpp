@@ -179,7 +179,8 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       d.msched = dms;
       d.nmv = (int)(h.msched.size() / 2);
     }
-    UP(nrec);
+    UP(nrec); UP(simg);
+    d.nsimg = (int)(h.simg.size() / 16);
     {  // two zero entries (not prefetchable) after the last load: the kernel reads one entry ahead without a bounds test
       std::vector<int> ld(h.ldsched);
       ld.push_back(0);

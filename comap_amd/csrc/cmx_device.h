@@ -50,6 +50,8 @@ struct DevModel {
   // simulator: running sums of the rows of P, [C][nn][S(x)][S], and a 32-entry guide table per row (see draw_guided)
   const double* CP;
   const uint8_t* CPG;      // [C][nn][S(x)][32]
+  const int* simg;         // [nsimg][16] groups of four nodes of equal depth: nodes | parents | taxa (or -1) | pad
+  int nsimg;
   const double* pi;        // [S]
   const double* rates;     // [C]
   const double* probs;     // [C]

@@ -410,6 +410,24 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   hm->NI = (int)hm->int_post.size();
   build_records(hm);
   record_walk(hm);
+  {  // simulator: nodes by depth, four of a level at a time (a level's draws only need the level above); a short group is
+     // padded by repeating its last node (drawing a node twice gives the same state twice)
+    std::vector<int> depth(nn, 0);
+    int maxd = 0;
+    for (int i = nn - 2; i >= 0; --i) { depth[i] = depth[hm->parent[i]] + 1; maxd = std::max(maxd, depth[i]); }
+    std::vector<std::vector<int>> level(maxd + 1);
+    for (int i = nn - 2; i >= 0; --i) level[depth[i]].push_back(i);
+    hm->simg.clear();
+    for (int d = 1; d <= maxd; ++d)
+      for (size_t i = 0; i < level[d].size(); i += 4) {
+        int g[16];
+        for (int j = 0; j < 4; ++j) {
+          const int n = level[d][std::min(i + j, level[d].size() - 1)];
+          g[j] = n; g[4 + j] = hm->parent[n]; g[8 + j] = hm->taxon_of[n]; g[12 + j] = 0;
+        }
+        hm->simg.insert(hm->simg.end(), g, g + 16);
+      }
+  }
   // ---- model checks
   const bool nh = model->nmodels > 0;
   const int NM = nh ? model->nmodels : 1;

@@ -122,23 +122,25 @@ template <int N>
 __device__ __forceinline__ void waitcnt_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 template <int S, int VL>
 __device__ __forceinline__ void wait_vm(int allowed) {
-  // what can have been issued after X: the next operator (R DMA rows, +1 with symbols), a workspace prefetch or a
-  // vector store (H instructions each).  Most frequent first.
+  // what can have been issued after X: the next operator (R DMA rows, +1 with symbols) and up to three workspace vectors
+  // (stores or loads, H instructions each).  Most frequent first.
   constexpr int R = MatStage<S>::ROWS, H = VL / 2;
-  static_assert(R + 1 + 2 * H < 64, "vmcnt is a 6-bit counter");
-  if (allowed < H && R + 1 < H) {
-    if (allowed >= R + 1) waitcnt_vm<R + 1>();
+  static_assert(R + 1 + 3 * H < 64, "vmcnt is a 6-bit counter");
+  if (allowed <= R + 1) {
+    if (allowed == R + 1) waitcnt_vm<R + 1>();
     else if (allowed == R) waitcnt_vm<R>();
     else waitcnt_vm<0>();
-  } else if (allowed < R + H) {
-    if (allowed >= H) waitcnt_vm<H>();
-    else if (allowed >= R) waitcnt_vm<R>();
-    else waitcnt_vm<0>();
-  } else if (allowed < R + 2 * H) {
-    if (allowed >= R + 1 + H) waitcnt_vm<R + 1 + H>();
-    else waitcnt_vm<R + H>();
+  } else if (allowed < H + R) {
+    if (allowed >= H && H > R + 1) waitcnt_vm<H>();
+    else waitcnt_vm<R + 1>();
+  } else if (allowed < 2 * H + R) {
+    if (allowed >= H + R + 1) waitcnt_vm<H + R + 1>();
+    else waitcnt_vm<H + R>();
+  } else if (allowed < 3 * H + R) {
+    if (allowed >= 2 * H + R + 1) waitcnt_vm<2 * H + R + 1>();
+    else waitcnt_vm<2 * H + R>();
   } else {
-    waitcnt_vm<R + 2 * H>();
+    waitcnt_vm<3 * H + R>();
   }
 }
 
@@ -431,12 +433,24 @@ struct DevWalk {
   int lane, c, c_end;
   double pc;
   double Lg[FUSE];
-  int mi, fi, ld_cur, ld_next;
-  bool pend;
-  unsigned pf_seq;
+  int mi;
 
   __device__ __forceinline__ DevWalk(OpState& os_, const ConstModel& cm_) : os(os_), cm(cm_) {}
 
+  // The lane index as an opaque value: address arithmetic built on it is redone at every use (a few VALU instructions)
+  // instead of being hoisted out of the walk as a dozen loop-invariant 64-bit per-lane addresses, which the register
+  // allocator then spills -- and every reload of a spilled address is a scratch load whose vmcnt(0) wait drains the
+  // DMAs in flight.
+  __device__ __forceinline__ int vlane() const {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  }
+  // site of the lane inside the wave's block (see map_sites_wave)
+  __device__ __forceinline__ int vsidx() const {
+    const int l = vlane();
+    return NG == 4 ? l : (((l >> 5) << 4) | (l & 15));
+  }
   template <int I>
   __device__ __forceinline__ double (&reg())[VL] {
     if constexpr (I == 0) return R0;
@@ -446,11 +460,6 @@ struct DevWalk {
   }
   __device__ __forceinline__ void begin_pass() {
     mi = 0;
-    fi = 0;
-    ld_cur = cm.ldsched[0];
-    ld_next = cm.ldsched[1];
-    pend = false;
-    pf_seq = 0;
 #pragma unroll
     for (int g = 0; g < FUSE; ++g) Lg[g] = 0.0;
   }
@@ -473,7 +482,7 @@ struct DevWalk {
     const int emat = os.pre_mat, etx = os.pre_tx;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads of the other buffer are done
     mat_dma_l<S>((more ? mat_c : mat_after) + emat /* element offset, premultiplied on the host */,
-                 lds_stage + (os.par ^ 1u) * MatStage<S>::BYTES, lane);
+                 lds_stage + (os.par ^ 1u) * MatStage<S>::BYTES, vlane());
     unsigned issued = MatStage<S>::ROWS;
     if (etx >= 0 && (more || c + 1 < c_end)) {
       code_dma_l(gcodes + (size_t)etx * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);
@@ -498,7 +507,7 @@ struct DevWalk {
   __device__ __forceinline__ void mv(int, int) {
     unsigned nseq;
     const uint8_t* buf = op_begin(nseq);
-    { CMX_TIC(); matvec_stage<S, TR, NG>(buf, lane, reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1])); CMX_TOC(TM_MV); }
+    { CMX_TIC(); matvec_stage<S, TR, NG>(buf, vlane(), reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1])); CMX_TOC(TM_MV); }
     op_end(nseq);
   }
   template <int MODE, int SRC, int DST>
@@ -506,7 +515,8 @@ struct DevWalk {
     unsigned nseq;
     const uint8_t* buf = op_begin(nseq);
     CMX_TIC();
-    const double tot = leaf_apply<S, MODE, NG>(buf, cslot + os.par * kCodeSlotBytes + 4 * (lane & 15), lane, reg<SRC>(), reg<DST>());
+    const int vl = vlane();
+    const double tot = leaf_apply<S, MODE, NG>(buf, cslot + os.par * kCodeSlotBytes + 4 * (vl & 15), vl, reg<SRC>(), reg<DST>());
     asm volatile("" :: "v"(tot), "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1]));
     CMX_TOC(TM_LEAF);
     op_end(nseq);
@@ -516,42 +526,24 @@ struct DevWalk {
   template <int SRC, int D> __device__ __forceinline__ void lmul(int, int) { (void)leaf<LEAF_MUL, SRC, D>(); }
   template <int SRC> __device__ __forceinline__ void ldot(int, int, int row) {
     const double tot = leaf<LEAF_DOT, SRC, SRC>();
-    pcnt[(size_t)row * kSites] = pc * tot;
+    pcnt[(size_t)row * kSites + vsidx()] = pc * tot;
   }
-  __device__ __forceinline__ const double* ws_addr(int w) const {
-    return ((w & 0x40000000) ? wsU : wsM) + (size_t)(w & 0x00ffffff) * VL * kWave + 2 * lane;
-  }
-  // workspace vector -> register: take the vector prefetched into LDS (or request it now, through the same LDS path -- a
-  // plain global load here would be a compiler-visible VMEM load whose pending destination registers make hipcc put
-  // conservative vmcnt waits, draining the DMAs in flight, into every following op), then start the LDS-DMA of the next
-  // schedule entry if the host marked it prefetchable (bit 31: its producing store precedes this point).  The DMA needs
-  // no VGPRs and overlaps the ops that follow; lgkmcnt(0) orders it behind the LDS read.
+  // workspace vector -> register: plain global loads straight into the destination register, which the walk has
+  // declared dead (kill) long before -- in the outside pass the two sibling messages of a node are requested before the
+  // first product and first read after it, so their latency hides behind ~100 MFMAs without a landing buffer.  The
+  // loads are compiler-visible (hipcc waits for them before the first use); they are counted in vs like every VMEM
+  // instruction this code issues so that the counted waits of the operator stream let them stay in flight.
   template <int D>
-  __device__ __forceinline__ void load(int, int) {
+  __device__ __forceinline__ void load(int arr, int slot) {
     CMX_TIC();
-    if (!pend) {
-      prefetch_vec_lds<VL>(ws_addr(ld_cur), pfl);
-      os.vs += VL / 2;
-      pf_seq = os.vs;
-    }
-    wait_vm<S, VL>((int)(os.vs - pf_seq));
-    read_vec_lds<VL>(pfl, lane, reg<D>());
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    ++fi;
-    ld_cur = ld_next;                 // entry fi, loaded one load early
-    ld_next = cm.ldsched[fi + 1];     // the schedule ends with two zero entries: no bounds test
-    pend = ld_cur < 0;
-    if (pend) {
-      prefetch_vec_lds<VL>(ws_addr(ld_cur), pfl);
-      os.vs += VL / 2;
-      pf_seq = os.vs;
-    }
+    load_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vlane(), reg<D>());
+    os.vs += VL / 2;
     CMX_TOC(TM_LOAD);
   }
   template <int SRC>
   __device__ __forceinline__ void store(int arr, int slot) {
     CMX_TIC();
-    store_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * lane, reg<SRC>());
+    store_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vlane(), reg<SRC>());
     os.vs += VL / 2;
     CMX_TOC(TM_STORE);
   }
@@ -570,7 +562,7 @@ struct DevWalk {
   template <int D> __device__ __forceinline__ void setpi() {
 #pragma unroll
     for (int sb = 0; sb < S / 4; ++sb) {
-      const double pv = pi[(4 * sb + (lane >> 4)) % (S / FUSE)];
+      const double pv = pi[(4 * sb + (vlane() >> 4)) % (S / FUSE)];
 #pragma unroll
       for (int g = 0; g < NG; ++g) reg<D>()[sb * NG + g] = pv;
     }
@@ -583,13 +575,13 @@ struct DevWalk {
       for (int g = 0; g < NG; ++g) p_[g] = 0.0;
 #pragma unroll
       for (int sb = 0; sb < S / 4; ++sb) {
-        const double pv = pi[4 * sb + (lane >> 4)];
+        const double pv = pi[4 * sb + (vlane() >> 4)];
 #pragma unroll
         for (int g = 0; g < NG; ++g) p_[g] = __builtin_fma(pv, reg<SRC>()[sb * NG + g], p_[g]);
       }
       Lg[0] = reduce_sites<NG>(p_);
     } else {   // one 4-state tile per fused class
-      const double pv = pi[lane >> 4];
+      const double pv = pi[vlane() >> 4];
 #pragma unroll
       for (int sb = 0; sb < FUSE; ++sb) {
         double p_[NG];
@@ -607,7 +599,7 @@ struct DevWalk {
     for (int sb = 0; sb < S / 4; ++sb)
 #pragma unroll
       for (int g = 0; g < NG; ++g) p_[g] = __builtin_fma(R3[sb * NG + g] * R1[sb * NG + g], R2[sb * NG + g], p_[g]);
-    pcnt[(size_t)row * kSites] = pc * reduce_sites<NG>(p_);
+    pcnt[(size_t)row * kSites + vsidx()] = pc * reduce_sites<NG>(p_);
   }
 };
 
@@ -664,7 +656,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     const double pc = FUSE > 1 ? 1.0 : cm.probs[c];  // fused: the class probabilities are folded into the count operators
     be.pc = pc;
     be.c = c;
-    be.pcnt = part + (size_t)c * m.B * K * kSites + sidx;
+    be.pcnt = part + (size_t)c * m.B * K * kSites;   // wave-uniform; the lane's site is added at each use
     be.begin_pass();
     walk_pass(be, m.NV, K);
     if constexpr (FUSE == 1) {
@@ -694,23 +686,36 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     return;
   }
   // ---------------- sum the classes in class order, divide by the site likelihood, norm (computeNormForSite)
-  // Rows r = b*K + k are taken eight at a time so that eight independent loads are in flight per class; the sums run
-  // in the same order as a plain (b, k, c) loop nest.
+  // Rows r = b*K + k are taken sixteen at a time and classes four at a time so that 64 independent loads are in flight
+  // (this phase is pure L2 latency); the sums run in the same order as a plain (b, k, c) loop nest.
   CMX_TIC();
   double nrm = 0.0, tot = 0.0;
   const int BK = m.B * K;
   int kk = 0;  // r % K
-  for (int r0 = 0; r0 < BK; r0 += 8) {
-    double v[8];
+  constexpr int RC = 16;
+  for (int r0 = 0; r0 < BK; r0 += RC) {
+    double v[RC];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = 0.0;
-    for (int c = 0; c < C; ++c) {
+    for (int u = 0; u < RC; ++u) v[u] = 0.0;
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+      double t[4][RC];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double* pp = part + ((size_t)(c + q) * BK + r0) * kSites + sidx;
+#pragma unroll
+        for (int u = 0; u < RC; ++u) t[q][u] = pp[(size_t)(r0 + u < BK ? u : 0) * kSites];
+      }
+#pragma unroll
+      for (int u = 0; u < RC; ++u) v[u] = (((v[u] + t[0][u]) + t[1][u]) + t[2][u]) + t[3][u];
+    }
+    for (; c < C; ++c) {
       const double* pp = part + ((size_t)c * BK + r0) * kSites + sidx;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] += pp[(size_t)(r0 + u < BK ? u : 0) * kSites];
+      for (int u = 0; u < RC; ++u) v[u] += pp[(size_t)(r0 + u < BK ? u : 0) * kSites];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < RC; ++u) {
       if (r0 + u < BK) {
         const double q = v[u] / Lsum;
         cnt[(size_t)(r0 + u) * kSites + sidx] = q;
@@ -740,12 +745,14 @@ __device__ __forceinline__ double pair_stat_strided(int kind, double param, int 
       const double* u1 = kind == 6 ? mv : nullptr;
       const double* u2 = kind == 6 ? mv + B : nullptr;
       double m1 = 0, m2 = 0;
+#pragma unroll 8
       for (int b = 0; b < B; ++b) {
         m1 += c1[(size_t)b * K * ld1] - (u1 ? u1[b] : 0.0);
         m2 += c2[(size_t)b * K * ld2] - (u2 ? u2[b] : 0.0);
       }
       m1 /= B; m2 /= B;
       double sxy = 0, sxx = 0, syy = 0;
+#pragma unroll 8
       for (int b = 0; b < B; ++b) {
         const double dx = c1[(size_t)b * K * ld1] - (u1 ? u1[b] : 0.0) - m1, dy = c2[(size_t)b * K * ld2] - (u2 ? u2[b] : 0.0) - m2;
         sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
@@ -816,7 +823,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   const ConstModel cm(m);
   const int lane = threadIdx.x & (kWave - 1);
   const int sidx = NG == 4 ? lane : (((lane >> 5) << 4) | (lane & 15));   // site of this lane in the wave's block
-  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  // wave index through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform and would keep every
+  // per-wave base pointer below as a per-lane 64-bit VGPR pair (spilled, and reloaded from scratch in the hot loop)
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int nwaves = gridDim.x * kWavesPerBlock;
   double* wsD = a.ws.D + (size_t)wave * m.NIW * VL * kWave;
   double* wsU = a.ws.U + (size_t)wave * m.NIW * VL * kWave;
@@ -824,7 +834,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   double* cnt1 = cnt0 + (size_t)m.B * m.K * kSites;
   double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kSites;
   // LDS per wave: workspace prefetch buffer (S*64*8 B), two operator stage buffers, two symbol slots
-  const int lds_off = (int)(threadIdx.x >> 6) * map_lds_per_wave<S>();
+  const int lds_off = wib * map_lds_per_wave<S>();
   const size_t nblocks = (a.nsites + kSites - 1) / kSites;
   // request the first op's operator (class 0, entry 0); every op then requests the next one
   OpState os;
@@ -903,15 +913,42 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
           uint8_t* stg = a.ws.st + (size_t)wave * m.nn * kSites + sidx;
           const uint8_t x0 = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S0);
           if (st_lds) stl[(size_t)m.root * kSites] = x0; else stg[(size_t)m.root * kSites] = x0;
-          for (int node = m.nn - 2; node >= 0; --node) {
-            const int pn = cm.parent[node];
-            const int x = st_lds ? stl[(size_t)pn * kSites] : stg[(size_t)pn * kSites];
-            const double u = philox_uniform(a.seed, g, 2u + (uint32_t)node);
-            const size_t row = ((size_t)c * m.nn + node) * S0 + x;
-            const int y = draw_guided(u, m.CP + row * S0, m.CPG + row * 32, S0);
-            if (st_lds) stl[(size_t)node * kSites] = (uint8_t)y; else stg[(size_t)node * kSites] = (uint8_t)y;
-            const int tx = cm.taxon_of[node];
-            if (tx >= 0) al[(size_t)tx * kSites] = (uint8_t)y;
+          // Nodes are drawn level by level, four at a time (m.simg: host-built groups of nodes of equal depth, padded by
+          // repetition): the draws of a group do not depend on each other, so their table reads -- lane-divergent
+          // gathers, two dependent round trips to L2 per node -- overlap instead of forming one serial chain of 2(nn-1).
+          for (int gi = 0; gi < m.nsimg; ++gi) {
+            cmx_i16 q;   // [0..3] node, [4..7] its parent, [8..11] its taxon or -1
+            sload_rec((cmx_cint)m.simg + gi * 16, q);
+            int x[4], idx[4];
+            double u[4];
+            size_t row[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) x[jj] = st_lds ? stl[(size_t)q[4 + jj] * kSites] : stg[(size_t)q[4 + jj] * kSites];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) u[jj] = philox_uniform(a.seed, g, 2u + (uint32_t)q[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              row[jj] = ((size_t)c * m.nn + q[jj]) * S0 + x[jj];
+              idx[jj] = m.CPG[row[jj] * 32 + (int)(u[jj] * 32.0)];
+            }
+            bool any;
+            do {   // the same index as draw_guided, the four searches advancing together
+              double cv[4];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) cv[jj] = m.CP[row[jj] * S0 + idx[jj]];
+              any = false;
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const bool adv = idx[jj] < S0 - 1 && u[jj] >= cv[jj];
+                idx[jj] += adv ? 1 : 0;
+                any |= adv;
+              }
+            } while (any);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              if (st_lds) stl[(size_t)q[jj] * kSites] = (uint8_t)idx[jj]; else stg[(size_t)q[jj] * kSites] = (uint8_t)idx[jj];
+              if (q[8 + jj] >= 0) al[(size_t)q[8 + jj] * kSites] = (uint8_t)idx[jj];
+            }
           }
           CMX_TOC(TM_SIM);
         }

@@ -163,7 +163,8 @@ CMX_HD void walk_pass(BE& be, int NV, int K) {
       be.template kill<0>();
       if (!(flags & FLAG_ROOT)) be.template load<0>(WS_U, r[REC_SLOT]);
     }
-    // ---- messages of the children: M_b -> R2, M_a -> R1
+    // ---- messages of the children: M_b -> R2, M_a -> R1 (stored ones: the device only ISSUES the loads here; they are
+    // first read by the count below, after the first product)
     walk_child_message<1>(be, r);
     walk_child_message<0>(be, r);
     // ---- count of branch f and its outside message below the branch: W = J^T U (K of them), Up = P^T U
