@@ -61,10 +61,13 @@ def build_inputs(w):
     return parent, blen, lot, mdl, Bk, clamp
 
 
-def flops_per_site(B, C, S, K, nn, ni_nonroot, nleaves):
-    algorithmic = 7.0 * B * C * S * S                      # F_map = 7 B C S^2 (K = 1)
-    executed = C * (ni_nonroot * 2.0 * S * S * (3 + K)     # inside, recomputed sibling message, J.D, outside
-                    + nleaves * 2.0 * S * K + nn * 3.0 * S)
+def flops_per_site(info, B, C, S, K):
+    """algorithmic: SURVEY 8(d), F_map = 7 B C S^2 (K = 1) -- every branch, leaf branches included, priced as dense
+    products.  executed: what the kernel issues on the matrix cores (info = cmx_get_info: products of one device-class
+    pass over device states; leaf branches are row gathers, sibling messages are stored, not recomputed)."""
+    algorithmic = 7.0 * B * C * S * S
+    dS, dC = info["device_states"], info["device_classes"]
+    executed = dC * (info["products_per_pass"] * 2.0 * dS * dS + info["leaf_ops_per_pass"] * 2.0 * dS)
     return algorithmic, executed
 
 
@@ -274,10 +277,7 @@ def main():
 
     # roofline of the dominant kernel (map_kernel<S, null>): HIP events on the launch stream
     null_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    nn = len(parent)
-    nleaves = len(lot)
-    ni_nonroot = nn - nleaves - 1
-    alg, exe = flops_per_site(eng.B, eng.C, eng.S, eng.K, nn, ni_nonroot, nleaves)
+    alg, exe = flops_per_site(info, eng.B, eng.C, eng.S, eng.K)
     sites_per_launch = 2 * n_local
     achieved = sites_per_launch * alg / (null_ms * 1e-3) / 1e12
     ach_exe = sites_per_launch * exe / (null_ms * 1e-3) / 1e12
@@ -306,7 +306,9 @@ def main():
                            null_pairs_total=nrep_total * ram, null_pairs_this_gpu=n_local,
                            sites_mapped_per_step_this_gpu=w["nsites"] + 2 * n_local,
                            parallelism=(f"null replicates sharded x{world}, one RCCL all-gather" if world > 1 else "single GPU"),
-                           cu_count=info["cu_count"], mapping_waves=info["waves"]),
+                           cu_count=info["cu_count"], mapping_waves=info["waves"],
+                           walk_per_pass=dict(products=info["products_per_pass"], leaf_ops=info["leaf_ops_per_pass"],
+                                              ws_loads=info["ws_loads_per_pass"], ws_stores=info["ws_stores_per_pass"])),
                roofline=roofline)
 
     # same step, host memory to host memory (BASELINE.md section 3 counting rule; never `value`): the alignment is

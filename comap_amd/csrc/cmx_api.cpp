@@ -251,6 +251,9 @@ cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info) {
   info->nbranches = ctx->hm.B; info->ntaxa = ctx->hm.T; info->ninternal = ctx->hm.NI;
   info->device = ctx->device; info->cu_count = ctx->cu_count; info->waves = ctx->waves;
   info->workspace_bytes = ctx->ws_bytes;
+  info->device_states = ctx->hm.dS; info->device_classes = ctx->hm.dC;
+  info->products_per_pass = (int32_t)ctx->hm.n_products; info->leaf_ops_per_pass = (int32_t)ctx->hm.n_leaf_ops;
+  info->ws_loads_per_pass = (int32_t)ctx->hm.n_loads; info->ws_stores_per_pass = (int32_t)ctx->hm.n_stores;
   return CMX_OK;
 }
 

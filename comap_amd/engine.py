@@ -104,7 +104,9 @@ PAIR_ROW = np.dtype([("i", np.int32), ("j", np.int32), ("stat", np.float64), ("r
 class _Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("nstates", "nclasses", "ntypes", "nnodes", "nbranches", "ntaxa",
                                                "ninternal", "device", "cu_count", "waves")] + \
-               [("workspace_bytes", ctypes.c_size_t)]
+               [("workspace_bytes", ctypes.c_size_t)] + \
+               [(n, ctypes.c_int32) for n in ("device_states", "device_classes", "products_per_pass", "leaf_ops_per_pass",
+                                              "ws_loads_per_pass", "ws_stores_per_pass")]
 
 
 _lib = None

@@ -98,6 +98,11 @@ typedef struct {
   int32_t nstates, nclasses, ntypes, nnodes, nbranches, ntaxa, ninternal;
   int32_t device, cu_count, waves; /* waves = resident mapping waves (workspace is sized for them) */
   size_t workspace_bytes;
+  /* the mapping kernel's walk of ONE rate-class pass over one block of 64 sites (device classes: nucleotide models with
+   * >= 4 classes run `device_classes` = ceil(C / 4 or 5) fused passes): matrix products issued, leaf gathers, S-vectors
+   * loaded from / stored to the per-wave workspace -- what roofline accounting needs */
+  int32_t device_states, device_classes;
+  int32_t products_per_pass, leaf_ops_per_pass, ws_loads_per_pass, ws_stores_per_pass;
 } cmx_info;
 
 const char* cmx_version(void);

@@ -4,7 +4,7 @@ TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-mica --no-host $@"
 i=20
 for PMC in "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_INSTS_VALU" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" ; do
