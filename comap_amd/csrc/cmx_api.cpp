@@ -39,6 +39,7 @@ struct cmx_ctx {
   std::vector<void*> model_allocs;
   std::map<std::string, DevBuf> scratch;
   uint32_t* d_default_masks = nullptr;
+  unsigned stat_mean_turn = 0;
   bool leaf_rows_custom = false;   // the leaf operators' ambiguity rows were built from a caller's mask table
   mutable std::string err;
 };
@@ -420,14 +421,18 @@ static cmx_status check_kind(cmx_ctx* ctx, int kind) {
   return CMX_OK;
 }
 // CorrectedCorrelation: params = the two mean vectors [2][B] in host memory -> device copy (null for other kinds)
-static cmx_status stat_mean_vectors(cmx_ctx* ctx, int kind, const double* params, const double** d_mean) {
+// CorrectedCorrelation's two mean vectors on the device for an asynchronous call: copied on the CALLER's stream (a
+// blocking copy on the null stream does not order against torch's non-blocking streams) into one of eight rotating
+// buffers, so that a later call cannot overwrite vectors a kernel still in flight is reading.
+static cmx_status stat_mean_vectors(cmx_ctx* ctx, int kind, const double* params, const double** d_mean, void* stream) {
   *d_mean = nullptr;
   if (kind != CMX_STAT_CORRECTED_CORRELATION) return CMX_OK;
   if (!params) return fail(ctx, CMX_ERR_INVALID, "CorrectedCorrelation needs its mean vectors: params = [2][nbranches]");
   void* p = nullptr;
-  cmx_status s = scratch(ctx, "stat_mean", sizeof(double) * 2 * ctx->hm.B, &p);
+  const std::string name = "stat_mean" + std::to_string(ctx->stat_mean_turn++ & 7);
+  cmx_status s = scratch(ctx, name.c_str(), sizeof(double) * 2 * ctx->hm.B, &p);
   if (s != CMX_OK) return s;
-  HIP_TRY(ctx, hipMemcpy(p, params, sizeof(double) * 2 * ctx->hm.B, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpyAsync(p, params, sizeof(double) * 2 * ctx->hm.B, hipMemcpyHostToDevice, (hipStream_t)stream));
   *d_mean = static_cast<const double*>(p);
   return CMX_OK;
 }
@@ -448,7 +453,7 @@ cmx_status cmx_pair_stats_dev(cmx_ctx* ctx, int kind, const double* params, cons
   hipStream_t st = (hipStream_t)stream;
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
   const double* d_mean = nullptr;
-  if ((s = stat_mean_vectors(ctx, kind, params, &d_mean)) != CMX_OK) return s;
+  if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;
   const int gk = kind == CMX_STAT_CORRECTED_CORRELATION ? CMX_STAT_CORRELATION : kind;   // same Gram + epilogue
   const int Bp = (h.B + 3) / 4 * 4;
   const size_t ldx1 = (n1 + 15) / 16 * 16, ldx2 = (n2 + 15) / 16 * 16;
@@ -516,7 +521,7 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   a.nsites = (rep_end - rep_begin) * rep_ram;
   a.stat_kind = kind;
   a.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
-  if ((s = stat_mean_vectors(ctx, kind, params, &a.stat_mean)) != CMX_OK) return s;
+  if ((s = stat_mean_vectors(ctx, kind, params, &a.stat_mean, stream)) != CMX_OK) return s;
   a.seed = seed; a.rep_begin = rep_begin; a.rep_ram = rep_ram; a.supplied = d_supplied;
   a.null_stat = d_stat; a.null_rcmin = d_rcmin; a.null_prmin = d_prmin; a.null_nmin = d_nmin;
   const size_t ks = (size_t)map_sites_per_wave(ctx->hm.dS);
@@ -604,7 +609,7 @@ cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const doub
   }
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
   const double* d_mean = nullptr;
-  if ((s = stat_mean_vectors(ctx1, kind, params, &d_mean)) != CMX_OK) return s;
+  if ((s = stat_mean_vectors(ctx1, kind, params, &d_mean, stream)) != CMX_OK) return s;
   HIP_TRY(ctx1, launch_pair_diag(kind, param, ctx1->hm.B, ctx1->hm.K, cnt[0], n, cnt[1], n, n, rc[0], rc[1], pr[0], pr[1],
                                  nm[0], nm[1], d_stat, d_rcmin, d_prmin, d_nmin, d_mean, st));
   return CMX_OK;
@@ -908,7 +913,7 @@ cmx_status cmx_group_stats_dev(cmx_ctx* ctx, int kind, const double* params, con
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
   const double* d_mean = nullptr;
-  if ((s = stat_mean_vectors(ctx, kind, params, &d_mean)) != CMX_OK) return s;
+  if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;
   HIP_TRY(ctx, launch_group_stats(kind, param, ctx->hm.B, ctx->hm.K, d_counts, ldc, d_offsets, d_sites, ngroups, d_out, d_mean,
                                   (hipStream_t)stream));
   return CMX_OK;

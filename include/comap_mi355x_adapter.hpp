@@ -143,10 +143,19 @@ class Engine {
     nbTypes_ = static_cast<size_t>(cm.ntypes);
     nbTaxa_ = static_cast<size_t>(ct.ntaxa);
   }
+  // model-free context: pair statistics / distances / Mica column MI only (cmx_ctx_create(NULL, NULL, ...))
+  explicit Engine(int device = 0) : S_(0) {
+    if (cmx_ctx_create(nullptr, nullptr, device, &ctx_) != CMX_OK) throw Exception(cmx_last_error(nullptr));
+  }
   ~Engine() { cmx_ctx_destroy(ctx_); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
 
+  // nijt.average / nijt.joint (CoETools.cpp:393-406).  The engine maps with average = joint = yes, the reference's
+  // defaults; the other three variants are "for benchmarking only" there and are refused here rather than approximated.
+  void setMappingOptions(bool average, bool joint) {
+    if (!average || !joint) throw Exception("nijt.average=no / nijt.joint=no are not offered by the MI355X engine");
+  }
   cmx_ctx* ctx() const { return ctx_; }
   size_t getNumberOfBranches() const { return nbBranches_; }
   size_t getNumberOfSubstitutionTypes() const { return nbTypes_; }
@@ -172,6 +181,7 @@ class ProbabilisticSubstitutionMapping {
   size_t getNumberOfBranches() const { return b_; }
   size_t getNumberOfSubstitutionTypes() const { return k_; }
   double operator()(size_t branch, size_t site, size_t type) const { return counts_[(site * b_ + branch) * k_ + type]; }
+  double& operator()(size_t branch, size_t site, size_t type) { return counts_[(site * b_ + branch) * k_ + type]; }
   VVdouble operator[](size_t site) const {
     VVdouble v(b_, Vdouble(k_));
     for (size_t b = 0; b < b_; ++b)

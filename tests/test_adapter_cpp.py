@@ -100,3 +100,22 @@ def test_reference_call_sequence_matches_oracle(adapter_exe, tmp_path):
     rel_close(rows["nm"], np.minimum(o["norm"][iu[0]], o["norm"][iu[1]]), 1e-6)
     # p-values: same sorted null to 1e-6 => counts may differ only where a null value ties the statistic to 1e-6
     assert np.mean(rows["pv"] == pv[iu]) > 0.99
+
+
+def test_bpp_seam_header_guard_and_signatures(tmp_path):
+    """include/comap_mi355x_bpp.hpp carries the reference's exact Bio++-typed seams (CoETools.h:317-399,
+    AnalysisTools.h:198-275).  Bio++ is absent from this image: the header must then compile to nothing but the adapter,
+    and its guarded block must declare every seam with the reference's parameter list."""
+    src = tmp_path / "tu.cpp"
+    src.write_text('#include "comap_mi355x_bpp.hpp"\n#ifdef CMX_HAVE_BPP\n#error "Bio++ unexpectedly present"\n#endif\n'
+                   'int main() { cmx::Domain d(0., 1., 4); return d.getIndex(0.3) == 1 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    text = open(os.path.join(ROOT, "include", "comap_mi355x_bpp.hpp")).read()
+    flat = " ".join(text.split())
+    for sig in [
+        "getVectors( std::shared_ptr<const ::bpp::DRTreeLikelihoodInterface> drtl, std::shared_ptr<::bpp::SubstitutionCountInterface> substitutionCount, const ::bpp::SiteContainerInterface& completeSites, std::map<std::string, std::string>& params, const std::string& suffix = \"\")",
+        "getNullDistributionIntraDR(std::shared_ptr<::bpp::DRTreeLikelihoodInterface> drtl, const ::bpp::SequenceSimulatorInterface& /*seqSim*/, std::shared_ptr<::bpp::SubstitutionCountInterface> nijt, const ::Statistic& statistic, std::ostream* out, ::bpp::VVdouble* simstats, const ::Domain* rateDomain, size_t repCPU, size_t repRAM, bool average, bool joint, bool verbose = true)",
+        "computeIntraStats(const ::bpp::DRTreeLikelihoodInterface& tl, const ::bpp::SequenceSimulatorInterface& /*seqSim*/, const ::bpp::SiteContainerInterface& completeSites, ::bpp::LegacyProbabilisticSubstitutionMapping& mapping, std::shared_ptr<::bpp::SubstitutionCountInterface> nijt, const ::Statistic& statistic, bool computeNull, std::map<std::string, std::string>& params)",
+    ]:
+        assert sig in flat, sig
+    assert "__has_include(<Bpp/Phyl/Legacy/Likelihood/DRTreeLikelihood.h>)" in text
