@@ -640,15 +640,11 @@ cmx_status cmx_null_inter(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* 
 }
 
 // ------------------------------------------------------------------------------------------------ p-values
-cmx_status cmx_intra_pvalues_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, const double* d_norms, size_t n,
-                                 int nclasses, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
-                                 double* d_pvalue, int32_t* d_nsim, void* stream) {
-  if (!ctx) return CMX_ERR_INVALID;
-  if (!d_stat || !d_norms || !d_pvalue || !d_nsim || n == 0 || ldo < n || nclasses < 1 || nclasses > 64 ||
-      (nnull > 0 && (!d_null_stat || !d_null_nmin)) || nnull > 0xfffffff0ull)
-    return fail(ctx, CMX_ERR_INVALID, "cmx_intra_pvalues: bad arguments (nclasses must be in 1..64)");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = (hipStream_t)stream;
+// The null distribution as the p-value kernel wants it (CoETools.cpp:636-652): Domain(0, max norm, nclasses) classes of
+// the null pairs' min norms, every class sorted ascending, classes laid out one after the other; hist = class sizes.
+static cmx_status prepare_null(cmx_ctx* ctx, const double* d_norms, size_t n, int nclasses, const double* d_null_stat,
+                               const double* d_null_nmin, size_t nnull, hipStream_t st, double** maxnorm_out, double** sorted_out,
+                               uint32_t** hist_out) {
   cmx_status s;
   double *maxnorm, *sa, *sb;
   uint32_t *ca, *cb, *hist;
@@ -669,6 +665,23 @@ cmx_status cmx_intra_pvalues_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo,
     if ((s = scratch(ctx, "pv_sorttmp", tmp_bytes, &tmp)) != CMX_OK) return s;
     HIP_TRY(ctx, sort_null_by_class(tmp, tmp_bytes, sa, sb, ca, cb, nnull, st));
   }
+  *maxnorm_out = maxnorm; *sorted_out = sa; *hist_out = hist;
+  return CMX_OK;
+}
+
+cmx_status cmx_intra_pvalues_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, const double* d_norms, size_t n,
+                                 int nclasses, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
+                                 double* d_pvalue, int32_t* d_nsim, void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!d_stat || !d_norms || !d_pvalue || !d_nsim || n == 0 || ldo < n || nclasses < 1 || nclasses > 64 ||
+      (nnull > 0 && (!d_null_stat || !d_null_nmin)) || nnull > 0xfffffff0ull)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_intra_pvalues: bad arguments (nclasses must be in 1..64)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  cmx_status s;
+  double *maxnorm, *sa;
+  uint32_t* hist;
+  if ((s = prepare_null(ctx, d_norms, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &maxnorm, &sa, &hist)) != CMX_OK) return s;
   HIP_TRY(ctx, launch_pvalues(d_stat, ldo, d_norms, n, maxnorm, nclasses, sa, hist, d_pvalue, d_nsim, st));
   return CMX_OK;
 }
@@ -724,6 +737,76 @@ cmx_status cmx_intra_rows_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, co
   if ((s = scratch(ctx, "rows_scan", tmp_bytes ? tmp_bytes : 16, &tmp)) != CMX_OK) return s;
   HIP_TRY(ctx, launch_pair_rows(d_stat, ldo, d_pvalue, d_nsim, n, d_rate_class, d_post_rate, d_norm, f, rowcount, tmp,
                                 tmp_bytes, d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), (hipStream_t)stream));
+  return CMX_OK;
+}
+
+// CoETools::computeIntraStats' pair loop (CoETools.cpp:672-724) for the rows [row_begin, row_end) of the upper triangle,
+// a block of rows at a time: Gram block on the matrix cores -> p-values -> filters -> compaction.  No N x N matrix exists;
+// the dense scratch is one row block (<= 256 MiB).  Ranks of a multi-GPU job call it with disjoint row ranges: rows come
+// out in the reference's (i, j) order, so the ranks' outputs concatenate to the single-GPU output.
+cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts, size_t n, size_t ldc,
+                                    const int32_t* d_rate_class, const double* d_post_rate, const double* d_norm,
+                                    const double* d_null_stat, const double* d_null_nmin, size_t nnull, int nclasses,
+                                    const cmx_pair_filters* filters, size_t row_begin, size_t row_end, cmx_pair_row* d_rows,
+                                    size_t capacity, uint64_t* d_count, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
+  const bool with_null = d_null_stat != nullptr;
+  if (!d_counts || n == 0 || ldc < n || !d_rate_class || !d_post_rate || !d_norm || !d_count || (capacity && !d_rows) ||
+      n > 0x7fffffffull || row_begin > row_end || row_end > n || (with_null && (!d_null_nmin || nclasses < 1 || nclasses > 64)) ||
+      nnull > 0xfffffff0ull)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_intra_rows_range: bad arguments");
+  const HostModel& h = ctx->hm;
+  if (h.B < 2) return fail(ctx, CMX_ERR_INVALID, "cmx_intra_rows_range: need at least two branches");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  cmx_pair_filters f{0, -1, 0.0, -1.0, 0.0};
+  if (filters) f = *filters;
+  HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(uint64_t), st));
+  if (row_begin == row_end) return CMX_OK;
+  // operand of the Gram kernel for all n sites (both sides of every pair)
+  const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  const double* d_mean = nullptr;
+  if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;
+  const int gk = kind == CMX_STAT_CORRECTED_CORRELATION ? CMX_STAT_CORRELATION : kind;
+  const int Bp = (h.B + 3) / 4 * 4;
+  const size_t ldx = (n + 15) / 16 * 16;
+  double *X, *sv, *rv;
+  if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx, (void**)&X)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pair_s1", sizeof(double) * n, (void**)&sv)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pair_r1", sizeof(double) * n, (void**)&rv)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts, n, ldc, h.B, h.K, X, ldx, Bp, sv, rv, d_mean, st));
+  double *maxnorm = nullptr, *sorted = nullptr;
+  uint32_t* hist = nullptr;
+  if (with_null && (s = prepare_null(ctx, d_norm, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &maxnorm, &sorted, &hist)) != CMX_OK)
+    return s;
+  // row blocks: a multiple of 64 rows (Gram tiles), dense scratch (f64 statistic + f64 p-value + i32 Nsim) <= 256 MiB
+  size_t RB = ((size_t)256 << 20) / (20 * n) / 64 * 64;
+  RB = std::max<size_t>(64, std::min<size_t>(RB, (row_end - row_begin + 63) / 64 * 64));
+  double *blk_stat, *blk_pv = nullptr;
+  int32_t* blk_ns = nullptr;
+  unsigned long long* rowcount;
+  if ((s = scratch(ctx, "blk_stat", sizeof(double) * RB * n, (void**)&blk_stat)) != CMX_OK) return s;
+  if (with_null) {
+    if ((s = scratch(ctx, "blk_pv", sizeof(double) * RB * n, (void**)&blk_pv)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "blk_ns", sizeof(int32_t) * RB * n, (void**)&blk_ns)) != CMX_OK) return s;
+  }
+  if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (RB + 1), (void**)&rowcount)) != CMX_OK) return s;
+  size_t tmp_bytes = 0;
+  HIP_TRY(ctx, launch_pair_rows(blk_stat, n, blk_pv, blk_ns, n, d_rate_class, d_post_rate, d_norm, f, rowcount, nullptr, tmp_bytes,
+                                d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), st, 0, RB));
+  void* tmp = nullptr;
+  if ((s = scratch(ctx, "rows_scan", tmp_bytes ? tmp_bytes : 16, &tmp)) != CMX_OK) return s;
+  for (size_t i0 = row_begin; i0 < row_end; i0 += RB) {
+    const size_t rb = std::min(RB, row_end - i0);
+    if (gk == CMX_STAT_EUCLIDIAN_DISTANCE) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_intra_rows_range: EuclidianDistance is a distance, not a statistic");
+    HIP_TRY(ctx, launch_pair_gram(gk, h.B, Bp, X + i0, sv + i0, rv + i0, rb, ldx, X, sv, rv, n, ldx, 2, blk_stat, n, st, 1, 0, 0, 0, i0));
+    if (with_null) HIP_TRY(ctx, launch_pvalues(blk_stat, n, d_norm, n, maxnorm, nclasses, sorted, hist, blk_pv, blk_ns, st, i0, rb));
+    HIP_TRY(ctx, launch_pair_rows(blk_stat, n, blk_pv, blk_ns, n, d_rate_class, d_post_rate, d_norm, f, rowcount, tmp, tmp_bytes,
+                                  d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), st, i0, rb,
+                                  reinterpret_cast<unsigned long long*>(d_count)));
+  }
   return CMX_OK;
 }
 

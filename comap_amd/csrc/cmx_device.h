@@ -142,19 +142,20 @@ hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size
 hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const double* d_s1, const double* d_r1,
                             size_t n1, size_t ldx1, const double* d_X2, const double* d_s2, const double* d_r2,
                             size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream,
-                            size_t nblk = 1, size_t zsite = 0, size_t zout = 0, size_t zx = 0);
+                            size_t nblk = 1, size_t zsite = 0, size_t zout = 0, size_t zx = 0, size_t irow0 = 0);
 hipError_t launch_max_reduce(const double* d_x, size_t n, double* d_out, hipStream_t stream);
 hipError_t launch_null_classify(const double* d_stat, const double* d_nmin, size_t nnull, const double* d_maxnorm,
                                 int nclasses, uint32_t* d_cls, uint32_t* d_hist, hipStream_t stream);
 hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norms, size_t n, const double* d_maxnorm,
                           int nclasses, const double* d_sorted, const uint32_t* d_hist, double* d_pvalue,
-                          int32_t* d_nsim, hipStream_t stream);
+                          int32_t* d_nsim, hipStream_t stream, size_t irow0 = 0, size_t nrows = 0);
 hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in, double* d_stat_tmp, uint32_t* d_cls_in,
                               uint32_t* d_cls_tmp, size_t n, hipStream_t stream);
 hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pvalue, const int32_t* d_nsim, size_t n,
                             const int32_t* d_rc, const double* d_pr, const double* d_norm, const cmx_pair_filters& f,
                             unsigned long long* d_rowcount /*[n + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
-                            size_t capacity, unsigned long long* d_count, hipStream_t stream);
+                            size_t capacity, unsigned long long* d_count, hipStream_t stream, size_t irow0 = 0, size_t nrows = 0,
+                            const unsigned long long* d_base = nullptr);
 hipError_t launch_mi_pairs(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t ld1, const uint8_t* d_aln2,
                            size_t ld2, const int64_t* d_idx1, const int64_t* d_idx2, size_t npairs, double* d_mi,
                            double* d_hj, hipStream_t stream);

@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(4 * kWave) void pair_gram_kernel(int kind, int B, i
                                                          size_t n1, size_t ldx1, const double* __restrict__ X2,
                                                          const double* __restrict__ s2, const double* __restrict__ r2,
                                                          size_t n2, size_t ldx2, int intra, double* __restrict__ out,
-                                                         size_t ldo, size_t zsite, size_t zout, size_t zx) {
+                                                         size_t ldo, size_t zsite, size_t zout, size_t zx, size_t irow0) {
   // blockIdx.z: independent blocks of sites (clustering null: one per replicate): per-site vectors side by side
   // (zsite apart), operands zx apart
   X1 += blockIdx.z * zx; s1 += blockIdx.z * zsite; r1 += blockIdx.z * zsite;
@@ -1308,8 +1308,10 @@ __global__ __launch_bounds__(4 * kWave) void pair_gram_kernel(int kind, int B, i
   const size_t i0 = ti * 64, j0 = tj * 64;
   if (j0 >= n2) return;
   const double nanv = __builtin_nan("");
-  if (intra == 2 && tj < ti) return;   // the caller fills the lower triangle itself (clustering: mirrored distances)
-  if (intra && tj < ti) {  // strictly below the diagonal: NaN fill (reference loop is j > i, CoETools.cpp:680)
+  // irow0: the rows are rows irow0 .. of the full matrix (row-block / multi-GPU processing); "below the diagonal" is
+  // then j <= irow0 + i.  A tile wholly below it is skipped (intra == 2: the caller never reads it) or NaN-filled.
+  if (intra == 2 && j0 + 63 < irow0 + i0) return;   // (clustering: mirrored distances; row blocks: only j > i is read)
+  if (intra && irow0 == 0 && tj < ti) {  // strictly below the diagonal: NaN fill (reference loop is j > i, CoETools.cpp:680)
     for (int r = 0; r < 64; ++r) {
       const size_t i = i0 + r, j = j0 + lane;
       if (i < n1 && j < n2) out[i * ldo + j] = nanv;
@@ -1373,7 +1375,7 @@ __global__ __launch_bounds__(4 * kWave) void pair_gram_kernel(int kind, int B, i
         const size_t j = j0 + 16 * q + li;
         if (j < n2) {
           double v = pair_epilogue(kind, B, acc[p][q][r], si, sjv[q], ri, rjv[q], fi, fj[q]);
-          if (intra && j <= i) v = nanv;
+          if (intra && j <= irow0 + i) v = nanv;
           out[i * ldo + j] = v;
         }
       }
@@ -1421,7 +1423,7 @@ __global__ __launch_bounds__(256) void pair_euclid_kernel(int B, const double* _
 hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const double* d_s1, const double* d_r1,
                             size_t n1, size_t ldx1, const double* d_X2, const double* d_s2, const double* d_r2,
                             size_t n2, size_t ldx2, int intra, double* d_out, size_t ldo, hipStream_t stream,
-                            size_t nblk, size_t zsite, size_t zout, size_t zx) {
+                            size_t nblk, size_t zsite, size_t zout, size_t zx, size_t irow0) {
   for (size_t z0 = 0; z0 < nblk; z0 += 65535) {     // grid.z limit
     const unsigned gz = (unsigned)std::min<size_t>(65535, nblk - z0);
     const size_t so = z0 * zsite, xo = z0 * zx;
@@ -1432,7 +1434,7 @@ hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const d
     } else {
       dim3 grid((unsigned)((n2 + 255) / 256), (unsigned)((n1 + 63) / 64), gz);
       hipLaunchKernelGGL(pair_gram_kernel, grid, dim3(4 * kWave), 0, stream, kind, B, Bp, d_X1 + xo, d_s1 + so, d_r1 + so, n1,
-                         ldx1, d_X2 + xo, d_s2 + so, d_r2 + so, n2, ldx2, intra, out, ldo, zsite, zout, zx);
+                         ldx1, d_X2 + xo, d_s2 + so, d_r2 + so, n2, ldx2, intra, out, ldo, zsite, zout, zx, irow0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1518,7 +1520,8 @@ hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in,
 // the sorted class makes it a lower_bound.  hist[c] = class sizes; classes are laid out in order in `sorted`.
 __global__ void pvalue_kernel(const double* __restrict__ stat, size_t ldo, const double* __restrict__ norms, size_t n,
                               const double* __restrict__ maxnorm, int nclasses, const double* __restrict__ sorted,
-                              const uint32_t* __restrict__ hist, double* __restrict__ pvalue, int32_t* __restrict__ nsim) {
+                              const uint32_t* __restrict__ hist, double* __restrict__ pvalue, int32_t* __restrict__ nsim,
+                              size_t irow0) {
   __shared__ uint32_t off[66];
   if (threadIdx.x == 0) {
     uint32_t o = 0;
@@ -1526,9 +1529,9 @@ __global__ void pvalue_kernel(const double* __restrict__ stat, size_t ldo, const
   }
   __syncthreads();
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i = blockIdx.y;
+  const size_t i = irow0 + blockIdx.y;          // row of the full matrix; the arrays hold rows irow0 ..
   if (j >= n) return;
-  const size_t o = i * ldo + j;
+  const size_t o = (size_t)blockIdx.y * ldo + j;
   if (j <= i) { pvalue[o] = __builtin_nan(""); nsim[o] = 0; return; }
   const double ni = norms[i], nj = norms[j];
   const double mn = ni < nj ? ni : nj;
@@ -1547,10 +1550,11 @@ __global__ void pvalue_kernel(const double* __restrict__ stat, size_t ldo, const
 
 hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norms, size_t n, const double* d_maxnorm,
                           int nclasses, const double* d_sorted, const uint32_t* d_hist, double* d_pvalue,
-                          int32_t* d_nsim, hipStream_t stream) {
-  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+                          int32_t* d_nsim, hipStream_t stream, size_t irow0, size_t nrows) {
+  if (nrows == 0) nrows = n;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)nrows);
   hipLaunchKernelGGL(pvalue_kernel, grid, dim3(256), 0, stream, d_stat, ldo, d_norms, n, d_maxnorm, nclasses, d_sorted,
-                     d_hist, d_pvalue, d_nsim);
+                     d_hist, d_pvalue, d_nsim, irow0);
   return hipGetLastError();
 }
 
@@ -1569,12 +1573,14 @@ __global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict_
                                                        size_t n, const int32_t* __restrict__ rc, const double* __restrict__ pr,
                                                        const double* __restrict__ norm, cmx_pair_filters f,
                                                        unsigned long long* __restrict__ rowcount /* counts, then offsets */,
-                                                       cmx_pair_row* __restrict__ rows, size_t capacity) {
-  const size_t i = blockIdx.x;
+                                                       cmx_pair_row* __restrict__ rows, size_t capacity, size_t irow0,
+                                                       const unsigned long long* __restrict__ base) {
+  // stat / pvalue / nsim hold rows irow0 .. of the full matrix (local row = blockIdx.x); rows are appended after *base
+  const size_t il = blockIdx.x, i = irow0 + il;
   const int lane = threadIdx.x;
   const int ci = rc[i];
   const double ri = pr[i];
-  unsigned long long run = WRITE ? rowcount[i] : 0ull;
+  unsigned long long run = WRITE ? rowcount[il] + (base ? *base : 0ull) : 0ull;
   const bool row_ok = !(ci < f.min_rate_class || ri < f.min_rate);
   if (row_ok)
     for (size_t j0 = i + 1; j0 < n; j0 += 64) {
@@ -1582,7 +1588,7 @@ __global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict_
       bool ok = false;
       double st = 0.0;
       if (j < n) {
-        st = stat[i * ldo + j];
+        st = stat[il * ldo + j];
         ok = pair_passes(f, ci, ri, rc[j], pr[j], st);
       }
       const unsigned long long m = __ballot(ok);
@@ -1594,38 +1600,44 @@ __global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict_
           r.rc_min = ci < rc[j] ? ci : rc[j];
           r.pr_min = ri < pr[j] ? ri : pr[j];
           r.n_min = norm[i] < norm[j] ? norm[i] : norm[j];
-          r.pvalue = pvalue ? pvalue[i * ldo + j] : __builtin_nan("");
-          r.nsim = nsim ? nsim[i * ldo + j] : 0;
+          r.pvalue = pvalue ? pvalue[il * ldo + j] : __builtin_nan("");
+          r.nsim = nsim ? nsim[il * ldo + j] : 0;
           rows[pos] = r;
         }
       }
       run += __popcll(m);
     }
-  if (!WRITE && lane == 0) rowcount[i] = run;
+  if (!WRITE && lane == 0) rowcount[il] = run;
 }
 
 __global__ void pair_rows_total_kernel(const unsigned long long* __restrict__ offsets, const unsigned long long* __restrict__ last_count,
-                                       size_t n, unsigned long long* __restrict__ total) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *total = offsets[n - 1] + *last_count;
+                                       size_t n, unsigned long long* __restrict__ total, const unsigned long long* __restrict__ base) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *total = (base ? *base : 0ull) + offsets[n - 1] + *last_count;
 }
 
+// nrows rows irow0 .. irow0 + nrows - 1 of an n-column matrix (nrows == 0: the whole matrix).  d_base (device, may be
+// null): number of rows already in d_rows -- this block's rows are appended behind them and *d_count becomes the new
+// total, so that consecutive row blocks fill one array in the reference's (i, j) order.
 hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pvalue, const int32_t* d_nsim, size_t n,
                             const int32_t* d_rc, const double* d_pr, const double* d_norm, const cmx_pair_filters& f,
-                            unsigned long long* d_rowcount /*[n + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
-                            size_t capacity, unsigned long long* d_count, hipStream_t stream) {
+                            unsigned long long* d_rowcount /*[nrows + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
+                            size_t capacity, unsigned long long* d_count, hipStream_t stream, size_t irow0, size_t nrows,
+                            const unsigned long long* d_base) {
+  if (nrows == 0) nrows = n;
   if (d_tmp == nullptr) {
-    return rocprim::exclusive_scan(nullptr, tmp_bytes, d_rowcount, d_rowcount, 0ull, n, rocprim::plus<unsigned long long>(), stream);
+    return rocprim::exclusive_scan(nullptr, tmp_bytes, d_rowcount, d_rowcount, 0ull, nrows, rocprim::plus<unsigned long long>(), stream);
   }
-  hipLaunchKernelGGL((pair_rows_kernel<false>), dim3((unsigned)n), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
-                     d_pr, d_norm, f, d_rowcount, d_rows, capacity);
+  hipLaunchKernelGGL((pair_rows_kernel<false>), dim3((unsigned)nrows), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
+                     d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base);
   // keep the last row's count (the scan overwrites it) to form the total
-  hipError_t e = hipMemcpyAsync(d_rowcount + n, d_rowcount + n - 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
+  hipError_t e = hipMemcpyAsync(d_rowcount + nrows, d_rowcount + nrows - 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) return e;
-  e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_rowcount, d_rowcount, 0ull, n, rocprim::plus<unsigned long long>(), stream);
+  e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_rowcount, d_rowcount, 0ull, nrows, rocprim::plus<unsigned long long>(), stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(pair_rows_total_kernel, dim3(1), dim3(64), 0, stream, d_rowcount, d_rowcount + n, n, d_count);
-  hipLaunchKernelGGL((pair_rows_kernel<true>), dim3((unsigned)n), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
-                     d_pr, d_norm, f, d_rowcount, d_rows, capacity);
+  hipLaunchKernelGGL((pair_rows_kernel<true>), dim3((unsigned)nrows), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
+                     d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base);
+  // (after the writes: d_count may be the very word d_base points to)
+  hipLaunchKernelGGL(pair_rows_total_kernel, dim3(1), dim3(64), 0, stream, d_rowcount, d_rowcount + nrows, nrows, d_count, d_base);
   return hipGetLastError();
 }
 

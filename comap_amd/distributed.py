@@ -54,3 +54,25 @@ def gather_shards(local, nitems, group=None):
     recv = torch.empty((world,) + tuple(send.shape), dtype=local.dtype, device=xdev)
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     return torch.cat([recv[r, : sizes[r]] for r in range(world)]).to(dev)
+
+
+def row_shard(rank, world, n):
+    """Rows [begin, end) of the upper triangle for this rank, balanced by PAIR count (row i holds n - 1 - i pairs): the
+    observed pair loop of CoETools.cpp:672-724 split over the ranks.  Contiguous in i, so the ranks' compacted rows
+    concatenate to the single-GPU output in the reference's (i, j) order."""
+    total = n * (n - 1) // 2
+
+    def first_row_with_prefix_at_least(target):
+        # smallest r with pairs(rows < r) >= target; pairs(rows < r) = r (n - 1) - r (r - 1) / 2
+        lo, hi = 0, n
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if mid * (n - 1) - mid * (mid - 1) // 2 >= target:
+                hi = mid
+            else:
+                lo = mid + 1
+        return lo
+
+    begin = first_row_with_prefix_at_least(total * rank // world) if rank else 0
+    end = first_row_with_prefix_at_least(total * (rank + 1) // world) if rank + 1 < world else n
+    return begin, end

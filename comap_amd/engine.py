@@ -40,7 +40,7 @@ EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
     "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
-    "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev",
+    "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev", "cmx_intra_rows_range_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
     "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
     "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups", "cmx_debug_candidate_cursor",
@@ -530,3 +530,19 @@ class Engine:
                                                  _sz(d_aln1.stride(0)), _vp(d_aln2), _sz(n2),
                                                  _sz(0 if d_aln2 is None else d_aln2.stride(0)), _vp(mi), _vp(hjoint),
                                                  _sz(mi.stride(0)), _vp(h1), _vp(h2), self._stream()))
+
+    def intra_rows_range_dev(self, kind, counts, rate_class, post_rate, norm, null_stat, null_nmin, nclasses, rows, count,
+                             row_begin=0, row_end=None, filters=None, threshold=0.99, mean_vectors=None):
+        """CoETools::computeIntraStats' pair loop for rows [row_begin, row_end) of the upper triangle, everything on the
+        device and no N x N matrix: counts float64 [B*K, ldc] CUDA (as map_sites_dev writes them), rows = CUDA uint8 tensor
+        of capacity * 48 bytes (PAIR_ROW records, reference (i, j) order), count = CUDA int64 tensor [1]."""
+        n = norm.shape[0]
+        row_end = n if row_end is None else int(row_end)
+        nnull = 0 if null_stat is None else null_stat.shape[0]
+        f = filters if filters is not None else PairFilters()
+        params = _stat_params(kind, threshold, mean_vectors)
+        cap = rows.numel() // PAIR_ROW.itemsize
+        self._check(self._lib.cmx_intra_rows_range_dev(
+            self._ctx, int(kind), _vp(params), _vp(counts), _sz(n), _sz(counts.stride(0)), _vp(rate_class), _vp(post_rate),
+            _vp(norm), _vp(null_stat), _vp(null_nmin), _sz(nnull), int(nclasses), ctypes.byref(f), _sz(row_begin),
+            _sz(row_end), _vp(rows), _sz(cap), _vp(count), self._stream()))

@@ -5,6 +5,8 @@ Names follow the reference's seams so that tests read like its call sites:
   compute_norms          <- AnalysisTools::computeNorms (CoMap/AnalysisTools.cpp:343-350) (fused into the mapping kernel)
   null_distribution      <- AnalysisTools::getNullDistributionIntraDR (CoMap/AnalysisTools.cpp:564-658)
   compute_intra_stats    <- CoETools::computeIntraStats (CoMap/CoETools.cpp:604-728), dense outputs instead of TSV rows
+  compute_intra_rows     <- the same pair loop for a range of rows i, compacted to the rows of statistics.txt on the device
+                            with no N x N matrix (what a rank of a multi-GPU job runs on its share of the upper triangle)
 torch is used for device memory, streams and (in bench.py) torch.distributed only; every number is produced by the
 HIP kernels behind the C-ABI (comap_amd/engine.py)."""
 import torch
@@ -27,10 +29,29 @@ class IntraAnalysis:
         self.post_rate = torch.empty(self.n, **f64)
         self.norm = torch.empty(self.n, **f64)
         self.rate_class = torch.empty(self.n, dtype=torch.int32, device=dev)
-        self.stat = torch.empty((self.n, self.n), **f64)
-        self.pvalue = torch.empty((self.n, self.n), **f64)
-        self.nsim = torch.empty((self.n, self.n), dtype=torch.int32, device=dev)
+        self._dense = None
+        self._rows = None
         self._null = {}
+
+    def _dense_buffers(self):
+        if self._dense is None:
+            dev = self.aln.device
+            self._dense = (torch.empty((self.n, self.n), dtype=torch.float64, device=dev),
+                           torch.empty((self.n, self.n), dtype=torch.float64, device=dev),
+                           torch.empty((self.n, self.n), dtype=torch.int32, device=dev))
+        return self._dense
+
+    @property
+    def stat(self):
+        return self._dense_buffers()[0]
+
+    @property
+    def pvalue(self):
+        return self._dense_buffers()[1]
+
+    @property
+    def nsim(self):
+        return self._dense_buffers()[2]
 
     def get_vectors(self, aln=None):
         self.eng.map_sites_dev(self.aln if aln is None else aln, self.counts, self.logL, self.post_rate, self.rate_class, self.norm)
@@ -59,3 +80,25 @@ class IntraAnalysis:
         if null_stat is not None:
             self.eng.intra_pvalues_dev(self.stat, self.norm, self.nclasses, null_stat, null_nmin, self.pvalue, self.nsim)
         return self.stat, self.pvalue, self.nsim
+
+    def compute_intra_rows(self, null_stat=None, null_nmin=None, row_begin=0, row_end=None, filters=None, capacity=None):
+        """-> (rows uint8 CUDA tensor viewable as engine.PAIR_ROW records, count int64 CUDA tensor [1])"""
+        from .engine import PAIR_ROW
+        row_end = self.n if row_end is None else row_end
+        # pairs (i, j > i) with row_begin <= i < row_end
+        npairs = sum_pairs(self.n, row_begin, row_end)
+        cap = npairs if capacity is None else int(capacity)
+        if self._rows is None or self._rows[0].numel() < max(cap, 1) * PAIR_ROW.itemsize:
+            dev = self.aln.device
+            self._rows = (torch.empty(max(cap, 1) * PAIR_ROW.itemsize, dtype=torch.uint8, device=dev),
+                          torch.zeros(1, dtype=torch.int64, device=dev))
+        rows, count = self._rows
+        self.eng.intra_rows_range_dev(self.kind, self.counts, self.rate_class, self.post_rate, self.norm, null_stat, null_nmin,
+                                      self.nclasses, rows, count, row_begin, row_end, filters, threshold=self.threshold)
+        return rows, count
+
+
+def sum_pairs(n, row_begin, row_end):
+    """number of pairs (i, j) with row_begin <= i < row_end and i < j < n"""
+    a, b = int(row_begin), int(row_end)
+    return (b - a) * (n - 1) - (b * (b - 1) - a * (a - 1)) // 2

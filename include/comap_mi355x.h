@@ -202,6 +202,17 @@ cmx_status cmx_intra_rows_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, co
                               const int32_t* d_nsim /*or NULL*/, size_t n, const int32_t* d_rate_class,
                               const double* d_post_rate, const double* d_norm, const cmx_pair_filters* filters,
                               cmx_pair_row* d_rows, size_t capacity, uint64_t* d_count, void* stream);
+
+/* The same pair loop for the rows [row_begin, row_end) of the upper triangle only, from the substitution vectors
+ * (branch-major device counts as cmx_map_sites_dev writes them) and the merged null, a block of rows at a time: no
+ * dense N x N matrix exists anywhere (scratch = one row block, <= 256 MiB).  This is what a multi-GPU job calls, each
+ * rank with its own row range (rows come out in the reference's (i, j) order, so the ranks' outputs concatenate to the
+ * single-GPU output), and the default single-GPU path for large N.  d_null_stat == NULL: no p-values (NaN, Nsim 0). */
+cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts, size_t n, size_t ldc,
+                                    const int32_t* d_rate_class, const double* d_post_rate, const double* d_norm,
+                                    const double* d_null_stat, const double* d_null_nmin, size_t nnull, int nclasses,
+                                    const cmx_pair_filters* filters, size_t row_begin, size_t row_end, cmx_pair_row* d_rows,
+                                    size_t capacity, uint64_t* d_count, void* stream);
 /* host pointers: counts [N][B][K] -> statistic -> (optional) p-values from a null -> compacted rows; only the rows
  * cross PCIe on the way back.  null_stat == NULL: no p-values (pvalue NaN, Nsim 0 in every row). */
 cmx_status cmx_intra_rows(cmx_ctx* ctx, int kind, const double* params, const double* counts, size_t n,

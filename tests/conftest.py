@@ -4,6 +4,13 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # torch bundles its own HIP runtime; it has to be the first one this process loads, or a test that later moves a
+    # tensor to the device finds "no HIP GPUs" (the engine library then binds to the runtime torch brought, as in bench.py)
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

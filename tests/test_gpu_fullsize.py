@@ -113,3 +113,136 @@ def test_configuration4_dna_10000x256_compensation_properties():
     assert np.isfinite(v).all() and v.min() >= -1e-12 and v.max() <= 1 + 1e-12
     rel_close(eng.pair_stats(1, sub[::-1].copy())[::-1, ::-1].T[iu], v, 1e-9, 1e-13)   # reversed site order, (j, i)
     rel_close(st[:16, :16][np.triu_indices(16, 1)], oracle.pair_stats_intra(1, c[:16])[np.triu_indices(16, 1)], 1e-6, 1e-12)
+
+
+def _rows_range(eng, counts_bm, rc, pr, norm, ns, nm, nclasses, kind, a, b, filters=None):
+    import torch
+    from comap_amd.pipeline import sum_pairs
+    dev = counts_bm.device
+    n = norm.shape[0]
+    cap = max(sum_pairs(n, a, b), 1)
+    rows = torch.zeros(cap * engine.PAIR_ROW.itemsize, dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    eng.intra_rows_range_dev(kind, counts_bm, rc, pr, norm, ns, nm, nclasses, rows, count, a, b, filters)
+    torch.cuda.synchronize()
+    k = int(count.item())
+    return np.frombuffer(rows[: k * engine.PAIR_ROW.itemsize].cpu().numpy().tobytes(), dtype=engine.PAIR_ROW).copy()
+
+
+def test_rows_range_equals_dense_path_and_concatenates():
+    """cmx_intra_rows_range_dev (no N x N matrix, a block of rows at a time) against the dense path, for the whole
+    triangle, for unbalanced ranges that do not fall on tile boundaries, and with filters"""
+    import torch
+    from comap_amd.distributed import row_shard
+    eng, om, aln = _protein_case(1500)
+    r = eng.map_sites(aln)
+    nl = eng.null_intra(0, 11, 0, 40, 500)
+    f = engine.PairFilters(min_rate_class=1, max_rate_class_diff=2, min_statistic=0.05)
+    dev = torch.device("cuda:0")
+    cbm = torch.from_numpy(np.ascontiguousarray(r["counts"].reshape(1500, -1).T)).to(dev)
+    rc, pr, nm = (torch.from_numpy(r[k]).to(dev) for k in ("rate_class", "post_rate", "norm"))
+    ns, nn = torch.from_numpy(nl["stat"]).to(dev), torch.from_numpy(nl["nmin"]).to(dev)
+    for flt in (None, f):
+        ref, cnt = eng.intra_rows(0, r["counts"], r["rate_class"], r["post_rate"], r["norm"], nl["stat"], nl["nmin"], 10, flt)
+        full = _rows_range(eng, cbm, rc, pr, nm, ns, nn, 10, 0, 0, 1500, flt)
+        assert len(full) == cnt == len(ref)
+        for k in ("i", "j", "rc_min", "nsim"):
+            assert np.array_equal(full[k], ref[k]), k
+        for k in ("stat", "pr_min", "n_min"):
+            assert np.array_equal(full[k], ref[k]), k
+        assert np.array_equal(np.isnan(full["pvalue"]), np.isnan(ref["pvalue"]))
+        assert np.array_equal(np.nan_to_num(full["pvalue"]), np.nan_to_num(ref["pvalue"]))
+        parts = [_rows_range(eng, cbm, rc, pr, nm, ns, nn, 10, 0, a, b, flt) for a, b in ((0, 1), (1, 130), (130, 777), (777, 1499), (1499, 1500))]
+        assert np.array_equal(np.concatenate(parts).tobytes(), full.tobytes())
+        shards = [_rows_range(eng, cbm, rc, pr, nm, ns, nn, 10, 0, *row_shard(q, 3, 1500), flt) for q in range(3)]
+        assert np.array_equal(np.concatenate(shards).tobytes(), full.tobytes())
+
+
+def test_configuration4_pair_stage_all_10000_sites_through_row_ranges():
+    """BASELINE configs[3] at full size: all 49 995 000 compensation statistics of the 10 000 x 256 DNA alignment through
+    cmx_intra_rows_range_dev (compacted on the device, nothing dense crosses PCIe), oracle blocks at the matrix corners"""
+    import torch
+    parent, blen, lot = sy.random_tree(256, 20260102)
+    mdl = sy.dna_model(0.5, 4)
+    Bk = sy.weighted_register(mdl["Q"], sy.compensation_weights_dna())[None]
+    eng = engine.Engine(parent, blen, lot, mdl["Q"], mdl["pi"], mdl["rates"], mdl["probs"], Bk=Bk, clamp_negative=False)
+    n = 10000
+    aln, _ = eng.simulate(20260103, 0, n)
+    dev = torch.device("cuda:0")
+    d_aln = torch.from_numpy(aln).to(dev)
+    counts = torch.empty((eng.B * eng.K, n), dtype=torch.float64, device=dev)
+    logL, pr, nm = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+    rc = torch.empty(n, dtype=torch.int32, device=dev)
+    eng.map_sites_dev(d_aln, counts, logL, pr, rc, nm)
+    # rows in two halves of the pair count (what two ranks would do); only a thinned set of rows crosses PCIe
+    from comap_amd.distributed import row_shard
+    f = engine.PairFilters(min_statistic=0.2)
+    tot, keep = 0, []
+    for q in range(2):
+        a, b = row_shard(q, 2, n)
+        rows = _rows_range(eng, counts, rc, pr, nm, None, None, 10, 1, a, b, f)
+        assert (rows["i"] >= a).all() and (rows["i"] < b).all() and (rows["j"] > rows["i"]).all()
+        key = rows["i"].astype(np.int64) * n + rows["j"]
+        assert (np.diff(key) > 0).all()                      # the reference's (i, j) order
+        assert (np.abs(rows["stat"]) >= 0.2).all() and rows["stat"].max() <= 1 + 1e-12
+        tot += len(rows)
+        keep.append(rows)
+    rows = np.concatenate(keep)
+    assert 0 < tot < n * (n - 1) // 2
+    # oracle at the corners of the matrix: first rows x last columns, last rows, a diagonal block in the middle
+    c = counts.T.cpu().numpy().reshape(n, eng.B, eng.K)
+    key = rows["i"].astype(np.int64) * n + rows["j"]
+    for ia, ja in ((0, n - 16), (n - 16, n - 16), (5000, 5000), (0, 0)):
+        blk_i, blk_j = np.arange(ia, ia + 16), np.arange(ja, ja + 16)
+        o = oracle.pair_stats_inter(1, c[blk_i], c[blk_j])
+        for x, i in enumerate(blk_i):
+            for y, j in enumerate(blk_j):
+                if j <= i:
+                    continue
+                pos = int(np.searchsorted(key, i * n + j))
+                found = pos < len(key) and key[pos] == i * n + j
+                if abs(o[x, y]) >= 0.2 * (1 + 1e-9):
+                    assert found and abs(rows["stat"][pos] - o[x, y]) <= 1e-6 * abs(o[x, y]) + 1e-12
+                elif abs(o[x, y]) < 0.2 * (1 - 1e-9):
+                    assert not found
+
+
+def test_target_size_null_replicate_against_the_oracle():
+    """the north-star workload's null: one replicate of 10 000 simulated site pairs (20 000 sites re-mapped) against the
+    oracle, statistic and all three minima"""
+    eng, om, aln = _protein_case(8)
+    g = eng.null_intra(0, 20260108, 3, 4, 10000)
+    o = oracle.null_intra(om, 0, 20260108, 3, 4, 10000)
+    rel_close(g["stat"], o["stat"], 1e-6, 1e-12)
+    rel_close(g["nmin"], o["nmin"], 1e-6)
+    rel_close(g["prmin"], o["prmin"], 1e-6)
+    assert np.array_equal(g["rcmin"], o["rcmin"])
+
+
+def test_configuration5_mica_5000x5000x256_identity_and_oracle_tiles():
+    """BASELINE configs[4] at full size: MI = H1 + H2 - Hjoint on all 25e6 cross pairs, and the oracle on scattered 8 x 8
+    tiles including the last (ragged: 5000 = 78 * 64 + 8) one"""
+    import torch
+    rng = np.random.default_rng(20260103)
+    T, A, n1, n2 = 256, 20, 5000, 5000
+    base = rng.integers(0, A, size=(T, 1))
+    a1 = np.where(rng.random((T, n1)) < 0.6, base, rng.integers(0, A, size=(T, n1))).astype(np.uint8)
+    a2 = np.where(rng.random((T, n2)) < 0.4, base, rng.integers(0, A, size=(T, n2))).astype(np.uint8)
+    a2[:, 4990:][rng.random((T, 10)) < 0.05] = A            # unknowns in the last columns
+    dev = torch.device("cuda:0")
+    d1, d2 = torch.from_numpy(a1).to(dev), torch.from_numpy(a2).to(dev)
+    mi = torch.empty((n1, n2), dtype=torch.float64, device=dev)
+    hj = torch.empty_like(mi)
+    h1 = torch.empty(n1, dtype=torch.float64, device=dev)
+    h2 = torch.empty(n2, dtype=torch.float64, device=dev)
+    eng = engine.Engine()
+    eng.mi_columns_dev(d1, mi, hj, d2, A, None, h1, h2)
+    torch.cuda.synchronize()
+    resid = (mi - (h1[:, None] + h2[None, :] - hj)).abs().max().item()
+    assert resid < 1e-12
+    assert torch.isfinite(mi).all() and mi.min().item() > -1e-12
+    mih, hjh = mi.cpu().numpy(), hj.cpu().numpy()
+    for i0, j0 in ((0, 0), (4992, 4992), (0, 4992), (4992, 0), (2496, 1234), (63, 4989)):
+        o = oracle.mi_columns(a1[:, i0:i0 + 8], a2[:, j0:j0 + 8], A)
+        assert np.max(np.abs(o["mi"] - mih[i0:i0 + 8, j0:j0 + 8])) < 1e-12
+        assert np.max(np.abs(o["hjoint"] - hjh[i0:i0 + 8, j0:j0 + 8])) < 1e-12

@@ -161,6 +161,28 @@ def test_map_sites_myoglobin_golden_with_ambiguity(myo):
     assert np.max(np.abs(r["logL"] - myo["infos_logl"]) / np.abs(myo["infos_logl"])) < 1e-5
 
 
+def test_map_sites_myoglobin_other_fixtures_on_the_device(myo):
+    """The HIP path itself (not only the CPU oracle) against the reference's other committed mappings:
+    Myo_naive.vec, Myo_unif_grantham.vec, Myo_naive_grantham.vec (examples/Proteins/Benchmark/CoMap)."""
+    from oracle import np_oracle as npo
+    Q, pi = pm.jtt92()
+    rates, probs = pm.gamma_rates(float(myo["alpha"]), 4)
+    W = pm.grantham_distance()
+    tree = (myo["parent"], myo["blen"], myo["leaf_of_taxon"])
+
+    def check(eng, fixture, max_rel):
+        r = eng.map_sites(myo["aln"], masks=myo["masks"])
+        v = myo[fixture].T
+        rel = np.abs(r["counts"][:, :, 0] - v) / np.where(np.abs(v) > 0, np.abs(v), 1.0)
+        assert rel.max() < max_rel and np.median(rel) < 5e-6, (fixture, rel.max(), np.median(rel))
+
+    check(engine.Engine(*tree, Q, pi, rates, probs, count_method=engine.COUNT_NAIVE), "vec_naive", 2e-4)
+    B = npo.rate_matrix_register(Q, W)
+    check(engine.Engine(*tree, Q, pi, rates, probs, Bk=B[None], clamp_negative=False), "vec_unif_grantham", 1e-4)
+    check(engine.Engine(*tree, Q, pi, rates, probs, count_method=engine.COUNT_NAIVE, naive_weights=W, clamp_negative=False),
+          "vec_naive_grantham", 2e-4)
+
+
 def test_map_sites_two_types_weighted_and_naive():
     case = make_case(10, 70, 20, 21)
     Q = case["Q"]
