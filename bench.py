@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mica", action="store_true")
     ap.add_argument("--no-host", action="store_true")
+    ap.add_argument("--pair-output", default="rows", choices=["rows", "dense"],
+                    help="observed pair loop: compacted statistics.txt rows of this rank's row range (default) or dense N x N matrices")
     args = ap.parse_args()
 
     import torch
@@ -227,11 +229,13 @@ def main():
     aln_h, _ = eng.simulate(w["seed"] + 1, 0, w["nsites"])
     d_aln = torch.from_numpy(aln_h).to(dev)
     ana = IntraAnalysis(eng, d_aln, w["statistic"], w["nclasses"])
-    from comap_amd.distributed import gather_null, replicate_shard
+    from comap_amd.distributed import gather_null, replicate_shard, row_shard
+    from comap_amd.pipeline import sum_pairs
     ram = w["rep_ram"]
     nrep_total = w["nrep"](world)
     rep_begin, rep_end = replicate_shard(rank, world, nrep_total)
     n_local = (rep_end - rep_begin) * ram
+    row_begin, row_end = row_shard(rank, world, w["nsites"])   # this rank's share of the observed pair loop
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     side = torch.cuda.Stream(device=dev)   # observed-alignment mapping overlaps the null kernel (independent work)
@@ -249,7 +253,10 @@ def main():
         main_s.wait_stream(side)
         # the path's one exchange: every rank needs the merged null before p-values (one RCCL all-gather)
         ns, nm = gather_null(nb["stat"], nb["nmin"], nrep_total, ram)
-        ana.compute_intra_stats(ns, nm)
+        if args.pair_output == "rows":   # statistic + p-value + filters + compaction for this rank's rows, no N x N matrix
+            return ana.compute_intra_rows(ns, nm, row_begin, row_end)
+        ana.compute_intra_stats(ns, nm)    # dense N x N statistic / p-value / Nsim (every rank, all pairs)
+        return None
 
     for i in range(args.warmup):
         step(i, False)
@@ -305,7 +312,8 @@ def main():
                config=dict(workload=f"{args.workload}: {w['desc']}", observed_pairs=pairs_obs,
                            null_pairs_total=nrep_total * ram, null_pairs_this_gpu=n_local,
                            sites_mapped_per_step_this_gpu=w["nsites"] + 2 * n_local,
-                           parallelism=(f"null replicates sharded x{world}, one RCCL all-gather" if world > 1 else "single GPU"),
+                           parallelism=(f"null replicates and observed row blocks sharded x{world}, one RCCL all-gather" if world > 1 else "single GPU"),
+                           pair_output=args.pair_output, observed_rows_this_gpu=[row_begin, row_end],
                            cu_count=info["cu_count"], mapping_waves=info["waves"],
                            walk_per_pass=dict(products=info["products_per_pass"], leaf_ops=info["leaf_ops_per_pass"],
                                               ws_loads=info["ws_loads_per_pass"], ws_stores=info["ws_stores_per_pass"])),
@@ -316,20 +324,30 @@ def main():
     if not args.no_host and world == 1:
         h_aln = torch.from_numpy(aln_h).pin_memory()
         d_in = torch.empty_like(d_aln)
-        hs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (ana.stat, ana.pvalue, ana.nsim)]
+        if args.pair_output == "rows":
+            hs = [torch.empty(sum_pairs(w["nsites"], row_begin, row_end) * E.PAIR_ROW.itemsize, dtype=torch.uint8, pin_memory=True)]
+        else:
+            hs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (ana.stat, ana.pvalue, ana.nsim)]
         reps = max(1, min(args.steps, 2))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(reps):
             d_in.copy_(h_aln, non_blocking=True)
-            step(0, False, d_in)
-            for h, t in zip(hs, (ana.stat, ana.pvalue, ana.nsim)):
-                h.copy_(t, non_blocking=True)
+            out_rows = step(0, False, d_in)
+            if args.pair_output == "rows":
+                nrows = int(out_rows[1].item())          # rows that passed the filters (all pairs by default)
+                hs[0][: nrows * E.PAIR_ROW.itemsize].copy_(out_rows[0][: nrows * E.PAIR_ROW.itemsize], non_blocking=True)
+            else:
+                for h, t in zip(hs, (ana.stat, ana.pvalue, ana.nsim)):
+                    h.copy_(t, non_blocking=True)
             torch.cuda.synchronize()
         th = (time.perf_counter() - t0) / reps
+        d2h = nrows * E.PAIR_ROW.itemsize if args.pair_output == "rows" else int(sum(h.numel() * h.element_size() for h in hs))
         out["host_to_host"] = dict(value=units_per_step / th, unit="site-pair statistics/s", ms_per_step=1e3 * th,
-                                   h2d_bytes=int(h_aln.numel()), d2h_bytes=int(sum(h.numel() * h.element_size() for h in hs)),
-                                   note="alignment H2D + dense statistic / p-value / Nsim D2H (pinned) inside the timed region")
+                                   h2d_bytes=int(h_aln.numel()), d2h_bytes=int(d2h),
+                                   note="alignment H2D + " + ("compacted statistics.txt rows (48 B per pair: i, j, Stat, RCmin, PRmin, Nmin, PValue, Nsim)"
+                                                              if args.pair_output == "rows" else "dense statistic / p-value / Nsim") +
+                                        " D2H (pinned) inside the timed region")
         del hs, h_aln, d_in
 
     if rank == 0:

@@ -26,6 +26,8 @@ constexpr int mat_unit(int S) { return (S + max_ambig(S)) * S; }   // doubles pe
 #endif
 constexpr int map_ng(int S) { return S >= 16 ? CMX_NG : 4; }
 constexpr int map_sites_per_wave(int S) { return 16 * map_ng(S); }
+// (three waves per SIMD were tried for the 16-state class-fused nucleotide layout -- vectors of 32 registers: at 168
+// registers the kernel spills 213 of them and the cfg 4 launch went from 7.7 to 10.7 ms)
 constexpr int map_waves_per_simd(int S) { return S == 4 ? CMX_WAVES_PER_SIMD_S4 : (map_ng(S) == 2 ? 3 : CMX_WAVES_PER_SIMD); }
 
 // Device-resident model + tree program.  All pointers are device pointers.
@@ -90,6 +92,7 @@ struct MapArgs {
   // class-split observed mode: [nblocks][C][B*K][64] per-class counts, [2][nblocks][C][64] p_c L_c and r_c p_c L_c
   double* split_part;
   double* split_lc;
+  int lds_per_wave;        // bytes of dynamic LDS per wave (set by launch_map)
   // null mode
   int stat_kind;
   double stat_param;       // discrete-MI threshold
@@ -104,7 +107,7 @@ struct MapArgs {
 };
 
 // launchers (cmx_kernels.hip)
-size_t map_lds_bytes(int S);
+int map_lds_per_wave(int S, int nn, int mode);
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream);
 hipError_t launch_map_finalize(const MapArgs& a, hipStream_t stream);
 // fills rows S.. of every leaf operator from d_masks[S .. S+max_ambig(S)) (null: every state compatible)

@@ -428,7 +428,7 @@ struct DevWalk {
   double *wsM, *wsU, *pcnt;
   const uint8_t* gcodes;
   size_t gstride;
-  uint8_t *pfl, *stage, *cslot;
+  uint8_t *stage, *cslot;
   uint32_t lds_stage, lds_codes;
   int lane, c, c_end;
   double pc;
@@ -632,8 +632,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   be.wsU = wsU;
   be.gcodes = gcodes;
   be.gstride = gstride;
-  be.pfl = cmx_smem + lds_off;                                   // prefetch landing buffer, VL*64*8 bytes
-  be.stage = be.pfl + VL * kWave * 8;                            // two operator buffers
+  be.stage = cmx_smem + lds_off;                                 // two operator buffers
   be.cslot = be.stage + 2 * MatStage<S>::BYTES;                  // two symbol slots
   be.lds_stage = lds_addr(be.stage);                             // wave-uniform LDS byte addresses (SGPRs)
   be.lds_codes = lds_addr(be.cslot);
@@ -814,7 +813,8 @@ __device__ __forceinline__ double pair_stat_lane(int kind, double param, int B, 
 // site groups of 16 per wave: 4 (64 sites, two waves per SIMD) or 2 (32 sites: the four live S-vectors take 80 registers
 // instead of 160 and three waves fit a SIMD; operators are then staged per 32 sites)
 template <int S>
-constexpr int map_lds_per_wave() { return S / 4 * map_ng(S) * kWave * 8 + 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }
+constexpr int map_lds_fixed() { return 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }   // stage buffers + symbol slots
+// + the simulator's node states (one byte per node and site) when they fit what is left of the CU's LDS share
 
 template <int S, int MODE, int FUSE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void map_kernel(const MapArgs a) {
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   double* cnt1 = cnt0 + (size_t)m.B * m.K * kSites;
   double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kSites;
   // LDS per wave: workspace prefetch buffer (S*64*8 B), two operator stage buffers, two symbol slots
-  const int lds_off = wib * map_lds_per_wave<S>();
+  const int lds_off = wib * a.lds_per_wave;
   const size_t nblocks = (a.nsites + kSites - 1) / kSites;
   // request the first op's operator (class 0, entry 0); every op then requests the next one
   OpState os;
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   os.par = 0;
   {
     const int c0 = (MODE == kModeObservedSplit) ? wave % m.C : 0;   // class of this wave's first pass
-    mat_dma<S>(m.MAT + (size_t)c0 * m.MC * MatStage<S>::UNIT + cm.msched[0], cmx_smem + lds_off + VL * kWave * 8, lane);
+    mat_dma<S>(m.MAT + (size_t)c0 * m.MC * MatStage<S>::UNIT + cm.msched[0], cmx_smem + lds_off, lane);
   }
   os.vs = MatStage<S>::ROWS;
   os.cur_seq = os.vs;
@@ -907,9 +907,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
           const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
           const int S0 = S / FUSE;
           const int c = draw_index(philox_uniform(a.seed, g, 0), cm.cum_probs, m.C0);
-          // states of the nodes: in the (idle) workspace prefetch buffer when nn * 64 bytes fit, else in HBM
-          const bool st_lds = m.nn * kSites <= VL * kWave * 8;
-          uint8_t* stl = cmx_smem + lds_off + sidx;
+          // states of the nodes: in LDS when nn * 64 bytes fit the wave's share, else in HBM
+          const bool st_lds = a.lds_per_wave >= map_lds_fixed<S>() + m.nn * kSites;
+          uint8_t* stl = cmx_smem + lds_off + map_lds_fixed<S>() + sidx;
           uint8_t* stg = a.ws.st + (size_t)wave * m.nn * kSites + sidx;
           const uint8_t x0 = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S0);
           if (st_lds) stl[(size_t)m.root * kSites] = x0; else stg[(size_t)m.root * kSites] = x0;
@@ -978,14 +978,20 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
 #endif
 }
 
-size_t map_lds_bytes(int S) {
-  const int per_wave = S == 20 ? map_lds_per_wave<20>() : (S == 16 ? map_lds_per_wave<16>() : map_lds_per_wave<4>());
-  return (size_t)kWavesPerBlock * (size_t)per_wave;
+// LDS per mapping wave: operator stage buffers + symbol slots, plus (null mode) the simulator's node states when
+// nn * 64 bytes still fit the workgroup's share of the CU (that many workgroups per CU as waves per SIMD)
+int map_lds_per_wave(int S, int nn, int mode) {
+  const int fixed = S == 20 ? map_lds_fixed<20>() : (S == 16 ? map_lds_fixed<16>() : map_lds_fixed<4>());
+  const int share = 160 * 1024 / map_waves_per_simd(S) / kWavesPerBlock;
+  const int states = (nn * map_sites_per_wave(S) + 15) / 16 * 16;
+  return (mode == kModeNull && fixed + states <= share) ? fixed + states : fixed;
 }
 
-hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream) {
+hipError_t launch_map(const MapArgs& a_in, int mode, int grid_blocks, hipStream_t stream) {
   dim3 grid(grid_blocks), block(kWave * kWavesPerBlock);
-  const size_t lds = map_lds_bytes(a.m.S);
+  MapArgs a = a_in;
+  a.lds_per_wave = map_lds_per_wave(a.m.S, a.m.nn, mode);
+  const size_t lds = (size_t)kWavesPerBlock * (size_t)a.lds_per_wave;
   const int lim = 160 * 1024 / map_waves_per_simd(a.m.S);  // dynamic LDS a workgroup may use (that many workgroups per CU)
   if ((int)lds > lim) return hipErrorInvalidValue;
 #define CMX_LAUNCH(S_, MODE_, F_)                                                                             \
