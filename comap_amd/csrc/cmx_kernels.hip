@@ -194,27 +194,27 @@ __device__ __forceinline__ double reduce_sites(const double (&p)[NG]) {
 }
 
 // step q of a product: output tile o = q / NB, input tile i = q % NB; the stored tile is (o, i), or (i, o) for the
-// transposed product.  Tiles are read two steps ahead of their use (an LDS read takes ~100+ cycles, the four MFMAs of a
-// step 64); the empty asm pins the read in front of the MFMAs it overlaps.
+// transposed product.  Tiles are read three steps ahead of their use (an LDS read takes ~100+ cycles and longer under
+// load, the four MFMAs of a step 64); the empty asm pins the read in front of the MFMAs it overlaps.
 template <int S, bool TR>
 __device__ __forceinline__ constexpr int mfma_tile(int q) {
   return TR ? (q % (S / 4)) * (S / 4) + q / (S / 4) : q;
 }
 template <int S, bool TR, int NG, int Q>
-__device__ __forceinline__ void mfma_steps(const uint8_t* tile0, double m0, double m1, const double (&x)[S / 4 * NG],
+__device__ __forceinline__ void mfma_steps(const uint8_t* tile0, double m0, double m1, double m2, const double (&x)[S / 4 * NG],
                                            double (&y)[S / 4 * NG]) {
   constexpr int NB = S / 4, NT = NB * NB;
   if constexpr (Q < NT) {
     constexpr int o = Q / NB, i = Q % NB;
-    double m2 = 0.0;
-    if constexpr (Q + 2 < NT) {
-      m2 = *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(Q + 2) * 128);
+    double m3 = 0.0;
+    if constexpr (Q + 3 < NT) {
+      m3 = *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(Q + 3) * 128);
       asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g)
       y[o * NG + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(m0, x[i * NG + g], i == 0 ? 0.0 : y[o * NG + g], 0, 0, 0);
-    mfma_steps<S, TR, NG, Q + 1>(tile0, m1, m2, x, y);
+    mfma_steps<S, TR, NG, Q + 1>(tile0, m1, m2, m3, x, y);
   }
 }
 
@@ -233,7 +233,8 @@ __device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const
   // (transposed product: the transposed tile, i.e. row l >> 4, column l & 3)
   const uint8_t* tile0 = buf + (TR ? (4 * (lane >> 4) + (lane & 3)) : (4 * (lane & 3) + (lane >> 4))) * 8;
   mfma_steps<S, TR, NG, 0>(tile0, *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(0) * 128),
-                       NB * NB > 1 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(1) * 128) : 0.0, x, y);
+                       NB * NB > 1 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(1) * 128) : 0.0,
+                       NB * NB > 2 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(2) * 128) : 0.0, x, y);
 }
 
 // Message of a leaf edge from the transposed operator staged in buf ([z][x] = M[x][z], rows >= S: ambiguity ids):
