@@ -1919,25 +1919,30 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int A, int T, int Tp,
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[ii][jj][v] = 0;
-  cmx_i4 st[2] = {};
-  auto fetch = [&](int ks) {
-    if (loader) {
+  // Operand fetch runs THREE k-steps ahead of the MFMAs (registers -> LDS at the top of each step): with one step of
+  // lookahead every k-step exposed most of an L2 / HBM round trip behind its barrier -- eight of them per tile at 256
+  // taxa were three quarters of the kernel's time, the matrix cores idle meanwhile.
+  constexpr int kAhead = 3;
+  cmx_i4 st[kAhead][2] = {};
+  auto fetch = [&](cmx_i4 (&dst)[2], int ks) {
+    if (loader && ks < Tp) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int l = l0 + u;
-        st[u] = *reinterpret_cast<const cmx_i4*>(Hq + (size_t)(l & 31) * Tp + ks + 16 * (l >> 5));
+        dst[u] = *reinterpret_cast<const cmx_i4*>(Hq + (size_t)(l & 31) * Tp + ks + 16 * (l >> 5));
       }
     }
   };
-  fetch(0);
+#pragma unroll
+  for (int d = 0; d < kAhead; ++d) fetch(st[d], d * kMicaK);
   int buf = 0;
-  for (int ks = 0; ks < Tp; ks += kMicaK) {
+  auto step = [&](cmx_i4 (&cur)[2], int ks) {
     if (loader) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) ops[(buf * NOP + q) * 64 + l0 + u] = st[u];
+      for (int u = 0; u < 2; ++u) ops[(buf * NOP + q) * 64 + l0 + u] = cur[u];
     }
     __syncthreads();
-    if (ks + kMicaK < Tp) fetch(ks + kMicaK);
+    fetch(cur, ks + kAhead * kMicaK);
     cmx_i4 a[2], b[2];
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) a[ii] = ops[(buf * NOP + 2 * wi + ii) * 64 + lane];
@@ -1948,6 +1953,11 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int A, int T, int Tp,
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
     buf ^= 1;
+  };
+  for (int ks = 0; ks < Tp; ks += kAhead * kMicaK) {
+    step(st[0], ks);
+    if (ks + kMicaK < Tp) step(st[1], ks + kMicaK);
+    if (ks + 2 * kMicaK < Tp) step(st[2], ks + 2 * kMicaK);
   }
   const double lnT = log((double)T), invT = 1.0 / (double)T;
   // sum_ab f(c_ab) of the wave's four pairs: 16 table lookups per lane and pair, then ONE reduce-scatter for all four
