@@ -31,18 +31,23 @@ def bootstrap_null(engine, aln, entropy, seed, nrep_cpu=10, nrep_ram=100, nalpha
     return out
 
 
-def parametric_null(engine, seed, nrep_cpu=10, nrep_ram=100, nalpha=20):
+def parametric_null(engine, seed, nrep_cpu=10, nrep_ram=100, nalpha=20, with_norms=False):
     """engine must hold the model (tree, Q, rates).  Simulated-site indices follow the intra null's scheme:
-    g = ((rep * 2 + h) * nrep_ram + j)."""
-    mi, hj, h1, h2 = [], [], [], []
-    idx = np.arange(nrep_ram, dtype=np.int64)
-    for rep in range(nrep_cpu):
-        a1, _ = engine.simulate(seed, (rep * 2 + 0) * nrep_ram, nrep_ram)
-        a2, _ = engine.simulate(seed, (rep * 2 + 1) * nrep_ram, nrep_ram)
-        r = engine.mi_pairs(a1, idx, idx, a2, nalpha)
-        mi.append(r["mi"])
-        hj.append(r["hjoint"])
-    return dict(mi=np.concatenate(mi), hjoint=np.concatenate(hj))
+    g = ((rep * 2 + h) * nrep_ram + j).  All replicates go through the device in ONE batch per stage: one simulation of
+    2 * nrep_cpu * nrep_ram sites, one MI call over the nrep_cpu * nrep_ram (j, j) column pairs and -- with_norms, Mica's
+    `use_model` case, Mica.cpp:505-530 -- one mapping of all simulated sites for their norms.
+    -> dict(mi, hjoint[, nmin]) in replicate order (the rows of the null output file, Mica.cpp:411-415)."""
+    n = nrep_cpu * nrep_ram
+    aln, _ = engine.simulate(seed, 0, 2 * n)
+    rep, j = np.divmod(np.arange(n, dtype=np.int64), nrep_ram)
+    i1 = (rep * 2) * nrep_ram + j
+    i2 = (rep * 2 + 1) * nrep_ram + j
+    r = engine.mi_pairs(aln, i1, i2, None, nalpha)
+    out = dict(mi=r["mi"], hjoint=r["hjoint"])
+    if with_norms:
+        norm = engine.map_sites(aln, want_counts=False)["norm"]
+        out["nmin"] = np.minimum(norm[i1], norm[i2])
+    return out
 
 
 def permutation_test(engine, aln, max_perm=1000, seed=0, nalpha=20):

@@ -459,6 +459,14 @@ def test_mica_bootstrap_nulls_match_oracle():
         o = oracle.mi_columns(a1, a2, 20)
         rel_close(pn["mi"][rep * 50:(rep + 1) * 50], np.diag(o["mi"]), 1e-6, 1e-12)
         rel_close(pn["hjoint"][rep * 50:(rep + 1) * 50], np.diag(o["hjoint"]), 1e-6, 1e-12)
+    # with the model norms (use_model, Mica.cpp:505-530): Nmin of the two simulated sites of a pair
+    pm_ = mica.parametric_null(em, seed=77, nrep_cpu=2, nrep_ram=50, with_norms=True)
+    assert np.array_equal(pm_["mi"], pn["mi"])
+    for rep in range(2):
+        a1, _ = oracle.simulate(om, 77, (rep * 2) * 50, 50)
+        a2, _ = oracle.simulate(om, 77, (rep * 2 + 1) * 50, 50)
+        n1, n2 = oracle.map_sites(om, a1)["norm"], oracle.map_sites(om, a2)["norm"]
+        rel_close(pm_["nmin"][rep * 50:(rep + 1) * 50], np.minimum(n1, n2), 1e-6, 1e-12)
 
 
 @pytest.mark.parametrize("with_model", [False, True])
