@@ -134,50 +134,61 @@ def cpu_baseline(w, parent, blen, lot, mdl, Bk, clamp, nrep_total):
                                       f"({t_full_mt:.0f}s)"))
 
 
-def mica_leg(dev, steps):
-    """BASELINE configs[4] on this GPU: Mica column MI of 5000 + 5000 columns, 256 taxa, protein alphabet, all 25e6 cross
-    pairs (Mica.cpp:349-361, 646-689), inputs resident in HBM.  Own roofline (one-hot Gram, 2 A^2 T int8 ops per pair)
-    and own CPU figure (oracle's SiteTools restatement on a 300 x 300 column sample)."""
+def mica_leg(dev, steps, world=1, rank=0, gloo=False):
+    """BASELINE configs[4]: Mica column MI of 5000 + 5000 columns, 256 taxa, protein alphabet, all 25e6 cross pairs
+    (Mica.cpp:349-361, 646-689), inputs resident in HBM.  With N ranks the rectangle is split by rows of the first
+    alignment and ONE all-reduce of the column sums gives the averages of APC / RCW (comap_amd.distributed.mica_rectangle).
+    Own roofline (one-hot Gram, 2 A^2 T int8 ops per pair) and, at N = 1, own CPU figure (oracle's SiteTools restatement on
+    a 300 x 300 column sample)."""
     import torch
+    import torch.distributed as dist
     from comap_amd import engine as E
+    from comap_amd.distributed import mica_rectangle
     rng = np.random.default_rng(20260103)
     T, A, n1, n2 = 256, 20, 5000, 5000
     base = rng.integers(0, A, size=(T, 1))
     a1 = np.where(rng.random((T, n1)) < 0.6, base, rng.integers(0, A, size=(T, n1))).astype(np.uint8)
     a2 = np.where(rng.random((T, n2)) < 0.4, base, rng.integers(0, A, size=(T, n2))).astype(np.uint8)
     d1, d2 = torch.from_numpy(a1).to(dev), torch.from_numpy(a2).to(dev)
-    mi = torch.empty((n1, n2), dtype=torch.float64, device=dev)
-    hj = torch.empty_like(mi)
-    h1 = torch.empty(n1, dtype=torch.float64, device=dev)
-    h2 = torch.empty(n2, dtype=torch.float64, device=dev)
     eng = E.Engine(device=dev.index)
-    eng.mi_columns_dev(d1, mi, hj, d2, A, None, h1, h2)
+    r = mica_rectangle(eng, d1, d2, A)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        eng.mi_columns_dev(d1, mi, hj, d2, A, None, h1, h2)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / steps
-    pairs = n1 * n2
-    ident = float((mi - (h1[:, None] + h2[None, :] - hj)).abs().max())
-    import oracle
-    ns = 300
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    o = oracle.mi_columns(a1[:, :ns], a2[:, :ns], A)
-    t_cpu = time.perf_counter() - t0
-    err = float(np.max(np.abs(o["mi"] - mi[:ns, :ns].cpu().numpy())))
+    for _ in range(steps):
+        r = mica_rectangle(eng, d1, d2, A)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=torch.device("cpu") if gloo else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    ms = 1e3 * el / steps
+    pairs = n1 * n2
+    b, e = r["rows"]
+    ident = float((r["mi"] - (r["h1"][:, None] + r["h2"][None, :] - r["hjoint"])).abs().max())
     tops = pairs * 2.0 * A * A * T / (ms * 1e-3) / 1e12
+    out = dict(workload="cfg5: Mica MI, 5000 + 5000 columns x 256 taxa, protein alphabet, all 25e6 cross pairs",
+               value=pairs / (ms * 1e-3), unit="column-pair MI/s", ms_per_step=ms, steps=steps, dtype="i8", n_gpus=world,
+               parallelism=("single GPU" if world == 1 else f"rows of alignment 1 split x{world}, one all-reduce of the column sums"),
+               roofline=dict(bound="mfma", kernel="mica_mfma_kernel (+ one-hot / epilogue / row and column means)", achieved=tops,
+                             peak=INT8_PEAK_TOPS * world, unit="TOP/s", frac=tops / (INT8_PEAK_TOPS * world), traffic=None,
+                             ops_per_pair_algorithmic=2.0 * A * A * T),
+               max_identity_residual=ident, full_mean_mi=float(r["full_mean"]))
+    if world == 1:
+        import oracle
+        ns = 300
+        t0 = time.perf_counter()
+        o = oracle.mi_columns(a1[:, :ns], a2[:, :ns], A)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=ns * ns / t_cpu, unit="column-pair MI/s", cores=1, kind="port",
+                                   sample=f"oracle/oracle.c orc_mi_columns on {ns} x {ns} columns: {t_cpu:.2f}s")
+        out["max_abs_diff_vs_oracle_sample"] = float(np.max(np.abs(o["mi"] - r["mi"][:ns, :ns].cpu().numpy())))
     eng.close()
-    return dict(workload="cfg5: Mica MI, 5000 + 5000 columns x 256 taxa, protein alphabet, all 25e6 cross pairs",
-                value=pairs / (ms * 1e-3), unit="column-pair MI/s", ms_per_step=ms, steps=steps, dtype="i8",
-                roofline=dict(bound="mfma", kernel="mica_mfma_kernel (+ one-hot / epilogue)", achieved=tops,
-                              peak=INT8_PEAK_TOPS, unit="TOP/s", frac=tops / INT8_PEAK_TOPS, traffic=None,
-                              ops_per_pair_algorithmic=2.0 * A * A * T),
-                cpu_baseline=dict(value=ns * ns / t_cpu, unit="column-pair MI/s", cores=1, kind="port",
-                                  sample=f"oracle/oracle.c orc_mi_columns on {ns} x {ns} columns: {t_cpu:.2f}s"),
-                max_identity_residual=ident, max_abs_diff_vs_oracle_sample=err)
+    return out
 
 
 def main():
@@ -355,10 +366,10 @@ def main():
             out["cpu_baseline"] = None
         else:
             out["cpu_baseline"] = cpu_baseline(w, parent, blen, lot, mdl, Bk, clamp, nrep_total)
-    if world == 1 and not args.no_mica:
+    if not args.no_mica:
         del ana
         torch.cuda.empty_cache()
-        out["mica_cfg5"] = mica_leg(dev, max(3, args.steps))
+        out["mica_cfg5"] = mica_leg(dev, max(3, args.steps), world, rank, rehearsal)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -76,3 +76,39 @@ def row_shard(rank, world, n):
     begin = first_row_with_prefix_at_least(total * rank // world) if rank else 0
     end = first_row_with_prefix_at_least(total * (rank + 1) // world) if rank + 1 < world else n
     return begin, end
+
+
+def mica_rectangle(engine, d_aln1, d_aln2, nalpha=20, group=None):
+    """Mica's N1 x N2 column-MI rectangle (Mica.cpp:349-361, 646-689) split by rows of the first alignment over the ranks:
+    every rank holds both alignments (they are small), computes MI / Hjoint of its contiguous block of columns of
+    alignment 1 against all of alignment 2 on its own GPU, and ONE all-reduce (sum) of the per-column MI sums gives every
+    rank the averages APC / RCW need (Mica.cpp:656-657: MI_i. MI_.j / MI_..).
+    -> dict(rows=(begin, end), mi, hjoint [rows_local, N2] CUDA, h1 [rows_local], h2 [N2], row_mean [rows_local],
+            col_mean [N2], full_mean) -- APC_ij = row_mean[i] * col_mean[j] / full_mean."""
+    import torch
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    n1, n2 = d_aln1.shape[1], d_aln2.shape[1]
+    b, e = replicate_shard(rank, world, n1)
+    dev = d_aln1.device
+    blk = d_aln1[:, b:e].contiguous()
+    mi = torch.empty((e - b, n2), dtype=torch.float64, device=dev)
+    hj = torch.empty_like(mi)
+    h1 = torch.empty(e - b, dtype=torch.float64, device=dev)
+    h2 = torch.empty(n2, dtype=torch.float64, device=dev)
+    engine.mi_columns_dev(blk, mi, hj, d_aln2, nalpha, None, h1, h2)
+    col_sum, tot = combine_mica_sums(mi.sum(dim=0), group)
+    return dict(rows=(b, e), mi=mi, hjoint=hj, h1=h1, h2=h2, row_mean=mi.mean(dim=1), col_mean=col_sum / n1,
+                full_mean=tot / (n1 * n2))
+
+
+def combine_mica_sums(col_sum_local, group=None):
+    """the path's one exchange for Mica: all-reduce (sum) of the per-column MI sums of every rank's row block
+    -> (column sums over all rows, grand total)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return col_sum_local, col_sum_local.sum()
+    dev = col_sum_local.device
+    x = col_sum_local.to("cpu") if dist.get_backend(group) == "gloo" else col_sum_local.clone()
+    dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+    x = x.to(dev)
+    return x, x.sum()

@@ -94,3 +94,79 @@ def test_two_rank_gloo_pair_shards_match_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_pv and ok_n
+
+
+def test_row_shard_partitions_the_upper_triangle_by_pair_count():
+    from comap_amd.distributed import row_shard
+    from comap_amd.pipeline import sum_pairs
+    for n in (2, 5, 129, 2000, 10000):
+        for world in (1, 2, 3, 8):
+            sh = [row_shard(r, world, n) for r in range(world)]
+            assert sh[0][0] == 0 and sh[-1][1] == n and all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+            pc = [sum_pairs(n, a, b) for a, b in sh]
+            assert sum(pc) == n * (n - 1) // 2
+            if n >= 2000:
+                assert max(pc) <= 1.01 * sum(pc) / world
+
+
+def _worker_rows_and_mica(rank, world, port, q):
+    """Observed stage sharded over two ranks, through the oracle: each rank computes the statistics.txt rows of its
+    row_shard range after the null all-gather; rank order concatenation must equal the single-process rows.  Then Mica's
+    rectangle: row blocks of MI + ONE all-reduce of the column sums must reproduce the single-process averages."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from comap_amd.distributed import combine_mica_sums, gather_null, gather_shards, replicate_shard, row_shard
+    from conftest import make_case
+    case = make_case(9, 40, 20, 5)
+    om = oracle.Model(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    m = oracle.map_sites(om, case["aln"])
+    nrep, ram, n = 6, 25, 40
+    b, e = replicate_shard(rank, world, nrep)
+    loc = oracle.null_intra(om, 0, 5, b, e, ram)
+    ns, nm = gather_null(torch.from_numpy(loc["stat"]), torch.from_numpy(loc["nmin"]), nrep, ram)
+    st = oracle.pair_stats_intra(0, m["counts"])
+    pv, nsim = oracle.intra_pvalues(st, m["norm"], 4, ns.numpy(), nm.numpy())
+    r0, r1 = row_shard(rank, world, n)
+    rows = [(i, j, st[i, j], pv[i, j], nsim[i, j]) for i in range(r0, r1) for j in range(i + 1, n)]
+    mine = torch.tensor(rows, dtype=torch.float64).reshape(-1, 5)
+    # (rows stay on their rank in production; gathered here only to compare)
+    sizes = [sum(n - 1 - i for i in range(*row_shard(r, world, n))) for r in range(world)]
+    pad = torch.full((max(sizes), 5), float("nan"), dtype=torch.float64)
+    pad[: mine.shape[0]] = mine
+    allr = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(allr, pad)
+    cat = torch.cat([allr[r][: sizes[r]] for r in range(world)]).numpy()
+    # Mica rectangle
+    rng = np.random.default_rng(3)
+    a1 = rng.integers(0, 20, size=(30, 11)).astype(np.uint8)
+    a2 = rng.integers(0, 20, size=(30, 7)).astype(np.uint8)
+    mb, me = replicate_shard(rank, world, 11)
+    blk = oracle.mi_columns(a1[:, mb:me], a2, 20)["mi"]
+    col_sum, tot = combine_mica_sums(torch.from_numpy(blk.sum(axis=0)))
+    if rank == 0:
+        nl = oracle.null_intra(om, 0, 5, 0, nrep, ram)
+        pv0, ns0 = oracle.intra_pvalues(st, m["norm"], 4, nl["stat"], nl["nmin"])
+        ref = np.array([(i, j, st[i, j], pv0[i, j], ns0[i, j]) for i in range(n) for j in range(i + 1, n)])
+        full = oracle.mi_columns(a1, a2, 20)["mi"]
+        q.put((np.array_equal(cat, ref, equal_nan=True), bool(np.allclose(col_sum.numpy(), full.sum(axis=0), rtol=1e-13)),
+               bool(abs(float(tot) - full.sum()) < 1e-12 * abs(full.sum()))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_observed_rows_and_mica_rectangle():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_rows_and_mica, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok_rows, ok_cols, ok_tot = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok_rows and ok_cols and ok_tot
