@@ -190,6 +190,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       if ((s = upload(ctx, ld, &dld)) != CMX_OK) return s;
       d.ldsched = dld;
     }
+    UP(eigV); UP(eigVi); UP(eigLam); UP(model_of); UP(blen);
     UP(CP); UP(CPG); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
 #undef UP
     // ambiguity rows of the leaf operators: default "every state compatible" until a call brings a mask table
@@ -412,6 +413,27 @@ cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(aln_out, d_aln, (size_t)h.T * n, hipMemcpyDeviceToHost));
   if (classes_out) HIP_TRY(ctx, hipMemcpy(classes_out, d_cls, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+cmx_status cmx_simulate_continuous(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, double gamma_alpha, double p_invariant,
+                                   uint8_t* aln_out, double* rates_out) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!aln_out || n == 0 || !(gamma_alpha > 0.0) || !(p_invariant >= 0.0 && p_invariant < 1.0))
+    return fail(ctx, CMX_ERR_INVALID, "cmx_simulate_continuous: bad arguments (alpha > 0, 0 <= p_invariant < 1)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const HostModel& h = ctx->hm;
+  TmpDev tmp;
+  uint8_t *d_aln = nullptr, *d_st = nullptr;
+  double* d_r = nullptr;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_aln, (size_t)h.T * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_st, (size_t)h.nn * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_r, n * sizeof(double)));
+  HIP_TRY(ctx, launch_simulate_continuous(ctx->dm, seed, g0, n, gamma_alpha, p_invariant, d_aln, n, d_r, d_st, nullptr));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(aln_out, d_aln, (size_t)h.T * n, hipMemcpyDeviceToHost));
+  if (rates_out) HIP_TRY(ctx, hipMemcpy(rates_out, d_r, n * sizeof(double), hipMemcpyDeviceToHost));
   return CMX_OK;
 }
 

@@ -54,6 +54,10 @@ struct DevModel {
   const uint8_t* CPG;      // [C][nn][S(x)][32]
   const int* simg;         // [nsimg][16] groups of four nodes of equal depth: nodes | parents | taxa (or -1) | pad
   int nsimg;
+  // continuous-rate simulator: eigensystems of the generators [NM][S*S] / [NM][S], generator and length of each branch
+  const double *eigV, *eigVi, *eigLam;
+  const int* model_of;     // [B]
+  const double* blen;      // [nn]
   const double* pi;        // [S]
   const double* rates;     // [C]
   const double* probs;     // [C]
@@ -139,6 +143,8 @@ hipError_t launch_cluster_props(int dist_kind, int n, int B, int K, size_t batch
                                 double* d_stat, double* d_nmin, hipStream_t stream);
 hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
                            int32_t* d_classes, uint8_t* d_states /*[nn][ld]*/, hipStream_t stream);
+hipError_t launch_simulate_continuous(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, double alpha, double p_inv,
+                                      uint8_t* d_aln, size_t ld, double* d_rates, uint8_t* d_states, hipStream_t stream);
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,
                             double* d_X, size_t ldx, int Bp, double* d_s, double* d_r, const double* d_mvec,
                             hipStream_t stream, size_t blk = 0);

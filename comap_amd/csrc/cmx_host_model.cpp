@@ -494,6 +494,13 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
     e.W.resize(K);   // Vinv B_k V
     for (int k = 0; k < K; ++k) e.W[k] = matmul(S, matmul(S, e.Vi, Bk[k]), e.V);
   }
+  hm->model_of = model_of;
+  hm->eigV.clear(); hm->eigVi.clear(); hm->eigLam.clear();
+  for (int m = 0; m < NM; ++m) {
+    hm->eigV.insert(hm->eigV.end(), eig[m].V.begin(), eig[m].V.end());
+    hm->eigVi.insert(hm->eigVi.end(), eig[m].Vi.begin(), eig[m].Vi.end());
+    hm->eigLam.insert(hm->eigLam.end(), eig[m].lam.begin(), eig[m].lam.end());
+  }
   // ---- per (class, branch) matrices, each branch with its own generator
   const int B = hm->B;
   hm->P.assign((size_t)C * B * S2, 0.0);

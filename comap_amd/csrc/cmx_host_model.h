@@ -25,6 +25,8 @@ struct HostModel {
   std::vector<double> PN;   // [C][B][K][S*S] P o N^k
   std::vector<double> MAT;  // [C][MC][S*S]     device matrices: packed P | packed PN | leaf P^T | leaf PN^T (cmx_host_model.cpp)
   int MC = 0;               // matrices per (device) class block = NI + NI*K + T + K*T
+  std::vector<double> eigV, eigVi, eigLam;   // [NM][S*S], [NM][S*S], [NM][S]: right / left eigenvectors and eigenvalues of the generators
+  std::vector<int> model_of;                  // [B] generator of each branch (all 0 for a homogeneous model)
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
   std::vector<uint8_t> CPG; // [C][nn][S][32]   guide table of the simulator's inverse-CDF search (cmx_kernels.hip: draw_guided)
   std::vector<int> simg;    // [nsimg][16] simulator: groups of four nodes of equal depth (DevModel::simg)

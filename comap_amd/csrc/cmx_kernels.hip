@@ -1206,6 +1206,113 @@ hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t
   return hipGetLastError();
 }
 
+// ---- simulations.continuous = yes (CoMap/CoMap.cpp:146, 213: NonHomogeneousSequenceSimulator::enableContinuousRates).
+// Every site draws its own rate from the CONTINUOUS Gamma(alpha, beta = alpha) distribution (Invariant(Gamma): rate 0 with
+// probability p_inv, else the Gamma draw divided by 1 - p_inv) and every branch uses exp(Q r t) of that very rate: the
+// row of the parent's state is rebuilt from the generator's eigensystem at each node (S exponentials + S^2 multiply-adds)
+// -- there is no table to look up.  Same counter RNG and draw numbering as the discrete simulator (draw 0 = rate).
+
+__host__ __device__ inline void cmx_gamma_pq(double a, double x, double* p, double* q) {
+  /* regularised incomplete gamma, lower P and upper Q = 1 - P, each from the expansion that gives it without
+   * cancellation: series for x < a + 1 (P), Lentz continued fraction otherwise (Q) */
+  if (x <= 0.0) { *p = 0.0; *q = 1.0; return; }
+  const double pre = exp(-x + a * log(x) - lgamma(a));
+  if (x < a + 1.0) {
+    double term = 1.0 / a, sum = term;
+    for (int n = 1; n < 1000; ++n) {
+      term *= x / (a + n);
+      sum += term;
+      if (fabs(term) < fabs(sum) * 1e-17) break;
+    }
+    *p = sum * pre;
+    *q = 1.0 - *p;
+    return;
+  }
+  const double tiny = 1e-300;
+  double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
+  for (int i = 1; i < 1000; ++i) {
+    const double an = -(double)i * ((double)i - a);
+    b += 2.0;
+    d = an * d + b;
+    if (fabs(d) < tiny) d = tiny;
+    c = b + an / c;
+    if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    const double del = d * c;
+    h *= del;
+    if (fabs(del - 1.0) < 1e-16) break;
+  }
+  *q = pre * h;
+  *p = 1.0 - *q;
+}
+/* "x is below the u-quantile": decided on the tail that carries the information (P < u, or Q > 1 - u for u > 1/2) */
+__host__ __device__ inline int cmx_gamma_below(double a, double x, double u) {
+  double p, q;
+  cmx_gamma_pq(a, x, &p, &q);
+  return u <= 0.5 ? p < u : q > 1.0 - u;
+}
+/* quantile of Gamma(shape a, scale 1): bracket [lo, 2 lo] by doubling / halving from 1, then 110 bisection steps
+ * (deterministic, no tolerance test) */
+__host__ __device__ inline double cmx_gamma_quantile(double a, double u) {
+  if (u <= 0.0) return 0.0;
+  double lo = 1.0, hi;
+  if (cmx_gamma_below(a, lo, u)) {
+    for (int i = 0; i < 1100 && cmx_gamma_below(a, 2.0 * lo, u); ++i) lo *= 2.0;
+    hi = 2.0 * lo;
+  } else {
+    hi = lo;
+    lo = 0.5 * hi;
+    for (int i = 0; i < 1070 && !cmx_gamma_below(a, lo, u); ++i) { hi = lo; lo *= 0.5; }
+  }
+  for (int i = 0; i < 110; ++i) {
+    const double mid = 0.5 * (lo + hi);
+    if (cmx_gamma_below(a, mid, u)) lo = mid; else hi = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+__global__ void simulate_continuous_kernel(const DevModel m, uint64_t seed, uint64_t g0, size_t n, double alpha, double p_inv,
+                                           uint8_t* aln, size_t ld, double* rates, uint8_t* states) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint64_t g = g0 + j;
+  const int S = m.S0;
+  const double u0 = philox_uniform(seed, g, 0);
+  double r = 0.0;
+  if (u0 >= p_inv) r = cmx_gamma_quantile(alpha, (u0 - p_inv) / (1.0 - p_inv)) / alpha / (1.0 - p_inv);
+  if (rates) rates[j] = r;
+  states[(size_t)m.root * ld + j] = (uint8_t)draw_index(philox_uniform(seed, g, 1), m.cum_pi, S);
+  for (int node = m.nn - 2; node >= 0; --node) {
+    const int x = states[(size_t)m.parent[node] * ld + j];
+    const double u = philox_uniform(seed, g, 2u + (uint32_t)node);
+    const size_t mo = (size_t)m.model_of[node];
+    const double *V = m.eigV + mo * S * S + (size_t)x * S, *Vi = m.eigVi + mo * S * S, *lam = m.eigLam + mo * S;
+    const double rt = r * m.blen[node];
+    double w[20];                         // S <= 20: V[x][k] exp(lambda_k r t)
+    for (int k = 0; k < S; ++k) w[k] = V[k] * exp(lam[k] * rt);
+    // index = #{ y < S-1 : u >= cum_y } with cum the running sum of the row P(x, .) -- the discrete simulator's rule
+    int idx = 0;
+    double cum = 0.0;
+    for (int y = 0; y < S - 1; ++y) {
+      double pxy = 0.0;
+      for (int k = 0; k < S; ++k) pxy += w[k] * Vi[(size_t)k * S + y];
+      cum += pxy;
+      idx += (u >= cum) ? 1 : 0;
+    }
+    states[(size_t)node * ld + j] = (uint8_t)idx;
+    const int tx = m.taxon_of[node];
+    if (tx >= 0) aln[(size_t)tx * ld + j] = (uint8_t)idx;
+  }
+}
+
+hipError_t launch_simulate_continuous(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, double alpha, double p_inv,
+                                      uint8_t* d_aln, size_t ld, double* d_rates, uint8_t* d_states, hipStream_t stream) {
+  const int block = 128;
+  hipLaunchKernelGGL(simulate_continuous_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, stream, m, seed, g0, n,
+                     alpha, p_inv, d_aln, ld, d_rates, d_states);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ pair statistics
 // prep: X[b][i] (Bp rows, zero padded) and per-site scalars s (sum of squares) and r (row sum of indicators)
 //   kind 0/4: X = type-0 count - mean;  3: X = type-0 count;  1: X = per-branch total;

@@ -38,7 +38,7 @@ COUNT_EXPECTED, COUNT_NAIVE = 0, 1
 
 EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
-    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate",
+    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate", "cmx_simulate_continuous",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev", "cmx_intra_rows_range_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
@@ -293,6 +293,26 @@ class Engine:
         self._check(self._lib.cmx_simulate(self._ctx, ctypes.c_uint64(seed), ctypes.c_uint64(g0), _sz(n), _vp(aln),
                                            _vp(cls)))
         return aln, cls
+
+    def simulate_continuous(self, seed, g0, n, gamma_alpha, p_invariant=0.0):
+        """simulations.continuous = yes (CoMap.cpp:146, 213) -> (aln uint8 [T, n], rates float64 [n])"""
+        aln = np.zeros((self.T, n), dtype=np.uint8)
+        rates = np.zeros(n)
+        self._check(self._lib.cmx_simulate_continuous(self._ctx, ctypes.c_uint64(seed), ctypes.c_uint64(g0), _sz(n),
+                                                      ctypes.c_double(gamma_alpha), ctypes.c_double(p_invariant), _vp(aln),
+                                                      _vp(rates)))
+        return aln, rates
+
+    def null_intra_continuous(self, kind, seed, rep_begin, rep_end, rep_ram, gamma_alpha, p_invariant=0.0, threshold=0.99,
+                              mean_vectors=None):
+        """AnalysisTools::getNullDistributionIntraDR with a continuous-rate simulator (simulations.continuous = yes): the
+        replicates' alignments come from simulate_continuous (global site index g = ((rep * 2 + h) * rep_ram + j), as
+        everywhere), the re-mapping and scoring from the fused null kernel on supplied alignments."""
+        nrep = rep_end - rep_begin
+        aln, _ = self.simulate_continuous(seed, rep_begin * 2 * rep_ram, nrep * 2 * rep_ram, gamma_alpha, p_invariant)
+        sup = np.ascontiguousarray(aln.reshape(self.T, nrep, 2, rep_ram).transpose(1, 2, 0, 3))
+        return self.null_intra(kind, seed, rep_begin, rep_end, rep_ram, supplied=sup, threshold=threshold,
+                               mean_vectors=mean_vectors)
 
     def pair_stats(self, kind, counts1, counts2=None, threshold=0.99, mean_vectors=None):
         c1 = _f64(counts1).reshape(len(counts1), self.B, self.K)

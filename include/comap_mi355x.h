@@ -136,6 +136,14 @@ cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, 
 /* ---- sequence simulator (NonHomogeneousSequenceSimulator::simulate, AnalysisTools.cpp:591): counter-based RNG,
  * global site indices g0 .. g0+n-1 (see DESIGN.md "RNG").  aln_out: [T][n]. */
 cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln_out, int32_t* classes_out);
+/* simulations.continuous = yes (CoMap.cpp:146, 213: NonHomogeneousSequenceSimulator::enableContinuousRates): every site
+ * draws its rate from the continuous Gamma(alpha, beta = alpha) distribution -- with probability p_invariant the rate is 0
+ * and the Gamma draw is divided by 1 - p_invariant, as Invariant(Gamma) does -- and every branch uses exp(Q r t) of that
+ * rate.  Same counter RNG and site indexing as cmx_simulate.  rates_out (may be NULL): the drawn rates.  A null
+ * distribution under continuous rates = this simulator + cmx_null_intra with `supplied` alignments (the mapping of the
+ * simulated sites still uses the discrete classes, as in the reference). */
+cmx_status cmx_simulate_continuous(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, double gamma_alpha, double p_invariant,
+                                   uint8_t* aln_out, double* rates_out);
 
 /* ---- all-pairs statistic.  counts2 == NULL: intra (CoETools.cpp:672-692), out[i*N1+j] filled for j > i, NaN
  * elsewhere.  Otherwise inter (CoETools.cpp:786-810), out[i*N2+j].  params: for CMX_STAT_DISCRETE_MI params[0] is

@@ -156,6 +156,16 @@ class Engine {
   void setMappingOptions(bool average, bool joint) {
     if (!average || !joint) throw Exception("nijt.average=no / nijt.joint=no are not offered by the MI355X engine");
   }
+  // simulations.continuous = yes (CoMap.cpp:146, 213: seqSim->enableContinuousRates(true)): n simulated sites [taxon][site]
+  // with global site indices g0 .. g0 + n - 1, every site with its own rate from the continuous Gamma(alpha, alpha)
+  // (+ invariant mass pInvariant); the drawn rates are returned in *rates when given
+  std::vector<uint8_t> simulateContinuous(uint64_t seed, uint64_t g0, size_t n, double gammaAlpha, double pInvariant = 0.,
+                                          Vdouble* rates = nullptr) const {
+    std::vector<uint8_t> aln(nbTaxa_ * n);
+    if (rates) rates->assign(n, 0.);
+    check(cmx_simulate_continuous(ctx_, seed, g0, n, gammaAlpha, pInvariant, aln.data(), rates ? rates->data() : nullptr));
+    return aln;
+  }
   cmx_ctx* ctx() const { return ctx_; }
   size_t getNumberOfBranches() const { return nbBranches_; }
   size_t getNumberOfSubstitutionTypes() const { return nbTypes_; }

@@ -101,6 +101,23 @@ def simulate(m, seed, g0, n):
     return aln, cls
 
 
+def simulate_continuous(m, seed, g0, n, alpha, p_inv=0.0):
+    """simulations.continuous = yes: -> (aln [T, n], rates [n])"""
+    aln = np.zeros((m.T, n), dtype=np.uint8)
+    rates = np.zeros(n)
+    D, I = ctypes.c_double, ctypes.c_int
+    lib().orc_simulate_continuous(m.nn, _p(m.parent, I), _p(m.blen, D), m.T, _p(m.lot, I), m.S, _p(m.Q, D), _p(m.pi, D),
+                                  D(alpha), D(p_inv), ctypes.c_uint64(seed), ctypes.c_uint64(g0), ctypes.c_long(n),
+                                  _p(aln, ctypes.c_uint8), _p(rates, D))
+    return aln, rates
+
+
+def gamma_quantile(a, u):
+    f = lib().orc_gamma_quantile
+    f.restype = ctypes.c_double
+    return f(ctypes.c_double(a), ctypes.c_double(u))
+
+
 def stat_params(kind, threshold=0.99):
     if kind == ST_DISCRETE_MI:
         return _f64([3, 0.0, threshold, 10000.0])

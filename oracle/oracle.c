@@ -387,6 +387,97 @@ void orc_simulate(int nn, const int* parent, const double* blen, int T, const in
   free(st); free(taxon_of); free(P); free(lam);
 }
 
+/* ------------------------------------------------------------------ simulations.continuous = yes (CoMap/CoMap.cpp:146, 213)
+ * NonHomogeneousSequenceSimulator::enableContinuousRates: per site a rate from the continuous Gamma(alpha, beta = alpha)
+ * (Invariant(Gamma): 0 with probability p_inv, else the draw / (1 - p_inv)), per branch P = exp(Q r t) of that rate (A.8).
+ * Quantile by the textbook route: regularised incomplete gamma (series / continued fraction), bracket by doubling, 110
+ * bisection steps.  orc_gamma_quantile is checked against scipy.stats.gamma.ppf in tests/test_oracle_continuous.py. */
+void orc_gamma_pq(double a, double x, double* p, double* q) {
+  /* regularised incomplete gamma, lower P and upper Q = 1 - P, each from the expansion that gives it without
+   * cancellation: series for x < a + 1 (P), Lentz continued fraction otherwise (Q) */
+  if (x <= 0.0) { *p = 0.0; *q = 1.0; return; }
+  const double pre = exp(-x + a * log(x) - lgamma(a));
+  if (x < a + 1.0) {
+    double term = 1.0 / a, sum = term;
+    for (int n = 1; n < 1000; ++n) {
+      term *= x / (a + n);
+      sum += term;
+      if (fabs(term) < fabs(sum) * 1e-17) break;
+    }
+    *p = sum * pre;
+    *q = 1.0 - *p;
+    return;
+  }
+  const double tiny = 1e-300;
+  double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
+  for (int i = 1; i < 1000; ++i) {
+    const double an = -(double)i * ((double)i - a);
+    b += 2.0;
+    d = an * d + b;
+    if (fabs(d) < tiny) d = tiny;
+    c = b + an / c;
+    if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    const double del = d * c;
+    h *= del;
+    if (fabs(del - 1.0) < 1e-16) break;
+  }
+  *q = pre * h;
+  *p = 1.0 - *q;
+}
+/* "x is below the u-quantile": decided on the tail that carries the information (P < u, or Q > 1 - u for u > 1/2) */
+int orc_gamma_below(double a, double x, double u) {
+  double p, q;
+  orc_gamma_pq(a, x, &p, &q);
+  return u <= 0.5 ? p < u : q > 1.0 - u;
+}
+/* quantile of Gamma(shape a, scale 1): bracket [lo, 2 lo] by doubling / halving from 1, then 110 bisection steps
+ * (deterministic, no tolerance test) */
+double orc_gamma_quantile(double a, double u) {
+  if (u <= 0.0) return 0.0;
+  double lo = 1.0, hi;
+  if (orc_gamma_below(a, lo, u)) {
+    for (int i = 0; i < 1100 && orc_gamma_below(a, 2.0 * lo, u); ++i) lo *= 2.0;
+    hi = 2.0 * lo;
+  } else {
+    hi = lo;
+    lo = 0.5 * hi;
+    for (int i = 0; i < 1070 && !orc_gamma_below(a, lo, u); ++i) { hi = lo; lo *= 0.5; }
+  }
+  for (int i = 0; i < 110; ++i) {
+    const double mid = 0.5 * (lo + hi);
+    if (orc_gamma_below(a, mid, u)) lo = mid; else hi = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+void orc_simulate_continuous(int nn, const int* parent, const double* blen, int T, const int* leaf_of_taxon, int S,
+                             const double* Q, const double* pi, double alpha, double p_inv, uint64_t seed, uint64_t g0,
+                             long n, uint8_t* aln, double* rates) {
+  int S2 = S * S, root = nn - 1;
+  double* lam = (double*)malloc(sizeof(double) * (S + 3 * S2));
+  double *V = lam + S, *Vinv = V + S2, *P = Vinv + S2;
+  orc_eigen_reversible(S, Q, pi, lam, V, Vinv);
+  int* taxon_of = (int*)malloc(sizeof(int) * nn);
+  for (int i = 0; i < nn; i++) taxon_of[i] = -1;
+  for (int t = 0; t < T; t++) taxon_of[leaf_of_taxon[t]] = t;
+  uint8_t* st = (uint8_t*)malloc(nn);
+  for (long j = 0; j < n; j++) {
+    uint64_t g = g0 + (uint64_t)j;
+    double u0 = orc_uniform(seed, g, 0), r = 0.0;
+    if (u0 >= p_inv) r = orc_gamma_quantile(alpha, (u0 - p_inv) / (1.0 - p_inv)) / alpha / (1.0 - p_inv);
+    if (rates) rates[j] = r;
+    st[root] = (uint8_t)draw_index(orc_uniform(seed, g, 1), pi, S);
+    for (int node = nn - 2; node >= 0; node--) {
+      int x = st[parent[node]];
+      orc_transition(S, lam, V, Vinv, blen[node] * r, P);   /* getPij_t(d * rate) of this very site */
+      st[node] = (uint8_t)draw_index(orc_uniform(seed, g, 2u + (uint32_t)node), P + (size_t)x * S, S);
+      if (taxon_of[node] >= 0) aln[(size_t)taxon_of[node] * n + j] = st[node];
+    }
+  }
+  free(st); free(taxon_of); free(lam);
+}
+
 /* ------------------------------------------------------------------ Domain (CoMap/Domain.cpp:46-59, 113-122) */
 int orc_domain_index(double a, double b, int n, double x) {
   double mini = a < b ? a : b, maxi = a < b ? b : a;

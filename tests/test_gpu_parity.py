@@ -183,6 +183,25 @@ def test_map_sites_myoglobin_other_fixtures_on_the_device(myo):
           "vec_naive_grantham", 2e-4)
 
 
+@pytest.mark.parametrize("nstates", [20, 4])
+def test_continuous_rate_simulator_matches_oracle(nstates):
+    """simulations.continuous = yes (CoMap.cpp:146, 213): device vs the oracle's restatement -- same rates (the Gamma
+    quantile runs on the device), same alignments; and a null distribution under continuous rates"""
+    case = make_case(17, 4, nstates, 31)
+    eng, om = _engine(case), _omodel(case)
+    for alpha, pinv in ((0.5, 0.0), (1.7, 0.2)):
+        a, r = eng.simulate_continuous(77, 1000, 600, alpha, pinv)
+        ao, ro = oracle.simulate_continuous(om, 77, 1000, 600, alpha, pinv)
+        rel_close(r, ro, 1e-12, 1e-300)
+        assert (a != ao).mean() < 1e-4          # identical but for draws within an ulp of a boundary of the cumulative row
+    g = eng.null_intra_continuous(0, 5, 2, 4, 64, 0.5, 0.1)
+    aln, _ = oracle.simulate_continuous(om, 5, 2 * 2 * 64, 2 * 2 * 64, 0.5, 0.1)
+    sup = np.ascontiguousarray(aln.reshape(17, 2, 2, 64).transpose(1, 2, 0, 3))
+    o = oracle.null_intra(om, 0, 5, 2, 4, 64, supplied=sup)
+    rel_close(g["stat"], o["stat"], 1e-6, 1e-12)
+    assert np.array_equal(g["rcmin"], o["rcmin"])
+
+
 def test_map_sites_two_types_weighted_and_naive():
     case = make_case(10, 70, 20, 21)
     Q = case["Q"]
