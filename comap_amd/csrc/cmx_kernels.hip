@@ -1757,10 +1757,11 @@ hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pv
 
 // ------------------------------------------------------------------------------------------------ Mica column MI
 // SiteTools::mutualInformation / jointEntropy / entropy (resolveUnknowns = true), natural log (Mica.cpp:93-95).
-// v1: one wave per (i, 64 columns j): lane = column j; joint table in LDS as [a][b][lane] would be A*A*64*8 bytes
-// (205 KB for A = 20) -- too large, so the joint counts are accumulated per row a in registers over two passes of
-// the taxa is avoided by sorting... (kept simple and exact here: A*A fp32-exact fractional counts are NOT assumed;
-// counts are fp64 in a per-lane scratch table in global workspace-free form using LDS tiles of 16 lanes).
+// LDS-table kernel (the general path: any ambiguity code, fractional counts in fp64): one wave per (column i, 16 columns
+// j); the 16 joint tables of A x A doubles live in LDS ([cell][pair slot]), four lanes share a pair and spread the
+// (fractional) unit counts of their quarter of the taxa into its table with LDS atomics.  The MFMA path below serves the
+// columns without partial ambiguity codes; this kernel then only sees the pairs that involve a flagged column (and
+// returns after one load when no column is flagged).
 template <int A>
 __global__ __launch_bounds__(64) void mi_columns_kernel(int T, const uint32_t* __restrict__ masks,
                                                         const uint8_t* __restrict__ aln1, size_t n1, size_t ld1,

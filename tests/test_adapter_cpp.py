@@ -99,7 +99,11 @@ def test_reference_call_sequence_matches_oracle(adapter_exe, tmp_path):
     assert np.array_equal(rows["rc"], np.minimum(o["rate_class"][iu[0]], o["rate_class"][iu[1]]))
     rel_close(rows["nm"], np.minimum(o["norm"][iu[0]], o["norm"][iu[1]]), 1e-6)
     # p-values: same sorted null to 1e-6 => counts may differ only where a null value ties the statistic to 1e-6
-    assert np.mean(rows["pv"] == pv[iu]) > 0.99
+    # ... and then by exactly ONE count of the rule p = (nsim - #{null < stat} + 1) / (nsim + 1), never more
+    same = (rows["pv"] == pv[iu]) | (np.isnan(rows["pv"]) & np.isnan(pv[iu]))
+    assert np.mean(same) > 0.99
+    off = np.abs(rows["pv"][~same] - pv[iu][~same]) * (ns[iu][~same] + 1)
+    assert np.all(np.abs(off - 1.0) < 1e-9)
 
 
 def test_bpp_seam_header_guard_and_signatures(tmp_path):
