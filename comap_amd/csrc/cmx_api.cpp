@@ -396,11 +396,19 @@ cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t
   return CMX_OK;
 }
 
+// the simulator's counter layout (cmx_kernels.hip philox_uniform): 47 bits of simulated-site index, 17 bits of draw index
+static cmx_status rng_range(cmx_ctx* ctx, uint64_t g_end, const char* who) {
+  if (g_end > (1ull << 47) || (uint64_t)ctx->hm.nn + 2 > (1ull << 17))
+    return fail(ctx, CMX_ERR_UNSUPPORTED, std::string(who) + ": simulated-site index beyond 2^47 or more than 2^17 - 2 nodes");
+  return CMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ simulator
 cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln_out, int32_t* classes_out) {
   cmx_status s = need_model(ctx);
   if (s != CMX_OK) return s;
   if (!aln_out || n == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_simulate: bad arguments");
+  if ((s = rng_range(ctx, g0 + n, "cmx_simulate")) != CMX_OK) return s;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const HostModel& h = ctx->hm;
   TmpDev tmp;
@@ -422,6 +430,7 @@ cmx_status cmx_simulate_continuous(cmx_ctx* ctx, uint64_t seed, uint64_t g0, siz
   if (s != CMX_OK) return s;
   if (!aln_out || n == 0 || !(gamma_alpha > 0.0) || !(p_invariant >= 0.0 && p_invariant < 1.0))
     return fail(ctx, CMX_ERR_INVALID, "cmx_simulate_continuous: bad arguments (alpha > 0, 0 <= p_invariant < 1)");
+  if ((s = rng_range(ctx, g0 + n, "cmx_simulate_continuous")) != CMX_OK) return s;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const HostModel& h = ctx->hm;
   TmpDev tmp;
@@ -537,6 +546,7 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   if (s != CMX_OK) return s;
   if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
   if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra: bad arguments");
+  if ((s = rng_range(ctx, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_intra")) != CMX_OK) return s;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
@@ -599,6 +609,8 @@ cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const doub
   if (!ctx2 || !ctx2->has_model) return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: second context has no model");
   if ((s = check_kind(ctx1, kind)) != CMX_OK) return s;
   if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: bad arguments");
+  if ((s = rng_range(ctx1, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_inter")) != CMX_OK) return s;
+  if ((s = rng_range(ctx2, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_inter")) != CMX_OK) return s;
   if (ctx1->device != ctx2->device) return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: contexts live on different devices");
   if (ctx1->hm.B != ctx2->hm.B || ctx1->hm.K != ctx2->hm.K)
     return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: the two data sets must have the same branches and substitution types "

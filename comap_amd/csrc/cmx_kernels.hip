@@ -337,17 +337,19 @@ __device__ __forceinline__ void read_vec_lds(const uint8_t* lds /* wave-uniform 
   }
 }
 
-// Philox4x32-10, counter (g_lo, g_hi, draw, 'CMX1'), key = seed.  Same scheme as oracle/oracle.c (DESIGN.md "RNG").
+// Philox2x32-10 (Random123): counter = (g_lo, g_hi[14:0] | draw << 15), key = seed_lo ^ seed_hi * 0x9E3779B9 ^ 'CMX2';
+// the 64 output bits give one 53-bit uniform.  Same scheme as oracle/oracle.c (DESIGN.md "RNG").  One 32 x 32 -> 64
+// multiply per round: the 4x32 variant (two per round, 128 output bits of which one draw uses 64) cost the fused null
+// kernel 4.7 % of its time in quarter-rate integer multiplies.  g < 2^47, draw < 2^17.
 __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
-  uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32), c2 = draw, c3 = 0x434d5831u;
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)g, c1 = ((uint32_t)(g >> 32) & 0x7fffu) | (draw << 15);
+  uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ 0x434d5832u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    const uint32_t hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
+    c0 = hi ^ k ^ c1;
+    c1 = lo;
+    k += 0x9E3779B9u;
   }
   const uint64_t bits = (((uint64_t)c0 << 32) | c1) >> 11;
   return (double)bits * (1.0 / 9007199254740992.0);

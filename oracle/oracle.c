@@ -324,10 +324,11 @@ int orc_map_sites(int nn, const int* parent, const double* blen, int T, const in
 
 /* ------------------------------------------------------------------ simulator (A.8; RNG scheme is this build's)
  * Bio++ draws from a global, time-seeded generator, so simulated alignments are not reproducible across
- * implementations; the product and this oracle share a counter-based scheme instead (Philox4x32-10):
- *   key = (seed_lo, seed_hi); counter = (g_lo, g_hi, draw, 0x434d5831) with g the global index of the simulated
- *   site and draw = 0 (rate class), 1 (root state), 2 + node (state at the lower end of branch `node`);
- *   u = ((r0 << 32 | r1) >> 11) * 2^-53;  index = #{ j < n-1 : u >= cum[j] } with cum the running sum. */
+ * implementations; the product and this oracle share a counter-based scheme instead (Philox2x32-10, Random123):
+ *   key = seed_lo ^ seed_hi * 0x9E3779B9 ^ 'CMX2'; counter = (g_lo, g_hi[14:0] | draw << 15) with g the global index of
+ *   the simulated site and draw = 0 (rate class), 1 (root state), 2 + node (state at the lower end of branch `node`);
+ *   u = ((r0 << 32 | r1) >> 11) * 2^-53;  index = #{ j < n-1 : u >= cum[j] } with cum the running sum.
+ *   (Philox4x32-10 below serves the Mica permutation test.) */
 static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                  uint32_t* out) {
   for (int r = 0; r < 10; r++) {
@@ -341,9 +342,16 @@ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
 }
 
 double orc_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
-  uint32_t r[4];
-  philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), draw, 0x434d5831u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  uint64_t bits = (((uint64_t)r[0] << 32) | r[1]) >> 11;
+  uint32_t c0 = (uint32_t)g, c1 = ((uint32_t)(g >> 32) & 0x7fffu) | (draw << 15);
+  uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ 0x434d5832u;
+  for (int r = 0; r < 10; r++) {
+    uint64_t p = (uint64_t)0xD256D193u * c0;
+    uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+    c1 = (uint32_t)p;
+    c0 = n0;
+    k += 0x9E3779B9u;
+  }
+  uint64_t bits = (((uint64_t)c0 << 32) | c1) >> 11;
   return (double)bits * (1.0 / 9007199254740992.0);
 }
 
