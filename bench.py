@@ -67,7 +67,8 @@ def flops_per_site(info, B, C, S, K):
     pass over device states; leaf branches are row gathers, sibling messages are stored, not recomputed)."""
     algorithmic = 7.0 * B * C * S * S
     dS, dC = info["device_states"], info["device_classes"]
-    executed = dC * (info["products_per_pass"] * 2.0 * dS * dS + info["leaf_ops_per_pass"] * 2.0 * dS)
+    fuse = max(1, dS // S)   # class-fused nucleotide model: block-diagonal operators, only the diagonal tiles are applied
+    executed = dC * (info["products_per_pass"] * 2.0 * dS * dS / fuse + info["leaf_ops_per_pass"] * 2.0 * dS)
     return algorithmic, executed
 
 

@@ -196,30 +196,32 @@ __device__ __forceinline__ double reduce_sites(const double (&p)[NG]) {
 // step q of a product: output tile o = q / NB, input tile i = q % NB; the stored tile is (o, i), or (i, o) for the
 // transposed product.  Tiles are read three steps ahead of their use (an LDS read takes ~100+ cycles and longer under
 // load, the four MFMAs of a step 64); the empty asm pins the read in front of the MFMAs it overlaps.
-template <int S, bool TR>
+// DIAG (class-fused nucleotide model: one 4-state tile per class, the operator is block diagonal): only the NB diagonal
+// tiles are applied, step q = tile (q, q) -- the same bits as the dense product, whose other tiles are exact zeros.
+template <int S, bool TR, bool DIAG>
 __device__ __forceinline__ constexpr int mfma_tile(int q) {
-  return TR ? (q % (S / 4)) * (S / 4) + q / (S / 4) : q;
+  return DIAG ? q * (S / 4) + q : (TR ? (q % (S / 4)) * (S / 4) + q / (S / 4) : q);
 }
-template <int S, bool TR, int NG, int Q>
+template <int S, bool TR, int NG, bool DIAG, int Q>
 __device__ __forceinline__ void mfma_steps(const uint8_t* tile0, double m0, double m1, double m2, const double (&x)[S / 4 * NG],
                                            double (&y)[S / 4 * NG]) {
-  constexpr int NB = S / 4, NT = NB * NB;
+  constexpr int NB = S / 4, NT = DIAG ? NB : NB * NB;
   if constexpr (Q < NT) {
-    constexpr int o = Q / NB, i = Q % NB;
+    constexpr int o = DIAG ? Q : Q / NB, i = DIAG ? Q : Q % NB;
     double m3 = 0.0;
     if constexpr (Q + 3 < NT) {
-      m3 = *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(Q + 3) * 128);
+      m3 = *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR, DIAG>(Q + 3) * 128);
       asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g)
-      y[o * NG + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(m0, x[i * NG + g], i == 0 ? 0.0 : y[o * NG + g], 0, 0, 0);
-    mfma_steps<S, TR, NG, Q + 1>(tile0, m1, m2, m3, x, y);
+      y[o * NG + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(m0, x[i * NG + g], (DIAG || i == 0) ? 0.0 : y[o * NG + g], 0, 0, 0);
+    mfma_steps<S, TR, NG, DIAG, Q + 1>(tile0, m1, m2, m3, x, y);
   }
 }
 
 // y = M x (TR = false) or y = M^T x (TR = true) with M = the packed matrix staged in buf (already landed)
-template <int S, bool TR, int NG>
+template <int S, bool TR, int NG, bool DIAG>
 __device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const double (&x)[S / 4 * NG],
                                              double (&y)[S / 4 * NG]) {
   static_assert(S % 4 == 0, "state count must be a multiple of 4");
@@ -228,13 +230,13 @@ __device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const
     for (int i = 0; i < S / 4 * NG; ++i) y[i] = x[i] * 0.5;
     return;
   }
-  constexpr int NB = S / 4;
+  constexpr int NT = DIAG ? S / 4 : (S / 4) * (S / 4);
   // element (row r, column c) of a packed tile sits at (4 r + c) * 8; the A slot of lane l is row l & 3, column l >> 4
   // (transposed product: the transposed tile, i.e. row l >> 4, column l & 3)
   const uint8_t* tile0 = buf + (TR ? (4 * (lane >> 4) + (lane & 3)) : (4 * (lane & 3) + (lane >> 4))) * 8;
-  mfma_steps<S, TR, NG, 0>(tile0, *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(0) * 128),
-                       NB * NB > 1 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(1) * 128) : 0.0,
-                       NB * NB > 2 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR>(2) * 128) : 0.0, x, y);
+  mfma_steps<S, TR, NG, DIAG, 0>(tile0, *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR, DIAG>(0) * 128),
+                       NT > 1 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR, DIAG>(1) * 128) : 0.0,
+                       NT > 2 ? *reinterpret_cast<const double*>(tile0 + mfma_tile<S, TR, DIAG>(2) * 128) : 0.0, x, y);
 }
 
 // Message of a leaf edge from the transposed operator staged in buf ([z][x] = M[x][z], rows >= S: ambiguity ids):
@@ -510,7 +512,7 @@ struct DevWalk {
   __device__ __forceinline__ void mv(int, int) {
     unsigned nseq;
     const uint8_t* buf = op_begin(nseq);
-    { CMX_TIC(); matvec_stage<S, TR, NG>(buf, vlane(), reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1])); CMX_TOC(TM_MV); }
+    { CMX_TIC(); matvec_stage<S, TR, NG, (FUSE > 1 && S / FUSE == 4)>(buf, vlane(), reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1])); CMX_TOC(TM_MV); }
     op_end(nseq);
   }
   template <int MODE, int SRC, int DST>
@@ -620,8 +622,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
                                                double& norm_out, int c_begin, int c_end, int c_after, bool finalize) {
   const DevModel& m = a.m;
   const ConstModel cm(m);
-  constexpr int VL = S / 4 * NG;       // doubles of an S-vector per lane (NG site groups of 16 sites per wave)
-  constexpr int kSites = 16 * NG;      // sites per wave
+  constexpr int kSites = 16 * NG;      // sites per wave (NG site groups of 16; an S-vector is S / 4 * NG doubles per lane)
   // site of this lane inside the wave's block for per-site scalars and arrays: NG = 4: the lane itself; NG = 2: lanes
   // l and l ^ 16 both carry site 16 (l >> 5) + (l & 15) and do the per-site work redundantly (identical values)
   const int sidx = NG == 4 ? lane : (((lane >> 5) << 4) | (lane & 15));
