@@ -1332,9 +1332,50 @@ cmx_status cmx_mica_zscore_null(cmx_ctx* ctx, int which, const double* mi, size_
   return CMX_OK;
 }
 
-cmx_status cmx_mica_permutation_test_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* d_aln, size_t n, size_t ld,
-                                         uint32_t max_perm, uint64_t seed, size_t pair_begin, size_t pair_end,
-                                         double* d_pvalue, int32_t* d_nperm, void* stream) {
+// extended codes of the permutation test: states 0..A-1; a code in [A, min(nmasks, 31)) with a partial mask keeps its
+// number; everything else (codes without an entry, gap, X, N: all states) is 31 = unknown.  L = lcm of the state counts.
+namespace {
+struct PermCodes {
+  uint8_t emap[256];
+  uint32_t emask[32], ewgt[32];
+  uint32_t L;
+  int sh;
+};
+cmx_status perm_codes(cmx_ctx* ctx, int A, const uint32_t* masks, size_t nmasks, int T, PermCodes* pc) {
+  const uint32_t all = (1u << A) - 1u;
+  unsigned long long L = (unsigned long long)A;
+  auto lcm = [](unsigned long long a, unsigned long long b) {
+    unsigned long long x = a, y = b;
+    while (y) { const unsigned long long r = x % y; x = y; y = r; }
+    return a / x * b;
+  };
+  int k[32];
+  for (int e = 0; e < 32; ++e) { pc->emask[e] = e < A ? (1u << e) : all; k[e] = e < A ? 1 : A; }
+  for (int c = 0; c < 256; ++c) {
+    if (c < A) { pc->emap[c] = (uint8_t)c; continue; }
+    if (!masks || (size_t)c >= nmasks) { pc->emap[c] = 31; continue; }
+    const uint32_t m = masks[c] & all;
+    if (m == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_permutation_test: mask of code " + std::to_string(c) + " has no state");
+    if (m == all) { pc->emap[c] = 31; continue; }
+    if (c >= 31) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: partial ambiguity codes must be < 31");
+    pc->emap[c] = (uint8_t)c;
+    pc->emask[c] = m;
+    k[c] = __builtin_popcount(m);
+    L = lcm(L, (unsigned long long)k[c]);
+  }
+  const double M = (double)L * (double)L * (double)T;
+  if (M > 67108864.0)
+    return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: lcm of the ambiguity codes' state counts too large for the fixed-point table");
+  pc->L = (uint32_t)L;
+  for (int e = 0; e < 32; ++e) pc->ewgt[e] = (uint32_t)(L / (unsigned long long)k[e]);
+  pc->sh = std::min(40, 62 - (int)std::ceil(std::log2(M * std::log(M))));
+  return CMX_OK;
+}
+}  // namespace
+
+cmx_status cmx_mica_permutation_test_masks_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks,
+                                               const uint8_t* d_aln, size_t n, size_t ld, uint32_t max_perm, uint64_t seed,
+                                               size_t pair_begin, size_t pair_end, double* d_pvalue, int32_t* d_nperm, void* stream) {
   if (!ctx) return CMX_ERR_INVALID;
   if (nalpha != 4 && nalpha != 20) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: alphabet size must be 4 or 20");
   if (ntaxa < 2 || ntaxa > mica_perm_max_taxa())
@@ -1343,14 +1384,22 @@ cmx_status cmx_mica_permutation_test_dev(cmx_ctx* ctx, int nalpha, int ntaxa, co
     return fail(ctx, CMX_ERR_INVALID, "cmx_mica_permutation_test: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  uint16_t* d_cnt;
+  PermCodes pc;
+  cmx_status s;
+  if ((s = perm_codes(ctx, nalpha, masks, nmasks, ntaxa, &pc)) != CMX_OK) return s;
+  uint16_t *d_cnt, *d_ext;
+  uint8_t *d_emap, *d_hasamb;
+  uint32_t* d_tab;   // emask[32] | ewgt[32]
   int* d_bad;
   long long* d_dF;
-  cmx_status s;
   if ((s = scratch(ctx, "perm_cnt", sizeof(uint16_t) * n * nalpha, (void**)&d_cnt)) != CMX_OK) return s;
-  if ((s = scratch(ctx, "perm_bad", sizeof(int), (void**)&d_bad)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "perm_ext", sizeof(uint16_t) * n * 32, (void**)&d_ext)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "perm_emap", 256, (void**)&d_emap)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "perm_hasamb", n, (void**)&d_hasamb)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "perm_tab", sizeof(uint32_t) * 64, (void**)&d_tab)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "perm_bad", 2 * sizeof(int), (void**)&d_bad)) != CMX_OK) return s;
   if ((s = scratch(ctx, "perm_dF", sizeof(long long) * ntaxa, (void**)&d_dF)) != CMX_OK) return s;
-  // F[c] = round(c ln c * 2^40); the kernel accumulates F[c+1] - F[c] per increment of a joint count
+  // resolved pairs: F[c] = round(c ln c * 2^40); the kernel accumulates F[c+1] - F[c] per increment of a joint count
   std::vector<long long> dF(ntaxa);
   long long prev = 0;
   for (int c = 1; c <= ntaxa; ++c) {
@@ -1359,22 +1408,56 @@ cmx_status cmx_mica_permutation_test_dev(cmx_ctx* ctx, int nalpha, int ntaxa, co
     prev = f;
   }
   HIP_TRY(ctx, hipMemcpyAsync(d_dF, dF.data(), sizeof(long long) * ntaxa, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), st));
-  HIP_TRY(ctx, launch_mica_colcount(d_aln, ntaxa, n, ld, nalpha, d_cnt, d_bad, st));
-  int bad = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  if (bad) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: the alignment has gaps or ambiguity codes "
-                                                 "(only fully resolved columns; use the bootstrap or z-score nulls)");
+  HIP_TRY(ctx, hipMemcpyAsync(d_emap, pc.emap, 256, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tab, pc.emask, sizeof(uint32_t) * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tab + 32, pc.ewgt, sizeof(uint32_t) * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 2 * sizeof(int), st));
+  HIP_TRY(ctx, launch_mica_colcount(d_aln, ntaxa, n, ld, nalpha, d_emap, d_cnt, d_ext, d_hasamb, d_bad, st));
+  int bad[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(bad, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));   // also: dF and the code tables have been read from this frame
   int cus = 0;
   HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-  HIP_TRY(ctx, launch_mica_perm(d_aln, ntaxa, n, ld, nalpha, d_cnt, d_dF, max_perm, seed, pair_begin, pair_end, d_pvalue, d_nperm,
-                                cus, st));
+  const size_t npairs = pair_end - pair_begin;
+  bool preset = false;
+  if (bad[0]) {
+    // pairs with gaps / unknowns / ambiguity codes (SiteTools::*(.., resolveUnknowns = true)): their own kernel, first
+    if (mica_perm_general_lds(ntaxa, nalpha, bad[1]) == 0)
+      return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: " + std::to_string(ntaxa) + " taxa with " + std::to_string(bad[1]) +
+                                            " distinct ambiguity codes in one column do not fit the LDS");
+    const size_t M = (size_t)pc.L * pc.L * (size_t)ntaxa;
+    std::vector<long long> F(M + 1, 0);
+    const double scale = std::ldexp(1.0, pc.sh);
+    for (size_t m = 1; m <= M; ++m) F[m] = std::llround((double)m * std::log((double)m) * scale);
+    long long* d_F;
+    uint16_t* d_order;
+    if ((s = scratch(ctx, "perm_F", sizeof(long long) * (M + 1), (void**)&d_F)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "perm_order", sizeof(uint16_t) * n * (size_t)ntaxa, (void**)&d_order)) != CMX_OK) return s;
+    HIP_TRY(ctx, hipMemcpyAsync(d_F, F.data(), sizeof(long long) * (M + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_mica_colorder(d_aln, ntaxa, n, ld, nalpha, d_emap, d_ext, d_order, st));
+    if (!mica_perm_opening_fits(ntaxa, nalpha)) {
+      HIP_TRY(ctx, hipMemsetAsync(d_nperm, 0xFF, sizeof(int32_t) * npairs, st));   // -1: undecided, no hits (resolved pairs)
+      preset = true;
+    }
+    HIP_TRY(ctx, launch_mica_perm_general(d_aln, ntaxa, n, ld, nalpha, d_emap, d_ext, d_order, d_hasamb, d_tab, d_tab + 32, d_F, pc.L,
+                                          bad[1], max_perm, seed, pair_begin, pair_end, d_pvalue, d_nperm, cus, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));   // F lives in this frame
+  }
+  HIP_TRY(ctx, launch_mica_perm(d_aln, ntaxa, n, ld, nalpha, d_cnt, d_hasamb, d_dF, preset, max_perm, seed, pair_begin, pair_end,
+                                d_pvalue, d_nperm, cus, st));
   return CMX_OK;
 }
 
-cmx_status cmx_mica_permutation_test(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* aln, size_t n, uint32_t max_perm,
-                                     uint64_t seed, double* pvalue, int32_t* nperm) {
+cmx_status cmx_mica_permutation_test_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* d_aln, size_t n, size_t ld,
+                                         uint32_t max_perm, uint64_t seed, size_t pair_begin, size_t pair_end,
+                                         double* d_pvalue, int32_t* d_nperm, void* stream) {
+  return cmx_mica_permutation_test_masks_dev(ctx, nalpha, ntaxa, nullptr, 0, d_aln, n, ld, max_perm, seed, pair_begin, pair_end,
+                                             d_pvalue, d_nperm, stream);
+}
+
+cmx_status cmx_mica_permutation_test_masks(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks,
+                                           const uint8_t* aln, size_t n, uint32_t max_perm, uint64_t seed, double* pvalue,
+                                           int32_t* nperm) {
   if (!ctx) return CMX_ERR_INVALID;
   if (!aln || n < 2 || ntaxa < 2 || !pvalue || !nperm) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_permutation_test: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1387,12 +1470,18 @@ cmx_status cmx_mica_permutation_test(cmx_ctx* ctx, int nalpha, int ntaxa, const 
   HIP_TRY(ctx, tmp.alloc((void**)&d_pv, sizeof(double) * np));
   HIP_TRY(ctx, tmp.alloc((void**)&d_np, sizeof(int32_t) * np));
   HIP_TRY(ctx, hipMemcpy(d_aln, aln, (size_t)ntaxa * n, hipMemcpyHostToDevice));
-  cmx_status s = cmx_mica_permutation_test_dev(ctx, nalpha, ntaxa, d_aln, n, n, max_perm, seed, 0, np, d_pv, d_np, nullptr);
+  cmx_status s = cmx_mica_permutation_test_masks_dev(ctx, nalpha, ntaxa, masks, nmasks, d_aln, n, n, max_perm, seed, 0, np, d_pv, d_np,
+                                                     nullptr);
   if (s != CMX_OK) return s;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(pvalue, d_pv, sizeof(double) * np, hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemcpy(nperm, d_np, sizeof(int32_t) * np, hipMemcpyDeviceToHost));
   return CMX_OK;
+}
+
+cmx_status cmx_mica_permutation_test(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* aln, size_t n, uint32_t max_perm,
+                                     uint64_t seed, double* pvalue, int32_t* nperm) {
+  return cmx_mica_permutation_test_masks(ctx, nalpha, ntaxa, nullptr, 0, aln, n, max_perm, seed, pvalue, nperm);
 }
 
 // ------------------------------------------------------------------------------------------------ clustering

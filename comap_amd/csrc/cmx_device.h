@@ -127,10 +127,20 @@ hipError_t launch_mica_average(const double* d_mi, size_t n, size_t ld, double* 
 hipError_t launch_mica_zscore(int which, const double* d_mi, size_t n, size_t ld, const double* d_avg, const double* d_full,
                               const double* d_key, double* d_stat, double* d_outkey, hipStream_t stream);
 int mica_perm_max_taxa();
-hipError_t launch_mica_colcount(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, uint16_t* d_cnt, int* d_bad, hipStream_t stream);
-hipError_t launch_mica_perm(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, const uint16_t* d_colcnt, const long long* d_dF,
-                            uint32_t max_perm, uint64_t seed, size_t pair_begin, size_t pair_end, double* d_pvalue, int32_t* d_nperm,
-                            int cu_count, hipStream_t stream);
+hipError_t launch_mica_colcount(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, const uint8_t* d_emap, uint16_t* d_cnt,
+                                uint16_t* d_ext, uint8_t* d_hasamb, int* d_bad, hipStream_t stream);
+hipError_t launch_mica_colorder(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, const uint8_t* d_emap, const uint16_t* d_ext,
+                                uint16_t* d_order, hipStream_t stream);
+bool mica_perm_opening_fits(int T, int A);   // the four-pairs-per-wave opening pass fits the LDS (else nperm must be preset to -1)
+size_t mica_perm_general_lds(int T, int A, int namb);
+hipError_t launch_mica_perm_general(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, const uint8_t* d_emap,
+                                    const uint16_t* d_ext, const uint16_t* d_order, const uint8_t* d_hasamb, const uint32_t* d_emask,
+                                    const uint32_t* d_ewgt, const long long* d_F, uint32_t L, int namb, uint32_t max_perm, uint64_t seed,
+                                    size_t pair_begin, size_t pair_end, double* d_pvalue, int32_t* d_nperm, int cu_count,
+                                    hipStream_t stream);
+hipError_t launch_mica_perm(const uint8_t* d_aln, int T, size_t n, size_t ld, int A, const uint16_t* d_colcnt,
+                            const uint8_t* d_hasamb, const long long* d_dF, bool nperm_preset, uint32_t max_perm, uint64_t seed,
+                            size_t pair_begin, size_t pair_end, double* d_pvalue, int32_t* d_nperm, int cu_count, hipStream_t stream);
 // clustering (cmx_cluster.hip)
 size_t hclust_lds_bytes(int n);
 size_t cluster_props_lds_bytes(int n);

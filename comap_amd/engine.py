@@ -42,7 +42,7 @@ EXPORTS = [
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev", "cmx_intra_rows_range_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
-    "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
+    "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_permutation_test_masks", "cmx_mica_permutation_test_masks_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
     "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups", "cmx_debug_candidate_cursor",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
 ]
@@ -451,14 +451,17 @@ class Engine:
         self._check(self._lib.cmx_mica_average_mi(self._ctx, _vp(m), _sz(n), _vp(avg), _vp(full)))
         return avg, float(full[0])
 
-    def mica_permutation_test(self, aln, max_perm, seed, nalpha=20):
-        """miTest of every column pair (Mica.cpp:93-118) -> (pvalue, nperm) [n(n-1)/2] in (i < j) row order"""
+    def mica_permutation_test(self, aln, max_perm, seed, nalpha=20, masks=None):
+        """miTest of every column pair (Mica.cpp:93-118) -> (pvalue, nperm) [n(n-1)/2] in (i < j) row order.  masks: table
+        indexed by alignment code (bit a = compatible with state a); codes >= nalpha without an entry are unknowns."""
         a = np.ascontiguousarray(aln, dtype=np.uint8)
         T, n = a.shape
         npairs = n * (n - 1) // 2
         pv, npm = np.zeros(npairs), np.zeros(npairs, dtype=np.int32)
-        self._check(self._lib.cmx_mica_permutation_test(self._ctx, int(nalpha), int(T), _vp(a), _sz(n), ctypes.c_uint32(max_perm),
-                                                        ctypes.c_uint64(seed), _vp(pv), _vp(npm)))
+        mk = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint32)
+        self._check(self._lib.cmx_mica_permutation_test_masks(self._ctx, int(nalpha), int(T), _vp(mk) if mk is not None else None,
+                                                              _sz(0 if mk is None else len(mk)), _vp(a), _sz(n),
+                                                              ctypes.c_uint32(max_perm), ctypes.c_uint64(seed), _vp(pv), _vp(npm)))
         return pv, npm
 
     def mica_zscore_null(self, which, mi, key):

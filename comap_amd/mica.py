@@ -50,10 +50,10 @@ def parametric_null(engine, seed, nrep_cpu=10, nrep_ram=100, nalpha=20, with_nor
     return out
 
 
-def permutation_test(engine, aln, max_perm=1000, seed=0, nalpha=20):
+def permutation_test(engine, aln, max_perm=1000, seed=0, nalpha=20, masks=None):
     """-> dense (pvalue [n, n], nperm [n, n]) filled for j > i: Perm.p.value / Perm.nb of Mica.cpp:667-668"""
     n = aln.shape[1]
-    pv, npm = engine.mica_permutation_test(aln, max_perm, seed, nalpha)
+    pv, npm = engine.mica_permutation_test(aln, max_perm, seed, nalpha, masks=masks)
     iu = np.triu_indices(n, 1)
     P, N = np.full((n, n), np.nan), np.zeros((n, n), dtype=np.int32)
     P[iu], N[iu] = pv, npm

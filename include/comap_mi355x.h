@@ -300,10 +300,23 @@ cmx_status cmx_debug_candidate_cursor(size_t ngroups, const int64_t* offsets, co
 /* Mica's permutation test, null.method = permutations: miTest (CoMap/Mica.cpp:93-118) for the pairs
  * [pair_begin, pair_end) of the row-major (i < j) order: columns are shuffled until 5 shuffles reach the observed MI or
  * max_perm (null.max_number_of_permutations) were done; pvalue = (count + 1) / (nperm + 1); pairs with a constant
- * column get pvalue 1, nperm 0.  "MI of the shuffle >= MI" is decided on sum c ln c of the joint table in 2^-40 fixed
- * point (exact, order-free).  Shuffles come from the counter RNG (seed, pair, permutation, position), so
- * results do not depend on how pairs are sharded.  Only fully resolved alignments (every code < nalpha), ntaxa <= 2047:
- * CMX_ERR_UNSUPPORTED otherwise. */
+ * column (SiteTools::isConstant(site, ignoreUnknown = true): at most one distinct symbol besides unknowns) get pvalue 1,
+ * nperm 0.  "MI of the shuffle >= MI" is decided on sum m ln m of the joint table in fixed point (exact, order-free;
+ * DESIGN.md 4.4).  Shuffles come from the counter RNG (seed, pair, permutation, position), so results do not depend on
+ * how pairs are sharded.  ntaxa <= 2047.
+ * Gaps, unknowns and ambiguity codes count as SiteTools::mutualInformation(.., resolveUnknowns = true) counts them: a
+ * symbol with k compatible states adds 1/k to each.  `masks` is a HOST table indexed by alignment code (bit a =
+ * compatible with state a), as for cmx_mi_columns; codes >= nalpha without an entry (and masks == NULL) are unknowns.
+ * Partial ambiguity codes must be < 31.  Pairs of fully resolved columns take the same path, and give the same
+ * results, with or without a mask table. */
+cmx_status cmx_mica_permutation_test_masks_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks,
+                                               const uint8_t* d_aln, size_t n, size_t ld, uint32_t max_perm, uint64_t seed,
+                                               size_t pair_begin, size_t pair_end, double* d_pvalue, int32_t* d_nperm,
+                                               void* stream);
+cmx_status cmx_mica_permutation_test_masks(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks,
+                                           const uint8_t* aln, size_t n, uint32_t max_perm, uint64_t seed,
+                                           double* pvalue /*[n(n-1)/2]*/, int32_t* nperm);
+/* the same with masks == NULL */
 cmx_status cmx_mica_permutation_test_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint8_t* d_aln, size_t n, size_t ld,
                                          uint32_t max_perm, uint64_t seed, size_t pair_begin, size_t pair_end,
                                          double* d_pvalue, int32_t* d_nperm, void* stream);

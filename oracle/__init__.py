@@ -245,17 +245,22 @@ def mica_zscore_null(which, mi, key):
     return v, np.minimum(key[iu[0]], key[iu[1]])
 
 
-def mica_permutation_test(aln, A, max_perm, seed, pair_begin=0, pair_end=None):
-    """miTest of CoMap/Mica.cpp:93-118 for column pairs in (i < j) row order -> (pvalue, nperm)"""
+def mica_permutation_test(aln, A, max_perm, seed, pair_begin=0, pair_end=None, masks=None):
+    """miTest of CoMap/Mica.cpp:93-118 for column pairs in (i < j) row order -> (pvalue, nperm).  masks: table indexed by
+    alignment code (bit a = compatible with state a); codes >= A without an entry are unknowns (gap, X, N)."""
     a = np.ascontiguousarray(aln, dtype=np.uint8)
     T, n = a.shape
     npairs = n * (n - 1) // 2
     pair_end = npairs if pair_end is None else pair_end
     pv, npm = np.zeros(pair_end - pair_begin), np.zeros(pair_end - pair_begin, dtype=np.int32)
     L = lib()
-    L.orc_mica_permutation_test.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_uint32,
-                                            ctypes.c_uint64, ctypes.c_long, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
-    st = L.orc_mica_permutation_test(a.ctypes.data, T, n, A, max_perm, seed, pair_begin, pair_end, pv.ctypes.data, npm.ctypes.data)
+    mk = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint32)
+    L.orc_mica_permutation_test_masks.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_long, ctypes.c_long,
+                                                  ctypes.c_void_p, ctypes.c_void_p]
+    st = L.orc_mica_permutation_test_masks(a.ctypes.data, T, n, A, None if mk is None else mk.ctypes.data,
+                                           0 if mk is None else len(mk), max_perm, seed, pair_begin, pair_end,
+                                           pv.ctypes.data, npm.ctypes.data)
     if st != 0:
-        raise ValueError("oracle: permutation test needs fully resolved columns")
+        raise ValueError(f"oracle: permutation test: bad mask table or too many ambiguity codes ({st})")
     return pv, npm

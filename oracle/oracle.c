@@ -748,14 +748,98 @@ void orc_mi_columns(int T, int A, const uint32_t* masks, long N1, const uint8_t*
 
 
 /* ------------------------------------------------------------------ Mica permutation test
- * miTest (CoMap/Mica.cpp:93-118) for the column pairs [pair_begin, pair_end) of the row-major (i < j) order, fully
- * resolved columns only.  PARITY UNPINNED (no reference output; Bio++'s Site::shuffle draws from a global generator).
+ * miTest (CoMap/Mica.cpp:93-118) for the column pairs [pair_begin, pair_end) of the row-major (i < j) order; first the
+ * scheme for fully resolved pairs, below it the one for pairs with unknowns.  PARITY UNPINNED (no reference output; Bio++'s Site::shuffle draws from a global generator).
  * This build's scheme, shared with the product: only column j is shuffled (same distribution of joint tables), by a
  * forward Fisher-Yates over the positions 0..T-1 with jj = t + mulhi32(r, T - t), r = word (t & 3) of Philox4x32-10
  * (key = seed, counter = (pair, pair >> 32, permutation, 'P' << 24 | t >> 2)); position t carries column i's states in
  * sorted order; "MI of the shuffle >= MI" is decided on sum_xy F[c_xy], F[c] = round(c ln c * 2^40) in int64. */
+/* Columns with gaps / unknowns / ambiguity codes (SiteTools::mutualInformation(.., resolveUnknowns = true): a symbol
+ * with k compatible states counts 1/k for each, a pair 1/(k_a k_b) for each compatible (x, y)).  A pair with such a
+ * column takes this path; fully resolved pairs keep the one above bit for bit.
+ *   extended codes: states 0..A-1; code c in [A, min(nmasks, 31)) -> itself with masks[c]; every other code -> 31 =
+ *   unknown (all states).  L = lcm of the state counts of all extended codes; the joint table is kept as integers
+ *   m_xy = sum_t [x in a_t][y in b_t] (L/k_a)(L/k_b) <= L^2 T, and "MI of the shuffle >= MI" is decided on
+ *   sum_xy F[m_xy], F[m] = round(m ln m * 2^sh), sh = min(40, 62 - ceil(log2(M ln M))), M = L^2 T (H1, H2 and
+ *   sum_xy m_xy do not change under a shuffle).
+ *   isConstant(site, ignoreUnknown = true): at most one distinct code among the symbols that are not unknowns.
+ *   positions are taken in the order (ambiguous / unknown codes of column i ascending, then states ascending; stable),
+ *   column j is carried along, and the Fisher-Yates of the resolved path shuffles that copy. */
+static long orc_lcm(long a, long b) {
+  long x = a, y = b;
+  while (y) { long r = x % y; x = y; y = r; }
+  return a / x * b;
+}
+typedef struct { int ext[256]; uint32_t mask[32]; int k[32]; long L; int sh; } orc_perm_codes;
+static int orc_perm_codes_init(orc_perm_codes* pc, int A, const uint32_t* masks, int nmasks, int T) {
+  const uint32_t all = A >= 32 ? 0xffffffffu : ((1u << A) - 1u);
+  for (int e = 0; e < 32; e++) { pc->mask[e] = e < A ? (1u << e) : all; pc->k[e] = e < A ? 1 : A; }
+  pc->L = A;
+  for (int c = 0; c < 256; c++) {
+    if (c < A) { pc->ext[c] = c; continue; }
+    if (!masks || c >= nmasks) { pc->ext[c] = 31; continue; }
+    const uint32_t m = masks[c] & all;
+    if (m == 0) return -1;
+    if (m == all) { pc->ext[c] = 31; continue; }
+    if (c >= 31) return -3;                      /* more partial ambiguity codes than the extended alphabet holds */
+    pc->ext[c] = c; pc->mask[c] = m; pc->k[c] = __builtin_popcount(m);
+    pc->L = orc_lcm(pc->L, pc->k[c]);
+  }
+  const double M = (double)pc->L * (double)pc->L * (double)T;
+  if (M > 67108864.0) return -3;
+  int sh = 62 - (int)ceil(log2(M * log(M)));
+  pc->sh = sh > 40 ? 40 : sh;
+  return 0;
+}
+static long long orc_perm_table_sum(const orc_perm_codes* pc, int A, int T, const uint8_t* xs, const uint8_t* q, const long long* F,
+                                    long* m) {
+  memset(m, 0, sizeof(long) * (size_t)A * A);
+  for (int t = 0; t < T; t++) {
+    const int a = xs[t], b = q[t];
+    const long w = (pc->L / pc->k[a]) * (pc->L / pc->k[b]);
+    for (int x = 0; x < A; x++)
+      if ((pc->mask[a] >> x) & 1u)
+        for (int y = 0; y < A; y++)
+          if ((pc->mask[b] >> y) & 1u) m[x * A + y] += w;
+  }
+  long long s = 0;
+  for (int e = 0; e < A * A; e++) s += F[m[e]];
+  return s;
+}
+
+/* the integer joint table of two columns (test hook: H_joint = ln(L^2 T) - sum m ln m / (L^2 T) must agree with
+ * orc_mi_columns); returns L, or a negative status */
+long orc_mica_joint_table(int A, const uint32_t* masks, int nmasks, int T, const uint8_t* col_i, const uint8_t* col_j, long* m) {
+  orc_perm_codes pc;
+  const int st = orc_perm_codes_init(&pc, A, masks, nmasks, T);
+  if (st) return st;
+  uint8_t* xi = (uint8_t*)malloc((size_t)T);
+  uint8_t* xj = (uint8_t*)malloc((size_t)T);
+  long long* F = (long long*)calloc((size_t)(pc.L * pc.L * T) + 1, sizeof(long long));
+  for (int t = 0; t < T; t++) { xi[t] = (uint8_t)pc.ext[col_i[t]]; xj[t] = (uint8_t)pc.ext[col_j[t]]; }
+  (void)orc_perm_table_sum(&pc, A, T, xi, xj, F, m);
+  free(xi); free(xj); free(F);
+  return pc.L;
+}
+
+int orc_mica_permutation_test_masks(const uint8_t* aln, int T, long n, int A, const uint32_t* masks, int nmasks, uint32_t max_perm,
+                                    uint64_t seed, long pair_begin, long pair_end, double* pvalue, int32_t* nperm);
+
 int orc_mica_permutation_test(const uint8_t* aln, int T, long n, int A, uint32_t max_perm, uint64_t seed, long pair_begin,
                               long pair_end, double* pvalue, int32_t* nperm) {
+  return orc_mica_permutation_test_masks(aln, T, n, A, NULL, 0, max_perm, seed, pair_begin, pair_end, pvalue, nperm);
+}
+
+int orc_mica_permutation_test_masks(const uint8_t* aln, int T, long n, int A, const uint32_t* masks, int nmasks, uint32_t max_perm,
+                                    uint64_t seed, long pair_begin, long pair_end, double* pvalue, int32_t* nperm) {
+  orc_perm_codes pc;
+  { const int st = orc_perm_codes_init(&pc, A, masks, nmasks, T); if (st) return st; }
+  const uint32_t all = (1u << A) - 1u;
+  long long* FG = NULL;                           /* general table, built on first use */
+  long* mtab = (long*)malloc(sizeof(long) * (size_t)A * A);
+  uint8_t* gxs = (uint8_t*)malloc((size_t)T);
+  uint8_t* gbase = (uint8_t*)malloc((size_t)T);
+
   long long* F = (long long*)calloc((size_t)T + 1, sizeof(long long));
   uint8_t* q = (uint8_t*)malloc((size_t)T);
   uint8_t* xs = (uint8_t*)malloc((size_t)T);
@@ -765,11 +849,47 @@ int orc_mica_permutation_test(const uint8_t* aln, int T, long n, int A, uint32_t
   for (long i = 0; i < n - 1; i++)
     for (long j = i + 1; j < n; j++, p++) {
       if (p < pair_begin || p >= pair_end) continue;
-      int ci[32] = {0}, cj[32] = {0}, nzi = 0, nzj = 0;
+      int ci[32] = {0}, cj[32] = {0}, nzi = 0, nzj = 0, general = 0;
       for (int t = 0; t < T; t++) {
-        if (aln[(size_t)t * n + i] >= A || aln[(size_t)t * n + j] >= A) { free(F); free(q); free(xs); free(joint); return -2; }
-        ci[aln[(size_t)t * n + i]]++;
-        cj[aln[(size_t)t * n + j]]++;
+        const int ei = pc.ext[aln[(size_t)t * n + i]], ej = pc.ext[aln[(size_t)t * n + j]];
+        general |= (ei >= A) | (ej >= A);
+        ci[ei]++;
+        cj[ej]++;
+      }
+      if (general) {
+        for (int e = 0; e < 32; e++) { nzi += ci[e] > 0 && pc.mask[e] != all; nzj += cj[e] > 0 && pc.mask[e] != all; }
+        if (nzi <= 1 || nzj <= 1) { pvalue[p - pair_begin] = 1.0; nperm[p - pair_begin] = 0; continue; }
+        if (!FG) {
+          const long M = pc.L * pc.L * (long)T;
+          FG = (long long*)calloc((size_t)M + 1, sizeof(long long));
+          for (long m = 1; m <= M; m++) FG[m] = llround((double)m * log((double)m) * ldexp(1.0, pc.sh));
+        }
+        { /* stable sort of the positions: ambiguous / unknown codes of column i ascending, then states ascending */
+          int tt = 0;
+          for (int pass = 0; pass < 2; pass++)
+            for (int e = pass ? 0 : A; e < (pass ? A : 32); e++)
+              for (int t = 0; t < T; t++)
+                if (pc.ext[aln[(size_t)t * n + i]] == e) { gxs[tt] = (uint8_t)e; gbase[tt] = (uint8_t)pc.ext[aln[(size_t)t * n + j]]; tt++; }
+        }
+        const long long sobs = orc_perm_table_sum(&pc, A, T, gxs, gbase, FG, mtab);
+        uint32_t k = 0, count = 0;
+        for (; count < 5 && k < max_perm; k++) {
+          memcpy(q, gbase, (size_t)T);
+          uint32_t r[4] = {0, 0, 0, 0};
+          for (int t = 0; t < T; t++) {
+            if ((t & 3) == 0)
+              philox4x32_10((uint32_t)p, (uint32_t)((uint64_t)p >> 32), k, 0x50000000u | (uint32_t)(t >> 2), (uint32_t)seed,
+                            (uint32_t)(seed >> 32), r);
+            const int jj = t + (int)(((uint64_t)r[t & 3] * (uint32_t)(T - t)) >> 32);
+            const uint8_t vj = q[jj];
+            q[jj] = q[t];
+            q[t] = vj;
+          }
+          if (orc_perm_table_sum(&pc, A, T, gxs, q, FG, mtab) >= sobs) count++;
+        }
+        pvalue[p - pair_begin] = (double)(count + 1) / (double)(k + 1);
+        nperm[p - pair_begin] = (int32_t)k;
+        continue;
       }
       for (int x = 0; x < A; x++) { nzi += ci[x] > 0; nzj += cj[x] > 0; }
       if (nzi <= 1 || nzj <= 1) { pvalue[p - pair_begin] = 1.0; nperm[p - pair_begin] = 0; continue; }
@@ -800,6 +920,6 @@ int orc_mica_permutation_test(const uint8_t* aln, int T, long n, int A, uint32_t
       pvalue[p - pair_begin] = (double)(count + 1) / (double)(k + 1);
       nperm[p - pair_begin] = (int32_t)k;
     }
-  free(F); free(q); free(xs); free(joint);
+  free(F); free(q); free(xs); free(joint); free(FG); free(mtab); free(gxs); free(gbase);
   return 0;
 }

@@ -571,8 +571,8 @@ def test_mica_permutation_test_matches_oracle(A, T, n, max_perm):
     assert np.allclose(pv[stopped & ~const], 6.0 / (npm[stopped & ~const] + 1.0))
 
 
-def test_mica_permutation_test_is_calibrated_and_rejects_gaps():
-    """independent columns: p-values roughly uniform; coupled columns: small p; gaps are refused, not guessed"""
+def test_mica_permutation_test_is_calibrated():
+    """independent columns: p-values roughly uniform; coupled columns: small p"""
     rng = np.random.default_rng(1)
     T, n = 100, 40
     aln = rng.integers(0, 4, size=(T, n)).astype(np.uint8)
@@ -582,9 +582,65 @@ def test_mica_permutation_test_is_calibrated_and_rejects_gaps():
     assert pv[0] < 0.01 and npm[0] == 1000                   # pair (0, 1)
     rest = pv[n - 1:]                                        # pairs not involving column 0... (row 0 is the first n-1 pairs)
     assert 0.3 < np.median(rest) < 0.8 and (rest < 0.05).mean() < 0.12
-    aln[3, 5] = 4
-    with pytest.raises(engine.CmxError, match="gaps or ambiguity"):
-        eng.mica_permutation_test(aln, 100, 3, nalpha=4)
+
+
+def _with_unknowns(rng, A, T, n, ncodes, frac):
+    """coupled columns with gaps / ambiguity codes sprinkled in; some columns stay fully resolved"""
+    base = rng.integers(0, A, size=(T, 1))
+    aln = np.where(rng.random((T, n)) < 0.55, base, rng.integers(0, A, size=(T, n))).astype(np.uint8)
+    hit = rng.random((T, n)) < frac
+    hit[:, :3] = False                                       # resolved columns: their mutual pairs take the resolved path
+    aln[hit] = rng.integers(A, A + ncodes, size=int(hit.sum()))
+    return aln
+
+
+@pytest.mark.parametrize("A,T,n,max_perm,partial", [(4, 40, 10, 300, False), (20, 33, 9, 200, False), (4, 64, 9, 500, True),
+                                                     (20, 130, 8, 140, True), (4, 7, 6, 63, True)])
+def test_mica_permutation_test_with_unknowns_matches_oracle(A, T, n, max_perm, partial):
+    """Mica.cpp:93-118 with SiteTools::*(.., resolveUnknowns = true): gaps / unknowns (and, with a mask table, partial
+    ambiguity codes) spread over their compatible states.  p-value and number of permutations per pair equal the
+    oracle's exactly; pairs of resolved columns are the same as without any unknown in the alignment."""
+    rng = np.random.default_rng(A * 77 + T)
+    if partial:
+        ncodes = 5
+        masks = oracle.default_masks(A)[:A + ncodes].copy()
+        for c in range(A, A + ncodes - 1):                   # the last code stays "all states" (a gap)
+            k = int(rng.integers(1 if c == A else 2, 4))     # one alias of a single state among them
+            masks[c] = sum(1 << int(x) for x in rng.choice(A, size=k, replace=False))
+    else:
+        ncodes, masks = 2, None                              # two unknown codes (gap, X): the same extended code
+    aln = _with_unknowns(rng, A, T, n, ncodes, 0.2)
+    aln[:, 4] = np.where(aln[:, 4] < A, 1, aln[:, 4])        # constant besides its unknowns: p = 1, 0 permutations
+    aln[:, 5] = A + ncodes - 1                               # nothing but gaps
+    eng = engine.Engine()
+    pv, npm = eng.mica_permutation_test(aln, max_perm, 41, nalpha=A, masks=masks)
+    po, no = oracle.mica_permutation_test(aln, A, max_perm, 41, masks=masks)
+    assert np.array_equal(npm, no) and np.array_equal(pv, po)
+    iu = np.triu_indices(n, 1)
+    const = np.isin(iu[0], (4, 5)) | np.isin(iu[1], (4, 5))
+    if not partial:
+        assert np.all(npm[const] == 0) and np.all(pv[const] == 1.0)
+    # pairs (0, 1) and (0, 2) carry the pair numbers 0 and 1 whatever n is: resolved columns, so the same shuffles and the
+    # same answer as in an alignment without any unknown
+    p3, n3 = eng.mica_permutation_test(aln[:, :3], max_perm, 41, nalpha=A)
+    assert np.array_equal(pv[:2], p3[:2]) and np.array_equal(npm[:2], n3[:2])
+
+
+def test_mica_permutation_test_unknowns_many_taxa_and_limits():
+    """T = 600 with gaps: one wave per workgroup; a mask table whose partial codes do not fit is refused loudly"""
+    rng = np.random.default_rng(5)
+    eng = engine.Engine()
+    aln = _with_unknowns(rng, 4, 600, 6, 1, 0.1)
+    pv, npm = eng.mica_permutation_test(aln, 70, 9, nalpha=4)
+    po, no = oracle.mica_permutation_test(aln, 4, 70, 9)
+    assert np.array_equal(npm, no) and np.array_equal(pv, po)
+    masks = oracle.default_masks(20)[:40].copy()
+    masks[33] = 0b11
+    with pytest.raises(engine.CmxError, match="< 31"):
+        eng.mica_permutation_test(_with_unknowns(rng, 20, 20, 5, 2, 0.1), 10, 1, nalpha=20, masks=masks)
+    masks[33] = 0
+    with pytest.raises(engine.CmxError, match="no state"):
+        eng.mica_permutation_test(_with_unknowns(rng, 20, 20, 5, 2, 0.1), 10, 1, nalpha=20, masks=masks)
 
 
 def _nh_case(nstates, seed):
