@@ -1984,7 +1984,8 @@ __device__ __forceinline__ double mica_dpp_f64(double v) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int A, int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
+template <int A>
+__global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
                                                            const uint8_t* __restrict__ flag1, const uint8_t* __restrict__ gap1,
                                                            const double* __restrict__ S1,
                                                            const int8_t* __restrict__ H2, size_t n2,
@@ -2079,9 +2080,12 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int A, int T, int Tp,
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
+      // register v of a lane holds table row 8 (v / 4) + v % 4 (+ 4 in the upper half of the wave): rows past the
+      // pseudo-state (row A) are padding of the 32-row tile, structurally zero -- no lookup for them
       double s = 0.0;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) s += ftab[acc[ii][jj][v]];
+      for (int v = 0; v < 16; ++v)
+        if (8 * (v / 4) + v % 4 <= A) s += ftab[acc[ii][jj][v]];   // compile-time after unrolling
       ps[2 * ii + jj] = s;
     }
   swap32(ps[0], ps[2]);
@@ -2142,6 +2146,219 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int A, int T, int Tp,
   }
 }
 
+// ---- protein alphabet, packed tiles.  A column needs 21 one-hot rows (20 states + the pseudo-state of unknowns), a
+// 32-row MFMA tile per column wastes a third of the rows and (32/21)^2 of the matrix work AND of the table epilogue.
+// Here THREE columns share a 64-row block (rows 21 c + state, row 63 = zero): a wave's 2 x 2 MFMA tiles are the 64 x 64
+// Gram block of 3 x 3 column pairs (9 pairs where the one-column-per-tile kernel has 4), same operand traffic, same
+// accumulators.  Workgroup tile: 12 columns of the first alignment x 6 of the second (4 x 2 blocks, one per wave).
+// The epilogue sums f(count) per (column of the block row, column of the block column): an accumulator register's row
+// block is known at compile time up to the lane's half (rows + 4 in lanes >= 32), its column block from the lane.
+constexpr int kMica3I = 12, kMica3J = 6, kMicaP = 21;
+__device__ __forceinline__ double mica_reduce4(double p0, double p1, double p2, double p3) {
+  // totals over the wave of four values at once: lanes with lane >> 4 == r end with the total of value r
+  swap32(p0, p2);
+  swap32(p1, p3);
+  double k0 = p0 + p2, k1 = p1 + p3;
+  swap16(k0, k1);
+  double s = k0 + k1;
+  s += mica_dpp_f64<0x128>(s);   // row_ror:8
+  s += mica_dpp_f64<0x124>(s);   // row_ror:4
+  s += mica_dpp_f64<0x122>(s);   // row_ror:2
+  s += mica_dpp_f64<0x121>(s);   // row_ror:1
+  return s;
+}
+__global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
+                                                            const uint8_t* __restrict__ flag1, const uint8_t* __restrict__ gap1,
+                                                            const double* __restrict__ S1,
+                                                            const int8_t* __restrict__ H2, size_t n2,
+                                                            const uint8_t* __restrict__ flag2, const uint8_t* __restrict__ gap2,
+                                                            const double* __restrict__ S2,
+                                                            const double* __restrict__ ftab_g, int intra,
+                                                            double* __restrict__ mi, double* __restrict__ hj, size_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t mica_smem[];
+  constexpr int A = 20, P = kMicaP;
+  double* ftab = reinterpret_cast<double*>(mica_smem);                       // [T + 1]
+  cmx_i4* ops = reinterpret_cast<cmx_i4*>(mica_smem + (((size_t)(T + 1) * 8 + 15) & ~(size_t)15));  // [2][12][64]
+  constexpr int NOP = 12, NI = 8;   // operand tiles per k-step: 8 of the first alignment (4 blocks), 4 of the second
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
+  for (int c = tid; c <= T; c += 512) ftab[c] = ftab_g[c];
+  const size_t i0 = (size_t)blockIdx.y * kMica3I, j0 = (size_t)blockIdx.x * kMica3J;
+  if (intra && j0 + kMica3J <= i0 + 1) {   // no pair with j > i in this tile: only the NaN convention of the intra layout
+    if (tid < kMica3I * kMica3J) {
+      const size_t i = i0 + tid / kMica3J, j = j0 + tid % kMica3J;
+      if (i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
+        mi[i * ldo + j] = __builtin_nan("");
+        hj[i * ldo + j] = __builtin_nan("");
+      }
+    }
+    return;
+  }
+  unsigned gapbits = 0;
+#pragma unroll
+  for (int c = 0; c < kMica3I; ++c) gapbits |= gap1[i0 + c < n1 ? i0 + c : n1 - 1];
+#pragma unroll
+  for (int c = 0; c < kMica3J; ++c) gapbits |= gap2[j0 + c < n2 ? j0 + c : n2 - 1];
+  // loader role: 12 operand tiles x 64 lanes = 768 slots of 16 bytes, threads 0..383 take two each.  Operand tile q:
+  // q < 8: rows 32 (q % 2) .. + 31 of block q / 2 of the first alignment, else of block (q - 8) / 2 of the second; packed
+  // row R = column R / 21 of the block, one-hot row R % 21; R = 63 reads a padding row of the one-hot matrix (zeros).
+  const bool loader = tid < NOP * 32;
+  const int q = loader ? tid >> 5 : 0;
+  const int l0 = 2 * (tid & 31);
+  // the thread's two lanes l0, l0 + 1 are two consecutive packed rows (same taxa group): one pointer and a 32-bit
+  // distance to the second row (at most three columns away)
+  const bool first = q < NI;
+  const size_t ncol = first ? n1 : n2, cbase = first ? i0 + 3 * (size_t)(q >> 1) : j0 + 3 * (size_t)((q - NI) >> 1);
+  auto row_off = [&](int l) -> size_t {
+    const int R = 32 * (q & 1) + (l & 31);
+    const int cb = R / P, st_ = R == 63 ? 31 : R % P;
+    const size_t want = cbase + (cb < 3 ? cb : 2);
+    const size_t col = want < ncol ? want : ncol - 1;
+    return (col * 32 + (size_t)st_) * (size_t)Tp;
+  };
+  const int8_t* Hrow0 = (first ? H1 : H2) + row_off(l0) + 16 * (l0 >> 5);
+  const int Hdelta = (int)((long long)row_off(l0 + 1) - (long long)row_off(l0));
+  cmx_i16v acc[2][2];
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[ii][jj][v] = 0;
+  constexpr int kAhead = 3;
+  cmx_i4 st[kAhead][2] = {};
+  auto fetch = [&](cmx_i4 (&dst)[2], int ks) {
+    if (loader && ks < Tp) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) dst[u] = *reinterpret_cast<const cmx_i4*>(Hrow0 + (u ? Hdelta : 0) + ks);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < kAhead; ++d) fetch(st[d], d * kMicaK);
+  int buf = 0;
+  auto step = [&](cmx_i4 (&cur)[2], int ks) {
+    if (loader) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) ops[(buf * NOP + q) * 64 + l0 + u] = cur[u];
+    }
+    __syncthreads();
+    fetch(cur, ks + kAhead * kMicaK);
+    cmx_i4 a[2], b[2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) a[ii] = ops[(buf * NOP + 2 * wi + ii) * 64 + lane];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) b[jj] = ops[(buf * NOP + NI + 2 * wj + jj) * 64 + lane];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 2   // timing only: no matrix products
+      for (int jj = 0; jj < 2; ++jj) acc[ii][jj][0] += a[ii][0] ^ b[jj][1];
+#else
+      for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
+#endif
+    buf ^= 1;
+  };
+  for (int ks = 0; ks < Tp; ks += kAhead * kMicaK) {
+    step(st[0], ks);
+    if (ks + kMicaK < Tp) step(st[1], ks + kMicaK);
+    if (ks + 2 * kMicaK < Tp) step(st[2], ks + 2 * kMicaK);
+  }
+  const double lnT = log((double)T), invT = 1.0 / (double)T;
+  const bool hi = lane >= 32;
+  const int cl = lane & 31;
+  // per lane: sums by (column a of the block row, MFMA tile column jj).  Register v of tile (ii, jj) is packed row
+  // R = 32 ii + 8 (v / 4) + v % 4 (+ 4 if hi), packed column 32 jj + cl.
+  double pa[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int R0 = 32 * ii + 8 * (v / 4) + v % 4, a0 = R0 / P, a1 = (R0 + 4) / P;
+#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 1   // timing only: no table lookups
+        const double val = (double)acc[ii][jj][v];
+#else
+        const double val = ftab[acc[ii][jj][v]];
+#endif
+        if (a0 == a1) {
+          pa[a0][jj] += val;
+        } else {
+          pa[a0][jj] += hi ? 0.0 : val;
+          if (a1 < 3) pa[a1][jj] += hi ? val : 0.0;   // a1 == 3: packed row 63, padding (its counts are zero)
+        }
+      }
+  // by column b of the block column: tile 0 holds packed columns 0..31 (b = 0 for cl < 21, else 1), tile 1 holds 32..63
+  // (b = 1 for cl < 10, else 2; packed column 63 is padding)
+  double sres[3];   // after the reductions: lanes with lane >> 4 == r hold pair 4 g + r in sres[g] (pair = 3 a + b)
+  {
+    double t[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      t[3 * a + 0] = cl < 21 ? pa[a][0] : 0.0;
+      t[3 * a + 1] = (cl >= 21 ? pa[a][0] : 0.0) + (cl < 10 ? pa[a][1] : 0.0);
+      t[3 * a + 2] = cl >= 10 ? pa[a][1] : 0.0;
+    }
+    sres[0] = mica_reduce4(t[0], t[1], t[2], t[3]);
+    sres[1] = mica_reduce4(t[4], t[5], t[6], t[7]);
+    sres[2] = mica_reduce4(t[8], 0.0, 0.0, 0.0);
+  }
+  if (gapbits != 0) {
+    // pairs with unknowns: expand the pseudo-state's counts (see mica_mfma_kernel) from the pair's 21 x 21 sub-block
+    __syncthreads();                                     // the operand buffers are free now: reuse them as count tables
+    int* tile = reinterpret_cast<int*>(ops) + w * 448;   // 21 x 21 = 441 ints per wave
+    const double invA = 1.0 / (double)A;
+    for (int pr = 0; pr < 9; ++pr) {
+      const int a = pr / 3, b = pr % 3;
+      const size_t i = i0 + 3 * (size_t)wi + a, j = j0 + 3 * (size_t)wj + b;
+      if (!(gap1[i < n1 ? i : n1 - 1] || gap2[j < n2 ? j : n2 - 1])) continue;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int R = 32 * ii + 8 * (v / 4) + v % 4 + (hi ? 4 : 0), C = 32 * jj + cl;
+            const int ra = R - P * a, cb = C - P * b;
+            if (ra >= 0 && ra < P && cb >= 0 && cb < P) tile[ra * P + cb] = acc[ii][jj][v];
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const double gam = (double)tile[A * P + A] * invA * invA;
+      double sg = 0.0;
+      for (int e = lane; e < A * A; e += 64) {
+        const int x = e / A, y = e % A;
+        const double c = (double)tile[x * P + y] + ((double)tile[x * P + A] + (double)tile[A * P + y]) * invA + gam;
+        if (c > 0.0) sg += c * log(c);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, 64);
+      if ((lane >> 4) == (pr & 3)) {
+        if ((pr >> 2) == 0) sres[0] = sg;
+        else if ((pr >> 2) == 1) sres[1] = sg;
+        else sres[2] = sg;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if ((lane & 15) == 0) {
+    const int r = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int pr = 4 * g + r;
+      if (pr < 9) {
+        const size_t i = i0 + 3 * (size_t)wi + pr / 3, j = j0 + 3 * (size_t)wj + pr % 3;
+        if (i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
+          const bool valid = !intra || j > i;
+          const double s = sres[g];
+          mi[i * ldo + j] = valid ? lnT + (s - S1[i] - S2[j]) * invT : __builtin_nan("");
+          hj[i * ldo + j] = valid ? lnT - s * invT : __builtin_nan("");
+        }
+      }
+    }
+  }
+}
+
 template <int A>
 __global__ void column_entropy_kernel(int T, const uint32_t* __restrict__ masks, const uint8_t* __restrict__ aln,
                                       size_t n, size_t ld, double* __restrict__ h) {
@@ -2165,6 +2382,12 @@ __global__ void column_entropy_kernel(int T, const uint32_t* __restrict__ masks,
   h[i] = s;
 }
 
+// CMX_MICA_TILES=1: the one-column-per-tile kernel for proteins too (A/B timing of the packed kernel; same results)
+static bool mica_one_column_tiles() {
+  static const bool v = [] { const char* e = getenv("CMX_MICA_TILES"); return e && e[0] == '1'; }();
+  return v;
+}
+
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
                              size_t ldo, double* d_h1, double* d_h2, const MicaWork* work, hipStream_t stream) {
@@ -2185,9 +2408,19 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
                          work->flag2, work->gap2, work->S2, work->anyflag);
     dim3 g2((unsigned)((n2 + kMicaTileJ - 1) / kMicaTileJ), (unsigned)((n1 + kMicaTileI - 1) / kMicaTileI));
     const size_t lds2 = (((size_t)(T + 1) * 8 + 15) & ~(size_t)15) + 2 * (kMicaTileI + kMicaTileJ) * 64 * sizeof(cmx_i4);
-    hipLaunchKernelGGL(mica_mfma_kernel, g2, dim3(512), lds2, stream, A, T, Tp, work->H1, n1,
-                       work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
-                       intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
+    if (A == 20 && !mica_one_column_tiles()) {
+      dim3 g3((unsigned)((n2 + kMica3J - 1) / kMica3J), (unsigned)((n1 + kMica3I - 1) / kMica3I));
+      hipLaunchKernelGGL(mica_mfma3_kernel, g3, dim3(512), lds2, stream, T, Tp, work->H1, n1,
+                         work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
+                         intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
+    } else if (A == 20)
+      hipLaunchKernelGGL(mica_mfma_kernel<20>, g2, dim3(512), lds2, stream, T, Tp, work->H1, n1,
+                         work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
+                         intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
+    else
+      hipLaunchKernelGGL(mica_mfma_kernel<4>, g2, dim3(512), lds2, stream, T, Tp, work->H1, n1,
+                         work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
+                         intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
     f1 = work->flag1;
     f2 = intra ? work->flag1 : work->flag2;
   }
