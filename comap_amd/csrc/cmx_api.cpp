@@ -923,11 +923,13 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
     w.Tp = (ntaxa + 31) / 32 * 32;
     const size_t hb = 32 * (size_t)w.Tp;
     if ((s = scratch(ctx, "mica_H1", hb * n1, (void**)&w.H1)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "mica_C1", (size_t)w.Tp * n1, (void**)&w.C1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_f1", n1, (void**)&w.flag1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_g1", n1, (void**)&w.gap1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_S1", sizeof(double) * n1, (void**)&w.S1)) != CMX_OK) return s;
     if (!intra) {
       if ((s = scratch(ctx, "mica_H2", hb * n2, (void**)&w.H2)) != CMX_OK) return s;
+      if ((s = scratch(ctx, "mica_C2", (size_t)w.Tp * n2, (void**)&w.C2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_f2", n2, (void**)&w.flag2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_g2", n2, (void**)&w.gap2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_S2", sizeof(double) * n2, (void**)&w.S2)) != CMX_OK) return s;

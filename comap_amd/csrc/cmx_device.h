@@ -180,7 +180,8 @@ hipError_t launch_mi_pairs(int A, int T, const uint32_t* d_masks, const uint8_t*
                            double* d_hj, hipStream_t stream);
 // scratch of the MFMA Mica path (all device pointers; H1 null = LDS-table kernel only)
 struct MicaWork {
-  int8_t *H1, *H2;         // one-hot [n][32][Tp] int8
+  int8_t *H1, *H2;         // one-hot [n][32][Tp] int8 (one-column-per-tile kernel)
+  uint8_t *C1, *C2;        // [n][Tp] one-hot row of each taxon (state, A = unknown, 255 = none): the packed protein kernel's operands
   uint8_t *flag1, *flag2;  // [n] column has ambiguous symbols other than "unknown" (-> LDS-table kernel)
   uint8_t *gap1, *gap2;    // [n] column has unknowns (gap / X / N: compatible with every state; handled on the matrix cores)
   double *S1, *S2;         // [n] sum_a f(count_a)

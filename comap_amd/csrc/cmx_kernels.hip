@@ -1930,7 +1930,8 @@ constexpr int kMicaK = 32;   // taxa per MFMA step (v_mfma_i32_32x32x32_i8)
 // (pairs of that column go to the LDS-table kernel).  S[col] = sum_a f(count_a) with the fractional counts.
 __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, const uint32_t* __restrict__ masks,
                                                           const uint8_t* __restrict__ aln, size_t ld,
-                                                          int8_t* __restrict__ H, uint8_t* __restrict__ flag,
+                                                          int8_t* __restrict__ H, uint8_t* __restrict__ codes /*[n][Tp]: the one-hot row of each taxon, 255 = none*/,
+                                                          uint8_t* __restrict__ flag,
                                                           uint8_t* __restrict__ gap, double* __restrict__ S,
                                                           int* __restrict__ anyflag) {
   __shared__ int cnt[33];
@@ -1949,8 +1950,11 @@ __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, 
       }
       if (c <= (unsigned)A) atomicAdd(&cnt[c], 1);
     }
+    codes[i * (size_t)Tp + t] = (uint8_t)c;
+    if (H) {
 #pragma unroll
-    for (int a = 0; a < 32; ++a) H[(i * 32 + a) * (size_t)Tp + t] = (int8_t)((c == (unsigned)a) ? 1 : 0);
+      for (int a = 0; a < 32; ++a) H[(i * 32 + a) * (size_t)Tp + t] = (int8_t)((c == (unsigned)a) ? 1 : 0);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2167,22 +2171,31 @@ __device__ __forceinline__ double mica_reduce4(double p0, double p1, double p2, 
   s += mica_dpp_f64<0x121>(s);   // row_ror:1
   return s;
 }
-__global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
+__global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const uint8_t* __restrict__ C1, size_t n1,
                                                             const uint8_t* __restrict__ flag1, const uint8_t* __restrict__ gap1,
                                                             const double* __restrict__ S1,
-                                                            const int8_t* __restrict__ H2, size_t n2,
+                                                            const uint8_t* __restrict__ C2, size_t n2,
                                                             const uint8_t* __restrict__ flag2, const uint8_t* __restrict__ gap2,
                                                             const double* __restrict__ S2,
                                                             const double* __restrict__ ftab_g, int intra,
-                                                            double* __restrict__ mi, double* __restrict__ hj, size_t ldo) {
+                                                            double* __restrict__ mi, double* __restrict__ hj, size_t ldo,
+                                                            unsigned ntx, unsigned ntiles, unsigned per_xcd) {
   extern __shared__ __attribute__((aligned(16))) uint8_t mica_smem[];
   constexpr int A = 20, P = kMicaP;
   double* ftab = reinterpret_cast<double*>(mica_smem);                       // [T + 1]
-  cmx_i4* ops = reinterpret_cast<cmx_i4*>(mica_smem + (((size_t)(T + 1) * 8 + 15) & ~(size_t)15));  // [2][12][64]
+  cmx_i4* ops = reinterpret_cast<cmx_i4*>(mica_smem + (((size_t)(T + 1) * 8 + 15) & ~(size_t)15));  // [4][12][64]
   constexpr int NOP = 12, NI = 8;   // operand tiles per k-step: 8 of the first alignment (4 blocks), 4 of the second
+  uint8_t* codes = reinterpret_cast<uint8_t*>(ops + 4 * NOP * 64);          // [18][Tp]: the tile's columns, one byte per taxon
+  double* Scol = reinterpret_cast<double*>(codes + (size_t)(kMica3I + kMica3J) * Tp);   // [18] S of the tile's columns (12 + 6)
+  int* fcol = reinterpret_cast<int*>(Scol + 18);   // [18] bit 0 partial ambiguity codes, bit 1 unknowns, bit 2 past the end
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
-  for (int c = tid; c <= T; c += 512) ftab[c] = ftab_g[c];
-  const size_t i0 = (size_t)blockIdx.y * kMica3I, j0 = (size_t)blockIdx.x * kMica3J;
+  // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8); each XCD has its own L2 and
+  // a tile writes 48-byte pieces of the output rows: with neighbouring tiles on different XCDs every L2 evicted partial
+  // lines (measured: the 400 MB of results cost 2.4 of 6.3 ms).  XCD x takes a contiguous run of the row-major tile
+  // order, so the tiles that complete a cache line -- and re-read the same symbol columns -- meet in one L2.
+  const unsigned tlin = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tlin >= ntiles) return;
+  const size_t i0 = (size_t)(tlin / ntx) * kMica3I, j0 = (size_t)(tlin % ntx) * kMica3J;
   if (intra && j0 + kMica3J <= i0 + 1) {   // no pair with j > i in this tile: only the NaN convention of the intra layout
     if (tid < kMica3I * kMica3J) {
       const size_t i = i0 + tid / kMica3J, j = j0 + tid % kMica3J;
@@ -2193,30 +2206,43 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
     }
     return;
   }
-  unsigned gapbits = 0;
-#pragma unroll
-  for (int c = 0; c < kMica3I; ++c) gapbits |= gap1[i0 + c < n1 ? i0 + c : n1 - 1];
-#pragma unroll
-  for (int c = 0; c < kMica3J; ++c) gapbits |= gap2[j0 + c < n2 ? j0 + c : n2 - 1];
+  // The operands are NOT read as one-hot matrices (21 rows x T bytes per column, 34 GB through the L2 for 5000 x 5000
+  // columns -- the workgroups spent their lives waiting for them): a column travels as its T symbol bytes (the one-hot
+  // row of each taxon), all 18 columns of the tile in one round trip, and the loader threads expand them to one-hot
+  // operand tiles in LDS k-step by k-step (a dword of four symbols XOR the row's state, zero-byte test -> 0x01 bytes).
+  const int chunks = Tp / 16;                  // 16-byte pieces per column
+  for (int e = tid; e < (kMica3I + kMica3J) * chunks; e += 512) {
+    const int c = e / chunks, o = e % chunks;
+    const bool fi = c < kMica3I;
+    const size_t want = fi ? i0 + c : j0 + (c - kMica3I);
+    const size_t col = want < (fi ? n1 : n2) ? want : (fi ? n1 : n2) - 1;
+    reinterpret_cast<cmx_i4*>(codes)[e] = *reinterpret_cast<const cmx_i4*>((fi ? C1 : C2) + col * (size_t)Tp + 16 * o);
+  }
+  for (int c = tid; c <= T; c += 512) ftab[c] = ftab_g[c];
+  // per-column scalars, once per workgroup (not per thread, and not at the very end where their latency would show)
+  if (tid < 18) {
+    const bool fi = tid < kMica3I;
+    const size_t c = fi ? i0 + tid : j0 + (tid - kMica3I), nc = fi ? n1 : n2;
+    const size_t cc = c < nc ? c : nc - 1;
+    Scol[tid] = (fi ? S1 : S2)[cc];
+    fcol[tid] = (int)(fi ? flag1 : flag2)[cc] | ((int)(fi ? gap1 : gap2)[cc] << 1) | (c < nc ? 0 : 4);
+  }
   // loader role: 12 operand tiles x 64 lanes = 768 slots of 16 bytes, threads 0..383 take two each.  Operand tile q:
   // q < 8: rows 32 (q % 2) .. + 31 of block q / 2 of the first alignment, else of block (q - 8) / 2 of the second; packed
-  // row R = column R / 21 of the block, one-hot row R % 21; R = 63 reads a padding row of the one-hot matrix (zeros).
+  // row R = column R / 21 of the block, one-hot row R % 21; R = 63 is padding (state 31 matches no symbol).
   const bool loader = tid < NOP * 32;
   const int q = loader ? tid >> 5 : 0;
   const int l0 = 2 * (tid & 31);
-  // the thread's two lanes l0, l0 + 1 are two consecutive packed rows (same taxa group): one pointer and a 32-bit
-  // distance to the second row (at most three columns away)
-  const bool first = q < NI;
-  const size_t ncol = first ? n1 : n2, cbase = first ? i0 + 3 * (size_t)(q >> 1) : j0 + 3 * (size_t)((q - NI) >> 1);
-  auto row_off = [&](int l) -> size_t {
-    const int R = 32 * (q & 1) + (l & 31);
+  unsigned srow[2];      // the row's state, replicated in the four bytes of a dword
+  const uint8_t* crow[2];  // the row's column in `codes`, at this lane's taxa group
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int R = 32 * (q & 1) + ((l0 + u) & 31);
     const int cb = R / P, st_ = R == 63 ? 31 : R % P;
-    const size_t want = cbase + (cb < 3 ? cb : 2);
-    const size_t col = want < ncol ? want : ncol - 1;
-    return (col * 32 + (size_t)st_) * (size_t)Tp;
-  };
-  const int8_t* Hrow0 = (first ? H1 : H2) + row_off(l0) + 16 * (l0 >> 5);
-  const int Hdelta = (int)((long long)row_off(l0 + 1) - (long long)row_off(l0));
+    const int slot = (q < NI ? 3 * (q >> 1) : kMica3I + 3 * ((q - NI) >> 1)) + (cb < 3 ? cb : 2);
+    srow[u] = (unsigned)st_ * 0x01010101u;
+    crow[u] = codes + (size_t)slot * Tp + 16 * (l0 >> 5);
+  }
   cmx_i16v acc[2][2];
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
@@ -2224,43 +2250,54 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[ii][jj][v] = 0;
-  constexpr int kAhead = 3;
-  cmx_i4 st[kAhead][2] = {};
-  auto fetch = [&](cmx_i4 (&dst)[2], int ks) {
-    if (loader && ks < Tp) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) dst[u] = *reinterpret_cast<const cmx_i4*>(Hrow0 + (u ? Hdelta : 0) + ks);
-    }
-  };
-#pragma unroll
-  for (int d = 0; d < kAhead; ++d) fetch(st[d], d * kMicaK);
+  __syncthreads();   // symbols, table and column scalars are in LDS
+  // two k-steps per barrier: four operand buffers, the pair being multiplied and the pair being expanded
   int buf = 0;
-  auto step = [&](cmx_i4 (&cur)[2], int ks) {
+  for (int ks = 0; ks < Tp; ks += 2 * kMicaK) {
+    const bool two = ks + kMicaK < Tp;
     if (loader) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) ops[(buf * NOP + q) * 64 + l0 + u] = cur[u];
+      for (int h = 0; h < 2; ++h) {
+        if (h == 0 || two) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const cmx_i4 sy = *reinterpret_cast<const cmx_i4*>(crow[u] + ks + h * kMicaK);
+            cmx_i4 oh;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const unsigned x = (unsigned)sy[d] ^ srow[u];
+              const unsigned t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 where the byte of x is zero
+#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 3   // timing only: no one-hot expansion
+              oh[d] = sy[d];
+#else
+              oh[d] = (int)(t >> 7);
+#endif
+            }
+            ops[((buf + h) * NOP + q) * 64 + l0 + u] = oh;
+          }
+        }
+      }
     }
     __syncthreads();
-    fetch(cur, ks + kAhead * kMicaK);
-    cmx_i4 a[2], b[2];
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) a[ii] = ops[(buf * NOP + 2 * wi + ii) * 64 + lane];
+    for (int h = 0; h < 2; ++h) {
+      if (h == 0 || two) {
+        cmx_i4 a[2], b[2];
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) b[jj] = ops[(buf * NOP + NI + 2 * wj + jj) * 64 + lane];
+        for (int ii = 0; ii < 2; ++ii) a[ii] = ops[((buf + h) * NOP + 2 * wi + ii) * 64 + lane];
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+        for (int jj = 0; jj < 2; ++jj) b[jj] = ops[((buf + h) * NOP + NI + 2 * wj + jj) * 64 + lane];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
 #if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 2   // timing only: no matrix products
-      for (int jj = 0; jj < 2; ++jj) acc[ii][jj][0] += a[ii][0] ^ b[jj][1];
+          for (int jj = 0; jj < 2; ++jj) acc[ii][jj][0] += a[ii][0] ^ b[jj][1];
 #else
-      for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
+          for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
 #endif
-    buf ^= 1;
-  };
-  for (int ks = 0; ks < Tp; ks += kAhead * kMicaK) {
-    step(st[0], ks);
-    if (ks + kMicaK < Tp) step(st[1], ks + kMicaK);
-    if (ks + 2 * kMicaK < Tp) step(st[2], ks + 2 * kMicaK);
+      }
+    }
+    buf ^= 2;
   }
   const double lnT = log((double)T), invT = 1.0 / (double)T;
   const bool hi = lane >= 32;
@@ -2278,7 +2315,11 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
 #if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 1   // timing only: no table lookups
         const double val = (double)acc[ii][jj][v];
 #else
+#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 1   // timing only: no table lookups
+        const double val = (double)acc[ii][jj][v];
+#else
         const double val = ftab[acc[ii][jj][v]];
+#endif
 #endif
         if (a0 == a1) {
           pa[a0][jj] += val;
@@ -2302,6 +2343,9 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
     sres[1] = mica_reduce4(t[4], t[5], t[6], t[7]);
     sres[2] = mica_reduce4(t[8], 0.0, 0.0, 0.0);
   }
+  int gapbits = 0;
+#pragma unroll
+  for (int c = 0; c < kMica3I + kMica3J; ++c) gapbits |= fcol[c] & 2;
   if (gapbits != 0) {
     // pairs with unknowns: expand the pseudo-state's counts (see mica_mfma_kernel) from the pair's 21 x 21 sub-block
     __syncthreads();                                     // the operand buffers are free now: reuse them as count tables
@@ -2309,8 +2353,7 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
     const double invA = 1.0 / (double)A;
     for (int pr = 0; pr < 9; ++pr) {
       const int a = pr / 3, b = pr % 3;
-      const size_t i = i0 + 3 * (size_t)wi + a, j = j0 + 3 * (size_t)wj + b;
-      if (!(gap1[i < n1 ? i : n1 - 1] || gap2[j < n2 ? j : n2 - 1])) continue;
+      if (!((fcol[3 * wi + a] | fcol[kMica3I + 3 * wj + b]) & 2)) continue;
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -2347,11 +2390,18 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
     for (int g = 0; g < 3; ++g) {
       const int pr = 4 * g + r;
       if (pr < 9) {
-        const size_t i = i0 + 3 * (size_t)wi + pr / 3, j = j0 + 3 * (size_t)wj + pr % 3;
-        if (i < n1 && j < n2 && !flag1[i] && !flag2[j]) {
+        const int ci = 3 * wi + pr / 3, cj = kMica3I + 3 * wj + pr % 3;
+        if (!((fcol[ci] | fcol[cj]) & 5)) {              // inside both alignments, no partial ambiguity code
+          const size_t i = i0 + ci, j = j0 + (cj - kMica3I);
           const bool valid = !intra || j > i;
           const double s = sres[g];
-          mi[i * ldo + j] = valid ? lnT + (s - S1[i] - S2[j]) * invT : __builtin_nan("");
+#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 4   // timing only: one store per tile
+          if (ci + cj == 0)
+#endif
+          mi[i * ldo + j] = valid ? lnT + (s - Scol[ci] - Scol[cj]) * invT : __builtin_nan("");
+#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 4
+          if (ci + cj == 0)
+#endif
           hj[i * ldo + j] = valid ? lnT - s * invT : __builtin_nan("");
         }
       }
@@ -2400,19 +2450,27 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
   const uint8_t *f1 = nullptr, *f2 = nullptr;
   if (work && work->H1) {
     const int Tp = work->Tp;
+    const bool needH = !(A == 20 && !mica_one_column_tiles());   // the packed protein kernel expands the symbol bytes itself
     hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)(T / 256 + 1)), dim3(256), 0, stream, T, work->ftab, work->anyflag);
-    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, work->H1, work->flag1,
+    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, needH ? work->H1 : nullptr, work->C1, work->flag1,
                        work->gap1, work->S1, work->anyflag);
     if (!intra)
-      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln2, ld2, work->H2,
+      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln2, ld2, needH ? work->H2 : nullptr, work->C2,
                          work->flag2, work->gap2, work->S2, work->anyflag);
     dim3 g2((unsigned)((n2 + kMicaTileJ - 1) / kMicaTileJ), (unsigned)((n1 + kMicaTileI - 1) / kMicaTileI));
     const size_t lds2 = (((size_t)(T + 1) * 8 + 15) & ~(size_t)15) + 2 * (kMicaTileI + kMicaTileJ) * 64 * sizeof(cmx_i4);
     if (A == 20 && !mica_one_column_tiles()) {
-      dim3 g3((unsigned)((n2 + kMica3J - 1) / kMica3J), (unsigned)((n1 + kMica3I - 1) / kMica3I));
-      hipLaunchKernelGGL(mica_mfma3_kernel, g3, dim3(512), lds2, stream, T, Tp, work->H1, n1,
-                         work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
-                         intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
+      const unsigned ntx = (unsigned)((n2 + kMica3J - 1) / kMica3J), nty = (unsigned)((n1 + kMica3I - 1) / kMica3I);
+      const unsigned ntiles = ntx * nty, per_xcd = (ntiles + 7) / 8;
+      const size_t lds3 = lds2 + 2 * (kMica3I / 3 * 2 + kMica3J / 3 * 2) * 64 * sizeof(cmx_i4) + (size_t)(kMica3I + kMica3J) * Tp + 18 * sizeof(double) + 20 * sizeof(int);
+      if (lds3 > 64 * 1024) {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&mica_mfma3_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (ea != hipSuccess) return ea;
+      }
+      hipLaunchKernelGGL(mica_mfma3_kernel, dim3(8 * per_xcd), dim3(512), lds3, stream, T, Tp, work->C1, n1,
+                         work->flag1, work->gap1, work->S1, intra ? work->C1 : work->C2, n2, intra ? work->flag1 : work->flag2,
+                         intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo, ntx, ntiles, per_xcd);
     } else if (A == 20)
       hipLaunchKernelGGL(mica_mfma_kernel<20>, g2, dim3(512), lds2, stream, T, Tp, work->H1, n1,
                          work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
