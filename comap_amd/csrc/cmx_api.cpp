@@ -41,6 +41,9 @@ struct cmx_ctx {
   uint32_t* d_default_masks = nullptr;
   unsigned stat_mean_turn = 0;
   bool leaf_rows_custom = false;   // the leaf operators' ambiguity rows were built from a caller's mask table
+  bool map_average = true;         // nijt.average (cmx_set_mapping_options); false: the no-averaging mapping of cmx_variants.hip
+  const double *va_P = nullptr, *va_N1 = nullptr;   // its operators, uploaded at first use
+  const int *va_first = nullptr, *va_next = nullptr;
   mutable std::string err;
 };
 
@@ -295,6 +298,38 @@ cmx_status cmx_synchronize(cmx_ctx* ctx) {
   return CMX_OK;
 }
 
+// nijt.average = no (cmx_set_mapping_options): counts and norms of the sites just mapped are replaced by those of
+// computeSubstitutionVectorsNoAveraging (cmx_variants.hip); likelihood, posterior rate and rate class stay.
+static cmx_status map_variant(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
+                              double* d_counts, size_t ldc, double* d_norm, void* stream) {
+  if (ctx->map_average || (!d_counts && !d_norm)) return CMX_OK;
+  const HostModel& h = ctx->hm;
+  cmx_status s;
+  if (!ctx->va_P) {
+    if ((s = upload(ctx, h.P, &ctx->va_P)) != CMX_OK) return s;
+    if ((s = upload(ctx, h.N1, &ctx->va_N1)) != CMX_OK) return s;
+    if ((s = upload(ctx, h.first_child, &ctx->va_first)) != CMX_OK) return s;
+    if ((s = upload(ctx, h.next_sib, &ctx->va_next)) != CMX_OK) return s;
+  }
+  if (!d_counts) {   // only the norms were asked for: they still need the counts
+    if ((s = scratch(ctx, "va_counts", sizeof(double) * (size_t)h.B * h.K * nsites, (void**)&d_counts)) != CMX_OK) return s;
+    ldc = nsites;
+  }
+  NoAvgArgs a{};
+  a.S = h.S; a.C = h.C; a.K = h.K; a.nn = h.nn; a.B = h.B; a.root = h.root;
+  a.first_child = ctx->va_first; a.next_sib = ctx->va_next; a.taxon_of = ctx->dm.taxon_of;
+  a.P = ctx->va_P; a.N1 = ctx->va_N1; a.pi = ctx->dm.pi; a.probs = ctx->dm.probs;
+  a.masks = d_masks; a.aln = d_aln; a.ld = ld;
+  // sites per pass: per-node vectors of a pass stay under 1 GiB
+  const size_t per_site = sizeof(double) * noavg_scratch_doubles(h.S, h.C, h.nn, 1);
+  a.chunk = std::max<size_t>(256, std::min<size_t>(nsites, ((size_t)1 << 30) / per_site / 256 * 256));
+  a.counts = d_counts; a.ldc = ldc;
+  double* buf;
+  if ((s = scratch(ctx, "va_nodes", sizeof(double) * noavg_scratch_doubles(h.S, h.C, h.nn, a.chunk), (void**)&buf)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_map_noavg(a, nsites, buf, d_norm, (hipStream_t)stream));
+  return CMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ mapping
 // full_grid: use the whole-chip workspace of the null launches instead of the quarter-chip slice reserved for
 // observed alignments (which exists so that a caller can overlap the observed mapping with cmx_null_intra_dev on a
@@ -330,12 +365,12 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
     const int grid = (int)((ntasks + kWavesPerBlock - 1) / kWavesPerBlock);
     HIP_TRY(ctx, launch_map(a, kModeObservedSplit, grid, (hipStream_t)stream));
     HIP_TRY(ctx, launch_map_finalize(a, (hipStream_t)stream));
-    return CMX_OK;
+    return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream);
   }
   const size_t blocks_needed = (nblocks + kWavesPerBlock - 1) / kWavesPerBlock;
   const int grid = (int)std::min<size_t>(blocks_needed, (size_t)max_blocks);
   HIP_TRY(ctx, launch_map(a, kModeObserved, grid, (hipStream_t)stream));
-  return CMX_OK;
+  return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream);
 }
 
 cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
@@ -393,6 +428,17 @@ cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t
   if (post_rate) HIP_TRY(ctx, hipMemcpy(post_rate, d_pr, nsites * sizeof(double), hipMemcpyDeviceToHost));
   if (norm) HIP_TRY(ctx, hipMemcpy(norm, d_norm, nsites * sizeof(double), hipMemcpyDeviceToHost));
   if (rate_class) HIP_TRY(ctx, hipMemcpy(rate_class, d_rc, nsites * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+// nijt.average / nijt.joint of CoETools.cpp:393-394 ("really for benchmarking only" there)
+cmx_status cmx_set_mapping_options(cmx_ctx* ctx, int average, int joint) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!joint)
+    return fail(ctx, CMX_ERR_UNSUPPORTED, "nijt.joint = no (computeSubstitutionVectors*Marginal) is not implemented: the algorithm is "
+                                          "bpp-phyl's, which the reference tree does not contain, and nothing pins it");
+  ctx->map_average = average != 0;
   return CMX_OK;
 }
 
@@ -547,6 +593,12 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
   if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra: bad arguments");
   if ((s = rng_range(ctx, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_intra")) != CMX_OK) return s;
+  if (!ctx->map_average) {
+    // nijt.average = no (AnalysisTools.cpp:598-610): the fused kernel only knows the averaged mapping; the same
+    // simulate -> map -> score sequence runs unfused, which is what the two-data-set null does with both sides equal
+    if (d_supplied) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_null_intra: supplied alignments are not available with nijt.average = no");
+    return cmx_null_inter_dev(ctx, ctx, kind, params, seed, rep_begin, rep_end, rep_ram, d_stat, d_rcmin, d_prmin, d_nmin, stream);
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;

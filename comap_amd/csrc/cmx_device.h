@@ -122,6 +122,22 @@ hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* 
                             const double* d_mean, hipStream_t stream);
 hipError_t launch_group_stats(int kind, double param, int B, int K, const double* d_counts, size_t ld, const int64_t* d_offsets,
                               const int32_t* d_sites, size_t ngroups, double* d_out, const double* d_mean, hipStream_t stream);
+// nijt.average = no (cmx_variants.hip): the no-averaging mapping as plain kernels over a global scratch
+struct NoAvgArgs {
+  int S, C, K, nn, B, root;
+  const int *first_child, *next_sib, *taxon_of;
+  const double* P;        // [C][B][S*S] row-major transition matrices
+  const double* N1;       // [B][K][S*S] conditional counts at the branch length itself
+  const double *pi, *probs;
+  const uint32_t* masks;  // compatibility masks of the codes >= S (NULL: every state)
+  const uint8_t* aln;
+  size_t ld, site0, nsites, chunk;
+  double *D, *M, *U, *Up;  // [C][nn][S][chunk]
+  double* counts;          // [B*K][ldc]
+  size_t ldc;
+};
+size_t noavg_scratch_doubles(int S, int C, int nn, size_t chunk);
+hipError_t launch_map_noavg(NoAvgArgs a, size_t nsites_total, double* scratch, double* d_norm, hipStream_t stream);
 // Mica post-processing (cmx_mica_post.hip)
 hipError_t launch_mica_average(const double* d_mi, size_t n, size_t ld, double* d_avg, double* d_full, hipStream_t stream);
 hipError_t launch_mica_zscore(int which, const double* d_mi, size_t n, size_t ld, const double* d_avg, const double* d_full,

@@ -506,41 +506,51 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   hm->P.assign((size_t)C * B * S2, 0.0);
   hm->PN.assign((size_t)C * B * K * S2, 0.0);
   Mat E(S2), Phi(S2);
-  for (int c = 0; c < C; ++c)
-    for (int b = 0; b < B; ++b) {
-      const Eig& e = eig[model_of[b]];
-      const Mat &V = e.V, &Vi = e.Vi;
-      const std::vector<double>& lam = e.lam;
-      const std::vector<Mat>& W = e.W;
-      const double t = hm->blen[b] * hm->rates[c];
-      double* P = &hm->P[((size_t)c * B + b) * S2];
-      for (int x = 0; x < S; ++x)
-        for (int j = 0; j < S; ++j) E[(size_t)x * S + j] = V[(size_t)x * S + j] * std::exp(lam[j] * t);
-      Mat Pm = matmul(S, E, Vi);
-      std::memcpy(P, Pm.data(), sizeof(double) * S2);
-      for (int k = 0; k < K; ++k) {
-        double* PNk = &hm->PN[(((size_t)c * B + b) * K + k) * S2];
-        if (model->count_method == CMX_COUNT_NAIVE) {
-          for (size_t i = 0; i < S2; ++i)
-            PNk[i] = (i / S == i % S) ? 0.0 : P[i] * (model->naive_weights ? model->naive_weights[i] : 1.0);
-          continue;
-        }
-        // J = V [ (Vinv B V) o Phi ] Vinv; Phi through expm1 (accurate O(t^2) diagonal on 1e-6 branches)
-        for (int i = 0; i < S; ++i)
-          for (int j = 0; j < S; ++j) {
-            const double d = (lam[i] - lam[j]) * t;
-            const double phi = std::fabs(d) < 1e-14 ? t * std::exp(lam[i] * t) : t * std::exp(lam[j] * t) * std::expm1(d) / d;
-            Phi[(size_t)i * S + j] = W[k][(size_t)i * S + j] * phi;
-          }
-        Mat J = matmul(S, matmul(S, V, Phi), Vi);
+  // P(t) of branch b and, per substitution type, either P o N^k (the joint count operator of the averaged mapping) or the
+  // conditional expectation N^k itself (nijt.average = no picks single entries of it)
+  auto branch_mats = [&](int b, double t, double* P, double* outK /*[K][S2]*/, bool conditional) {
+    const Eig& e = eig[model_of[b]];
+    const Mat &V = e.V, &Vi = e.Vi;
+    const std::vector<double>& lam = e.lam;
+    const std::vector<Mat>& W = e.W;
+    for (int x = 0; x < S; ++x)
+      for (int j = 0; j < S; ++j) E[(size_t)x * S + j] = V[(size_t)x * S + j] * std::exp(lam[j] * t);
+    Mat Pm = matmul(S, E, Vi);
+    std::memcpy(P, Pm.data(), sizeof(double) * S2);
+    for (int k = 0; k < K; ++k) {
+      double* Ok = outK + (size_t)k * S2;
+      if (model->count_method == CMX_COUNT_NAIVE) {
         for (size_t i = 0; i < S2; ++i) {
-          double nxy = J[i] / P[i];  // conditional count; Bio++ guards: non-finite -> 0, unweighted negatives -> 0
-          if (std::isnan(nxy) || std::isinf(nxy)) nxy = 0.0;
-          if (model->clamp_negative && nxy < 0.0) nxy = 0.0;
-          PNk[i] = P[i] * nxy;
+          const double nxy = (i / S == i % S) ? 0.0 : (model->naive_weights ? model->naive_weights[i] : 1.0);
+          Ok[i] = conditional ? nxy : P[i] * nxy;
         }
+        continue;
+      }
+      // J = V [ (Vinv B V) o Phi ] Vinv; Phi through expm1 (accurate O(t^2) diagonal on 1e-6 branches)
+      for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+          const double d = (lam[i] - lam[j]) * t;
+          const double phi = std::fabs(d) < 1e-14 ? t * std::exp(lam[i] * t) : t * std::exp(lam[j] * t) * std::expm1(d) / d;
+          Phi[(size_t)i * S + j] = W[k][(size_t)i * S + j] * phi;
+        }
+      Mat J = matmul(S, matmul(S, V, Phi), Vi);
+      for (size_t i = 0; i < S2; ++i) {
+        double nxy = J[i] / P[i];  // conditional count; Bio++ guards: non-finite -> 0, unweighted negatives -> 0
+        if (std::isnan(nxy) || std::isinf(nxy)) nxy = 0.0;
+        if (model->clamp_negative && nxy < 0.0) nxy = 0.0;
+        Ok[i] = conditional ? nxy : P[i] * nxy;
       }
     }
+  };
+  for (int c = 0; c < C; ++c)
+    for (int b = 0; b < B; ++b)
+      branch_mats(b, hm->blen[b] * hm->rates[c], &hm->P[((size_t)c * B + b) * S2], &hm->PN[((size_t)c * B + b) * K * S2], false);
+  // N^k(x, y; t_b) at the branch length itself: computeSubstitutionVectorsNoAveraging reads single entries of it
+  hm->N1.assign((size_t)B * K * S2, 0.0);
+  {
+    Mat P1(S2);
+    for (int b = 0; b < B; ++b) branch_mats(b, hm->blen[b], P1.data(), &hm->N1[(size_t)b * K * S2], true);
+  }
   // ---- device layouts
   // One allocation, per class a block of MC matrices of S*S doubles (the unit the kernel DMAs into LDS):
   //   [0, NI)                    P of internal edges, 4x4-block packed (matrix-vector products)

@@ -1,0 +1,168 @@
+// nijt.average = no, nijt.joint = yes: LegacySubstitutionMappingTools::computeSubstitutionVectorsNoAveraging (call sites
+// CoMap/CoETools.cpp:395-403 for the observed data, CoMap/AnalysisTools.cpp:598-610 inside the null).  "For benchmarking
+// only" says the reference -- but it is the only way it runs nijt = Label with the MI statistic (CoETools.cpp:577-588).
+//   per branch b (father f, son n), site i:  pxy(x, y) = sum_c p_c U_b(i,c,x) P_c,b(x,y) D_n(i,c,y);
+//   (x*, y*) = first maximum of pxy in row-major order (MatrixTools::whichMax);  count(b, i, k) = N^k(x*, y*; t_b).
+// The algorithm is bpp-phyl's (absent from the reference tree): restated in oracle/oracle.c orc_map_sites_noavg, which
+// tests/test_oracle_noavg.py pins to the definition by brute force; this file follows that restatement loop for loop.
+// This is NOT the hot path: three plain kernels, one thread per (site, class) or (site, branch), every
+// per-node vector in a global scratch of [class][node][state][site] (coalesced over sites; operators are wave-uniform
+// and come through the scalar cache).  The likelihood, posterior rate and rate class of a site do not depend on the
+// mapping variant and still come from the mapping kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "cmx_device.h"
+
+namespace cmx {
+
+namespace {
+
+template <int S>
+__global__ __launch_bounds__(256) void noavg_inside_kernel(const NoAvgArgs a) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.nsites) return;
+  const int c = blockIdx.y, nn = a.nn;
+  const size_t ch = a.chunk;
+  double* Dc = a.D + (size_t)c * nn * S * ch;
+  double* Mc = a.M + (size_t)c * nn * S * ch;
+  const uint32_t all = (1u << S) - 1u;
+  for (int n = 0; n < nn; ++n) {
+    double d[S];
+    if (a.first_child[n] < 0) {
+      const unsigned code = a.aln[(size_t)a.taxon_of[n] * a.ld + a.site0 + j];
+      const unsigned row = code < (unsigned)(S + max_ambig(S)) ? code : (unsigned)(S + max_ambig(S) - 1);
+      const uint32_t m = code < (unsigned)S ? (1u << code) : (a.masks ? a.masks[row] : all);
+#pragma unroll
+      for (int x = 0; x < S; ++x) d[x] = (double)((m >> x) & 1u);
+    } else {
+#pragma unroll
+      for (int x = 0; x < S; ++x) d[x] = 1.0;
+      for (int e = a.first_child[n]; e >= 0; e = a.next_sib[e]) {
+#pragma unroll
+        for (int x = 0; x < S; ++x) d[x] *= Mc[((size_t)e * S + x) * ch + j];
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < S; ++x) Dc[((size_t)n * S + x) * ch + j] = d[x];
+    if (n != a.root) {
+      const double* Pn = a.P + ((size_t)c * a.B + n) * S * S;
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        double s = 0.0;
+#pragma unroll
+        for (int z = 0; z < S; ++z) s += Pn[x * S + z] * d[z];
+        Mc[((size_t)n * S + x) * ch + j] = s;
+      }
+    }
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void noavg_outside_kernel(const NoAvgArgs a) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.nsites) return;
+  const int c = blockIdx.y, nn = a.nn;
+  const size_t ch = a.chunk;
+  const double* Mc = a.M + (size_t)c * nn * S * ch;
+  double* Uc = a.U + (size_t)c * nn * S * ch;
+  double* Upc = a.Up + (size_t)c * nn * S * ch;
+#pragma unroll
+  for (int x = 0; x < S; ++x) Upc[((size_t)a.root * S + x) * ch + j] = a.pi[x];
+  for (int f = nn - 1; f >= 0; --f) {
+    if (a.first_child[f] < 0) continue;
+    double upf[S];
+#pragma unroll
+    for (int x = 0; x < S; ++x) upf[x] = Upc[((size_t)f * S + x) * ch + j];
+    for (int n = a.first_child[f]; n >= 0; n = a.next_sib[n]) {
+      double u[S];
+#pragma unroll
+      for (int x = 0; x < S; ++x) u[x] = upf[x];
+      for (int m = a.first_child[f]; m >= 0; m = a.next_sib[m])
+        if (m != n) {
+#pragma unroll
+          for (int x = 0; x < S; ++x) u[x] *= Mc[((size_t)m * S + x) * ch + j];
+        }
+#pragma unroll
+      for (int x = 0; x < S; ++x) Uc[((size_t)n * S + x) * ch + j] = u[x];
+      if (a.first_child[n] >= 0) {
+        const double* Pn = a.P + ((size_t)c * a.B + n) * S * S;
+#pragma unroll
+        for (int z = 0; z < S; ++z) {
+          double s = 0.0;
+#pragma unroll
+          for (int x = 0; x < S; ++x) s += Pn[x * S + z] * u[x];
+          Upc[((size_t)n * S + z) * ch + j] = s;
+        }
+      }
+    }
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void noavg_pick_kernel(const NoAvgArgs a) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.nsites) return;
+  const int b = blockIdx.y, nn = a.nn, C = a.C;
+  const size_t ch = a.chunk;
+  double best = -__builtin_inf();
+  int bidx = 0;
+  for (int x = 0; x < S; ++x)
+    for (int y = 0; y < S; ++y) {
+      double s = 0.0;
+      for (int c = 0; c < C; ++c) {
+        const double u = a.U[(((size_t)c * nn + b) * S + x) * ch + j];
+        const double d = a.D[(((size_t)c * nn + b) * S + y) * ch + j];
+        s += a.probs[c] * ((u * a.P[((size_t)c * a.B + b) * S * S + x * S + y]) * d);
+      }
+      if (s > best) { best = s; bidx = x * S + y; }
+    }
+  for (int k = 0; k < a.K; ++k)
+    a.counts[((size_t)b * a.K + k) * a.ldc + a.site0 + j] = a.N1[((size_t)b * a.K + k) * S * S + bidx];
+}
+
+// computeNormForSite over the (branch-major) counts: sqrt(sum_b (sum_k count)^2), branches in order
+__global__ __launch_bounds__(256) void counts_norm_kernel(const double* __restrict__ counts, size_t ldc, int B, int K, size_t n,
+                                                          double* __restrict__ norm) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  double nrm = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double tot = 0.0;
+    for (int k = 0; k < K; ++k) tot += counts[((size_t)b * K + k) * ldc + j];
+    nrm += tot * tot;
+  }
+  norm[j] = sqrt(nrm);
+}
+
+}  // namespace
+
+size_t noavg_scratch_doubles(int S, int C, int nn, size_t chunk) { return 4 * (size_t)C * nn * S * chunk; }
+
+hipError_t launch_map_noavg(NoAvgArgs a, size_t nsites_total, double* scratch, double* d_norm, hipStream_t stream) {
+  const size_t per = (size_t)a.C * a.nn * a.S * a.chunk;
+  a.D = scratch; a.M = scratch + per; a.U = scratch + 2 * per; a.Up = scratch + 3 * per;
+  for (size_t s0 = 0; s0 < nsites_total; s0 += a.chunk) {
+    a.site0 = s0;
+    a.nsites = std::min(a.chunk, nsites_total - s0);
+    const unsigned gx = (unsigned)((a.nsites + 255) / 256);
+    if (a.S == 20) {
+      hipLaunchKernelGGL(noavg_inside_kernel<20>, dim3(gx, a.C), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(noavg_outside_kernel<20>, dim3(gx, a.C), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(noavg_pick_kernel<20>, dim3(gx, a.B), dim3(256), 0, stream, a);
+    } else if (a.S == 4) {
+      hipLaunchKernelGGL(noavg_inside_kernel<4>, dim3(gx, a.C), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(noavg_outside_kernel<4>, dim3(gx, a.C), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(noavg_pick_kernel<4>, dim3(gx, a.B), dim3(256), 0, stream, a);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  if (d_norm)
+    hipLaunchKernelGGL(counts_norm_kernel, dim3((unsigned)((nsites_total + 255) / 256)), dim3(256), 0, stream, a.counts, a.ldc, a.B,
+                       a.K, nsites_total, d_norm);
+  return hipGetLastError();
+}
+
+}  // namespace cmx

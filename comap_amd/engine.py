@@ -38,7 +38,7 @@ COUNT_EXPECTED, COUNT_NAIVE = 0, 1
 
 EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
-    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_map_sites_dev", "cmx_simulate", "cmx_simulate_continuous",
+    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_set_mapping_options", "cmx_map_sites_dev", "cmx_simulate", "cmx_simulate_continuous",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev", "cmx_intra_rows_range_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
@@ -286,6 +286,11 @@ class Engine:
                                             _sz(0 if mk is None else len(mk)), _vp(counts), _vp(logL), _vp(pr),
                                             _vp(rc), _vp(norm)))
         return dict(counts=counts, logL=logL, post_rate=pr, rate_class=rc, norm=norm)
+
+    def set_mapping_options(self, average=True, joint=True):
+        """nijt.average / nijt.joint (CoETools.cpp:393-406).  (False, True): computeSubstitutionVectorsNoAveraging for every
+        later mapping of this engine (observed data and nulls); joint = False raises (not implemented, see the header)."""
+        self._check(self._lib.cmx_set_mapping_options(self._ctx, int(bool(average)), int(bool(joint))))
 
     def simulate(self, seed, g0, n):
         aln = np.zeros((self.T, n), dtype=np.uint8)

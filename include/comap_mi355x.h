@@ -132,6 +132,15 @@ cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t
 cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
                              double* d_counts /*[B*K][ldc]*/, size_t ldc, double* d_logL, double* d_post_rate,
                              int32_t* d_rate_class, double* d_norm, void* stream);
+/* nijt.average / nijt.joint (CoMap/CoETools.cpp:393-406, CoMap/AnalysisTools.cpp:598-610: which of
+ * LegacySubstitutionMappingTools::computeSubstitutionVectors{, NoAveraging, Marginal, NoAveragingMarginal} maps the
+ * sites; "for benchmarking only" in the reference, but nijt = Label with the MI statistic requires average = no,
+ * CoETools.cpp:577-588).  Default (1, 1).  (0, 1): every later cmx_map_sites* / cmx_null_* / clustering / candidate call
+ * of this context returns the counts and norms of computeSubstitutionVectorsNoAveraging -- the conditional count
+ * N^k(x*, y*; t_b) of the most probable pair of ancestral states of each branch -- through plain (slow) kernels; the
+ * null then runs unfused.  joint = 0: CMX_ERR_UNSUPPORTED.  Parity unpinned: bpp-phyl is not in the reference tree
+ * (DESIGN.md 4.5). */
+cmx_status cmx_set_mapping_options(cmx_ctx* ctx, int average, int joint);
 
 /* ---- sequence simulator (NonHomogeneousSequenceSimulator::simulate, AnalysisTools.cpp:591): counter-based RNG,
  * global site indices g0 .. g0+n-1 (see DESIGN.md "RNG").  aln_out: [T][n]. */

@@ -151,11 +151,10 @@ class Engine {
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
 
-  // nijt.average / nijt.joint (CoETools.cpp:393-406).  The engine maps with average = joint = yes, the reference's
-  // defaults; the other three variants are "for benchmarking only" there and are refused here rather than approximated.
-  void setMappingOptions(bool average, bool joint) {
-    if (!average || !joint) throw Exception("nijt.average=no / nijt.joint=no are not offered by the MI355X engine");
-  }
+  // nijt.average / nijt.joint (CoETools.cpp:393-406; "for benchmarking only" there).  average = no, joint = yes maps with
+  // computeSubstitutionVectorsNoAveraging from here on (observed data and nulls; what nijt = Label with the MI statistic
+  // needs, CoETools.cpp:577-588); joint = no throws (the Marginal variants are not implemented).
+  void setMappingOptions(bool average, bool joint) { check(cmx_set_mapping_options(ctx_, average ? 1 : 0, joint ? 1 : 0)); }
   // simulations.continuous = yes (CoMap.cpp:146, 213: seqSim->enableContinuousRates(true)): n simulated sites [taxon][site]
   // with global site indices g0 .. g0 + n - 1, every site with its own rate from the continuous Gamma(alpha, alpha)
   // (+ invariant mass pInvariant); the drawn rates are returned in *rates when given

@@ -91,6 +91,24 @@ def map_sites(m, aln, masks=None):
     return dict(counts=counts, logL=logL, post_rate=pr, rate_class=rc, norm=norm)
 
 
+def map_sites_noavg(m, aln, masks=None):
+    """nijt.average = no, nijt.joint = yes (computeSubstitutionVectorsNoAveraging; oracle.c orc_map_sites_noavg) ->
+    counts [N, B, K], norm [N], argmax [N, B] (x * S + y of the most probable pair of ancestral states), margin [N, B]"""
+    aln = np.ascontiguousarray(aln, dtype=np.uint8)
+    T, N = aln.shape
+    assert T == m.T
+    masks = default_masks(m.S) if masks is None else np.ascontiguousarray(masks, dtype=np.uint32)
+    counts = np.zeros((N, m.B, m.K))
+    norm, margin = np.zeros(N), np.zeros((N, m.B))
+    arg = np.zeros((N, m.B), dtype=np.int32)
+    D, I, U8, U32 = ctypes.c_double, ctypes.c_int, ctypes.c_uint8, ctypes.c_uint32
+    lib().orc_map_sites_noavg(m.nn, _p(m.parent, I), _p(m.blen, D), m.T, _p(m.lot, I), ctypes.c_long(N), _p(aln, U8),
+                              _p(masks, U32), m.S, m.C, m.K, _p(m.Q, D), _p(m.pi, D), _p(m.rates, D), _p(m.probs, D),
+                              _p(m.Bk, D), m.method, m.nonneg, _p(m.naive_W, D), _p(counts, D), _p(norm, D), _p(arg, I),
+                              _p(margin, D))
+    return dict(counts=counts, norm=norm, argmax=arg, margin=margin)
+
+
 def simulate(m, seed, g0, n):
     aln = np.zeros((m.T, n), dtype=np.uint8)
     cls = np.zeros(n, dtype=np.int32)

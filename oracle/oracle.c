@@ -322,6 +322,138 @@ int orc_map_sites(int nn, const int* parent, const double* blen, int T, const in
   return 0;
 }
 
+/* LegacySubstitutionMappingTools::computeSubstitutionVectorsNoAveraging -- nijt.average = no, nijt.joint = yes
+ * (call sites CoMap/CoETools.cpp:395-403, CoMap/AnalysisTools.cpp:598-610; "for benchmarking only" there, but the only
+ * way the reference runs nijt = Label with the MI statistic, CoETools.cpp:577-588).  The algorithm lives in bpp-phyl
+ * (Bio++ 3.0 legacy classes), which is not part of the reference tree: PARITY UNPINNED, restated from the published
+ * source as far as it is remembered:
+ *   per branch b (father f, son n) and site i:  pxy(x, y) = sum_c p_c U_b(i,c,x) P_c,b(x,y) D_n(i,c,y)   (the joint
+ *   posterior of the two ancestral states up to the factor 1 / L_i; U_b and D_n as in orc_map_sites / A.3);
+ *   (x*, y*) = MatrixTools::whichMax(pxy): the FIRST maximum in row-major order;
+ *   count(b, i, k) = N^k(x*, y*; t_b), the conditional expectation J/P of A.4 at the branch length itself (the rate
+ *   class has been summed out, no r_c here).
+ * Assumption where memory does not decide: the class weight p_c inside pxy (it does not matter for equiprobable
+ * classes, i.e. for every Gamma(n) distribution).
+ * margin[i*B + b] = (best - second best) / best of pxy: where it is below ~1e-9 another implementation may pick the
+ * other cell; the parity tests skip those entries. */
+int orc_map_sites_noavg(int nn, const int* parent, const double* blen, int T, const int* leaf_of_taxon, long N,
+                        const uint8_t* aln, const uint32_t* masks, int S, int C, int K, const double* Q, const double* pi,
+                        const double* rates, const double* probs, const double* Bk, int method, int nonneg,
+                        const double* naiveW, double* counts, double* norm, int* argmax_xy, double* margin) {
+  int B = nn - 1, root = nn - 1, S2 = S * S;
+  int *first, *next;
+  child_lists(nn, parent, &first, &next);
+  int* taxon_of = (int*)malloc(sizeof(int) * nn);
+  for (int i = 0; i < nn; i++) taxon_of[i] = -1;
+  for (int t = 0; t < T; t++) taxon_of[leaf_of_taxon[t]] = t;
+  double* lam = (double*)malloc(sizeof(double) * (S + 2 * S2));
+  double *V = lam + S, *Vinv = V + S2;
+  orc_eigen_reversible(S, Q, pi, lam, V, Vinv);
+  double* P = (double*)malloc(sizeof(double) * (size_t)B * C * S2);
+  double* N1 = (double*)malloc(sizeof(double) * (size_t)B * K * S2);   /* N^k(x, y; t_b) at rate 1 */
+  double* Jtmp = (double*)malloc(sizeof(double) * S2 * 2);
+  double* P1 = Jtmp + S2;
+  for (int b = 0; b < B; b++) {
+    for (int c = 0; c < C; c++) orc_transition(S, lam, V, Vinv, blen[b] * rates[c], P + ((size_t)b * C + c) * S2);
+    orc_transition(S, lam, V, Vinv, blen[b], P1);
+    for (int k = 0; k < K; k++) {
+      double* Nk = N1 + ((size_t)b * K + k) * S2;
+      if (method == 2) {
+        for (int i = 0; i < S2; i++) Nk[i] = ((i / S) == (i % S)) ? 0.0 : (naiveW ? naiveW[i] : 1.0);
+      } else {
+        if (method == 0) orc_count_unif(S, Q, Bk + (size_t)k * S2, blen[b], Jtmp);
+        else orc_count_decomp(S, lam, V, Vinv, Bk + (size_t)k * S2, blen[b], Jtmp);
+        for (int i = 0; i < S2; i++) {
+          double nxy = Jtmp[i] / P1[i];
+          if (isnan(nxy) || isinf(nxy)) nxy = 0;
+          if (nonneg && nxy < 0) nxy = 0;
+          Nk[i] = nxy;
+        }
+      }
+    }
+  }
+  size_t vsz = (size_t)nn * C * S;
+  double* D = (double*)malloc(sizeof(double) * vsz * 3);
+  double *M = D + vsz, *Up = M + vsz;
+  double* U = (double*)malloc(sizeof(double) * (size_t)C * S);
+  double* pxy = (double*)malloc(sizeof(double) * S2);
+  for (long i = 0; i < N; i++) {
+    for (int n = 0; n < nn; n++)
+      for (int c = 0; c < C; c++) {
+        double* Dn = D + ((size_t)n * C + c) * S;
+        if (first[n] < 0) {
+          uint8_t code = aln[(size_t)taxon_of[n] * N + i];
+          uint32_t m = code < S ? (1u << code) : masks[code];
+          for (int x = 0; x < S; x++) Dn[x] = (m >> x) & 1u;
+        } else {
+          for (int x = 0; x < S; x++) Dn[x] = 1.0;
+          for (int e = first[n]; e >= 0; e = next[e]) {
+            const double* Me = M + ((size_t)e * C + c) * S;
+            for (int x = 0; x < S; x++) Dn[x] *= Me[x];
+          }
+        }
+        if (n != root) {
+          const double* Pn = P + ((size_t)n * C + c) * S2;
+          double* Mn = M + ((size_t)n * C + c) * S;
+          for (int x = 0; x < S; x++) {
+            double s = 0;
+            for (int z = 0; z < S; z++) s += Pn[x * S + z] * Dn[z];
+            Mn[x] = s;
+          }
+        }
+      }
+    for (int c = 0; c < C; c++)
+      for (int x = 0; x < S; x++) Up[((size_t)root * C + c) * S + x] = pi[x];
+    double* ci = counts + (size_t)i * B * K;
+    for (int f = nn - 1; f >= 0; f--) {
+      if (first[f] < 0) continue;
+      for (int n = first[f]; n >= 0; n = next[n]) {
+        for (int e = 0; e < S2; e++) pxy[e] = 0;
+        for (int c = 0; c < C; c++) {
+          const double* Upf = Up + ((size_t)f * C + c) * S;
+          double* Uc = U + (size_t)c * S;
+          for (int x = 0; x < S; x++) Uc[x] = Upf[x];
+          for (int m = first[f]; m >= 0; m = next[m])
+            if (m != n) {
+              const double* Mm = M + ((size_t)m * C + c) * S;
+              for (int x = 0; x < S; x++) Uc[x] *= Mm[x];
+            }
+          const double* Dn = D + ((size_t)n * C + c) * S;
+          const double* Pn = P + ((size_t)n * C + c) * S2;
+          for (int x = 0; x < S; x++)
+            for (int y = 0; y < S; y++) pxy[x * S + y] += probs[c] * (Uc[x] * Pn[x * S + y] * Dn[y]);
+          if (first[n] >= 0) {
+            double* Upn = Up + ((size_t)n * C + c) * S;
+            for (int z = 0; z < S; z++) {
+              double s = 0;
+              for (int x = 0; x < S; x++) s += Pn[x * S + z] * Uc[x];
+              Upn[z] = s;
+            }
+          }
+        }
+        int best = 0;
+        double bv = -INFINITY, second = -INFINITY;
+        for (int e = 0; e < S2; e++) {
+          if (pxy[e] > bv) { second = bv; bv = pxy[e]; best = e; }
+          else if (pxy[e] > second) second = pxy[e];
+        }
+        for (int k = 0; k < K; k++) ci[(size_t)n * K + k] = N1[((size_t)n * K + k) * S2 + best];
+        if (argmax_xy) argmax_xy[(size_t)i * B + n] = best;
+        if (margin) margin[(size_t)i * B + n] = bv > 0 ? (bv - second) / bv : 0.0;
+      }
+    }
+    double nrm = 0;
+    for (int b = 0; b < B; b++) {
+      double tot = 0;
+      for (int k = 0; k < K; k++) tot += ci[(size_t)b * K + k];
+      nrm += tot * tot;
+    }
+    norm[i] = sqrt(nrm);
+  }
+  free(D); free(U); free(pxy); free(P); free(N1); free(Jtmp); free(lam); free(taxon_of); free(first); free(next);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ simulator (A.8; RNG scheme is this build's)
  * Bio++ draws from a global, time-seeded generator, so simulated alignments are not reproducible across
  * implementations; the product and this oracle share a counter-based scheme instead (Philox2x32-10, Random123):

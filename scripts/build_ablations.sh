@@ -7,11 +7,11 @@ mkdir -p ../../build/abl
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form=1"
 for n in ${1:-1 2 3 4 5 6}; do
   if [ "${n:0:1}" = "m" ]; then
-    /opt/rocm/bin/hipcc $FLAGS -DCMX_MICA_ABLATE=${n:1} -shared cmx_kernels.hip cmx_cluster.hip cmx_mica_post.hip -x hip cmx_api.cpp cmx_host_model.cpp -o ../../build/abl/libcmx_mica_abl${n:1}.so &
+    /opt/rocm/bin/hipcc $FLAGS -DCMX_MICA_ABLATE=${n:1} -shared cmx_kernels.hip cmx_cluster.hip cmx_mica_post.hip cmx_variants.hip -x hip cmx_api.cpp cmx_host_model.cpp -o ../../build/abl/libcmx_mica_abl${n:1}.so &
   elif [ "$n" = "t" ]; then   # phase timing with s_memtime, printed by waves 0 and 777 of the null kernel
-    /opt/rocm/bin/hipcc $FLAGS -DCMX_TIMING -shared cmx_kernels.hip cmx_cluster.hip cmx_mica_post.hip -x hip cmx_api.cpp cmx_host_model.cpp -o ../../build/abl/libcmx_timing.so &
+    /opt/rocm/bin/hipcc $FLAGS -DCMX_TIMING -shared cmx_kernels.hip cmx_cluster.hip cmx_mica_post.hip cmx_variants.hip -x hip cmx_api.cpp cmx_host_model.cpp -o ../../build/abl/libcmx_timing.so &
   else
-    /opt/rocm/bin/hipcc $FLAGS -DCMX_ABLATE=$n -shared cmx_kernels.hip cmx_cluster.hip cmx_mica_post.hip -x hip cmx_api.cpp cmx_host_model.cpp -o ../../build/abl/libcmx_abl$n.so &
+    /opt/rocm/bin/hipcc $FLAGS -DCMX_ABLATE=$n -shared cmx_kernels.hip cmx_cluster.hip cmx_mica_post.hip cmx_variants.hip -x hip cmx_api.cpp cmx_host_model.cpp -o ../../build/abl/libcmx_abl$n.so &
   fi
 done
 wait

@@ -768,3 +768,70 @@ def test_mi_columns_with_gaps_everywhere(A, T):
     rel_close(g3["mi"], o3["mi"], 1e-6, 1e-10)
     keep = np.arange(n1) != 4
     assert np.array_equal(g3["mi"][keep], g["mi"][keep])
+
+
+@pytest.mark.parametrize("S,ntaxa,nsites,ncat", [(20, 9, 70, 4), (4, 12, 90, 4), (4, 6, 40, 2)])
+def test_noavg_mapping_matches_oracle(S, ntaxa, nsites, ncat):
+    """nijt.average = no, nijt.joint = yes (computeSubstitutionVectorsNoAveraging, CoETools.cpp:401): counts = the table
+    entry N^k(x*, y*; t_b) of the most probable pair of ancestral states; the oracle's restatement is pinned to that
+    definition by brute force (tests/test_oracle_noavg.py).  Entries whose two best pairs are closer than 1e-9 relative
+    may be decided differently by rounding and are skipped; likelihoods etc. stay those of the averaged call."""
+    case = make_case(ntaxa, nsites, S, 300 + S)
+    case["aln"][2, ::7] = S                                   # some unknowns at a leaf
+    om = oracle.Model(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    o = oracle.map_sites_noavg(om, case["aln"])
+    avg = oracle.map_sites(om, case["aln"])
+    eng = engine.Engine(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    eng.set_mapping_options(average=False, joint=True)
+    g = eng.map_sites(case["aln"])
+    clear = o["margin"] > 1e-9
+    assert clear.mean() > 0.97
+    got, want = g["counts"][clear], o["counts"][clear]
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-12), np.abs(got - want).max()
+    full = clear.all(axis=1)
+    rel_close(g["norm"][full], o["norm"][full], 1e-6, 1e-12)
+    rel_close(g["logL"], avg["logL"], 1e-9)
+    assert np.array_equal(g["rate_class"], avg["rate_class"])
+    # back to the default: the averaged mapping again
+    eng.set_mapping_options(True, True)
+    rel_close(eng.map_sites(case["aln"])["counts"], avg["counts"], 1e-6, 1e-300)
+    with pytest.raises(engine.CmxError, match="joint"):
+        eng.set_mapping_options(True, False)
+
+
+def test_noavg_null_is_simulate_map_score():
+    """AnalysisTools.cpp:598-610 with nijt.average = no: replicate r scores site j of its first simulated batch against
+    site j of the second, both mapped without averaging -- rebuilt here from the engine's own simulator and mapping and
+    the oracle's statistic"""
+    case = make_case(8, 10, 20, 77)
+    eng = engine.Engine(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    eng.set_mapping_options(False, True)
+    rep_begin, rep_end, ram, seed = 1, 3, 40, 909
+    nl = eng.null_intra(engine.STAT_CORRELATION, seed, rep_begin, rep_end, ram)
+    for r in range(rep_begin, rep_end):
+        a0, _ = eng.simulate(seed, (r * 2 + 0) * ram, ram)
+        a1, _ = eng.simulate(seed, (r * 2 + 1) * ram, ram)
+        m0, m1 = eng.map_sites(a0), eng.map_sites(a1)
+        st = np.array([oracle.stat_pair(0, m0["counts"][j], m1["counts"][j]) for j in range(ram)])
+        sl = slice((r - rep_begin) * ram, (r - rep_begin + 1) * ram)
+        rel_close(nl["stat"][sl], st, 1e-9, 1e-12)
+        rel_close(nl["nmin"][sl], np.minimum(m0["norm"], m1["norm"]), 1e-12)
+        assert np.array_equal(nl["rcmin"][sl], np.minimum(m0["rate_class"], m1["rate_class"]))
+
+
+def test_label_counts_without_averaging_feed_the_mi_statistic():
+    """the reference's MI statistic as it actually runs (CoETools.cpp:577-588): nijt = Label needs nijt.average = no, the
+    substitution vector of a site is then the label of the most probable substitution on every branch -- integers -- and
+    DiscreteMutualInformationStatistic bins them with the bounds -0.5, 0.5, ..., S(S-1) + 0.5"""
+    case = make_case(10, 50, 4, 31)
+    W = engine.label_substitution_weights(4)
+    eng = _engine(case, count_method=engine.COUNT_NAIVE, naive_weights=W)
+    eng.set_mapping_options(False, True)
+    r = eng.map_sites(case["aln"])
+    o = oracle.map_sites_noavg(_omodel(case, method=oracle.METHOD_NAIVE, naive_W=W), case["aln"])
+    clear = o["margin"] > 1e-9
+    assert np.array_equal(r["counts"][clear], o["counts"][clear])
+    lab = r["counts"][clear]
+    assert np.all(lab == np.round(lab)) and lab.min() >= 0 and lab.max() <= 12
+    x, y = o["argmax"][clear] // 4, o["argmax"][clear] % 4
+    assert np.array_equal(lab[:, 0], W[x, y])
