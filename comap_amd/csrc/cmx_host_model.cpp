@@ -568,7 +568,7 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   const size_t MU = (size_t)mat_unit(dS);   // doubles per device matrix: dS*dS plus max_ambig(dS) extra leaf rows
   const size_t dS2 = (size_t)dS * dS;
   hm->MAT.assign((size_t)dC * MC * MU, 0.0);
-  hm->CP.assign((size_t)C * nn * S2, 0.0);
+  hm->CP.assign((size_t)C * nn * S2 + 4, 0.0);   // + 4: the fused simulator reads four running sums at a time
   for (int c = 0; c < C; ++c)
     for (int b = 0; b < B; ++b) {
       const double* P = &hm->P[((size_t)c * B + b) * S2];

@@ -936,16 +936,28 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
               idx[jj] = m.CPG[row[jj] * 32 + (int)(u[jj] * 32.0)];
             }
             bool any;
-            do {   // the same index as draw_guided, the four searches advancing together
-              double cv[4];
+            do {   // the same index as draw_guided, the four searches advancing together -- and four running sums per
+                   // search and round trip: the loop runs until the slowest of the wave's 256 searches is done, and one
+                   // sum per trip made that 4-5 dependent L2 gathers per group (487 -> 478 ms at the target, same box).
+                   // Tried on top and slower: groups of eight nodes (480 -> 507 ms: registers), the next group's random
+                   // numbers computed under this group's gathers (488 -> 528 ms: the copies of the group state)
+              double cv[4][4];
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) cv[jj] = m.CP[row[jj] * S0 + idx[jj]];
+              for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) cv[jj][d] = m.CP[row[jj] * S0 + idx[jj] + d];   // the table is padded by 4 sums
               any = false;
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) {
-                const bool adv = idx[jj] < S0 - 1 && u[jj] >= cv[jj];
-                idx[jj] += adv ? 1 : 0;
-                any |= adv;
+                bool go = true;
+                int adv = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                  go = go && idx[jj] + d < S0 - 1 && u[jj] >= cv[jj][d];
+                  adv += go ? 1 : 0;
+                }
+                idx[jj] += adv;
+                any |= adv == 4;
               }
             } while (any);
 #pragma unroll
