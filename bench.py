@@ -311,7 +311,9 @@ def main():
         try:
             t = json.load(open(tf))
             if t.get("kernel_source_sha") == kernel_source_sha() and args.workload in t:
-                roofline["traffic"] = t[args.workload]
+                # per-launch bytes measured at N = 1; a sharded launch maps fewer sites (the traffic is per-site state)
+                ref_sites = t.get("sites_per_launch", {}).get(args.workload, sites_per_launch)
+                roofline["traffic"] = t[args.workload] * sites_per_launch / ref_sites
                 roofline["traffic_source"] = os.path.relpath(tf, ROOT)
                 break
         except Exception:
