@@ -986,7 +986,7 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
       if ((s = scratch(ctx, "mica_g2", n2, (void**)&w.gap2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_S2", sizeof(double) * n2, (void**)&w.S2)) != CMX_OK) return s;
     }
-    if ((s = scratch(ctx, "mica_ftab", sizeof(double) * (size_t)(ntaxa + 1), (void**)&w.ftab)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "mica_ftab", sizeof(double) * ((size_t)(ntaxa + 1) + (size_t)nalpha * nalpha * ntaxa + 1), (void**)&w.ftab)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_any", sizeof(int), (void**)&w.anyflag)) != CMX_OK) return s;
   }
   HIP_TRY(ctx, launch_mi_columns(nalpha, ntaxa, d_masks, d_aln1, n1, ld1, d_aln2, n2, ld2, intra ? 1 : 0, d_mi, d_hjoint,

@@ -201,7 +201,7 @@ struct MicaWork {
   uint8_t *flag1, *flag2;  // [n] column has ambiguous symbols other than "unknown" (-> LDS-table kernel)
   uint8_t *gap1, *gap2;    // [n] column has unknowns (gap / X / N: compatible with every state; handled on the matrix cores)
   double *S1, *S2;         // [n] sum_a f(count_a)
-  double* ftab;            // [T + 1] c ln c
+  double* ftab;            // [T + 1] c ln c, then [A*A*T + 1] (m / A^2) ln(m / A^2) (pairs with unknowns)
   int* anyflag;            // some column of either alignment has ambiguous symbols
   int Tp;                  // T rounded up to a multiple of 32 (taxa per MFMA step)
 };

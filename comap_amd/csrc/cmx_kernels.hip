@@ -1983,10 +1983,18 @@ __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, 
   }
 }
 
-__global__ void mica_ftable_kernel(int T, double* __restrict__ f, int* __restrict__ anyflag) {
+// f[c] = c ln c for the integer counts 0..T, followed by f2[m] = (m / A^2) ln(m / A^2) for m = 0..A^2 T: the fractional
+// count of a pair with unknowns is c_ab = N_ab + (N_aA + N_Ab) / A + N_AA / A^2 = m / A^2 with the INTEGER
+// m = A^2 N_ab + A (N_aA + N_Ab) + N_AA, so those pairs need no logarithm at run time either
+__global__ void mica_ftable_kernel(int T, int A, double* __restrict__ f, int* __restrict__ anyflag) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0) *anyflag = 0;
   if (c <= T) f[c] = c > 1 ? (double)c * log((double)c) : 0.0;
+  const int M = A * A * T;
+  if (c <= M) {
+    const double v = (double)c / (double)(A * A);
+    f[T + 1 + c] = c > 0 ? v * log(v) : 0.0;
+  }
 }
 
 // One workgroup (8 waves) per 8 x 4 tile of column pairs (8 columns of the first alignment, 4 of the second), wave w owns
@@ -2123,7 +2131,7 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const 
       __syncthreads();                                  // the operand buffers are free now: reuse them as count tables
       int* tile = reinterpret_cast<int*>(ops) + w * 448;   // (A + 1)^2 <= 441 ints per wave
       const int A1 = A + 1;
-      const double invA = 1.0 / (double)A;
+      const double* f2 = ftab_g + T + 1;   // (m / A^2) ln(m / A^2), global (A^2 T + 1 entries, L2-resident)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ii = r >> 1, jj = r & 1;
@@ -2136,13 +2144,16 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        const double gam = (double)tile[A * A1 + A] * invA * invA;
-        double sg = 0.0;
-        for (int e = lane; e < A * A; e += 64) {
-          const int x = e / A, y = e % A;
-          const double c = (double)tile[x * A1 + y] + ((double)tile[x * A1 + A] + (double)tile[A * A1 + y]) * invA + gam;
-          if (c > 0.0) sg += c * log(c);
+        const int gg = tile[A * A1 + A];
+        int mm[(A * A + 63) / 64];   // all table indices first, then all gathers (not one dependent L2 round trip each)
+#pragma unroll
+        for (int k = 0; k < (A * A + 63) / 64; ++k) {
+          const int e = lane + 64 * k, x = e / A, y = e % A;
+          mm[k] = e < A * A ? A * A * tile[x * A1 + y] + A * (tile[x * A1 + A] + tile[A * A1 + y]) + gg : 0;   // f2[0] = 0
         }
+        double sg = 0.0;
+#pragma unroll
+        for (int k = 0; k < (A * A + 63) / 64; ++k) sg += f2[mm[k]];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, 64);
         if ((lane >> 4) == r) s = sg;
@@ -2197,7 +2208,7 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
   double* ftab = reinterpret_cast<double*>(mica_smem);                       // [T + 1]
   cmx_i4* ops = reinterpret_cast<cmx_i4*>(mica_smem + (((size_t)(T + 1) * 8 + 15) & ~(size_t)15));  // [4][12][64]
   constexpr int NOP = 12, NI = 8;   // operand tiles per k-step: 8 of the first alignment (4 blocks), 4 of the second
-  uint8_t* codes = reinterpret_cast<uint8_t*>(ops + 4 * NOP * 64);          // [18][Tp]: the tile's columns, one byte per taxon
+  uint8_t* codes = reinterpret_cast<uint8_t*>(ops + 4 * NOP * 64) + 16384;   // the unknowns' path lays 8 x 8 KiB over the operand buffers + 16 KiB          // [18][Tp]: the tile's columns, one byte per taxon
   double* Scol = reinterpret_cast<double*>(codes + (size_t)(kMica3I + kMica3J) * Tp);   // [18] S of the tile's columns (12 + 6)
   int* fcol = reinterpret_cast<int*>(Scol + 18);   // [18] bit 0 partial ambiguity codes, bit 1 unknowns, bit 2 past the end
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
@@ -2359,41 +2370,51 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
 #pragma unroll
   for (int c = 0; c < kMica3I + kMica3J; ++c) gapbits |= fcol[c] & 2;
   if (gapbits != 0) {
-    // pairs with unknowns: expand the pseudo-state's counts (see mica_mfma_kernel) from the pair's 21 x 21 sub-block
-    __syncthreads();                                     // the operand buffers are free now: reuse them as count tables
-    int* tile = reinterpret_cast<int*>(ops) + w * 448;   // 21 x 21 = 441 ints per wave
-    const double invA = 1.0 / (double)A;
+    // Pairs with unknowns: the fractional counts of resolveUnknowns = true are m / A^2 with the integer
+    // m = A^2 N_ab + A (N_aG + N_Gb) + N_GG (G = the pseudo-state, row / column 20 of the pair's 21 x 21 block), and
+    // sum_ab f2[m] comes from the second table (global, L2-resident).  The wave drops its 64 x 64 accumulator block into
+    // LDS once (16-bit counts: T <= 2047), every pair with an unknown reads its cells from there; the nine sums are
+    // reduced together like the fast path's.
+    __syncthreads();                                     // the operand buffers are free now
+    uint16_t* t16 = reinterpret_cast<uint16_t*>(ops) + (size_t)w * 4096;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int R = 32 * ii + 8 * (v / 4) + v % 4 + (hi ? 4 : 0), C = 32 * jj + cl;
+          t16[R * 64 + C] = (uint16_t)acc[ii][jj][v];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const double* f2 = ftab_g + T + 1;   // (m / A^2) ln(m / A^2), A^2 T + 1 entries
+    double sg[9];
+#pragma unroll
     for (int pr = 0; pr < 9; ++pr) {
+      sg[pr] = 0.0;
       const int a = pr / 3, b = pr % 3;
-      if (!((fcol[3 * wi + a] | fcol[kMica3I + 3 * wj + b]) & 2)) continue;
+      if (!((fcol[3 * wi + a] | fcol[kMica3I + 3 * wj + b]) & 2)) continue;   // wave-uniform
+      const uint16_t* tb = t16 + (P * a) * 64 + P * b;
+      const int gg = tb[A * 64 + A];
+      int mm[(A * A + 63) / 64];   // all table indices first, then all gathers
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const int R = 32 * ii + 8 * (v / 4) + v % 4 + (hi ? 4 : 0), C = 32 * jj + cl;
-            const int ra = R - P * a, cb = C - P * b;
-            if (ra >= 0 && ra < P && cb >= 0 && cb < P) tile[ra * P + cb] = acc[ii][jj][v];
-          }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      const double gam = (double)tile[A * P + A] * invA * invA;
-      double sg = 0.0;
-      for (int e = lane; e < A * A; e += 64) {
-        const int x = e / A, y = e % A;
-        const double c = (double)tile[x * P + y] + ((double)tile[x * P + A] + (double)tile[A * P + y]) * invA + gam;
-        if (c > 0.0) sg += c * log(c);
+      for (int q_ = 0; q_ < (A * A + 63) / 64; ++q_) {
+        const int e = lane + 64 * q_, x = e / A, y = e % A;
+        mm[q_] = e < A * A ? A * A * (int)tb[x * 64 + y] + A * ((int)tb[x * 64 + A] + (int)tb[A * 64 + y]) + gg : 0;   // f2[0] = 0
       }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, 64);
-      if ((lane >> 4) == (pr & 3)) {
-        if ((pr >> 2) == 0) sres[0] = sg;
-        else if ((pr >> 2) == 1) sres[1] = sg;
-        else sres[2] = sg;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
+      for (int q_ = 0; q_ < (A * A + 63) / 64; ++q_) sg[pr] += f2[mm[q_]];
+    }
+    const double g0 = mica_reduce4(sg[0], sg[1], sg[2], sg[3]);
+    const double g1 = mica_reduce4(sg[4], sg[5], sg[6], sg[7]);
+    const double g2 = mica_reduce4(sg[8], 0.0, 0.0, 0.0);
+    // lanes with lane >> 4 == r hold pair 4 g + r: take the general sum where that pair has an unknown
+    const int r_ = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int pr = 4 * g + r_;
+      if (pr < 9 && ((fcol[3 * wi + pr / 3] | fcol[kMica3I + 3 * wj + pr % 3]) & 2)) sres[g] = g == 0 ? g0 : (g == 1 ? g1 : g2);
     }
   }
   if ((lane & 15) == 0) {
@@ -2463,7 +2484,7 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
   if (work && work->H1) {
     const int Tp = work->Tp;
     const bool needH = !(A == 20 && !mica_one_column_tiles());   // the packed protein kernel expands the symbol bytes itself
-    hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)(T / 256 + 1)), dim3(256), 0, stream, T, work->ftab, work->anyflag);
+    hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)((A * A * T) / 256 + 1)), dim3(256), 0, stream, T, A, work->ftab, work->anyflag);
     hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, needH ? work->H1 : nullptr, work->C1, work->flag1,
                        work->gap1, work->S1, work->anyflag);
     if (!intra)
@@ -2474,7 +2495,7 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
     if (A == 20 && !mica_one_column_tiles()) {
       const unsigned ntx = (unsigned)((n2 + kMica3J - 1) / kMica3J), nty = (unsigned)((n1 + kMica3I - 1) / kMica3I);
       const unsigned ntiles = ntx * nty, per_xcd = (ntiles + 7) / 8;
-      const size_t lds3 = lds2 + 2 * (kMica3I / 3 * 2 + kMica3J / 3 * 2) * 64 * sizeof(cmx_i4) + (size_t)(kMica3I + kMica3J) * Tp + 18 * sizeof(double) + 20 * sizeof(int);
+      const size_t lds3 = lds2 + 2 * (kMica3I / 3 * 2 + kMica3J / 3 * 2) * 64 * sizeof(cmx_i4) + 16384 + (size_t)(kMica3I + kMica3J) * Tp + 18 * sizeof(double) + 20 * sizeof(int);
       if (lds3 > 64 * 1024) {
         const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&mica_mfma3_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
