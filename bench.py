@@ -257,11 +257,8 @@ def main():
         side.wait_stream(main_s)
         with torch.cuda.stream(side):
             ana.get_vectors(aln)
-        if timed:
-            ev[i][0].record()
-        nb = ana.null_distribution(w["seed"] + 7, rep_begin, rep_end, ram)
-        if timed:
-            ev[i][1].record()
+        # the null: simulate (own kernel, full occupancy) then map + score; the events bracket the mapping launch alone
+        nb = ana.null_distribution(w["seed"] + 7, rep_begin, rep_end, ram, map_events=ev[i] if timed else None)
         main_s.wait_stream(side)
         # the path's one exchange: every rank needs the merged null before p-values (one RCCL all-gather)
         ns, nm = gather_null(nb["stat"], nb["nmin"], nrep_total, ram)

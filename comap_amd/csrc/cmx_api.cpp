@@ -585,6 +585,31 @@ cmx_status cmx_pair_stats(cmx_ctx* ctx, int kind, const double* params, const do
 }
 
 // ------------------------------------------------------------------------------------------------ null distribution
+// CMX_NULL_FUSED=1: simulate inside the mapping waves (the round-1 arrangement; A/B timing, same results)
+static bool null_fused() {
+  static const bool v = [] { const char* e = getenv("CMX_NULL_FUSED"); return e && e[0] == '1'; }();
+  return v;
+}
+
+// The null's alignments, [replicate][batch][taxon][rep_ram] bytes (what cmx_null_intra_dev takes as `supplied`):
+// NonHomogeneousSequenceSimulator::simulate(repRAM) twice per replicate (AnalysisTools.cpp:591, 612), simulated-site index
+// g = ((rep * 2 + batch) * rep_ram + j) as everywhere.
+cmx_status cmx_null_simulate_dev(cmx_ctx* ctx, uint64_t seed, size_t rep_begin, size_t rep_end, size_t rep_ram, uint8_t* d_aln,
+                                 void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (rep_end <= rep_begin || rep_ram == 0 || !d_aln) return fail(ctx, CMX_ERR_INVALID, "cmx_null_simulate: bad arguments");
+  if ((s = rng_range(ctx, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_simulate")) != CMX_OK) return s;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t nsites = (rep_end - rep_begin) * 2 * rep_ram;
+  const size_t chunk = std::min<size_t>(nsites, (size_t)1 << 21);
+  uint8_t* d_states;
+  if ((s = scratch(ctx, "null_states", (size_t)ctx->hm.nn * chunk, (void**)&d_states)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_simulate_blocked(ctx->dm, seed, (uint64_t)rep_begin * 2 * rep_ram, nsites, rep_ram, d_aln, d_states, chunk,
+                                       (hipStream_t)stream));
+  return CMX_OK;
+}
+
 cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin,
                               size_t rep_end, size_t rep_ram, const uint8_t* d_supplied, double* d_stat,
                               int32_t* d_rcmin, double* d_prmin, double* d_nmin, void* stream) {
@@ -600,6 +625,17 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
     return cmx_null_inter_dev(ctx, ctx, kind, params, seed, rep_begin, rep_end, rep_ram, d_stat, d_rcmin, d_prmin, d_nmin, stream);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!d_supplied && !null_fused()) {
+    // simulate first, at full occupancy, then map the alignments as "supplied" ones: the same draws, the same results
+    // as the fused kernel (the simulator inside a mapping wave was 7.8 % of the launch, latency nobody could hide)
+    const size_t bytes = (rep_end - rep_begin) * 2 * (size_t)ctx->hm.T * rep_ram;
+    if (bytes <= ((size_t)16 << 30)) {
+      uint8_t* d_aln;
+      if ((s = scratch(ctx, "null_aln", bytes, (void**)&d_aln)) != CMX_OK) return s;
+      if ((s = cmx_null_simulate_dev(ctx, seed, rep_begin, rep_end, rep_ram, d_aln, stream)) != CMX_OK) return s;
+      d_supplied = d_aln;
+    }
+  }
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.nsites = (rep_end - rep_begin) * rep_ram;

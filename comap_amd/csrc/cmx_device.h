@@ -114,6 +114,8 @@ struct MapArgs {
 int map_lds_per_wave(int S, int nn, int mode);
 hipError_t launch_map(const MapArgs& a, int mode, int grid_blocks, hipStream_t stream);
 hipError_t launch_map_finalize(const MapArgs& a, hipStream_t stream);
+hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0, size_t nsites, size_t blk, uint8_t* d_aln,
+                                   uint8_t* d_states, size_t chunk, hipStream_t stream);
 // fills rows S.. of every leaf operator from d_masks[S .. S+max_ambig(S)) (null: every state compatible)
 hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, hipStream_t stream);
 hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* c1, size_t ld1, const double* c2, size_t ld2,

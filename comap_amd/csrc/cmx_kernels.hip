@@ -1221,6 +1221,79 @@ hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t
   return hipGetLastError();
 }
 
+// The null's simulator since round 2 (cmx_null_intra_dev): the SAME draws as simulate_kernel / the fused loop of
+// map_kernel<S, null>, but one thread per site at full occupancy instead of 64 sites inside a mapping wave that holds
+// half a SIMD's registers.  Inside the mapping kernel the simulator was 7.8 % of a wave's time, all of it dependent L2
+// gathers that two waves per SIMD cannot hide; here thousands of waves hide them (cfg3, same box: fused 12.96 ms,
+// mapping of supplied alignments 11.98 ms + this kernel).  Nodes are drawn level by level in groups of four (m.simg),
+// four running sums per round trip of the search, exactly as the fused loop does.
+// Sites s = 0 .. of one null launch: g = g0 + s; (replicate, batch) block s / blk, column s % blk of an alignment stored
+// as [block][taxon][blk] -- the layout map_kernel<S, null> reads supplied alignments in.
+__global__ __launch_bounds__(256) void simulate_blocked_kernel(const DevModel m, uint64_t seed, uint64_t g0, size_t s0, size_t n,
+                                                               size_t blk, uint8_t* __restrict__ aln,
+                                                               uint8_t* __restrict__ states /*[nn][n]*/) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const size_t s = s0 + j;
+  const uint64_t g = g0 + s;
+  const int S0 = m.S0;
+  uint8_t* out = aln + (s / blk) * (size_t)m.T * blk + s % blk;
+  const int c = draw_index(philox_uniform(seed, g, 0), m.cum_probs, m.C0);
+  states[(size_t)m.root * n + j] = (uint8_t)draw_index(philox_uniform(seed, g, 1), m.cum_pi, S0);
+  for (int gi = 0; gi < m.nsimg; ++gi) {
+    const cmx_cint q = (cmx_cint)m.simg + gi * 16;   // [0..3] node, [4..7] its parent, [8..11] its taxon or -1
+    int x[4], idx[4];
+    double u[4];
+    size_t row[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) x[jj] = states[(size_t)q[4 + jj] * n + j];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) u[jj] = philox_uniform(seed, g, 2u + (uint32_t)q[jj]);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      row[jj] = ((size_t)c * m.nn + q[jj]) * S0 + x[jj];
+      idx[jj] = m.CPG[row[jj] * 32 + (int)(u[jj] * 32.0)];
+    }
+    bool any;
+    do {
+      double cv[4][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) cv[jj][d] = m.CP[row[jj] * S0 + idx[jj] + d];   // the table is padded by 4 sums
+      any = false;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        bool go = true;
+        int adv = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          go = go && idx[jj] + d < S0 - 1 && u[jj] >= cv[jj][d];
+          adv += go ? 1 : 0;
+        }
+        idx[jj] += adv;
+        any |= adv == 4;
+      }
+    } while (any);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      states[(size_t)q[jj] * n + j] = (uint8_t)idx[jj];
+      if (q[8 + jj] >= 0) out[(size_t)q[8 + jj] * blk] = (uint8_t)idx[jj];
+    }
+  }
+}
+
+// nsites sites with global indices g0 .. in passes of at most `chunk` (the states scratch holds nn * chunk bytes)
+hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0, size_t nsites, size_t blk, uint8_t* d_aln,
+                                   uint8_t* d_states, size_t chunk, hipStream_t stream) {
+  for (size_t s0 = 0; s0 < nsites; s0 += chunk) {
+    const size_t n = std::min(chunk, nsites - s0);
+    hipLaunchKernelGGL(simulate_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m, seed, g0, s0, n, blk,
+                       d_aln, d_states);
+  }
+  return hipGetLastError();
+}
+
 // ---- simulations.continuous = yes (CoMap/CoMap.cpp:146, 213: NonHomogeneousSequenceSimulator::enableContinuousRates).
 // Every site draws its own rate from the CONTINUOUS Gamma(alpha, beta = alpha) distribution (Invariant(Gamma): rate 0 with
 // probability p_inv, else the Gamma draw divided by 1 - p_inv) and every branch uses exp(Q r t) of that very rate: the

@@ -39,7 +39,7 @@ COUNT_EXPECTED, COUNT_NAIVE = 0, 1
 EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
     "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_set_mapping_options", "cmx_map_sites_dev", "cmx_simulate", "cmx_simulate_continuous",
-    "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_intra_dev", "cmx_null_inter",
+    "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_simulate_dev", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev", "cmx_intra_rows_range_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
     "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_permutation_test_masks", "cmx_mica_permutation_test_masks_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
@@ -529,6 +529,12 @@ class Engine:
                                                  _sz(counts1.stride(0)), _vp(counts2), _sz(n2),
                                                  _sz(0 if counts2 is None else counts2.stride(0)), _vp(out),
                                                  _sz(out.stride(0)), self._stream()))
+
+    def null_simulate_dev(self, seed, rep_begin, rep_end, rep_ram, aln):
+        """the null's simulated alignments into `aln` (uint8 CUDA tensor, >= nrep * 2 * T * rep_ram bytes, laid out
+        [replicate][batch][taxon][rep_ram]): what null_intra_dev takes as `supplied`"""
+        self._check(self._lib.cmx_null_simulate_dev(self._ctx, ctypes.c_uint64(seed), _sz(rep_begin), _sz(rep_end), _sz(rep_ram),
+                                                    _vp(aln), self._stream()))
 
     def null_intra_dev(self, kind, seed, rep_begin, rep_end, rep_ram, stat, rcmin=None, prmin=None, nmin=None,
                        supplied=None, threshold=0.99, mean_vectors=None):

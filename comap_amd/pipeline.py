@@ -9,6 +9,8 @@ Names follow the reference's seams so that tests read like its call sites:
                             with no N x N matrix (what a rank of a multi-GPU job runs on its share of the upper triangle)
 torch is used for device memory, streams and (in bench.py) torch.distributed only; every number is produced by the
 HIP kernels behind the C-ABI (comap_amd/engine.py)."""
+import os
+
 import torch
 
 
@@ -32,6 +34,7 @@ class IntraAnalysis:
         self._dense = None
         self._rows = None
         self._null = {}
+        self._null_aln = None
 
     def _dense_buffers(self):
         if self._dense is None:
@@ -69,10 +72,23 @@ class IntraAnalysis:
                               rcmin=torch.empty(n, dtype=torch.int32, device=dev))
         return self._null
 
-    def null_distribution(self, seed, rep_begin, rep_end, rep_ram, supplied=None):
+    def null_distribution(self, seed, rep_begin, rep_end, rep_ram, supplied=None, map_events=None):
+        """AnalysisTools::getNullDistributionIntraDR for replicates [rep_begin, rep_end).  map_events = (start, end) CUDA
+        events: the alignments are simulated into a buffer of this object first (cmx_null_simulate_dev) and the events
+        bracket the mapping launch alone -- what bench.py's roofline is about; otherwise one call does both."""
         b = self.null_buffers((rep_end - rep_begin) * rep_ram)
+        if map_events is not None and supplied is None and os.environ.get("CMX_NULL_FUSED") != "1":   # (=1: the fused A/B arrangement)
+            nbytes = (rep_end - rep_begin) * 2 * self.eng.T * rep_ram
+            if self._null_aln is None or self._null_aln.numel() < nbytes:
+                self._null_aln = torch.empty(nbytes, dtype=torch.uint8, device=self.aln.device)
+            self.eng.null_simulate_dev(seed, rep_begin, rep_end, rep_ram, self._null_aln)
+            supplied = self._null_aln
+        if map_events is not None:
+            map_events[0].record()
         self.eng.null_intra_dev(self.kind, seed, rep_begin, rep_end, rep_ram, b["stat"], b["rcmin"], b["prmin"],
                                 b["nmin"], supplied=supplied, threshold=self.threshold)
+        if map_events is not None:
+            map_events[1].record()
         return b
 
     def compute_intra_stats(self, null_stat=None, null_nmin=None):

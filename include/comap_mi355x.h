@@ -163,6 +163,12 @@ cmx_status cmx_pair_stats_dev(cmx_ctx* ctx, int kind, const double* params, cons
                               size_t ld1, const double* d_counts2, size_t n2, size_t ld2, double* d_out, size_t ldo,
                               void* stream);
 
+/* The simulated alignments of a null, on the device: [replicate][batch 0 / 1][taxon][rep_ram] bytes -- the two
+ * seqSim.simulate(repRAM) calls of every replicate (AnalysisTools.cpp:591, 612).  cmx_null_intra_dev does this itself
+ * when no alignments are supplied; a caller that wants the mapping launch alone on its clock (bench.py) fills a buffer
+ * here and passes it as `d_supplied`. */
+cmx_status cmx_null_simulate_dev(cmx_ctx* ctx, uint64_t seed, size_t rep_begin, size_t rep_end, size_t rep_ram,
+                                 uint8_t* d_aln, void* stream);
 /* ---- parametric-bootstrap null, replicates [rep_begin, rep_end) of AnalysisTools::getNullDistributionIntraDR
  * (AnalysisTools.cpp:587-653): per replicate two batches of rep_ram simulated sites are mapped and site j of
  * batch 1 is scored against site j of batch 2.  Outputs have (rep_end-rep_begin)*rep_ram entries, the four
