@@ -183,7 +183,7 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       d.msched = dms;
       d.nmv = (int)(h.msched.size() / 2);
     }
-    UP(nrec); UP(simg);
+    UP(nrec); UP(simg); UP(simord);
     d.nsimg = (int)(h.simg.size() / 16);
     {  // two zero entries (not prefetchable) after the last load: the kernel reads one entry ahead without a bounds test
       std::vector<int> ld(h.ldsched);

@@ -54,6 +54,7 @@ struct DevModel {
   const uint8_t* CPG;      // [C][nn][S(x)][32]
   const int* simg;         // [nsimg][16] groups of four nodes of equal depth: nodes | parents | taxa (or -1) | pad
   int nsimg;
+  const int* simord;       // [nn - 1] the non-root nodes level by level: a node's parent was drawn a whole level earlier
   // continuous-rate simulator: eigensystems of the generators [NM][S*S] / [NM][S], generator and length of each branch
   const double *eigV, *eigVi, *eigLam;
   const int* model_of;     // [B]

@@ -418,6 +418,8 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
     std::vector<std::vector<int>> level(maxd + 1);
     for (int i = nn - 2; i >= 0; --i) level[depth[i]].push_back(i);
     hm->simg.clear();
+    hm->simord.clear();
+    for (int d = 1; d <= maxd; ++d) hm->simord.insert(hm->simord.end(), level[d].begin(), level[d].end());
     for (int d = 1; d <= maxd; ++d)
       for (size_t i = 0; i < level[d].size(); i += 4) {
         int g[16];

@@ -31,6 +31,7 @@ struct HostModel {
   std::vector<double> CP;   // [C][nn][S][S]    running row sums of P
   std::vector<uint8_t> CPG; // [C][nn][S][32]   guide table of the simulator's inverse-CDF search (cmx_kernels.hip: draw_guided)
   std::vector<int> simg;    // [nsimg][16] simulator: groups of four nodes of equal depth (DevModel::simg)
+  std::vector<int> simord;  // [nn - 1] the non-root nodes by depth (DevModel::simord)
   int NV = 0;               // visited nodes of the binary device tree (internal, not inlined; pseudo nodes included)
   int NIW = 0;              // workspace slots: NI + pseudo nodes of split multifurcations
   std::vector<int> nrec;    // [NV][16] per-visited-node records (cmx_walk.h)

@@ -382,6 +382,7 @@ typedef const int __attribute__((address_space(4)))* cmx_cint;
 typedef const double __attribute__((address_space(4)))* cmx_cdbl;
 // per-visited-node record of the tree walk (cmx_walk.h): 16 ints, one scalar load
 typedef int cmx_i16 __attribute__((ext_vector_type(16)));
+typedef int cmx_i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void sload_rec(cmx_cint p, cmx_i16& r) {
   asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
 }
@@ -1283,13 +1284,112 @@ __global__ __launch_bounds__(256) void simulate_blocked_kernel(const DevModel m,
   }
 }
 
+// The same simulator with the tables of the node being drawn in LDS.  A draw needs one guide byte and a few running
+// sums of ONE of C * S rows of its node; gathered from L2 by every thread that is ~100 bytes of traffic per draw
+// (2.5e9 draws per target launch: the gather kernel above was L2-bound, 22 ms).  Here a workgroup draws 1 024 sites
+// (four per thread), node by node, parents first: the node's C * S rows (12.8 KB for proteins) and guide bytes are copied
+// into LDS once per workgroup, double-buffered (global -> registers while the current node is drawn, registers -> LDS
+// behind a barrier), and every search runs on LDS.  Same draws, same states as simulate_kernel.
+constexpr int kSimLdsChunks = 8;   // 16-byte pieces of a node's tables per thread (256 threads): up to 32 KiB per buffer
+template <int SPT>
+__global__ __launch_bounds__(256) void simulate_lds_kernel(const DevModel m, uint64_t seed, uint64_t g0, size_t s0, size_t n,
+                                                           size_t blk, uint8_t* __restrict__ aln, uint8_t* __restrict__ states) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t sim_smem[];
+  const int S0 = m.S0, C0 = m.C0, tid = threadIdx.x;
+  const int rowb = S0 * 8, tabb = C0 * S0 * rowb, guib = C0 * S0 * 32;       // bytes: one row of sums, all rows, all guides
+  const int bufb = (tabb + guib + 15) & ~15, nch = bufb / 16;
+  // piece q (16 bytes) of node `node`'s tables: the sums of class q / (S0 * rowb / 16) ... are contiguous per class in CP,
+  // the guide bytes per class in CPG
+  auto piece_src = [&](int node, int q) -> const cmx_i4* {
+    const int off = q * 16;
+    if (off < tabb) {
+      const int c = off / (S0 * rowb), r = off % (S0 * rowb);
+      return reinterpret_cast<const cmx_i4*>(reinterpret_cast<const uint8_t*>(m.CP + ((size_t)c * m.nn + node) * S0 * S0) + r);
+    }
+    const int o2 = off - tabb, c = o2 / (S0 * 32), r = o2 % (S0 * 32);
+    return reinterpret_cast<const cmx_i4*>(m.CPG + ((size_t)c * m.nn + node) * S0 * 32 + r);
+  };
+  size_t j[SPT];
+  uint64_t g[SPT];
+  int cls[SPT];
+  uint8_t* out[SPT];
+  bool on[SPT];
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    j[k] = ((size_t)blockIdx.x * SPT + k) * 256 + tid;
+    on[k] = j[k] < n;
+    const size_t jj = on[k] ? j[k] : n - 1, s = s0 + jj;
+    j[k] = jj;
+    g[k] = g0 + s;
+    out[k] = aln + (s / blk) * (size_t)m.T * blk + s % blk;
+    cls[k] = draw_index(philox_uniform(seed, g[k], 0), m.cum_probs, C0);
+    if (on[k]) states[(size_t)m.root * n + jj] = (uint8_t)draw_index(philox_uniform(seed, g[k], 1), m.cum_pi, S0);
+  }
+  // tables of the first node
+  const cmx_cint ord = (cmx_cint)m.simord;
+  int buf = 0;
+  for (int q = tid; q < nch; q += 256)
+    reinterpret_cast<cmx_i4*>(sim_smem)[q] = (q * 16 < tabb + guib) ? *piece_src(ord[0], q) : cmx_i4{0, 0, 0, 0};
+  __syncthreads();
+  // nodes level by level (m.simord): the parent's state was written a whole level ago, not by the previous iteration
+  for (int it = 0; it < m.nn - 1; ++it) {
+    const int node = ord[it];
+    const bool more = it + 1 < m.nn - 1;
+    cmx_i4 nxt[kSimLdsChunks];
+    if (more) {
+      const int nnode = ord[it + 1];
+#pragma unroll
+      for (int i = 0; i < kSimLdsChunks; ++i) {
+        const int q = tid + 256 * i;
+        if (q < nch && q * 16 < tabb + guib) nxt[i] = *piece_src(nnode, q);
+      }
+    }
+    const double* T_ = reinterpret_cast<const double*>(sim_smem + (size_t)buf * bufb);
+    const uint8_t* G_ = sim_smem + (size_t)buf * bufb + tabb;
+    const int par = m.parent[node], tx = m.taxon_of[node];
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+      const int x = states[(size_t)par * n + j[k]];
+      const double u = philox_uniform(seed, g[k], 2u + (uint32_t)node);
+      const int row = cls[k] * S0 + x;
+      int idx = G_[row * 32 + (int)(u * 32.0)];
+      const double* cum = T_ + row * S0;
+      while (idx < S0 - 1 && u >= cum[idx]) ++idx;
+      if (on[k]) {
+        states[(size_t)node * n + j[k]] = (uint8_t)idx;
+        if (tx >= 0) out[k][(size_t)tx * blk] = (uint8_t)idx;
+      }
+    }
+    if (more) {
+      __syncthreads();   // nobody reads the other buffer any more (it held the previous node)
+#pragma unroll
+      for (int i = 0; i < kSimLdsChunks; ++i) {
+        const int q = tid + 256 * i;
+        if (q < nch && q * 16 < tabb + guib) reinterpret_cast<cmx_i4*>(sim_smem + (size_t)(buf ^ 1) * bufb)[q] = nxt[i];
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+}
+
 // nsites sites with global indices g0 .. in passes of at most `chunk` (the states scratch holds nn * chunk bytes)
 hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0, size_t nsites, size_t blk, uint8_t* d_aln,
                                    uint8_t* d_states, size_t chunk, hipStream_t stream) {
+  // tables in LDS when a node's rows + guides fit 8 pieces per thread (every model this engine takes: S <= 20, C <= 8)
+  const size_t bufb = ((size_t)m.C0 * m.S0 * (m.S0 * 8 + 32) + 15) & ~(size_t)15;
+  static const bool gather = [] { const char* e = getenv("CMX_SIM_GATHER"); return e && e[0] == '1'; }();   // A/B timing
+  // (DNA: 512-byte tables that sit in L1 / L2 anyway, and 2 barriers x 511 nodes: gathering is faster, cfg4 step 11.7 vs 13.0 ms)
+  const bool lds = !gather && m.S0 > 4 && bufb <= (size_t)kSimLdsChunks * 256 * 16;
+  constexpr int SPT = 4;
   for (size_t s0 = 0; s0 < nsites; s0 += chunk) {
     const size_t n = std::min(chunk, nsites - s0);
-    hipLaunchKernelGGL(simulate_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m, seed, g0, s0, n, blk,
-                       d_aln, d_states);
+    if (lds)
+      hipLaunchKernelGGL(simulate_lds_kernel<SPT>, dim3((unsigned)((n + 256 * SPT - 1) / (256 * SPT))), dim3(256), 2 * bufb, stream, m,
+                         seed, g0, s0, n, blk, d_aln, d_states);
+    else
+      hipLaunchKernelGGL(simulate_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m, seed, g0, s0, n, blk,
+                         d_aln, d_states);
   }
   return hipGetLastError();
 }
