@@ -585,12 +585,6 @@ cmx_status cmx_pair_stats(cmx_ctx* ctx, int kind, const double* params, const do
 }
 
 // ------------------------------------------------------------------------------------------------ null distribution
-// CMX_NULL_FUSED=1: simulate inside the mapping waves (the round-1 arrangement; A/B timing, same results)
-static bool null_fused() {
-  static const bool v = [] { const char* e = getenv("CMX_NULL_FUSED"); return e && e[0] == '1'; }();
-  return v;
-}
-
 // The null's alignments, [replicate][batch][taxon][rep_ram] bytes (what cmx_null_intra_dev takes as `supplied`):
 // NonHomogeneousSequenceSimulator::simulate(repRAM) twice per replicate (AnalysisTools.cpp:591, 612), simulated-site index
 // g = ((rep * 2 + batch) * rep_ram + j) as everywhere.
@@ -625,17 +619,28 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
     return cmx_null_inter_dev(ctx, ctx, kind, params, seed, rep_begin, rep_end, rep_ram, d_stat, d_rcmin, d_prmin, d_nmin, stream);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (!d_supplied && !null_fused()) {
+#ifndef CMX_FUSED_SIM
+  if (!d_supplied) {
     // simulate first, at full occupancy, then map the alignments as "supplied" ones: the same draws, the same results
-    // as the fused kernel (the simulator inside a mapping wave was 7.8 % of the launch, latency nobody could hide)
-    const size_t bytes = (rep_end - rep_begin) * 2 * (size_t)ctx->hm.T * rep_ram;
-    if (bytes <= ((size_t)16 << 30)) {
-      uint8_t* d_aln;
-      if ((s = scratch(ctx, "null_aln", bytes, (void**)&d_aln)) != CMX_OK) return s;
-      if ((s = cmx_null_simulate_dev(ctx, seed, rep_begin, rep_end, rep_ram, d_aln, stream)) != CMX_OK) return s;
-      d_supplied = d_aln;
+    // as a simulator inside the mapping waves (round 1; 7.8 % of the launch there, latency nobody could hide).  The
+    // alignments of a pass stay under 4 GiB: a larger null runs as several passes over replicate ranges.
+    const size_t per_rep = 2 * (size_t)ctx->hm.T * rep_ram;
+    const size_t reps_per_pass = std::max<size_t>(1, ((size_t)4 << 30) / per_rep);
+    if (rep_end - rep_begin > reps_per_pass) {
+      for (size_t r0 = rep_begin; r0 < rep_end; r0 += reps_per_pass) {
+        const size_t r1 = std::min(rep_end, r0 + reps_per_pass), o = (r0 - rep_begin) * rep_ram;
+        if ((s = cmx_null_intra_dev(ctx, kind, params, seed, r0, r1, rep_ram, nullptr, d_stat + o, d_rcmin ? d_rcmin + o : nullptr,
+                                    d_prmin ? d_prmin + o : nullptr, d_nmin ? d_nmin + o : nullptr, stream)) != CMX_OK)
+          return s;
+      }
+      return CMX_OK;
     }
+    uint8_t* d_aln;
+    if ((s = scratch(ctx, "null_aln", (rep_end - rep_begin) * per_rep, (void**)&d_aln)) != CMX_OK) return s;
+    if ((s = cmx_null_simulate_dev(ctx, seed, rep_begin, rep_end, rep_ram, d_aln, stream)) != CMX_OK) return s;
+    d_supplied = d_aln;
   }
+#endif
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.nsites = (rep_end - rep_begin) * rep_ram;

@@ -900,6 +900,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
         const size_t rep_local = s / a.rep_ram, j = s % a.rep_ram;
         const uint8_t* gbase;
         size_t gstride;
+#ifdef CMX_FUSED_SIM   // round 1's arrangement (the simulator inside the mapping wave), kept for A/B builds only
         if (a.supplied) {
           gbase = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
           gstride = a.rep_ram;
@@ -969,6 +970,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
           }
           CMX_TOC(TM_SIM);
         }
+#else
+        // the alignments were simulated by simulate_lds_kernel / simulate_blocked_kernel (cmx_null_simulate_dev) or
+        // supplied by the caller: [replicate][batch][taxon][rep_ram]
+        gbase = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
+        gstride = a.rep_ram;
+#endif
         double L, pr, nrm;
         int rc;
         map_sites_wave<S, FUSE, NG>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
@@ -1001,7 +1008,12 @@ int map_lds_per_wave(int S, int nn, int mode) {
   const int fixed = S == 20 ? map_lds_fixed<20>() : (S == 16 ? map_lds_fixed<16>() : map_lds_fixed<4>());
   const int share = 160 * 1024 / map_waves_per_simd(S) / kWavesPerBlock;
   const int states = (nn * map_sites_per_wave(S) + 15) / 16 * 16;
+#ifdef CMX_FUSED_SIM
   return (mode == kModeNull && fixed + states <= share) ? fixed + states : fixed;
+#else
+  (void)share; (void)states; (void)mode;   // the node states of a simulator inside the wave: not needed any more
+  return fixed;
+#endif
 }
 
 hipError_t launch_map(const MapArgs& a_in, int mode, int grid_blocks, hipStream_t stream) {

@@ -9,8 +9,6 @@ Names follow the reference's seams so that tests read like its call sites:
                             with no N x N matrix (what a rank of a multi-GPU job runs on its share of the upper triangle)
 torch is used for device memory, streams and (in bench.py) torch.distributed only; every number is produced by the
 HIP kernels behind the C-ABI (comap_amd/engine.py)."""
-import os
-
 import torch
 
 
@@ -77,7 +75,7 @@ class IntraAnalysis:
         events: the alignments are simulated into a buffer of this object first (cmx_null_simulate_dev) and the events
         bracket the mapping launch alone -- what bench.py's roofline is about; otherwise one call does both."""
         b = self.null_buffers((rep_end - rep_begin) * rep_ram)
-        if map_events is not None and supplied is None and os.environ.get("CMX_NULL_FUSED") != "1":   # (=1: the fused A/B arrangement)
+        if map_events is not None and supplied is None:
             nbytes = (rep_end - rep_begin) * 2 * self.eng.T * rep_ram
             if self._null_aln is None or self._null_aln.numel() < nbytes:
                 self._null_aln = torch.empty(nbytes, dtype=torch.uint8, device=self.aln.device)
