@@ -14,8 +14,9 @@
 //   Inside vectors / outside messages that must survive go to a per-wave HBM workspace as [S/2][lane][2]: every
 //   access is one fully coalesced 1 KiB row; loads are prefetched into LDS by DMA under a host-built schedule.
 //   DESIGN.md 4.1 has the full description and the measurements.
-//   MODE == kModeNull fuses simulate -> map (x2 batches) -> per-pair statistic of
-//   AnalysisTools::getNullDistributionIntraDR (CoMap/AnalysisTools.cpp:587-653).
+//   MODE == kModeNull: map (x2 batches) -> per-pair statistic of AnalysisTools::getNullDistributionIntraDR
+//   (CoMap/AnalysisTools.cpp:587-653) per wave, on alignments simulated beforehand by simulate_lds_kernel /
+//   simulate_blocked_kernel at full occupancy (round 1 simulated inside the mapping wave: CMX_FUSED_SIM builds).
 // pair_gram_kernel: all-pairs statistic as X.X^T on v_mfma_f64_16x16x4_f64 with per-statistic epilogues
 //   (CoMap/Statistics.h:164-329; loops CoMap/CoETools.cpp:672-692, 786-810).
 // mica_mfma_kernel: column mutual information as a one-hot Gram on v_mfma_i32_32x32x32_i8 (CoMap/Mica.cpp:349-361).
