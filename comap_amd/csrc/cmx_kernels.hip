@@ -1394,12 +1394,14 @@ hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0
   static const bool gather = [] { const char* e = getenv("CMX_SIM_GATHER"); return e && e[0] == '1'; }();   // A/B timing
   // (DNA: 512-byte tables that sit in L1 / L2 anyway, and 2 barriers x 511 nodes: gathering is faster, cfg4 step 11.7 vs 13.0 ms)
   const bool lds = !gather && m.S0 > 4 && bufb <= (size_t)kSimLdsChunks * 256 * 16;
-  constexpr int SPT = 4;
   for (size_t s0 = 0; s0 < nsites; s0 += chunk) {
     const size_t n = std::min(chunk, nsites - s0);
-    if (lds)
-      hipLaunchKernelGGL(simulate_lds_kernel<SPT>, dim3((unsigned)((n + 256 * SPT - 1) / (256 * SPT))), dim3(256), 2 * bufb, stream, m,
-                         seed, g0, s0, n, blk, d_aln, d_states);
+    // tables in LDS, four sites per thread (a node's tables are copied once per 1 024 sites), when that fills the chip
+    // several times over; below that (cfg3: 500 000 sites = 488 such workgroups on 256 CUs) its two barriers per node are
+    // a floor of ~1 ms and the gather kernel, one thread per site and no barrier, is quicker
+    if (lds && n >= (size_t)256 * 4 * 2048)
+      hipLaunchKernelGGL(simulate_lds_kernel<4>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 2 * bufb, stream, m, seed, g0, s0, n,
+                         blk, d_aln, d_states);
     else
       hipLaunchKernelGGL(simulate_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m, seed, g0, s0, n, blk,
                          d_aln, d_states);
