@@ -625,7 +625,11 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
     // as a simulator inside the mapping waves (round 1; 7.8 % of the launch there, latency nobody could hide).  The
     // alignments of a pass stay under 4 GiB: a larger null runs as several passes over replicate ranges.
     const size_t per_rep = 2 * (size_t)ctx->hm.T * rep_ram;
-    const size_t reps_per_pass = std::max<size_t>(1, ((size_t)4 << 30) / per_rep);
+    static const size_t pass_bytes = [] {   // CMX_NULL_PASS_BYTES: tests exercise the multi-pass path with small nulls
+      const char* e = getenv("CMX_NULL_PASS_BYTES");
+      return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)4 << 30);
+    }();
+    const size_t reps_per_pass = std::max<size_t>(1, pass_bytes / per_rep);
     if (rep_end - rep_begin > reps_per_pass) {
       for (size_t r0 = rep_begin; r0 < rep_end; r0 += reps_per_pass) {
         const size_t r1 = std::min(rep_end, r0 + reps_per_pass), o = (r0 - rep_begin) * rep_ram;

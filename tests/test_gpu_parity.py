@@ -835,3 +835,46 @@ def test_label_counts_without_averaging_feed_the_mi_statistic():
     assert np.all(lab == np.round(lab)) and lab.min() >= 0 and lab.max() <= 12
     x, y = o["argmax"][clear] // 4, o["argmax"][clear] % 4
     assert np.array_equal(lab[:, 0], W[x, y])
+
+
+def test_null_simulator_kernels_and_passes_agree_with_the_plain_simulator(tmp_path):
+    """cmx_null_simulate_dev lays the replicates' alignments out as [replicate][batch][taxon][rep_ram] with the draws of
+    cmx_simulate at g = ((rep * 2 + batch) * rep_ram + j) -- for both of its kernels (tables in LDS above 2 M sites,
+    gathers below) -- and a null computed in several passes (alignment buffer capped) equals the one-pass null."""
+    import os, subprocess, sys, textwrap
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    case = make_case(8, 10, 20, 5)
+    eng = _engine(case)
+    dev = torch.device("cuda:0")
+    T = len(case["lot"])
+    for rb, re, ram in ((3, 5, 700), (0, 2, 600_000)):        # 2 800 sites (gather kernel); 2.4 M sites (LDS-table kernel)
+        n = (re - rb) * 2 * ram
+        buf = torch.empty(n * T, dtype=torch.uint8, device=dev)
+        eng.null_simulate_dev(77, rb, re, ram, buf)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().reshape(re - rb, 2, T, ram)
+        want, _ = eng.simulate(77, rb * 2 * ram, n)              # [T, n], column s <-> g = rb * 2 * ram + s
+        want = want.reshape(T, re - rb, 2, ram).transpose(1, 2, 0, 3)
+        assert np.array_equal(got, want)
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import torch
+        sys.path.insert(0, %r + '/tests')
+        from conftest import make_case
+        from comap_amd import engine
+        case = make_case(8, 10, 20, 5)
+        eng = engine.Engine(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+        nl = eng.null_intra(engine.STAT_CORRELATION, 5, 2, 9, 50)
+        np.save(sys.argv[1], np.stack([nl["stat"], nl["nmin"], nl["prmin"], nl["rcmin"].astype(float)]))
+    """ % (ROOT, ROOT))
+    outs = []
+    for cap in (None, str(3 * 2 * T * 50)):                      # one pass; passes of three replicates
+        env = dict(os.environ)
+        if cap:
+            env["CMX_NULL_PASS_BYTES"] = cap
+        f = tmp_path / ("null_%s.npy" % (cap or "all"))
+        subprocess.check_call([sys.executable, "-c", code, str(f)], env=env, cwd=ROOT)
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
