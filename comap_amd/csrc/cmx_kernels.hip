@@ -349,9 +349,9 @@ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t g, uint
   uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ 0x434d5832u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
-    c0 = hi ^ k ^ c1;
-    c1 = lo;
+    const uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0;   // one v_mad_u64_u32 instead of v_mul_hi + v_mul_lo
+    c0 = (uint32_t)(p >> 32) ^ k ^ c1;
+    c1 = (uint32_t)p;
     k += 0x9E3779B9u;
   }
   const uint64_t bits = (((uint64_t)c0 << 32) | c1) >> 11;
