@@ -20,11 +20,16 @@ ap.add_argument("--taxa", type=int, default=256)
 ap.add_argument("--alpha", type=int, default=20)
 ap.add_argument("--max-perm", type=int, default=1000)
 ap.add_argument("--shared", type=float, default=0.3, help="fraction of each column copied from a common ancestor column (0: independent columns)")
+ap.add_argument("--gap-columns", type=float, default=0.0, help="fraction of columns that get gaps (10 % of their symbols)")
 a = ap.parse_args()
 rng = np.random.default_rng(20260103)
 T, A, n = a.taxa, a.alpha, a.n
 base = rng.integers(0, A, size=(T, 1))
 aln = np.where(rng.random((T, n)) < a.shared, base, rng.integers(0, A, size=(T, n))).astype(np.uint8)
+if a.gap_columns > 0:
+    cols = rng.random(n) < a.gap_columns
+    hit = (rng.random((T, n)) < 0.10) & cols[None, :]
+    aln[hit] = A                                # unknown: resolveUnknowns = true spreads it over the states
 d = torch.from_numpy(aln).cuda()
 npairs = n * (n - 1) // 2
 pv = torch.empty(npairs, dtype=torch.float64, device="cuda")
@@ -46,7 +51,7 @@ run(0, npairs)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 perms = int(npm.sum().item())
-print(json.dumps({"workload": f"mica permutation test: {n} columns ({npairs} pairs), {T} taxa, A={A}, max {a.max_perm}",
+print(json.dumps({"workload": f"mica permutation test: {n} columns ({npairs} pairs), {T} taxa, A={A}, max {a.max_perm}, gaps in {a.gap_columns:.0%} of the columns",
                   "seconds": dt, "pairs_per_s": npairs / dt, "permutations": perms, "permutations_per_s": perms / dt,
                   "mean_permutations_per_pair": perms / npairs, "median_pvalue": float(pv.median().item()),
                   "frac_p_below_0.05": float((pv < 0.05).double().mean().item())}))
