@@ -246,3 +246,51 @@ def test_configuration5_mica_5000x5000x256_identity_and_oracle_tiles():
         o = oracle.mi_columns(a1[:, i0:i0 + 8], a2[:, j0:j0 + 8], A)
         assert np.max(np.abs(o["mi"] - mih[i0:i0 + 8, j0:j0 + 8])) < 1e-12
         assert np.max(np.abs(o["hjoint"] - hjh[i0:i0 + 8, j0:j0 + 8])) < 1e-12
+
+
+def test_mica_unknowns_at_size_mixed_tiles_and_intra_layout():
+    """gaps in a third of the columns of a 1 501 x 1 300 x 256 protein rectangle (tiles with none, some and only gapped
+    pairs; ragged last tiles of the packed 12 x 6 layout), partial ambiguity codes in a few columns (those pairs go to
+    the LDS-table kernel), and the intra layout of the first alignment: identity on every pair, oracle on scattered tiles"""
+    import torch
+    rng = np.random.default_rng(7)
+    T, A, n1, n2 = 256, 20, 1501, 1300
+    base = rng.integers(0, A, size=(T, 1))
+    a1 = np.where(rng.random((T, n1)) < 0.5, base, rng.integers(0, A, size=(T, n1))).astype(np.uint8)
+    a2 = np.where(rng.random((T, n2)) < 0.5, base, rng.integers(0, A, size=(T, n2))).astype(np.uint8)
+    for a in (a1, a2):
+        cols = rng.random(a.shape[1]) < 0.33
+        a[(rng.random(a.shape) < 0.12) & cols[None, :]] = A          # unknown (default mask: every state)
+    masks = oracle.default_masks(A)
+    masks[A + 1] = 0b1100000                                          # a two-state ambiguity code
+    a1[rng.random(T) < 0.05, 17] = A + 1
+    a2[rng.random(T) < 0.05, 1294] = A + 1
+    dev = torch.device("cuda:0")
+    d1, d2 = torch.from_numpy(a1).to(dev), torch.from_numpy(a2).to(dev)
+    d_masks = torch.from_numpy(masks.astype(np.int64)).to(torch.int32).to(dev)
+    eng = engine.Engine()
+    mi = torch.empty((n1, n2), dtype=torch.float64, device=dev)
+    hj = torch.empty_like(mi)
+    h1 = torch.empty(n1, dtype=torch.float64, device=dev)
+    h2 = torch.empty(n2, dtype=torch.float64, device=dev)
+    eng.mi_columns_dev(d1, mi, hj, d2, A, d_masks, h1, h2)
+    torch.cuda.synchronize()
+    assert (mi - (h1[:, None] + h2[None, :] - hj)).abs().max().item() < 1e-11
+    mih, hjh = mi.cpu().numpy(), hj.cpu().numpy()
+    for i0, j0 in ((0, 0), (1493, 1292), (12, 1288), (1490, 0), (700, 650), (10, 1290)):
+        o = oracle.mi_columns(a1[:, i0:i0 + 8], a2[:, j0:j0 + 8], A, masks=masks)
+        assert np.max(np.abs(o["mi"] - mih[i0:i0 + 8, j0:j0 + 8])) < 1e-11
+        assert np.max(np.abs(o["hjoint"] - hjh[i0:i0 + 8, j0:j0 + 8])) < 1e-11
+    # intra layout: upper triangle filled, the rest NaN
+    mii = torch.empty((n1, n1), dtype=torch.float64, device=dev)
+    hji = torch.empty_like(mii)
+    eng.mi_columns_dev(d1, mii, hji, None, A, d_masks, h1, None)
+    torch.cuda.synchronize()
+    m = mii.cpu().numpy()
+    iu = np.triu_indices(n1, 1)
+    assert np.isfinite(m[iu]).all() and np.isnan(m[np.tril_indices(n1)]).all()
+    for i0, j0 in ((0, 8), (12, 24), (1480, 1490), (5, 1493)):
+        o = oracle.mi_columns(a1[:, i0:i0 + 8], a1[:, j0:j0 + 8], A, masks=masks)
+        blk = m[i0:i0 + 8, j0:j0 + 8]
+        keep = np.add.outer(np.arange(i0, i0 + 8), np.zeros(8, int)) < np.add.outer(np.zeros(8, int), np.arange(j0, j0 + 8))
+        assert np.max(np.abs(o["mi"][keep] - blk[keep])) < 1e-11
