@@ -14,6 +14,7 @@
 #include "../../include/comap_mi355x.h"
 #include "cmx_device.h"
 #include "cmx_host_model.h"
+#include "cmx_nuc.h"
 
 using namespace cmx;
 
@@ -40,10 +41,18 @@ struct cmx_ctx {
   std::map<std::string, DevBuf> scratch;
   uint32_t* d_default_masks = nullptr;
   unsigned stat_mean_turn = 0;
+  // host copies of asynchronously uploaded parameter blocks (mean vectors, MI bounds): the source of a hipMemcpyAsync must
+  // outlive the copy, and the caller's array need not
+  std::vector<double> param_host[8];
   bool leaf_rows_custom = false;   // the leaf operators' ambiguity rows were built from a caller's mask table
   bool map_average = true;         // nijt.average (cmx_set_mapping_options); false: the no-averaging mapping of cmx_variants.hip
   const double *va_P = nullptr, *va_N1 = nullptr;   // its operators, uploaded at first use
   const int *va_first = nullptr, *va_next = nullptr;
+  // 4-state models: the nucleotide mapping kernel (cmx_nuc.h); the 20-state machinery above is then not allocated
+  bool nuc = false;
+  NucProgram np;
+  NucDev nd{};
+  NucWs nws{}, nws_obs{};
   mutable std::string err;
 };
 
@@ -134,6 +143,18 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       return bail((cmx_status)code);
     }
     ctx->has_model = true;
+    const char* legacy = getenv("CMX_NUC_LEGACY");   // A/B timing against the class-fused 16-state path of rounds 1-2
+    if (ctx->hm.S == 4 && !(legacy && legacy[0] == '1')) {
+      const char* e = getenv("CMX_NUC_NB");          // block capacity: tuning only
+      const int NB = e ? atoi(e) : 10;
+      msg = build_nuc_program(ctx->hm, NB, &ctx->np);
+      if (msg.empty()) msg = verify_nuc_program(ctx->hm, ctx->np);
+      if (!msg.empty()) {
+        ctx->err = msg;
+        return bail(CMX_ERR_INVALID);
+      }
+      ctx->nuc = true;
+    }
   }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -203,6 +224,33 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     // ambiguity masks default: code c >= S compatible with every state; fix the table for this S
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
+    if (ctx->nuc) {
+      const NucProgram& np = ctx->np;
+      NucDev& nd = ctx->nd;
+      nd.C = np.C; nd.K = np.K; nd.B = np.B; nd.T = np.T; nd.nblocks = np.nblocks; nd.nroots = np.nroots; nd.nops = np.nops; nd.NB = np.NB;
+      if ((s = upload(ctx, np.ops, &nd.ops)) != CMX_OK) return s;
+      if ((s = upload(ctx, np.blk, &nd.blk)) != CMX_OK) return s;
+      if ((s = upload(ctx, np.irec, &nd.irec)) != CMX_OK) return s;
+      if ((s = upload(ctx, np.orec, &nd.orec)) != CMX_OK) return s;
+      nd.pi = d.pi; nd.rates = d.rates; nd.probs = d.probs;
+      ctx->grid_blocks = ctx->cu_count * nuc_waves_per_simd(np.NB);
+      ctx->waves = ctx->grid_blocks * kWavesPerBlock;
+      ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
+      ctx->ws_bytes = 0;
+      auto alloc_nws = [&](NucWs* ws, size_t w) -> cmx_status {
+        const size_t bR = w * (size_t)np.C * std::max(1, np.nroots) * 256 * sizeof(double);
+        const size_t bC = w * 2 * (size_t)np.B * np.K * 64 * sizeof(double);
+        HIP_TRY(ctx, hipMalloc((void**)&ws->WM, bR));
+        HIP_TRY(ctx, hipMalloc((void**)&ws->WU, bR));
+        HIP_TRY(ctx, hipMalloc((void**)&ws->cnt, bC));
+        ws->waves = (int)w;
+        ctx->ws_bytes += 2 * bR + bC;
+        return CMX_OK;
+      };
+      if ((s = alloc_nws(&ctx->nws, (size_t)ctx->waves)) != CMX_OK) return s;
+      if ((s = alloc_nws(&ctx->nws_obs, (size_t)ctx->obs_blocks * kWavesPerBlock)) != CMX_OK) return s;
+      return CMX_OK;
+    }
     // per-wave workspaces: 1 wave per SIMD on every CU for the null; a quarter of that for observed alignments
     ctx->grid_blocks = ctx->cu_count * map_waves_per_simd(h.dS);   // 4-wave workgroups, that many per CU
     ctx->waves = ctx->grid_blocks * kWavesPerBlock;
@@ -246,6 +294,11 @@ void cmx_ctx_destroy(cmx_ctx* ctx) {
     if (ws->st) (void)hipFree(ws->st);
     if (ws->aln) (void)hipFree(ws->aln);
   }
+  for (NucWs* ws : {&ctx->nws, &ctx->nws_obs}) {
+    if (ws->WM) (void)hipFree(ws->WM);
+    if (ws->WU) (void)hipFree(ws->WU);
+    if (ws->cnt) (void)hipFree(ws->cnt);
+  }
   delete ctx;
 }
 
@@ -259,6 +312,11 @@ cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info) {
   info->device_states = ctx->hm.dS; info->device_classes = ctx->hm.dC;
   info->products_per_pass = (int32_t)ctx->hm.n_products; info->leaf_ops_per_pass = (int32_t)ctx->hm.n_leaf_ops;
   info->ws_loads_per_pass = (int32_t)ctx->hm.n_loads; info->ws_stores_per_pass = (int32_t)ctx->hm.n_stores;
+  if (ctx->nuc) {   // nucleotide kernel: 4x4 operator applications of a class pass (leaves included), block-root messages through HBM
+    info->device_states = 4; info->device_classes = ctx->hm.C;
+    info->products_per_pass = (int32_t)ctx->np.n_apply; info->leaf_ops_per_pass = 0;
+    info->ws_loads_per_pass = (int32_t)ctx->np.n_root_loads; info->ws_stores_per_pass = (int32_t)ctx->np.n_root_stores;
+  }
   return CMX_OK;
 }
 
@@ -291,6 +349,25 @@ cmx_status cmx_debug_walk(const cmx_model* model, const cmx_tree* tree, int32_t*
   return CMX_OK;
 }
 
+cmx_status cmx_debug_nuc_program(const cmx_model* model, const cmx_tree* tree, int block_capacity, uint64_t* stats) {
+  HostModel hm;
+  int code = CMX_OK;
+  std::string msg = build_host_model(model, tree, &hm, &code);
+  if (msg.empty() && hm.S != 4) { msg = "cmx_debug_nuc_program: 4 states required"; code = CMX_ERR_INVALID; }
+  NucProgram np;
+  if (msg.empty()) { msg = build_nuc_program(hm, block_capacity, &np); code = CMX_ERR_INVALID; }
+  if (msg.empty()) msg = verify_nuc_program(hm, np);
+  if (!msg.empty()) {
+    g_create_error = msg;
+    return (cmx_status)code;
+  }
+  if (stats) {
+    stats[0] = (uint64_t)np.nblocks; stats[1] = (uint64_t)np.nroots; stats[2] = np.n_apply; stats[3] = np.n_root_loads;
+    stats[4] = np.n_root_stores; stats[5] = np.irec.size() / 8; stats[6] = np.orec.size() / 16; stats[7] = (uint64_t)np.nops;
+  }
+  return CMX_OK;
+}
+
 cmx_status cmx_synchronize(cmx_ctx* ctx) {
   if (!ctx) return CMX_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -300,8 +377,11 @@ cmx_status cmx_synchronize(cmx_ctx* ctx) {
 
 // nijt.average = no (cmx_set_mapping_options): counts and norms of the sites just mapped are replaced by those of
 // computeSubstitutionVectorsNoAveraging (cmx_variants.hip); likelihood, posterior rate and rate class stay.
+// full_grid names the caller as in map_sites_impl: the engine's own null / clustering / candidate pipelines (true) and the
+// public observed-alignment mapping (false) may run on two streams at once, so each has its own scratch -- the averaged
+// path keeps ws and ws_obs apart for the same reason.
 static cmx_status map_variant(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
-                              double* d_counts, size_t ldc, double* d_norm, void* stream) {
+                              double* d_counts, size_t ldc, double* d_norm, void* stream, bool full_grid) {
   if (ctx->map_average || (!d_counts && !d_norm)) return CMX_OK;
   const HostModel& h = ctx->hm;
   cmx_status s;
@@ -312,7 +392,7 @@ static cmx_status map_variant(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites,
     if ((s = upload(ctx, h.next_sib, &ctx->va_next)) != CMX_OK) return s;
   }
   if (!d_counts) {   // only the norms were asked for: they still need the counts
-    if ((s = scratch(ctx, "va_counts", sizeof(double) * (size_t)h.B * h.K * nsites, (void**)&d_counts)) != CMX_OK) return s;
+    if ((s = scratch(ctx, full_grid ? "va_counts_null" : "va_counts_obs", sizeof(double) * (size_t)h.B * h.K * nsites, (void**)&d_counts)) != CMX_OK) return s;
     ldc = nsites;
   }
   NoAvgArgs a{};
@@ -325,7 +405,7 @@ static cmx_status map_variant(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites,
   a.chunk = std::max<size_t>(256, std::min<size_t>(nsites, ((size_t)1 << 30) / per_site / 256 * 256));
   a.counts = d_counts; a.ldc = ldc;
   double* buf;
-  if ((s = scratch(ctx, "va_nodes", sizeof(double) * noavg_scratch_doubles(h.S, h.C, h.nn, a.chunk), (void**)&buf)) != CMX_OK) return s;
+  if ((s = scratch(ctx, full_grid ? "va_nodes_null" : "va_nodes_obs", sizeof(double) * noavg_scratch_doubles(h.S, h.C, h.nn, a.chunk), (void**)&buf)) != CMX_OK) return s;
   HIP_TRY(ctx, launch_map_noavg(a, nsites, buf, d_norm, (hipStream_t)stream));
   return CMX_OK;
 }
@@ -343,9 +423,18 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
   if (!d_aln || nsites == 0 || ld < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: bad alignment arguments");
   if (d_counts && ldc < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: ldc < nsites");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int max_blocks = full_grid ? ctx->grid_blocks : ctx->obs_blocks;
+  if (ctx->nuc) {
+    NucArgs na{};
+    na.m = ctx->nd; na.ws = full_grid ? ctx->nws : ctx->nws_obs;
+    na.aln = d_aln; na.ld = ld; na.nsites = nsites; na.masks = d_masks;
+    na.counts = d_counts; na.ldc = ldc; na.logL = d_logL; na.post_rate = d_post_rate; na.rate_class = d_rate_class; na.norm = d_norm;
+    const size_t need = ((nsites + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;
+    HIP_TRY(ctx, launch_map_nuc(na, false, (int)std::min<size_t>(need, (size_t)max_blocks), (hipStream_t)stream));
+    return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream, full_grid);
+  }
   MapArgs a{};
   a.m = ctx->dm; a.ws = full_grid ? ctx->ws : ctx->ws_obs;
-  const int max_blocks = full_grid ? ctx->grid_blocks : ctx->obs_blocks;
   a.aln = d_aln; a.ld = ld; a.nsites = nsites;
   // ambiguity ids S .. S+max_ambig(S)-1: rebuild the extra rows of the leaf operators when the table changes
   if (d_masks || ctx->leaf_rows_custom) {
@@ -365,12 +454,12 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
     const int grid = (int)((ntasks + kWavesPerBlock - 1) / kWavesPerBlock);
     HIP_TRY(ctx, launch_map(a, kModeObservedSplit, grid, (hipStream_t)stream));
     HIP_TRY(ctx, launch_map_finalize(a, (hipStream_t)stream));
-    return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream);
+    return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream, full_grid);
   }
   const size_t blocks_needed = (nblocks + kWavesPerBlock - 1) / kWavesPerBlock;
   const int grid = (int)std::min<size_t>(blocks_needed, (size_t)max_blocks);
   HIP_TRY(ctx, launch_map(a, kModeObserved, grid, (hipStream_t)stream));
-  return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream);
+  return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream, full_grid);
 }
 
 cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
@@ -494,7 +583,7 @@ cmx_status cmx_simulate_continuous(cmx_ctx* ctx, uint64_t seed, uint64_t g0, siz
 
 // ------------------------------------------------------------------------------------------------ pair statistics
 static cmx_status check_kind(cmx_ctx* ctx, int kind) {
-  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_EUCLIDIAN_DISTANCE) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
+  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_DISCRETE_MI_BOUNDS) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
   return CMX_OK;
 }
 // CorrectedCorrelation: params = the two mean vectors [2][B] in host memory -> device copy (null for other kinds)
@@ -506,11 +595,54 @@ static cmx_status stat_mean_vectors(cmx_ctx* ctx, int kind, const double* params
   if (kind != CMX_STAT_CORRECTED_CORRELATION) return CMX_OK;
   if (!params) return fail(ctx, CMX_ERR_INVALID, "CorrectedCorrelation needs its mean vectors: params = [2][nbranches]");
   void* p = nullptr;
-  const std::string name = "stat_mean" + std::to_string(ctx->stat_mean_turn++ & 7);
+  const unsigned turn = ctx->stat_mean_turn++ & 7;
+  const std::string name = "stat_mean" + std::to_string(turn);
   cmx_status s = scratch(ctx, name.c_str(), sizeof(double) * 2 * ctx->hm.B, &p);
   if (s != CMX_OK) return s;
-  HIP_TRY(ctx, hipMemcpyAsync(p, params, sizeof(double) * 2 * ctx->hm.B, hipMemcpyHostToDevice, (hipStream_t)stream));
+  ctx->param_host[turn].assign(params, params + 2 * (size_t)ctx->hm.B);
+  HIP_TRY(ctx, hipMemcpyAsync(p, ctx->param_host[turn].data(), sizeof(double) * 2 * ctx->hm.B, hipMemcpyHostToDevice, (hipStream_t)stream));
   *d_mean = static_cast<const double*>(p);
+  return CMX_OK;
+}
+
+// ---- DiscreteMutualInformationStatistic with a bounds vector (CMX_STAT_DISCRETE_MI_BOUNDS, cmx_stat_mi.hip):
+// params = [nbounds, b_0 .. b_{nbounds-1}]
+struct MiBounds {
+  int nb = 0;
+  const double* d_bounds = nullptr;
+};
+static cmx_status mi_bounds(cmx_ctx* ctx, const double* params, MiBounds* out, void* stream) {
+  if (!params) return fail(ctx, CMX_ERR_INVALID, "DiscreteMI with bounds: params = [nbounds, b_0 .. b_{nbounds-1}] is required");
+  const double nbd = params[0];
+  if (!(nbd >= 2.0) || nbd > 65535.0 || nbd != std::floor(nbd))
+    return fail(ctx, CMX_ERR_INVALID, "DiscreteMI with bounds: the number of bounds must be an integer in 2 .. 65535");
+  const int nb = (int)nbd;
+  for (int i = 0; i < nb; ++i) {
+    if (params[1 + i] != params[1 + i]) return fail(ctx, CMX_ERR_INVALID, "DiscreteMI with bounds: a bound is NaN");
+    if (i && params[1 + i] < params[i])   // Domain::Domain(const Vdouble&) throws for decreasing bounds (Domain.cpp:62-72)
+      return fail(ctx, CMX_ERR_INVALID, "DiscreteMI with bounds: bound " + std::to_string(i) + " is < to bound " + std::to_string(i - 1));
+  }
+  if (ctx->hm.B > 4096) return fail(ctx, CMX_ERR_UNSUPPORTED, "DiscreteMI with bounds: at most 4096 branches (the joint table of a pair lives in LDS)");
+  void* p = nullptr;
+  const unsigned turn = ctx->stat_mean_turn++ & 7;
+  const std::string name = "mi_bounds" + std::to_string(turn);
+  cmx_status s = scratch(ctx, name.c_str(), sizeof(double) * nb, &p);
+  if (s != CMX_OK) return s;
+  ctx->param_host[turn].assign(params + 1, params + 1 + nb);
+  HIP_TRY(ctx, hipMemcpyAsync(p, ctx->param_host[turn].data(), sizeof(double) * nb, hipMemcpyHostToDevice, (hipStream_t)stream));
+  out->nb = nb;
+  out->d_bounds = static_cast<const double*>(p);
+  return CMX_OK;
+}
+// class words of n sites (branch-major [B][ldx]) + per-site out-of-range flags, in scratch buffers named after `tag`
+static cmx_status mi_classify(cmx_ctx* ctx, const MiBounds& mb, const double* d_counts, size_t n, size_t ldc, const char* tag,
+                              uint32_t** cls, uint8_t** bad, size_t* ldx, void* stream) {
+  const HostModel& h = ctx->hm;
+  *ldx = (n + 15) / 16 * 16;
+  cmx_status s;
+  if ((s = scratch(ctx, (std::string("mi_cls_") + tag).c_str(), sizeof(uint32_t) * (size_t)h.B * *ldx, (void**)cls)) != CMX_OK) return s;
+  if ((s = scratch(ctx, (std::string("mi_bad_") + tag).c_str(), n, (void**)bad)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_mi_classify(d_counts, n, ldc, h.B, h.K, mb.d_bounds, mb.nb, *cls, *ldx, *bad, (hipStream_t)stream));
   return CMX_OK;
 }
 
@@ -528,6 +660,18 @@ cmx_status cmx_pair_stats_dev(cmx_ctx* ctx, int kind, const double* params, cons
   if (h.B < 2) return fail(ctx, CMX_ERR_INVALID, "cmx_pair_stats: need at least two branches");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
+  if (kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+    MiBounds mb;
+    uint32_t *c1, *c2;
+    uint8_t *b1, *b2;
+    size_t lx1, lx2;
+    if ((s = mi_bounds(ctx, params, &mb, stream)) != CMX_OK) return s;
+    if ((s = mi_classify(ctx, mb, d_counts1, n1, ld1, "1", &c1, &b1, &lx1, stream)) != CMX_OK) return s;
+    if (intra) { c2 = c1; b2 = b1; lx2 = lx1; }
+    else if ((s = mi_classify(ctx, mb, d_counts2, n2, ld2, "2", &c2, &b2, &lx2, stream)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_mi_pairs_block(h.B, c1, b1, n1, lx1, c2, b2, n2, lx2, intra ? 1 : 0, d_out, ldo, 0, st));
+    return CMX_OK;
+  }
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
   const double* d_mean = nullptr;
   if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;
@@ -604,6 +748,10 @@ cmx_status cmx_null_simulate_dev(cmx_ctx* ctx, uint64_t seed, size_t rep_begin, 
   return CMX_OK;
 }
 
+static cmx_status null_unfused_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed,
+                                   size_t rep_begin, size_t rep_end, size_t rep_ram, const uint8_t* d_supplied, double* d_stat,
+                                   int32_t* d_rcmin, double* d_prmin, double* d_nmin, void* stream);
+
 cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin,
                               size_t rep_end, size_t rep_ram, const uint8_t* d_supplied, double* d_stat,
                               int32_t* d_rcmin, double* d_prmin, double* d_nmin, void* stream) {
@@ -612,11 +760,11 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
   if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra: bad arguments");
   if ((s = rng_range(ctx, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_intra")) != CMX_OK) return s;
-  if (!ctx->map_average) {
-    // nijt.average = no (AnalysisTools.cpp:598-610): the fused kernel only knows the averaged mapping; the same
-    // simulate -> map -> score sequence runs unfused, which is what the two-data-set null does with both sides equal
-    if (d_supplied) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_null_intra: supplied alignments are not available with nijt.average = no");
-    return cmx_null_inter_dev(ctx, ctx, kind, params, seed, rep_begin, rep_end, rep_ram, d_stat, d_rcmin, d_prmin, d_nmin, stream);
+  if (!ctx->map_average || kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+    // nijt.average = no (AnalysisTools.cpp:598-610): the fused kernel only knows the averaged mapping; and a statistic that
+    // needs a joint table per pair cannot be evaluated per lane inside the mapping wave.  The same simulate -> map ->
+    // score sequence then runs unfused, which is what the two-data-set null does with both sides equal.
+    return null_unfused_dev(ctx, ctx, kind, params, seed, rep_begin, rep_end, rep_ram, d_supplied, d_stat, d_rcmin, d_prmin, d_nmin, stream);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
 #ifndef CMX_FUSED_SIM
@@ -645,6 +793,19 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
     d_supplied = d_aln;
   }
 #endif
+  if (ctx->nuc) {
+    NucArgs na{};
+    na.m = ctx->nd; na.ws = ctx->nws;
+    na.nsites = (rep_end - rep_begin) * rep_ram;
+    na.stat_kind = kind;
+    na.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+    if ((s = stat_mean_vectors(ctx, kind, params, &na.stat_mean, stream)) != CMX_OK) return s;
+    na.rep_ram = rep_ram; na.supplied = d_supplied;
+    na.null_stat = d_stat; na.null_rcmin = d_rcmin; na.null_prmin = d_prmin; na.null_nmin = d_nmin;
+    const size_t need = ((na.nsites + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;
+    HIP_TRY(ctx, launch_map_nuc(na, true, (int)std::min<size_t>(need, (size_t)ctx->grid_blocks), (hipStream_t)stream));
+    return CMX_OK;
+  }
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.nsites = (rep_end - rep_begin) * rep_ram;
@@ -698,9 +859,10 @@ cmx_status cmx_null_intra(cmx_ctx* ctx, int kind, const double* params, uint64_t
 // under data set 1 and rep_ram sites under data set 2, then score site j of the one against site j of the other.
 // Not fused (a "next" row of SURVEY 8f): simulate -> map -> diagonal-pair kernel, everything resident in HBM.
 // Simulated-site indices follow the intra scheme: g = ((rep*2 + h)*rep_ram + j), h = 0 for ctx1 and 1 for ctx2.
-cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed,
-                              size_t rep_begin, size_t rep_end, size_t rep_ram, double* d_stat, int32_t* d_rcmin,
-                              double* d_prmin, double* d_nmin, void* stream) {
+// d_supplied (intra use only: both contexts the same): [nrep][2][T][rep_ram] alignments to map instead of simulating
+static cmx_status null_unfused_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed,
+                                   size_t rep_begin, size_t rep_end, size_t rep_ram, const uint8_t* d_supplied, double* d_stat,
+                                   int32_t* d_rcmin, double* d_prmin, double* d_nmin, void* stream) {
   cmx_status s = need_model(ctx1);
   if (s != CMX_OK) return s;
   if (!ctx2 || !ctx2->has_model) return fail(ctx1, CMX_ERR_INVALID, "cmx_null_inter: second context has no model");
@@ -732,11 +894,29 @@ cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const doub
     if ((s = scratch(ctx1, (tag + "_nm").c_str(), sizeof(double) * n, (void**)&nm[h])) != CMX_OK) return s;
     if ((s = scratch(ctx1, (tag + "_rc").c_str(), sizeof(int32_t) * n, (void**)&rc[h])) != CMX_OK) return s;
     for (size_t r = 0; r < nrep; ++r) {
+      if (d_supplied) {   // batch h of replicate r: [T][rep_ram] -> columns r * rep_ram .. of the [T][n] alignment
+        HIP_TRY(ctx1, hipMemcpy2DAsync(d_aln + r * rep_ram, n, d_supplied + ((r * 2 + h) * (size_t)c->hm.T) * rep_ram, rep_ram, rep_ram,
+                                       (size_t)c->hm.T, hipMemcpyDeviceToDevice, st));
+        continue;
+      }
       const uint64_t g0 = ((uint64_t)(rep_begin + r) * 2 + h) * (uint64_t)rep_ram;
       HIP_TRY(ctx1, launch_simulate(c->dm, seed, g0, rep_ram, d_aln + r * rep_ram, n, d_cls, d_st, st));
     }
     s = map_sites_impl(c, d_aln, n, n, nullptr, cnt[h], n, nullptr, pr[h], rc[h], nm[h], stream, true);
     if (s != CMX_OK) { if (c != ctx1) ctx1->err = c->err; return s; }
+  }
+  if (kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+    MiBounds mb;
+    uint32_t *c1, *c2;
+    uint8_t *b1, *b2;
+    size_t lx1, lx2;
+    if ((s = mi_bounds(ctx1, params, &mb, stream)) != CMX_OK) return s;
+    if ((s = mi_classify(ctx1, mb, cnt[0], n, n, "n1", &c1, &b1, &lx1, stream)) != CMX_OK) return s;
+    if ((s = mi_classify(ctx1, mb, cnt[1], n, n, "n2", &c2, &b2, &lx2, stream)) != CMX_OK) return s;
+    HIP_TRY(ctx1, launch_mi_pairs_diag(ctx1->hm.B, c1, b1, lx1, c2, b2, lx2, n, d_stat, st));
+    HIP_TRY(ctx1, launch_pair_diag(kind, 0.0, ctx1->hm.B, ctx1->hm.K, cnt[0], n, cnt[1], n, n, rc[0], rc[1], pr[0], pr[1], nm[0], nm[1],
+                                   nullptr, d_rcmin, d_prmin, d_nmin, nullptr, st));   // the minima only
+    return CMX_OK;
   }
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
   const double* d_mean = nullptr;
@@ -744,6 +924,12 @@ cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const doub
   HIP_TRY(ctx1, launch_pair_diag(kind, param, ctx1->hm.B, ctx1->hm.K, cnt[0], n, cnt[1], n, n, rc[0], rc[1], pr[0], pr[1],
                                  nm[0], nm[1], d_stat, d_rcmin, d_prmin, d_nmin, d_mean, st));
   return CMX_OK;
+}
+
+cmx_status cmx_null_inter_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed,
+                              size_t rep_begin, size_t rep_end, size_t rep_ram, double* d_stat, int32_t* d_rcmin,
+                              double* d_prmin, double* d_nmin, void* stream) {
+  return null_unfused_dev(ctx1, ctx2, kind, params, seed, rep_begin, rep_end, rep_ram, nullptr, d_stat, d_rcmin, d_prmin, d_nmin, stream);
 }
 
 cmx_status cmx_null_inter(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* params, uint64_t seed, size_t rep_begin,
@@ -903,11 +1089,20 @@ cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params
   const int gk = kind == CMX_STAT_CORRECTED_CORRELATION ? CMX_STAT_CORRELATION : kind;
   const int Bp = (h.B + 3) / 4 * 4;
   const size_t ldx = (n + 15) / 16 * 16;
-  double *X, *sv, *rv;
-  if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx, (void**)&X)) != CMX_OK) return s;
-  if ((s = scratch(ctx, "pair_s1", sizeof(double) * n, (void**)&sv)) != CMX_OK) return s;
-  if ((s = scratch(ctx, "pair_r1", sizeof(double) * n, (void**)&rv)) != CMX_OK) return s;
-  HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts, n, ldc, h.B, h.K, X, ldx, Bp, sv, rv, d_mean, st));
+  double *X = nullptr, *sv = nullptr, *rv = nullptr;
+  uint32_t* mcls = nullptr;
+  uint8_t* mbad = nullptr;
+  size_t mldx = 0;
+  if (kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+    MiBounds mb;
+    if ((s = mi_bounds(ctx, params, &mb, stream)) != CMX_OK) return s;
+    if ((s = mi_classify(ctx, mb, d_counts, n, ldc, "1", &mcls, &mbad, &mldx, stream)) != CMX_OK) return s;
+  } else {
+    if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx, (void**)&X)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_s1", sizeof(double) * n, (void**)&sv)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_r1", sizeof(double) * n, (void**)&rv)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts, n, ldc, h.B, h.K, X, ldx, Bp, sv, rv, d_mean, st));
+  }
   double *maxnorm = nullptr, *sorted = nullptr;
   uint32_t* hist = nullptr;
   if (with_null && (s = prepare_null(ctx, d_norm, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &maxnorm, &sorted, &hist)) != CMX_OK)
@@ -932,7 +1127,8 @@ cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params
   for (size_t i0 = row_begin; i0 < row_end; i0 += RB) {
     const size_t rb = std::min(RB, row_end - i0);
     if (gk == CMX_STAT_EUCLIDIAN_DISTANCE) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_intra_rows_range: EuclidianDistance is a distance, not a statistic");
-    HIP_TRY(ctx, launch_pair_gram(gk, h.B, Bp, X + i0, sv + i0, rv + i0, rb, ldx, X, sv, rv, n, ldx, 2, blk_stat, n, st, 1, 0, 0, 0, i0));
+    if (mcls) HIP_TRY(ctx, launch_mi_pairs_block(h.B, mcls + i0, mbad + i0, rb, mldx, mcls, mbad, n, mldx, 2, blk_stat, n, i0, st));
+    else HIP_TRY(ctx, launch_pair_gram(gk, h.B, Bp, X + i0, sv + i0, rv + i0, rb, ldx, X, sv, rv, n, ldx, 2, blk_stat, n, st, 1, 0, 0, 0, i0));
     if (with_null) HIP_TRY(ctx, launch_pvalues(blk_stat, n, d_norm, n, maxnorm, nclasses, sorted, hist, blk_pv, blk_ns, st, i0, rb));
     HIP_TRY(ctx, launch_pair_rows(blk_stat, n, blk_pv, blk_ns, n, d_rate_class, d_post_rate, d_norm, f, rowcount, tmp, tmp_bytes,
                                   d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), st, i0, rb,
@@ -1127,6 +1323,16 @@ cmx_status cmx_group_stats_dev(cmx_ctx* ctx, int kind, const double* params, con
   if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
   if (!d_counts || n == 0 || ldc < n || !d_offsets || !d_sites || !d_out) return fail(ctx, CMX_ERR_INVALID, "cmx_group_stats: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+    MiBounds mb;
+    uint32_t* cls;
+    uint8_t* bad;
+    size_t ldx;
+    if ((s = mi_bounds(ctx, params, &mb, stream)) != CMX_OK) return s;
+    if ((s = mi_classify(ctx, mb, d_counts, n, ldc, "g", &cls, &bad, &ldx, stream)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_mi_group(ctx->hm.B, cls, bad, ldx, d_offsets, d_sites, ngroups, d_out, (hipStream_t)stream));
+    return CMX_OK;
+  }
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
   const double* d_mean = nullptr;
   if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;

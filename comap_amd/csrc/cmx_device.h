@@ -125,6 +125,17 @@ hipError_t launch_pair_diag(int kind, double param, int B, int K, const double* 
                             const double* d_mean, hipStream_t stream);
 hipError_t launch_group_stats(int kind, double param, int B, int K, const double* d_counts, size_t ld, const int64_t* d_offsets,
                               const int32_t* d_sites, size_t ngroups, double* d_out, const double* d_mean, hipStream_t stream);
+// DiscreteMI with a bounds vector (cmx_stat_mi.hip): class words [B][ldx] (class | marginal count << 16) + per-site
+// out-of-range flags; all-pairs block, diagonal pairs, groups
+hipError_t launch_mi_classify(const double* d_counts, size_t n, size_t ldc, int B, int K, const double* d_bounds, int nb,
+                              uint32_t* d_cls, size_t ldx, uint8_t* d_bad, hipStream_t stream);
+hipError_t launch_mi_pairs_block(int B, const uint32_t* d_cls1, const uint8_t* d_bad1, size_t nrows, size_t ld1, const uint32_t* d_cls2,
+                                 const uint8_t* d_bad2, size_t n2, size_t ld2, int intra, double* d_out, size_t ldo, size_t irow0,
+                                 hipStream_t stream);
+hipError_t launch_mi_pairs_diag(int B, const uint32_t* d_cls1, const uint8_t* d_bad1, size_t ld1, const uint32_t* d_cls2,
+                                const uint8_t* d_bad2, size_t ld2, size_t n, double* d_out, hipStream_t stream);
+hipError_t launch_mi_group(int B, const uint32_t* d_cls, const uint8_t* d_bad, size_t ld, const int64_t* d_offsets,
+                           const int32_t* d_sites, size_t ngroups, double* d_out, hipStream_t stream);
 // nijt.average = no (cmx_variants.hip): the no-averaging mapping as plain kernels over a global scratch
 struct NoAvgArgs {
   int S, C, K, nn, B, root;

@@ -14,13 +14,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COMAP_MI355X_LIB", os.path.join(_HERE, "libcomap_mi355x.so"))  # override: diagnostic builds
 
 STAT_CORRELATION, STAT_COMPENSATION, STAT_COSUBSTITUTION, STAT_COSINUS, STAT_COVARIANCE, STAT_DISCRETE_MI, \
-    STAT_CORRECTED_CORRELATION, STAT_EUCLIDIAN_DISTANCE = range(8)
+    STAT_CORRECTED_CORRELATION, STAT_EUCLIDIAN_DISTANCE, STAT_DISCRETE_MI_BOUNDS = range(9)
 STAT_BY_NAME = {
     # names of the reference's `statistic=` option (CoMap/CoETools.cpp:540-599)
     "Correlation": STAT_CORRELATION, "Compensation": STAT_COMPENSATION, "Cosubstitution": STAT_COSUBSTITUTION,
     "Cosinus": STAT_COSINUS, "Covariance": STAT_COVARIANCE, "MI": STAT_DISCRETE_MI,
     "CorrectedCorrelation": STAT_CORRECTED_CORRELATION, "EuclidianDistance": STAT_EUCLIDIAN_DISTANCE,
+    "MI(bounds)": STAT_DISCRETE_MI_BOUNDS,   # DiscreteMutualInformationStatistic(const Vdouble& bounds): pass the bounds as `threshold`
 }
+
+
+def label_mi_bounds(nstates):
+    """bounds of the MI statistic under nijt = Label (CoMap/CoETools.cpp:577-588): -0.5, 0.5, .., S(S-1) + 0.5, i.e. one
+    unit bin per substitution label 0 (none) .. S(S-1)"""
+    n = nstates * (nstates - 1)
+    return -0.5 + np.arange(n + 2, dtype=np.float64)
 
 
 def _stat_params(kind, threshold, mean_vectors):
@@ -33,12 +41,15 @@ def _stat_params(kind, threshold, mean_vectors):
         if mv.ndim == 1:
             mv = np.stack([mv, mv])
         return np.ascontiguousarray(mv)
+    if int(kind) == STAT_DISCRETE_MI_BOUNDS:      # [nbounds, b_0 .. b_{n-1}]; the bounds arrive in `threshold`
+        b = _f64(threshold).ravel()
+        return np.ascontiguousarray(np.concatenate([[float(len(b))], b]))
     return _f64([threshold])
 COUNT_EXPECTED, COUNT_NAIVE = 0, 1
 
 EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
-    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_set_mapping_options", "cmx_map_sites_dev", "cmx_simulate", "cmx_simulate_continuous",
+    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_debug_nuc_program", "cmx_map_sites", "cmx_set_mapping_options", "cmx_map_sites_dev", "cmx_simulate", "cmx_simulate_continuous",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_simulate_dev", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev", "cmx_intra_rows_range_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
@@ -168,6 +179,25 @@ def debug_walk(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
     return dict(nrec=nrec[: n1.value].reshape(-1, 16).copy(), ldsched=ld[: n2.value].copy(),
                 msched=ms[: n3.value].reshape(-1, 2).copy(), slot=slot, loads=int(stats[0]), stores=int(stats[1]),
                 products=int(stats[2]), leaf_ops=int(stats[3]))
+
+
+def debug_nuc_program(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None, block_capacity=10):
+    """Host-side build + self-check of the nucleotide mapping kernel's program (no GPU): dict(blocks, roots, applies,
+    root_loads, root_stores, inside_records, outside_records, operators); raises CmxError when the check fails."""
+    lib = load_library()
+    keep = [np.ascontiguousarray(parent, dtype=np.int32), _f64(blen), np.ascontiguousarray(leaf_of_taxon, dtype=np.int32),
+            _f64(Q), _f64(pi), _f64(rates), _f64(probs), None if Bk is None else _f64(Bk)]
+    p, bl, lot, Qa, pia, ra, pr, Bka = keep
+    S, C = len(pia), len(ra)
+    K = 1 if Bka is None else Bka.reshape(-1, S, S).shape[0]
+    model = _Model(S, C, K, _vp(Qa), _vp(pia), _vp(ra), _vp(pr), _vp(Bka), 0, 1, _vp(None))
+    tree = _Tree(len(p), _vp(p), _vp(bl), len(lot), _vp(lot))
+    stats = np.zeros(8, dtype=np.uint64)
+    st = lib.cmx_debug_nuc_program(ctypes.byref(model), ctypes.byref(tree), ctypes.c_int(block_capacity), _vp(stats))
+    if st != 0:
+        raise CmxError(st, lib.cmx_last_error(None).decode())
+    names = ("blocks", "roots", "applies", "root_loads", "root_stores", "inside_records", "outside_records", "operators")
+    return {k: int(v) for k, v in zip(names, stats)}
 
 
 def debug_candidate_cursor(norm_windows, analysable, min_sim, norms, max_trials):

@@ -238,14 +238,38 @@ class CovarianceStatistic : public Statistic { public: int kind() const override
 class CosinusStatistic : public Statistic { public: int kind() const override { return CMX_STAT_COSINUS; } };
 class CosubstitutionNumberStatistic : public Statistic { public: int kind() const override { return CMX_STAT_COSUBSTITUTION; } };
 class CompensationStatistic : public Statistic { public: int kind() const override { return CMX_STAT_COMPENSATION; } };
-class DiscreteMutualInformationStatistic : public Statistic {  // bounds {0, threshold, 10000}, CoETools.cpp:590-593
+// Statistics.h:296-329.  The reference constructs it from a bounds vector (DiscreteMutualInformationStatistic(const
+// Vdouble& bounds)); its factory (CoETools.cpp:577-593) builds {0, threshold, 10000} for MI(threshold) and, for
+// nijt = Label, -0.5, 0.5, .., S(S-1) + 0.5 (labelBounds).  The two-bound-interval form runs on the indicator Gram
+// (CMX_STAT_DISCRETE_MI), any other vector on the joint-table kernel (CMX_STAT_DISCRETE_MI_BOUNDS).
+class DiscreteMutualInformationStatistic : public Statistic {
  public:
-  explicit DiscreteMutualInformationStatistic(double threshold = 0.99) : threshold_(threshold) {}
-  int kind() const override { return CMX_STAT_DISCRETE_MI; }
-  const double* params() const override { return &threshold_; }
+  explicit DiscreteMutualInformationStatistic(double threshold = 0.99) : params_{3., 0., threshold, 10000.} {}
+  explicit DiscreteMutualInformationStatistic(const Vdouble& bounds) {
+    if (bounds.size() < 2) throw Exception("DiscreteMutualInformationStatistic: at least two bounds are needed.");
+    for (size_t i = 0; i + 1 < bounds.size(); ++i)   // Domain::Domain(const Vdouble&), Domain.cpp:62-72
+      if (bounds[i + 1] < bounds[i])
+        throw Exception("Bound " + std::to_string(i + 1) + " (" + std::to_string(bounds[i + 1]) + ") is < to bound " +
+                        std::to_string(i) + " (" + std::to_string(bounds[i]) + ").");
+    params_.push_back(static_cast<double>(bounds.size()));
+    params_.insert(params_.end(), bounds.begin(), bounds.end());
+  }
+  // CoETools.cpp:583-588: one unit bin per substitution label 0 .. S(S-1)
+  static Vdouble labelBounds(size_t alphabetSize) {
+    const size_t n = alphabetSize * (alphabetSize - 1);
+    Vdouble b(n + 2);
+    b[0] = -0.5;
+    for (size_t i = 0; i < n + 1; ++i) b[i + 1] = b[i] + 1;
+    return b;
+  }
+  bool isThresholdForm() const { return params_.size() == 4 && params_[1] == 0. && params_[3] == 10000.; }
+  int kind() const override { return isThresholdForm() ? CMX_STAT_DISCRETE_MI : CMX_STAT_DISCRETE_MI_BOUNDS; }
+  // threshold form: the C-ABI takes the threshold alone; else [nbounds, bounds..]
+  const double* params() const override { return isThresholdForm() ? &params_[2] : params_.data(); }
+  Vdouble getBounds() const { return Vdouble(params_.begin() + 1, params_.end()); }
 
  private:
-  double threshold_;
+  Vdouble params_;   // [nbounds, bounds..]
 };
 
 // Statistics.h:176-204: correlation of the vectors minus a per-branch mean vector; CoMap.cpp:350-359 sets it to the mean

@@ -195,8 +195,11 @@ inline std::unique_ptr<cmx::Statistic> toEngineStatistic(const ::Statistic& stat
   if (dynamic_cast<const ::CosinusStatistic*>(&statistic)) return std::make_unique<cmx::CosinusStatistic>();
   if (dynamic_cast<const ::CosubstitutionNumberStatistic*>(&statistic)) return std::make_unique<cmx::CosubstitutionNumberStatistic>();
   if (dynamic_cast<const ::CompensationStatistic*>(&statistic)) return std::make_unique<cmx::CompensationStatistic>();
+  // The reference keeps the bounds in a private Domain (Statistics.h:309) without an accessor: INTEGRATION.md section 2 adds
+  // the one-line getter `const Domain& getDomain() const { return domain_; }` this needs.  Every bounds vector the factory
+  // builds (CoETools.cpp:577-593: MI(threshold) and the unit bins of nijt = Label) goes through as it is.
   if (const auto* mi = dynamic_cast<const ::DiscreteMutualInformationStatistic*>(&statistic))
-    return std::make_unique<cmx::DiscreteMutualInformationStatistic>(mi->getDomain().getBound(1));   // MI(threshold), CoETools.cpp:590-593
+    return std::make_unique<cmx::DiscreteMutualInformationStatistic>(mi->getDomain().getBounds());
   throw cmx::Exception("cmx::bpp: this Statistic has no device kernel (MutualInformationStatistic on continuous counts)");
 }
 
