@@ -45,6 +45,7 @@ WORKLOADS = {
 }
 FP64_PEAK_TFLOPS = 78.6   # MI355X public spec, vector == matrix fp64 (the microarch guide has no fp64 row);
 # measured here (scripts/ubench_f64.hip): v_mfma_f64_16x16x4 72-75, v_mfma_f64_4x4x4_4b 65-68, v_fma_f64 55-59 TFLOP/s
+HBM_PEAK_TBPS = 8.0       # guide, HBM: 8.0 TB/s spec (6.3 TB/s measured with a streaming copy)
 INT8_PEAK_TOPS = 5000.0   # guide, Matrix cores: I8 = 2x the BF16 rate per clock, BF16 ~2.5 PF dense
 
 
@@ -250,6 +251,8 @@ def main():
     row_begin, row_end = row_shard(rank, world, w["nsites"])   # this rank's share of the observed pair loop
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
+    ev_sim = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
     side = torch.cuda.Stream(device=dev)   # observed-alignment mapping overlaps the null kernel (independent work)
     main_s = torch.cuda.current_stream()
 
@@ -258,7 +261,8 @@ def main():
         with torch.cuda.stream(side):
             ana.get_vectors(aln)
         # the null: simulate (own kernel, full occupancy) then map + score; the events bracket the mapping launch alone
-        nb = ana.null_distribution(w["seed"] + 7, rep_begin, rep_end, ram, map_events=ev[i] if timed else None)
+        nb = ana.null_distribution(w["seed"] + 7, rep_begin, rep_end, ram, map_events=ev[i] if timed else None,
+                                   sim_events=ev_sim[i] if timed else None)
         main_s.wait_stream(side)
         # the path's one exchange: every rank needs the merged null before p-values (one RCCL all-gather)
         ns, nm = gather_null(nb["stat"], nb["nmin"], nrep_total, ram)
@@ -300,9 +304,13 @@ def main():
     # `achieved` / `frac` follow SURVEY 8(d): ALGORITHMIC flops (7 B C S^2 per site, leaf edges counted as dense
     # products) / time / peak.  `frac_executed` counts only the matrix products the kernel issues (leaf edges are row
     # gathers, sibling messages are stored instead of recomputed): the matrix pipe's duty, always lower.
-    roofline = dict(bound="mfma", kernel=f"map_kernel<{eng.S},null>", achieved=achieved, peak=FP64_PEAK_TFLOPS,
+    # (4-state models: map_nuc_kernel applies its 4x4 operators with v_fma_f64 -- the fp64 vector roof equals the matrix
+    # one -- and `executed` counts operator applications + the 8 flops behind each leaf-table gather.)
+    sim_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_sim]))
+    kname = f"map_kernel<{eng.S},null>" if eng.S != 4 or os.environ.get("CMX_NUC_LEGACY") == "1" else "map_nuc_kernel<null>"
+    roofline = dict(bound="mfma", kernel=kname, achieved=achieved, peak=FP64_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
-                    launch_ms=null_ms, sites_per_launch=sites_per_launch, flops_per_site_algorithmic=alg,
+                    launch_ms=null_ms, simulate_ms=sim_ms, sites_per_launch=sites_per_launch, flops_per_site_algorithmic=alg,
                     flops_per_site_executed=exe, achieved_executed=ach_exe, frac_executed=ach_exe / FP64_PEAK_TFLOPS)
     for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
         try:
@@ -315,6 +323,13 @@ def main():
                 break
         except Exception:
             pass
+    # next to the contract's algorithmic figure, say which roof the kernel really sits nearer to -- the fraction
+    # of the fp64 pipe it keeps busy (executed flops) against the fraction of the HBM rate its measured bytes take
+    if roofline["traffic"] is not None:
+        hbm_tbs = roofline["traffic"] / (null_ms * 1e-3) / 1e12
+        roofline["hbm_achieved_TBps"] = hbm_tbs
+        roofline["hbm_frac"] = hbm_tbs / HBM_PEAK_TBPS
+        roofline["nearest_roof"] = ("hbm" if roofline["hbm_frac"] > roofline["frac_executed"] else "fp64")
 
     out = dict(metric="site-pair coevolution statistics/s (incl. null sims)", value=value,
                unit="site-pair statistics/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

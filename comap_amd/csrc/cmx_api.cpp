@@ -14,7 +14,6 @@
 #include "../../include/comap_mi355x.h"
 #include "cmx_device.h"
 #include "cmx_host_model.h"
-#include "cmx_nuc.h"
 
 using namespace cmx;
 
@@ -46,13 +45,9 @@ struct cmx_ctx {
   std::vector<double> param_host[8];
   bool leaf_rows_custom = false;   // the leaf operators' ambiguity rows were built from a caller's mask table
   bool map_average = true;         // nijt.average (cmx_set_mapping_options); false: the no-averaging mapping of cmx_variants.hip
-  const double *va_P = nullptr, *va_N1 = nullptr;   // its operators, uploaded at first use
+  bool map_joint = true;           // nijt.joint; false: the ...Marginal variants of cmx_variants.hip
+  const double *va_P = nullptr, *va_N1 = nullptr, *va_NC = nullptr;   // their operators, uploaded at first use
   const int *va_first = nullptr, *va_next = nullptr;
-  // 4-state models: the nucleotide mapping kernel (cmx_nuc.h); the 20-state machinery above is then not allocated
-  bool nuc = false;
-  NucProgram np;
-  NucDev nd{};
-  NucWs nws{}, nws_obs{};
   mutable std::string err;
 };
 
@@ -143,18 +138,6 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       return bail((cmx_status)code);
     }
     ctx->has_model = true;
-    const char* legacy = getenv("CMX_NUC_LEGACY");   // A/B timing against the class-fused 16-state path of rounds 1-2
-    if (ctx->hm.S == 4 && !(legacy && legacy[0] == '1')) {
-      const char* e = getenv("CMX_NUC_NB");          // block capacity: tuning only
-      const int NB = e ? atoi(e) : 10;
-      msg = build_nuc_program(ctx->hm, NB, &ctx->np);
-      if (msg.empty()) msg = verify_nuc_program(ctx->hm, ctx->np);
-      if (!msg.empty()) {
-        ctx->err = msg;
-        return bail(CMX_ERR_INVALID);
-      }
-      ctx->nuc = true;
-    }
   }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -224,33 +207,6 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     // ambiguity masks default: code c >= S compatible with every state; fix the table for this S
     for (int i = 0; i < 256; ++i) dm[i] = i < h.S ? (1u << i) : ((h.S >= 32) ? 0xffffffffu : ((1u << h.S) - 1u));
     HIP_TRY(ctx, hipMemcpy(ctx->d_default_masks, dm.data(), sizeof(uint32_t) * 256, hipMemcpyHostToDevice));
-    if (ctx->nuc) {
-      const NucProgram& np = ctx->np;
-      NucDev& nd = ctx->nd;
-      nd.C = np.C; nd.K = np.K; nd.B = np.B; nd.T = np.T; nd.nblocks = np.nblocks; nd.nroots = np.nroots; nd.nops = np.nops; nd.NB = np.NB;
-      if ((s = upload(ctx, np.ops, &nd.ops)) != CMX_OK) return s;
-      if ((s = upload(ctx, np.blk, &nd.blk)) != CMX_OK) return s;
-      if ((s = upload(ctx, np.irec, &nd.irec)) != CMX_OK) return s;
-      if ((s = upload(ctx, np.orec, &nd.orec)) != CMX_OK) return s;
-      nd.pi = d.pi; nd.rates = d.rates; nd.probs = d.probs;
-      ctx->grid_blocks = ctx->cu_count * nuc_waves_per_simd(np.NB);
-      ctx->waves = ctx->grid_blocks * kWavesPerBlock;
-      ctx->obs_blocks = std::max(1, ctx->grid_blocks / 4);
-      ctx->ws_bytes = 0;
-      auto alloc_nws = [&](NucWs* ws, size_t w) -> cmx_status {
-        const size_t bR = w * (size_t)np.C * std::max(1, np.nroots) * 256 * sizeof(double);
-        const size_t bC = w * 2 * (size_t)np.B * np.K * 64 * sizeof(double);
-        HIP_TRY(ctx, hipMalloc((void**)&ws->WM, bR));
-        HIP_TRY(ctx, hipMalloc((void**)&ws->WU, bR));
-        HIP_TRY(ctx, hipMalloc((void**)&ws->cnt, bC));
-        ws->waves = (int)w;
-        ctx->ws_bytes += 2 * bR + bC;
-        return CMX_OK;
-      };
-      if ((s = alloc_nws(&ctx->nws, (size_t)ctx->waves)) != CMX_OK) return s;
-      if ((s = alloc_nws(&ctx->nws_obs, (size_t)ctx->obs_blocks * kWavesPerBlock)) != CMX_OK) return s;
-      return CMX_OK;
-    }
     // per-wave workspaces: 1 wave per SIMD on every CU for the null; a quarter of that for observed alignments
     ctx->grid_blocks = ctx->cu_count * map_waves_per_simd(h.dS);   // 4-wave workgroups, that many per CU
     ctx->waves = ctx->grid_blocks * kWavesPerBlock;
@@ -294,11 +250,6 @@ void cmx_ctx_destroy(cmx_ctx* ctx) {
     if (ws->st) (void)hipFree(ws->st);
     if (ws->aln) (void)hipFree(ws->aln);
   }
-  for (NucWs* ws : {&ctx->nws, &ctx->nws_obs}) {
-    if (ws->WM) (void)hipFree(ws->WM);
-    if (ws->WU) (void)hipFree(ws->WU);
-    if (ws->cnt) (void)hipFree(ws->cnt);
-  }
   delete ctx;
 }
 
@@ -312,11 +263,6 @@ cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info) {
   info->device_states = ctx->hm.dS; info->device_classes = ctx->hm.dC;
   info->products_per_pass = (int32_t)ctx->hm.n_products; info->leaf_ops_per_pass = (int32_t)ctx->hm.n_leaf_ops;
   info->ws_loads_per_pass = (int32_t)ctx->hm.n_loads; info->ws_stores_per_pass = (int32_t)ctx->hm.n_stores;
-  if (ctx->nuc) {   // nucleotide kernel: 4x4 operator applications of a class pass (leaves included), block-root messages through HBM
-    info->device_states = 4; info->device_classes = ctx->hm.C;
-    info->products_per_pass = (int32_t)ctx->np.n_apply; info->leaf_ops_per_pass = 0;
-    info->ws_loads_per_pass = (int32_t)ctx->np.n_root_loads; info->ws_stores_per_pass = (int32_t)ctx->np.n_root_stores;
-  }
   return CMX_OK;
 }
 
@@ -349,25 +295,6 @@ cmx_status cmx_debug_walk(const cmx_model* model, const cmx_tree* tree, int32_t*
   return CMX_OK;
 }
 
-cmx_status cmx_debug_nuc_program(const cmx_model* model, const cmx_tree* tree, int block_capacity, uint64_t* stats) {
-  HostModel hm;
-  int code = CMX_OK;
-  std::string msg = build_host_model(model, tree, &hm, &code);
-  if (msg.empty() && hm.S != 4) { msg = "cmx_debug_nuc_program: 4 states required"; code = CMX_ERR_INVALID; }
-  NucProgram np;
-  if (msg.empty()) { msg = build_nuc_program(hm, block_capacity, &np); code = CMX_ERR_INVALID; }
-  if (msg.empty()) msg = verify_nuc_program(hm, np);
-  if (!msg.empty()) {
-    g_create_error = msg;
-    return (cmx_status)code;
-  }
-  if (stats) {
-    stats[0] = (uint64_t)np.nblocks; stats[1] = (uint64_t)np.nroots; stats[2] = np.n_apply; stats[3] = np.n_root_loads;
-    stats[4] = np.n_root_stores; stats[5] = np.irec.size() / 8; stats[6] = np.orec.size() / 16; stats[7] = (uint64_t)np.nops;
-  }
-  return CMX_OK;
-}
-
 cmx_status cmx_synchronize(cmx_ctx* ctx) {
   if (!ctx) return CMX_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -382,12 +309,13 @@ cmx_status cmx_synchronize(cmx_ctx* ctx) {
 // path keeps ws and ws_obs apart for the same reason.
 static cmx_status map_variant(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
                               double* d_counts, size_t ldc, double* d_norm, void* stream, bool full_grid) {
-  if (ctx->map_average || (!d_counts && !d_norm)) return CMX_OK;
+  if ((ctx->map_average && ctx->map_joint) || (!d_counts && !d_norm)) return CMX_OK;
   const HostModel& h = ctx->hm;
   cmx_status s;
   if (!ctx->va_P) {
     if ((s = upload(ctx, h.P, &ctx->va_P)) != CMX_OK) return s;
     if ((s = upload(ctx, h.N1, &ctx->va_N1)) != CMX_OK) return s;
+    if ((s = upload(ctx, h.NC, &ctx->va_NC)) != CMX_OK) return s;
     if ((s = upload(ctx, h.first_child, &ctx->va_first)) != CMX_OK) return s;
     if ((s = upload(ctx, h.next_sib, &ctx->va_next)) != CMX_OK) return s;
   }
@@ -397,8 +325,9 @@ static cmx_status map_variant(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites,
   }
   NoAvgArgs a{};
   a.S = h.S; a.C = h.C; a.K = h.K; a.nn = h.nn; a.B = h.B; a.root = h.root;
-  a.first_child = ctx->va_first; a.next_sib = ctx->va_next; a.taxon_of = ctx->dm.taxon_of;
-  a.P = ctx->va_P; a.N1 = ctx->va_N1; a.pi = ctx->dm.pi; a.probs = ctx->dm.probs;
+  a.mode = ctx->map_joint ? kVariantNoAvg : (ctx->map_average ? kVariantMarginal : kVariantNoAvgMarginal);
+  a.first_child = ctx->va_first; a.next_sib = ctx->va_next; a.taxon_of = ctx->dm.taxon_of; a.parent = ctx->dm.parent;
+  a.P = ctx->va_P; a.N1 = ctx->va_N1; a.NC = ctx->va_NC; a.pi = ctx->dm.pi; a.probs = ctx->dm.probs;
   a.masks = d_masks; a.aln = d_aln; a.ld = ld;
   // sites per pass: per-node vectors of a pass stay under 1 GiB
   const size_t per_site = sizeof(double) * noavg_scratch_doubles(h.S, h.C, h.nn, 1);
@@ -424,15 +353,6 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
   if (d_counts && ldc < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: ldc < nsites");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int max_blocks = full_grid ? ctx->grid_blocks : ctx->obs_blocks;
-  if (ctx->nuc) {
-    NucArgs na{};
-    na.m = ctx->nd; na.ws = full_grid ? ctx->nws : ctx->nws_obs;
-    na.aln = d_aln; na.ld = ld; na.nsites = nsites; na.masks = d_masks;
-    na.counts = d_counts; na.ldc = ldc; na.logL = d_logL; na.post_rate = d_post_rate; na.rate_class = d_rate_class; na.norm = d_norm;
-    const size_t need = ((nsites + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;
-    HIP_TRY(ctx, launch_map_nuc(na, false, (int)std::min<size_t>(need, (size_t)max_blocks), (hipStream_t)stream));
-    return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream, full_grid);
-  }
   MapArgs a{};
   a.m = ctx->dm; a.ws = full_grid ? ctx->ws : ctx->ws_obs;
   a.aln = d_aln; a.ld = ld; a.nsites = nsites;
@@ -524,10 +444,8 @@ cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t
 cmx_status cmx_set_mapping_options(cmx_ctx* ctx, int average, int joint) {
   cmx_status s = need_model(ctx);
   if (s != CMX_OK) return s;
-  if (!joint)
-    return fail(ctx, CMX_ERR_UNSUPPORTED, "nijt.joint = no (computeSubstitutionVectors*Marginal) is not implemented: the algorithm is "
-                                          "bpp-phyl's, which the reference tree does not contain, and nothing pins it");
   ctx->map_average = average != 0;
+  ctx->map_joint = joint != 0;
   return CMX_OK;
 }
 
@@ -539,23 +457,52 @@ static cmx_status rng_range(cmx_ctx* ctx, uint64_t g_end, const char* who) {
 }
 
 // ------------------------------------------------------------------------------------------------ simulator
+cmx_status cmx_simulate_dev(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld, int32_t* d_classes,
+                            void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!d_aln || n == 0 || ld < n) return fail(ctx, CMX_ERR_INVALID, "cmx_simulate: bad arguments");
+  if ((s = rng_range(ctx, g0 + n, "cmx_simulate")) != CMX_OK) return s;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // node states of the n sites: a scratch of their own per stream would be needed to overlap two simulations of one
+  // context; calls on one context are serialised by the caller (header)
+  uint8_t* d_st;
+  int32_t* d_cls = d_classes;
+  if ((s = scratch(ctx, "sim_states", (size_t)ctx->hm.nn * ld, (void**)&d_st)) != CMX_OK) return s;
+  if (!d_cls && (s = scratch(ctx, "sim_classes", sizeof(int32_t) * n, (void**)&d_cls)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_simulate(ctx->dm, seed, g0, n, d_aln, ld, d_cls, d_st, (hipStream_t)stream));
+  return CMX_OK;
+}
+
 cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln_out, int32_t* classes_out) {
   cmx_status s = need_model(ctx);
   if (s != CMX_OK) return s;
   if (!aln_out || n == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_simulate: bad arguments");
-  if ((s = rng_range(ctx, g0 + n, "cmx_simulate")) != CMX_OK) return s;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const HostModel& h = ctx->hm;
   TmpDev tmp;
-  uint8_t *d_aln = nullptr, *d_st = nullptr;
+  uint8_t* d_aln = nullptr;
   int32_t* d_cls = nullptr;
   HIP_TRY(ctx, tmp.alloc((void**)&d_aln, (size_t)h.T * n));
-  HIP_TRY(ctx, tmp.alloc((void**)&d_st, (size_t)h.nn * n));
   HIP_TRY(ctx, tmp.alloc((void**)&d_cls, n * sizeof(int32_t)));
-  HIP_TRY(ctx, launch_simulate(ctx->dm, seed, g0, n, d_aln, n, d_cls, d_st, nullptr));
+  if ((s = cmx_simulate_dev(ctx, seed, g0, n, d_aln, n, d_cls, nullptr)) != CMX_OK) return s;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(aln_out, d_aln, (size_t)h.T * n, hipMemcpyDeviceToHost));
   if (classes_out) HIP_TRY(ctx, hipMemcpy(classes_out, d_cls, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
+cmx_status cmx_simulate_continuous_dev(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, double gamma_alpha, double p_invariant,
+                                       uint8_t* d_aln, size_t ld, double* d_rates, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!d_aln || n == 0 || ld < n || !(gamma_alpha > 0.0) || !(p_invariant >= 0.0 && p_invariant < 1.0))
+    return fail(ctx, CMX_ERR_INVALID, "cmx_simulate_continuous: bad arguments (alpha > 0, 0 <= p_invariant < 1)");
+  if ((s = rng_range(ctx, g0 + n, "cmx_simulate_continuous")) != CMX_OK) return s;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t* d_st;
+  if ((s = scratch(ctx, "sim_states", (size_t)ctx->hm.nn * ld, (void**)&d_st)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_simulate_continuous(ctx->dm, seed, g0, n, gamma_alpha, p_invariant, d_aln, ld, d_rates, d_st, (hipStream_t)stream));
   return CMX_OK;
 }
 
@@ -563,18 +510,15 @@ cmx_status cmx_simulate_continuous(cmx_ctx* ctx, uint64_t seed, uint64_t g0, siz
                                    uint8_t* aln_out, double* rates_out) {
   cmx_status s = need_model(ctx);
   if (s != CMX_OK) return s;
-  if (!aln_out || n == 0 || !(gamma_alpha > 0.0) || !(p_invariant >= 0.0 && p_invariant < 1.0))
-    return fail(ctx, CMX_ERR_INVALID, "cmx_simulate_continuous: bad arguments (alpha > 0, 0 <= p_invariant < 1)");
-  if ((s = rng_range(ctx, g0 + n, "cmx_simulate_continuous")) != CMX_OK) return s;
+  if (!aln_out || n == 0) return fail(ctx, CMX_ERR_INVALID, "cmx_simulate_continuous: bad arguments (alpha > 0, 0 <= p_invariant < 1)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const HostModel& h = ctx->hm;
   TmpDev tmp;
-  uint8_t *d_aln = nullptr, *d_st = nullptr;
+  uint8_t* d_aln = nullptr;
   double* d_r = nullptr;
   HIP_TRY(ctx, tmp.alloc((void**)&d_aln, (size_t)h.T * n));
-  HIP_TRY(ctx, tmp.alloc((void**)&d_st, (size_t)h.nn * n));
   HIP_TRY(ctx, tmp.alloc((void**)&d_r, n * sizeof(double)));
-  HIP_TRY(ctx, launch_simulate_continuous(ctx->dm, seed, g0, n, gamma_alpha, p_invariant, d_aln, n, d_r, d_st, nullptr));
+  if ((s = cmx_simulate_continuous_dev(ctx, seed, g0, n, gamma_alpha, p_invariant, d_aln, n, d_r, nullptr)) != CMX_OK) return s;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(aln_out, d_aln, (size_t)h.T * n, hipMemcpyDeviceToHost));
   if (rates_out) HIP_TRY(ctx, hipMemcpy(rates_out, d_r, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -760,7 +704,7 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
   if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra: bad arguments");
   if ((s = rng_range(ctx, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_intra")) != CMX_OK) return s;
-  if (!ctx->map_average || kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+  if (!ctx->map_average || !ctx->map_joint || kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
     // nijt.average = no (AnalysisTools.cpp:598-610): the fused kernel only knows the averaged mapping; and a statistic that
     // needs a joint table per pair cannot be evaluated per lane inside the mapping wave.  The same simulate -> map ->
     // score sequence then runs unfused, which is what the two-data-set null does with both sides equal.
@@ -793,19 +737,6 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
     d_supplied = d_aln;
   }
 #endif
-  if (ctx->nuc) {
-    NucArgs na{};
-    na.m = ctx->nd; na.ws = ctx->nws;
-    na.nsites = (rep_end - rep_begin) * rep_ram;
-    na.stat_kind = kind;
-    na.stat_param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
-    if ((s = stat_mean_vectors(ctx, kind, params, &na.stat_mean, stream)) != CMX_OK) return s;
-    na.rep_ram = rep_ram; na.supplied = d_supplied;
-    na.null_stat = d_stat; na.null_rcmin = d_rcmin; na.null_prmin = d_prmin; na.null_nmin = d_nmin;
-    const size_t need = ((na.nsites + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;
-    HIP_TRY(ctx, launch_map_nuc(na, true, (int)std::min<size_t>(need, (size_t)ctx->grid_blocks), (hipStream_t)stream));
-    return CMX_OK;
-  }
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.nsites = (rep_end - rep_begin) * rep_ram;
@@ -818,6 +749,60 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   const size_t blocks_needed = ((a.nsites + ks - 1) / ks + kWavesPerBlock - 1) / kWavesPerBlock;
   const int grid = (int)std::min<size_t>(blocks_needed, (size_t)ctx->grid_blocks);
   HIP_TRY(ctx, launch_map(a, kModeNull, grid, (hipStream_t)stream));
+  return CMX_OK;
+}
+
+// simulations.continuous = yes (CoMap.cpp:146, 213): the replicates' alignments come from the continuous-rate simulator,
+// straight into the device buffer cmx_null_intra_dev maps as "supplied" alignments -- nothing crosses PCIe
+cmx_status cmx_null_intra_continuous_dev(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin, size_t rep_end,
+                                         size_t rep_ram, double gamma_alpha, double p_invariant, double* d_stat, int32_t* d_rcmin,
+                                         double* d_prmin, double* d_nmin, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra_continuous: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t T = (size_t)ctx->hm.T, per_rep = 2 * T * rep_ram;
+  const size_t reps_per_pass = std::max<size_t>(1, ((size_t)4 << 30) / per_rep);   // alignments of a pass stay under 4 GiB
+  uint8_t* d_aln;
+  if ((s = scratch(ctx, "null_aln", std::min(reps_per_pass, rep_end - rep_begin) * per_rep, (void**)&d_aln)) != CMX_OK) return s;
+  for (size_t r0 = rep_begin; r0 < rep_end; r0 += reps_per_pass) {
+    const size_t r1 = std::min(rep_end, r0 + reps_per_pass), o = (r0 - rep_begin) * rep_ram;
+    for (size_t r = r0; r < r1; ++r)
+      for (int h = 0; h < 2; ++h) {   // [replicate][batch][taxon][rep_ram]; simulated-site index g = (rep * 2 + batch) * rep_ram + j
+        if ((s = cmx_simulate_continuous_dev(ctx, seed, ((uint64_t)r * 2 + h) * rep_ram, rep_ram, gamma_alpha, p_invariant,
+                                             d_aln + ((r - r0) * 2 + h) * T * rep_ram, rep_ram, nullptr, stream)) != CMX_OK)
+          return s;
+      }
+    if ((s = cmx_null_intra_dev(ctx, kind, params, seed, r0, r1, rep_ram, d_aln, d_stat + o, d_rcmin ? d_rcmin + o : nullptr,
+                                d_prmin ? d_prmin + o : nullptr, d_nmin ? d_nmin + o : nullptr, stream)) != CMX_OK)
+      return s;
+  }
+  return CMX_OK;
+}
+
+cmx_status cmx_null_intra_continuous(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin, size_t rep_end,
+                                     size_t rep_ram, double gamma_alpha, double p_invariant, double* stat, int32_t* rcmin,
+                                     double* prmin, double* nmin) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (rep_end <= rep_begin || rep_ram == 0 || !stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra_continuous: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = (rep_end - rep_begin) * rep_ram;
+  TmpDev tmp;
+  double *d_stat, *d_pr, *d_nm;
+  int32_t* d_rc;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_stat, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_pr, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_nm, n * sizeof(double)));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_rc, n * sizeof(int32_t)));
+  s = cmx_null_intra_continuous_dev(ctx, kind, params, seed, rep_begin, rep_end, rep_ram, gamma_alpha, p_invariant, d_stat, d_rc, d_pr,
+                                    d_nm, nullptr);
+  if (s != CMX_OK) return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(stat, d_stat, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (rcmin) HIP_TRY(ctx, hipMemcpy(rcmin, d_rc, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (prmin) HIP_TRY(ctx, hipMemcpy(prmin, d_pr, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (nmin) HIP_TRY(ctx, hipMemcpy(nmin, d_nm, n * sizeof(double), hipMemcpyDeviceToHost));
   return CMX_OK;
 }
 
@@ -1271,6 +1256,30 @@ cmx_status cmx_mi_columns(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* m
   return CMX_OK;
 }
 
+// d_masks: device table of 256 compatibility masks (NULL: codes >= nalpha are unknowns); column indices are validated by
+// the caller (the host entry point checks them)
+cmx_status cmx_mi_pairs_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
+                            const uint8_t* d_aln2, size_t n2, size_t ld2, const int64_t* d_idx1, const int64_t* d_idx2, size_t npairs,
+                            double* d_mi, double* d_hjoint, void* stream) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (nalpha != 4 && nalpha != 20) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mi_pairs: alphabet size must be 4 or 20");
+  if (!d_aln2) { d_aln2 = d_aln1; n2 = n1; ld2 = ld1; }
+  if (!d_aln1 || !d_idx1 || !d_idx2 || !d_mi || !d_hjoint || n1 == 0 || n2 == 0 || ld1 < n1 || ld2 < n2 || ntaxa < 1 || npairs == 0)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_mi_pairs: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!d_masks) {
+    std::vector<uint32_t> mk(256, (1u << nalpha) - 1u);
+    for (int i = 0; i < nalpha; ++i) mk[i] = 1u << i;
+    void* p = nullptr;
+    cmx_status s = scratch(ctx, "mi_masks", 256 * sizeof(uint32_t), &p);
+    if (s != CMX_OK) return s;
+    HIP_TRY(ctx, hipMemcpy(p, mk.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    d_masks = static_cast<const uint32_t*>(p);
+  }
+  HIP_TRY(ctx, launch_mi_pairs(nalpha, ntaxa, d_masks, d_aln1, ld1, d_aln2, ld2, d_idx1, d_idx2, npairs, d_mi, d_hjoint, (hipStream_t)stream));
+  return CMX_OK;
+}
+
 cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks, const uint8_t* aln1,
                         size_t n1, const uint8_t* aln2, size_t n2, const int64_t* idx1, const int64_t* idx2, size_t npairs,
                         double* mi, double* hjoint) {
@@ -1289,14 +1298,13 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
   for (size_t i = 0; i < 256; ++i) if (mk[i] == 0) mk[i] = (1u << nalpha) - 1u;
   TmpDev tmp;
   uint32_t* d_masks;
-  uint8_t *d1, *d2;
+  uint8_t *d1, *d2 = nullptr;
   int64_t *di1, *di2;
   double *d_mi, *d_hj;
   HIP_TRY(ctx, tmp.alloc((void**)&d_masks, 256 * sizeof(uint32_t)));
   HIP_TRY(ctx, hipMemcpy(d_masks, mk.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIP_TRY(ctx, tmp.alloc((void**)&d1, (size_t)ntaxa * n1));
   HIP_TRY(ctx, hipMemcpy(d1, aln1, (size_t)ntaxa * n1, hipMemcpyHostToDevice));
-  d2 = d1;
   if (aln2) {
     HIP_TRY(ctx, tmp.alloc((void**)&d2, (size_t)ntaxa * n2));
     HIP_TRY(ctx, hipMemcpy(d2, aln2, (size_t)ntaxa * n2, hipMemcpyHostToDevice));
@@ -1307,7 +1315,8 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
   HIP_TRY(ctx, hipMemcpy(di2, idx2, npairs * sizeof(int64_t), hipMemcpyHostToDevice));
   HIP_TRY(ctx, tmp.alloc((void**)&d_mi, npairs * sizeof(double)));
   HIP_TRY(ctx, tmp.alloc((void**)&d_hj, npairs * sizeof(double)));
-  HIP_TRY(ctx, launch_mi_pairs(nalpha, ntaxa, d_masks, d1, n1, d2, n2, di1, di2, npairs, d_mi, d_hj, nullptr));
+  cmx_status s = cmx_mi_pairs_dev(ctx, nalpha, ntaxa, d_masks, d1, n1, n1, d2, n2, n2, di1, di2, npairs, d_mi, d_hj, nullptr);
+  if (s != CMX_OK) return s;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(mi, d_mi, npairs * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemcpy(hjoint, d_hj, npairs * sizeof(double), hipMemcpyDeviceToHost));

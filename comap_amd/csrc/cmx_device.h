@@ -137,11 +137,14 @@ hipError_t launch_mi_pairs_diag(int B, const uint32_t* d_cls1, const uint8_t* d_
 hipError_t launch_mi_group(int B, const uint32_t* d_cls, const uint8_t* d_bad, size_t ld, const int64_t* d_offsets,
                            const int32_t* d_sites, size_t ngroups, double* d_out, hipStream_t stream);
 // nijt.average = no (cmx_variants.hip): the no-averaging mapping as plain kernels over a global scratch
+// mode: which LegacySubstitutionMappingTools function (CoETools.cpp:395-405)
+enum { kVariantNoAvg = 0 /* NoAveraging */, kVariantMarginal = 1 /* Marginal */, kVariantNoAvgMarginal = 2 /* NoAveragingMarginal */ };
 struct NoAvgArgs {
-  int S, C, K, nn, B, root;
-  const int *first_child, *next_sib, *taxon_of;
+  int S, C, K, nn, B, root, mode;
+  const int *first_child, *next_sib, *taxon_of, *parent;
   const double* P;        // [C][B][S*S] row-major transition matrices
   const double* N1;       // [B][K][S*S] conditional counts at the branch length itself
+  const double* NC;       // [C][B][K][S*S] conditional counts at r_c t_b (kVariantMarginal)
   const double *pi, *probs;
   const uint32_t* masks;  // compatibility masks of the codes >= S (NULL: every state)
   const uint8_t* aln;

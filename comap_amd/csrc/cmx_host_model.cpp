@@ -547,11 +547,15 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   for (int c = 0; c < C; ++c)
     for (int b = 0; b < B; ++b)
       branch_mats(b, hm->blen[b] * hm->rates[c], &hm->P[((size_t)c * B + b) * S2], &hm->PN[((size_t)c * B + b) * K * S2], false);
-  // N^k(x, y; t_b) at the branch length itself: computeSubstitutionVectorsNoAveraging reads single entries of it
+  // N^k(x, y; t_b) at the branch length itself: computeSubstitutionVectorsNoAveraging reads single entries of it; and at
+  // r_c t_b per class: computeSubstitutionVectorsMarginal weights it with the two marginal posteriors
   hm->N1.assign((size_t)B * K * S2, 0.0);
+  hm->NC.assign((size_t)C * B * K * S2, 0.0);
   {
     Mat P1(S2);
     for (int b = 0; b < B; ++b) branch_mats(b, hm->blen[b], P1.data(), &hm->N1[(size_t)b * K * S2], true);
+    for (int c = 0; c < C; ++c)
+      for (int b = 0; b < B; ++b) branch_mats(b, hm->blen[b] * hm->rates[c], P1.data(), &hm->NC[((size_t)c * B + b) * K * S2], true);
   }
   // ---- device layouts
   // One allocation, per class a block of MC matrices of S*S doubles (the unit the kernel DMAs into LDS):

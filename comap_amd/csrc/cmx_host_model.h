@@ -24,6 +24,7 @@ struct HostModel {
   std::vector<double> P;    // [C][B][S*S] row-major (x -> y)
   std::vector<double> PN;   // [C][B][K][S*S] P o N^k
   std::vector<double> N1;   // [B][K][S*S] N^k at the branch length itself (rate 1): the no-averaging mapping
+  std::vector<double> NC;   // [C][B][K][S*S] N^k at r_c t_b (conditional, not P o N): the marginal mapping (nijt.joint = no)
   std::vector<double> MAT;  // [C][MC][S*S]     device matrices: packed P | packed PN | leaf P^T | leaf PN^T (cmx_host_model.cpp)
   int MC = 0;               // matrices per (device) class block = NI + NI*K + T + K*T
   std::vector<double> eigV, eigVi, eigLam;   // [NM][S*S], [NM][S*S], [NM][S]: right / left eigenvectors and eigenvalues of the generators

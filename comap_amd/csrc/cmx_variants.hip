@@ -1,3 +1,4 @@
+// The non-default mapping variants (nijt.average / nijt.joint, "for benchmarking only" in the reference).  First
 // nijt.average = no, nijt.joint = yes: LegacySubstitutionMappingTools::computeSubstitutionVectorsNoAveraging (call sites
 // CoMap/CoETools.cpp:395-403 for the observed data, CoMap/AnalysisTools.cpp:598-610 inside the null).  "For benchmarking
 // only" says the reference -- but it is the only way it runs nijt = Label with the MI statistic (CoETools.cpp:577-588).
@@ -122,6 +123,70 @@ __global__ __launch_bounds__(256) void noavg_pick_kernel(const NoAvgArgs a) {
     a.counts[((size_t)b * a.K + k) * a.ldc + a.site0 + j] = a.N1[((size_t)b * a.K + k) * S * S + bidx];
 }
 
+// ---- nijt.joint = no (computeSubstitutionVectorsMarginal / ...NoAveragingMarginal, CoETools.cpp:399-405).  Restated in
+// oracle/oracle.c orc_map_sites_marginal (pinned to its definition by tests/test_oracle_marginal.py; parity unpinned against
+// the reference, which ships no output of these variants):
+//   post_n(c, x) = p_c Up_n(c, x) D_n(c, x) / L  at an internal node (DRTreeLikelihoodTools::
+//   getPosteriorProbabilitiesPerStatePerRate: the likelihood re-rooted at the node; Up_root = pi), e(x) p_c / sum e at a leaf;
+//   Marginal:            count(b, k) = sum_c sum_x sum_y post_f(c, x) post_n(c, y) N^k(x, y; r_c t_b)
+//   NoAveragingMarginal: x*(n) = first maximum of sum_c post_n(c, x) (leaf: of e);  count(b, k) = N^k(x*(f), x*(n); t_b)
+// One thread per (site, branch); same global scratch as the NoAveraging kernels above.
+template <int S>
+__global__ __launch_bounds__(256) void marginal_kernel(const NoAvgArgs a) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.nsites) return;
+  const int b = blockIdx.y, nn = a.nn, C = a.C, f = a.parent[b];
+  const size_t ch = a.chunk;
+  const bool leaf = a.first_child[b] < 0;
+  double L = 0.0;
+  for (int c = 0; c < C; ++c) {
+    double s = 0.0;
+    for (int x = 0; x < S; ++x) s += a.pi[x] * a.D[(((size_t)c * nn + a.root) * S + x) * ch + j];
+    L += a.probs[c] * s;
+  }
+  double se = 0.0;
+  if (leaf)
+    for (int x = 0; x < S; ++x) se += a.D[((size_t)b * S + x) * ch + j];   // the leaf vector is the same in every class
+  if (a.mode == kVariantMarginal) {
+    for (int k = 0; k < a.K; ++k) {
+      double v = 0.0;
+      for (int c = 0; c < C; ++c) {
+        const double* Nk = a.NC + (((size_t)c * a.B + b) * a.K + k) * S * S;
+        double pn[S];
+#pragma unroll
+        for (int y = 0; y < S; ++y) {
+          const double d = a.D[(((size_t)c * nn + b) * S + y) * ch + j];
+          pn[y] = leaf ? d * a.probs[c] / se : a.Up[(((size_t)c * nn + b) * S + y) * ch + j] * d * a.probs[c] / L;
+        }
+        for (int x = 0; x < S; ++x) {
+          const double pf = a.Up[(((size_t)c * nn + f) * S + x) * ch + j] * a.D[(((size_t)c * nn + f) * S + x) * ch + j] * a.probs[c] / L;
+          double s = 0.0;
+#pragma unroll
+          for (int y = 0; y < S; ++y) s += Nk[x * S + y] * pn[y];
+          v += pf * s;
+        }
+      }
+      a.counts[((size_t)b * a.K + k) * a.ldc + a.site0 + j] = v;
+    }
+    return;
+  }
+  // marginal ancestral states of the father and of the node: first maximum over the states
+  int xs = 0, ys = 0;
+  double bf = -__builtin_inf(), bn = -__builtin_inf();
+  for (int x = 0; x < S; ++x) {
+    double sf = 0.0, sn = 0.0;
+    for (int c = 0; c < C; ++c) {
+      sf += a.Up[(((size_t)c * nn + f) * S + x) * ch + j] * a.D[(((size_t)c * nn + f) * S + x) * ch + j] * a.probs[c] / L;
+      if (!leaf) sn += a.Up[(((size_t)c * nn + b) * S + x) * ch + j] * a.D[(((size_t)c * nn + b) * S + x) * ch + j] * a.probs[c] / L;
+    }
+    if (leaf) sn = a.D[((size_t)b * S + x) * ch + j];
+    if (sf > bf) { bf = sf; xs = x; }
+    if (sn > bn) { bn = sn; ys = x; }
+  }
+  for (int k = 0; k < a.K; ++k)
+    a.counts[((size_t)b * a.K + k) * a.ldc + a.site0 + j] = a.N1[((size_t)b * a.K + k) * S * S + xs * S + ys];
+}
+
 // computeNormForSite over the (branch-major) counts: sqrt(sum_b (sum_k count)^2), branches in order
 __global__ __launch_bounds__(256) void counts_norm_kernel(const double* __restrict__ counts, size_t ldc, int B, int K, size_t n,
                                                           double* __restrict__ norm) {
@@ -150,11 +215,13 @@ hipError_t launch_map_noavg(NoAvgArgs a, size_t nsites_total, double* scratch, d
     if (a.S == 20) {
       hipLaunchKernelGGL(noavg_inside_kernel<20>, dim3(gx, a.C), dim3(256), 0, stream, a);
       hipLaunchKernelGGL(noavg_outside_kernel<20>, dim3(gx, a.C), dim3(256), 0, stream, a);
-      hipLaunchKernelGGL(noavg_pick_kernel<20>, dim3(gx, a.B), dim3(256), 0, stream, a);
+      if (a.mode == kVariantNoAvg) hipLaunchKernelGGL(noavg_pick_kernel<20>, dim3(gx, a.B), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL(marginal_kernel<20>, dim3(gx, a.B), dim3(256), 0, stream, a);
     } else if (a.S == 4) {
       hipLaunchKernelGGL(noavg_inside_kernel<4>, dim3(gx, a.C), dim3(256), 0, stream, a);
       hipLaunchKernelGGL(noavg_outside_kernel<4>, dim3(gx, a.C), dim3(256), 0, stream, a);
-      hipLaunchKernelGGL(noavg_pick_kernel<4>, dim3(gx, a.B), dim3(256), 0, stream, a);
+      if (a.mode == kVariantNoAvg) hipLaunchKernelGGL(noavg_pick_kernel<4>, dim3(gx, a.B), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL(marginal_kernel<4>, dim3(gx, a.B), dim3(256), 0, stream, a);
     } else {
       return hipErrorInvalidValue;
     }

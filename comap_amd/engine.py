@@ -49,7 +49,8 @@ COUNT_EXPECTED, COUNT_NAIVE = 0, 1
 
 EXPORTS = [
     "cmx_version", "cmx_ctx_create", "cmx_ctx_destroy", "cmx_last_error", "cmx_get_info",
-    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_debug_nuc_program", "cmx_map_sites", "cmx_set_mapping_options", "cmx_map_sites_dev", "cmx_simulate", "cmx_simulate_continuous",
+    "cmx_get_transition_matrices", "cmx_synchronize", "cmx_debug_walk", "cmx_map_sites", "cmx_set_mapping_options", "cmx_map_sites_dev", "cmx_simulate", "cmx_simulate_dev", "cmx_simulate_continuous",
+    "cmx_simulate_continuous_dev", "cmx_null_intra_continuous", "cmx_null_intra_continuous_dev", "cmx_mi_pairs_dev",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_simulate_dev", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev", "cmx_intra_rows_range_dev",
     "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
@@ -181,25 +182,6 @@ def debug_walk(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
                 products=int(stats[2]), leaf_ops=int(stats[3]))
 
 
-def debug_nuc_program(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None, block_capacity=10):
-    """Host-side build + self-check of the nucleotide mapping kernel's program (no GPU): dict(blocks, roots, applies,
-    root_loads, root_stores, inside_records, outside_records, operators); raises CmxError when the check fails."""
-    lib = load_library()
-    keep = [np.ascontiguousarray(parent, dtype=np.int32), _f64(blen), np.ascontiguousarray(leaf_of_taxon, dtype=np.int32),
-            _f64(Q), _f64(pi), _f64(rates), _f64(probs), None if Bk is None else _f64(Bk)]
-    p, bl, lot, Qa, pia, ra, pr, Bka = keep
-    S, C = len(pia), len(ra)
-    K = 1 if Bka is None else Bka.reshape(-1, S, S).shape[0]
-    model = _Model(S, C, K, _vp(Qa), _vp(pia), _vp(ra), _vp(pr), _vp(Bka), 0, 1, _vp(None))
-    tree = _Tree(len(p), _vp(p), _vp(bl), len(lot), _vp(lot))
-    stats = np.zeros(8, dtype=np.uint64)
-    st = lib.cmx_debug_nuc_program(ctypes.byref(model), ctypes.byref(tree), ctypes.c_int(block_capacity), _vp(stats))
-    if st != 0:
-        raise CmxError(st, lib.cmx_last_error(None).decode())
-    names = ("blocks", "roots", "applies", "root_loads", "root_stores", "inside_records", "outside_records", "operators")
-    return {k: int(v) for k, v in zip(names, stats)}
-
-
 def debug_candidate_cursor(norm_windows, analysable, min_sim, norms, max_trials):
     """Host-side run of the candidate cursor (no GPU).  norms: [nbatches, rep_ram].
     -> dict(n2, trials, batches, pseudo_groups=[(group, batch, [sites])])"""
@@ -318,8 +300,8 @@ class Engine:
         return dict(counts=counts, logL=logL, post_rate=pr, rate_class=rc, norm=norm)
 
     def set_mapping_options(self, average=True, joint=True):
-        """nijt.average / nijt.joint (CoETools.cpp:393-406).  (False, True): computeSubstitutionVectorsNoAveraging for every
-        later mapping of this engine (observed data and nulls); joint = False raises (not implemented, see the header)."""
+        """nijt.average / nijt.joint (CoETools.cpp:393-406): which of computeSubstitutionVectors{, NoAveraging, Marginal,
+        NoAveragingMarginal} every later mapping of this engine (observed data and nulls) uses; default (True, True)."""
         self._check(self._lib.cmx_set_mapping_options(self._ctx, int(bool(average)), int(bool(joint))))
 
     def simulate(self, seed, g0, n):
@@ -343,6 +325,20 @@ class Engine:
         """AnalysisTools::getNullDistributionIntraDR with a continuous-rate simulator (simulations.continuous = yes): the
         replicates' alignments come from simulate_continuous (global site index g = ((rep * 2 + h) * rep_ram + j), as
         everywhere), the re-mapping and scoring from the fused null kernel on supplied alignments."""
+        n = (rep_end - rep_begin) * rep_ram
+        stat, pr, nm = np.zeros(n), np.zeros(n), np.zeros(n)
+        rc = np.zeros(n, dtype=np.int32)
+        params = _stat_params(kind, threshold, mean_vectors)
+        # simulator and mapping both on the device, the alignments never leave it (cmx_null_intra_continuous)
+        self._check(self._lib.cmx_null_intra_continuous(self._ctx, int(kind), _vp(params), ctypes.c_uint64(seed), _sz(rep_begin),
+                                                        _sz(rep_end), _sz(rep_ram), ctypes.c_double(gamma_alpha),
+                                                        ctypes.c_double(p_invariant), _vp(stat), _vp(rc), _vp(pr), _vp(nm)))
+        return dict(stat=stat, rcmin=rc, prmin=pr, nmin=nm)
+
+    def null_intra_continuous_via_host(self, kind, seed, rep_begin, rep_end, rep_ram, gamma_alpha, p_invariant=0.0,
+                                       threshold=0.99, mean_vectors=None):
+        """the same null assembled from the two public pieces through host memory (simulate_continuous, then null_intra on
+        supplied alignments): what null_intra_continuous must equal bit for bit"""
         nrep = rep_end - rep_begin
         aln, _ = self.simulate_continuous(seed, rep_begin * 2 * rep_ram, nrep * 2 * rep_ram, gamma_alpha, p_invariant)
         sup = np.ascontiguousarray(aln.reshape(self.T, nrep, 2, rep_ram).transpose(1, 2, 0, 3))
@@ -550,6 +546,19 @@ class Engine:
         self._check(self._lib.cmx_map_sites_dev(self._ctx, _vp(d_aln), _sz(n), _sz(d_aln.stride(0)), _vp(masks),
                                                 _vp(counts), _sz(0 if counts is None else counts.stride(0)), _vp(logL),
                                                 _vp(post_rate), _vp(rate_class), _vp(norm), self._stream()))
+
+    def simulate_dev(self, seed, g0, n, aln, classes=None):
+        """aln: uint8 [T, ld] CUDA tensor (ld >= n)"""
+        self._check(self._lib.cmx_simulate_dev(self._ctx, ctypes.c_uint64(seed), ctypes.c_uint64(g0), _sz(n), _vp(aln),
+                                               _sz(aln.stride(0)), _vp(classes), self._stream()))
+
+    def mi_pairs_dev(self, d_aln1, idx1, idx2, mi, hjoint, d_aln2=None, nalpha=20, masks=None):
+        """MI / joint entropy of the listed column pairs, everything on the device (int64 index tensors, float64 outputs)"""
+        self._check(self._lib.cmx_mi_pairs_dev(self._ctx, int(nalpha), int(d_aln1.shape[0]), _vp(masks), _vp(d_aln1),
+                                               _sz(d_aln1.shape[1]), _sz(d_aln1.stride(0)), _vp(d_aln2),
+                                               _sz(0 if d_aln2 is None else d_aln2.shape[1]),
+                                               _sz(0 if d_aln2 is None else d_aln2.stride(0)), _vp(idx1), _vp(idx2),
+                                               _sz(idx1.numel()), _vp(mi), _vp(hjoint), self._stream()))
 
     def pair_stats_dev(self, kind, counts1, out, counts2=None, threshold=0.99, mean_vectors=None):
         params = _stat_params(kind, threshold, mean_vectors)

@@ -37,6 +37,28 @@ def parametric_null(engine, seed, nrep_cpu=10, nrep_ram=100, nalpha=20, with_nor
     2 * nrep_cpu * nrep_ram sites, one MI call over the nrep_cpu * nrep_ram (j, j) column pairs and -- with_norms, Mica's
     `use_model` case, Mica.cpp:505-530 -- one mapping of all simulated sites for their norms.
     -> dict(mi, hjoint[, nmin]) in replicate order (the rows of the null output file, Mica.cpp:411-415)."""
+    import torch
+    n = nrep_cpu * nrep_ram
+    dev = torch.device("cuda", engine.device)
+    # simulator -> MI of the (j, j) pairs -> (norms) without leaving the device (cmx_simulate_dev, cmx_mi_pairs_dev,
+    # cmx_map_sites_dev); only the null's columns come back
+    d_aln = torch.empty((engine.T, 2 * n), dtype=torch.uint8, device=dev)
+    engine.simulate_dev(seed, 0, 2 * n, d_aln)
+    q = torch.arange(n, dtype=torch.int64, device=dev)
+    rep, j = q // nrep_ram, q % nrep_ram
+    i1, i2 = (rep * 2) * nrep_ram + j, (rep * 2 + 1) * nrep_ram + j
+    mi, hj = torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
+    engine.mi_pairs_dev(d_aln, i1, i2, mi, hj, nalpha=nalpha)
+    out = dict(mi=mi.cpu().numpy(), hjoint=hj.cpu().numpy())
+    if with_norms:
+        norm = torch.empty(2 * n, dtype=torch.float64, device=dev)
+        engine.map_sites_dev(d_aln, norm=norm)
+        out["nmin"] = torch.minimum(norm[i1], norm[i2]).cpu().numpy()
+    return out
+
+
+def parametric_null_via_host(engine, seed, nrep_cpu=10, nrep_ram=100, nalpha=20, with_norms=False):
+    """the same null through host memory (simulate -> numpy -> mi_pairs): what parametric_null must equal bit for bit"""
     n = nrep_cpu * nrep_ram
     aln, _ = engine.simulate(seed, 0, 2 * n)
     rep, j = np.divmod(np.arange(n, dtype=np.int64), nrep_ram)

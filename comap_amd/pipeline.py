@@ -70,16 +70,21 @@ class IntraAnalysis:
                               rcmin=torch.empty(n, dtype=torch.int32, device=dev))
         return self._null
 
-    def null_distribution(self, seed, rep_begin, rep_end, rep_ram, supplied=None, map_events=None):
+    def null_distribution(self, seed, rep_begin, rep_end, rep_ram, supplied=None, map_events=None, sim_events=None):
         """AnalysisTools::getNullDistributionIntraDR for replicates [rep_begin, rep_end).  map_events = (start, end) CUDA
         events: the alignments are simulated into a buffer of this object first (cmx_null_simulate_dev) and the events
-        bracket the mapping launch alone -- what bench.py's roofline is about; otherwise one call does both."""
+        bracket the mapping launch alone -- what bench.py's roofline is about (sim_events bracket the simulator, so that
+        the two can be read side by side); otherwise one call does both."""
         b = self.null_buffers((rep_end - rep_begin) * rep_ram)
         if map_events is not None and supplied is None:
             nbytes = (rep_end - rep_begin) * 2 * self.eng.T * rep_ram
             if self._null_aln is None or self._null_aln.numel() < nbytes:
                 self._null_aln = torch.empty(nbytes, dtype=torch.uint8, device=self.aln.device)
+            if sim_events is not None:
+                sim_events[0].record()
             self.eng.null_simulate_dev(seed, rep_begin, rep_end, rep_ram, self._null_aln)
+            if sim_events is not None:
+                sim_events[1].record()
             supplied = self._null_aln
         if map_events is not None:
             map_events[0].record()

@@ -120,12 +120,6 @@ cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info);
 /* transition probabilities the engine uses, for inspection/tests: P[C][B][S][S] (row x -> column y) */
 cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P);
 cmx_status cmx_synchronize(cmx_ctx* ctx);
-/* host-side only (no GPU needed), 4-state models: cut the tree into blocks of at most `block_capacity` internal nodes,
- * write the visit records of the nucleotide mapping kernel (comap_amd/csrc/cmx_nuc.h) and run the engine's self-check
- * (the program executed numerically on the host against a direct pruning computation).  stats (may be NULL) [8]: blocks,
- * block roots kept in HBM, 4x4 operator applications per class pass, root-message loads, root-message stores, inside
- * records, outside records, operators per class. */
-cmx_status cmx_debug_nuc_program(const cmx_model* model, const cmx_tree* tree, int block_capacity, uint64_t* stats);
 /* host-side only (no GPU needed): compile the tree into what the mapping kernel's walk of a rate-class pass reads
  * (comap_amd/csrc/cmx_walk.h) and copy it out for inspection/tests.  nrec: [nvisited][16] node records; ldsched:
  * workspace loads; msched: operator uses, pairs (matrix index in a class block, taxon or -1), in program order.  The walk
@@ -145,19 +139,24 @@ cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t
 cmx_status cmx_map_sites_dev(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
                              double* d_counts /*[B*K][ldc]*/, size_t ldc, double* d_logL, double* d_post_rate,
                              int32_t* d_rate_class, double* d_norm, void* stream);
-/* nijt.average / nijt.joint (CoMap/CoETools.cpp:393-406, CoMap/AnalysisTools.cpp:598-610: which of
+/* nijt.average / nijt.joint (CoMap/CoETools.cpp:393-406, CoMap/AnalysisTools.cpp:598-633: which of
  * LegacySubstitutionMappingTools::computeSubstitutionVectors{, NoAveraging, Marginal, NoAveragingMarginal} maps the
  * sites; "for benchmarking only" in the reference, but nijt = Label with the MI statistic requires average = no,
- * CoETools.cpp:577-588).  Default (1, 1).  (0, 1): every later cmx_map_sites* / cmx_null_* / clustering / candidate call
- * of this context returns the counts and norms of computeSubstitutionVectorsNoAveraging -- the conditional count
- * N^k(x*, y*; t_b) of the most probable pair of ancestral states of each branch -- through plain (slow) kernels; the
- * null then runs unfused.  joint = 0: CMX_ERR_UNSUPPORTED.  Parity unpinned: bpp-phyl is not in the reference tree
- * (DESIGN.md 4.5). */
+ * CoETools.cpp:577-588).  Default (1, 1).  Any other combination: every later cmx_map_sites* / cmx_null_* / clustering /
+ * candidate call of this context returns the counts and norms of that variant -- (0, 1): the conditional count
+ * N^k(x*, y*; t_b) of the most probable PAIR of ancestral states of each branch; (1, 0): the conditional counts weighted
+ * with the product of the two ends' marginal posteriors per state and rate; (0, 0): N^k at the two ends' marginal
+ * ancestral states -- through plain (slow) kernels; the null then runs unfused.  Likelihood, posterior rate and rate
+ * class do not depend on the variant.  Parity unpinned: bpp-phyl is not in the reference tree. */
 cmx_status cmx_set_mapping_options(cmx_ctx* ctx, int average, int joint);
 
 /* ---- sequence simulator (NonHomogeneousSequenceSimulator::simulate, AnalysisTools.cpp:591): counter-based RNG,
  * global site indices g0 .. g0+n-1 (see DESIGN.md "RNG").  aln_out: [T][n]. */
 cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln_out, int32_t* classes_out);
+/* the same into device memory: d_aln [T][ld] (ld >= n), d_classes [n] or NULL -- what Mica's parametric bootstrap feeds to
+ * cmx_mi_pairs_dev without leaving the device */
+cmx_status cmx_simulate_dev(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld, int32_t* d_classes,
+                            void* stream);
 /* simulations.continuous = yes (CoMap.cpp:146, 213: NonHomogeneousSequenceSimulator::enableContinuousRates): every site
  * draws its rate from the continuous Gamma(alpha, beta = alpha) distribution -- with probability p_invariant the rate is 0
  * and the Gamma draw is divided by 1 - p_invariant, as Invariant(Gamma) does -- and every branch uses exp(Q r t) of that
@@ -166,6 +165,8 @@ cmx_status cmx_simulate(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, uint
  * simulated sites still uses the discrete classes, as in the reference). */
 cmx_status cmx_simulate_continuous(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, double gamma_alpha, double p_invariant,
                                    uint8_t* aln_out, double* rates_out);
+cmx_status cmx_simulate_continuous_dev(cmx_ctx* ctx, uint64_t seed, uint64_t g0, size_t n, double gamma_alpha, double p_invariant,
+                                       uint8_t* d_aln, size_t ld, double* d_rates, void* stream);
 
 /* ---- all-pairs statistic.  counts2 == NULL: intra (CoETools.cpp:672-692), out[i*N1+j] filled for j > i, NaN
  * elsewhere.  Otherwise inter (CoETools.cpp:786-810), out[i*N2+j].  params: for CMX_STAT_DISCRETE_MI params[0] is
@@ -195,6 +196,16 @@ cmx_status cmx_null_intra(cmx_ctx* ctx, int kind, const double* params, uint64_t
 cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin,
                               size_t rep_end, size_t rep_ram, const uint8_t* d_supplied, double* d_stat,
                               int32_t* d_rcmin, double* d_prmin, double* d_nmin, void* stream);
+
+/* the same null under simulations.continuous = yes (CoMap.cpp:146, 213): the two batches of every replicate are drawn by
+ * the continuous-rate simulator on the device and mapped there (cmx_simulate_continuous_dev + cmx_null_intra_dev with
+ * supplied alignments in one call; results equal that sequence bit for bit) */
+cmx_status cmx_null_intra_continuous(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin, size_t rep_end,
+                                     size_t rep_ram, double gamma_alpha, double p_invariant, double* stat, int32_t* rcmin,
+                                     double* prmin, double* nmin);
+cmx_status cmx_null_intra_continuous_dev(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin, size_t rep_end,
+                                         size_t rep_ram, double gamma_alpha, double p_invariant, double* d_stat, int32_t* d_rcmin,
+                                         double* d_prmin, double* d_nmin, void* stream);
 
 /* Inter-gene null: AnalysisTools::getNullDistributionInterDR (CoMap/AnalysisTools.cpp:662-735, driver
  * CoETools::computeInterNullDistribution CoETools.cpp:873-897).  Per replicate rep_ram sites are simulated and mapped
@@ -275,6 +286,10 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
 cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks, const uint8_t* aln1,
                         size_t n1, const uint8_t* aln2, size_t n2, const int64_t* idx1, const int64_t* idx2,
                         size_t npairs, double* mi, double* hjoint);
+/* device pointers throughout (alignments [T][ld], indices, outputs); d_masks: 256 masks or NULL; indices are not checked */
+cmx_status cmx_mi_pairs_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
+                            const uint8_t* d_aln2, size_t n2, size_t ld2, const int64_t* d_idx1, const int64_t* d_idx2, size_t npairs,
+                            double* d_mi, double* d_hjoint, void* stream);
 
 /* ---- Mica, after the all-pairs matrix (intra, n columns, upper triangle j > i is what is read):
  * cmx_mica_average_mi: averageMI[i] = sum_{j != i} MI(i,j) / (n-1) and fullAverageMI = mean(averageMI)

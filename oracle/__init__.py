@@ -109,6 +109,25 @@ def map_sites_noavg(m, aln, masks=None):
     return dict(counts=counts, norm=norm, argmax=arg, margin=margin)
 
 
+def map_sites_marginal(m, aln, average, masks=None, want_post=False):
+    """nijt.joint = no (computeSubstitutionVectorsMarginal / ...NoAveragingMarginal; oracle.c orc_map_sites_marginal) ->
+    counts [N, B, K], norm [N], anc [N, nn] marginal ancestral states, margin [N, nn], post [N, nn, C, S] on request"""
+    aln = np.ascontiguousarray(aln, dtype=np.uint8)
+    T, N = aln.shape
+    assert T == m.T
+    masks = default_masks(m.S) if masks is None else np.ascontiguousarray(masks, dtype=np.uint32)
+    counts = np.zeros((N, m.B, m.K))
+    norm, margin = np.zeros(N), np.zeros((N, m.nn))
+    anc = np.zeros((N, m.nn), dtype=np.int32)
+    post = np.zeros((N, m.nn, m.C, m.S)) if want_post else None
+    D, I, U8, U32 = ctypes.c_double, ctypes.c_int, ctypes.c_uint8, ctypes.c_uint32
+    lib().orc_map_sites_marginal(m.nn, _p(m.parent, I), _p(m.blen, D), m.T, _p(m.lot, I), ctypes.c_long(N), _p(aln, U8),
+                                 _p(masks, U32), m.S, m.C, m.K, _p(m.Q, D), _p(m.pi, D), _p(m.rates, D), _p(m.probs, D),
+                                 _p(m.Bk, D), m.method, m.nonneg, _p(m.naive_W, D), int(bool(average)), _p(counts, D),
+                                 _p(norm, D), _p(post, D) if want_post else None, _p(anc, I), _p(margin, D))
+    return dict(counts=counts, norm=norm, anc=anc, margin=margin, post=post)
+
+
 def simulate(m, seed, g0, n):
     aln = np.zeros((m.T, n), dtype=np.uint8)
     cls = np.zeros(n, dtype=np.int32)

@@ -454,6 +454,186 @@ int orc_map_sites_noavg(int nn, const int* parent, const double* blen, int T, co
   return 0;
 }
 
+/* nijt.joint = no: LegacySubstitutionMappingTools::computeSubstitutionVectorsMarginal (average = yes) and
+ * computeSubstitutionVectorsNoAveragingMarginal (average = no) -- CoMap/CoETools.cpp:399-405,
+ * CoMap/AnalysisTools.cpp:598-610, 620-633; "for benchmarking only" in the reference.  bpp-phyl (Bio++ 3.0 legacy
+ * classes) is not part of the reference tree: PARITY UNPINNED, restated from the published source as far as it is
+ * remembered, and pinned to its definition by brute force in tests/test_oracle_marginal.py:
+ *   DRTreeLikelihoodTools::getPosteriorProbabilitiesPerStatePerRate(drtl, node)[i][c][x]
+ *     internal node: p_c L_node(i, c, x) / L_i with L_node(i, c, x) = P(data, state x at the node | class c) -- the
+ *       likelihood re-rooted at the node, root frequencies included (computeLikelihoodAtNode); in the arrays of
+ *       orc_map_sites: Up_node(c, x) D_node(c, x) (Up_root = pi).  This IS the joint posterior of (class, state).
+ *     leaf: e(x) p_c / sum_s e(s), e the leaf's 0/1 compatibility vector -- the PRIOR class weight, as the remembered
+ *       source has it (`larray[x] * rcProbs[c] / sumprobs`), not the posterior one.
+ *   average = yes:  n(b, i, k) = sum_c sum_x sum_y post_father(i,c,x) post_node(i,c,y) N^k(x, y; r_c t_b)
+ *     (the product of the two marginal posteriors in place of the joint one; note the class weight enters twice).
+ *   average = no:   MarginalAncestralStateReconstruction: x*(node) = first maximum over x of sum_c p_c L_node(i,c,x)
+ *     (leaf: first maximum of e, i.e. the observed state, state 0 for an unknown); n(b, i, k) = N^k(x*(father),
+ *     x*(node); t_b) at the branch length itself.
+ * post (optional): [N][nn][C][S]; anc (optional): [N][nn]; margin (optional, [N][nn]): (best - second) / best of the
+ * marginal state posterior -- where it is tiny another implementation may pick the other state. */
+int orc_map_sites_marginal(int nn, const int* parent, const double* blen, int T, const int* leaf_of_taxon, long N,
+                           const uint8_t* aln, const uint32_t* masks, int S, int C, int K, const double* Q, const double* pi,
+                           const double* rates, const double* probs, const double* Bk, int method, int nonneg,
+                           const double* naiveW, int average, double* counts, double* norm, double* post, int* anc,
+                           double* margin) {
+  int B = nn - 1, root = nn - 1, S2 = S * S;
+  int *first, *next;
+  child_lists(nn, parent, &first, &next);
+  int* taxon_of = (int*)malloc(sizeof(int) * nn);
+  for (int i = 0; i < nn; i++) taxon_of[i] = -1;
+  for (int t = 0; t < T; t++) taxon_of[leaf_of_taxon[t]] = t;
+  double* lam = (double*)malloc(sizeof(double) * (S + 2 * S2));
+  double *V = lam + S, *Vinv = V + S2;
+  orc_eigen_reversible(S, Q, pi, lam, V, Vinv);
+  double* P = (double*)malloc(sizeof(double) * (size_t)B * C * S2);
+  /* conditional counts N^k(x, y; t): per class at r_c t_b (slots 0 .. C-1) and at t_b itself (slot C) */
+  double* NC = (double*)malloc(sizeof(double) * (size_t)B * (C + 1) * K * S2);
+  double* Jtmp = (double*)malloc(sizeof(double) * S2 * 2);
+  double* Pt = Jtmp + S2;
+  for (int b = 0; b < B; b++)
+    for (int c = 0; c <= C; c++) {
+      double t = blen[b] * (c < C ? rates[c] : 1.0);
+      orc_transition(S, lam, V, Vinv, t, Pt);
+      if (c < C) memcpy(P + ((size_t)b * C + c) * S2, Pt, sizeof(double) * S2);
+      for (int k = 0; k < K; k++) {
+        double* Nk = NC + (((size_t)b * (C + 1) + c) * K + k) * S2;
+        if (method == 2) {
+          for (int i = 0; i < S2; i++) Nk[i] = ((i / S) == (i % S)) ? 0.0 : (naiveW ? naiveW[i] : 1.0);
+        } else {
+          if (method == 0) orc_count_unif(S, Q, Bk + (size_t)k * S2, t, Jtmp);
+          else orc_count_decomp(S, lam, V, Vinv, Bk + (size_t)k * S2, t, Jtmp);
+          for (int i = 0; i < S2; i++) {
+            double nxy = Jtmp[i] / Pt[i];
+            if (isnan(nxy) || isinf(nxy)) nxy = 0;
+            if (nonneg && nxy < 0) nxy = 0;
+            Nk[i] = nxy;
+          }
+        }
+      }
+    }
+  size_t vsz = (size_t)nn * C * S;
+  double* D = (double*)malloc(sizeof(double) * vsz * 4);
+  double *M = D + vsz, *Up = M + vsz, *PP = Up + vsz;   /* PP: posterior per node, class, state */
+  double* U = (double*)malloc(sizeof(double) * S);
+  int* st = (int*)malloc(sizeof(int) * nn);
+  for (long i = 0; i < N; i++) {
+    for (int n = 0; n < nn; n++)
+      for (int c = 0; c < C; c++) {
+        double* Dn = D + ((size_t)n * C + c) * S;
+        if (first[n] < 0) {
+          uint8_t code = aln[(size_t)taxon_of[n] * N + i];
+          uint32_t m = code < S ? (1u << code) : masks[code];
+          for (int x = 0; x < S; x++) Dn[x] = (m >> x) & 1u;
+        } else {
+          for (int x = 0; x < S; x++) Dn[x] = 1.0;
+          for (int e = first[n]; e >= 0; e = next[e]) {
+            const double* Me = M + ((size_t)e * C + c) * S;
+            for (int x = 0; x < S; x++) Dn[x] *= Me[x];
+          }
+        }
+        if (n != root) {
+          const double* Pn = P + ((size_t)n * C + c) * S2;
+          double* Mn = M + ((size_t)n * C + c) * S;
+          for (int x = 0; x < S; x++) {
+            double s = 0;
+            for (int z = 0; z < S; z++) s += Pn[x * S + z] * Dn[z];
+            Mn[x] = s;
+          }
+        }
+      }
+    double L = 0;
+    for (int c = 0; c < C; c++) {
+      const double* Dr = D + ((size_t)root * C + c) * S;
+      double s = 0;
+      for (int x = 0; x < S; x++) s += pi[x] * Dr[x];
+      L += probs[c] * s;
+    }
+    for (int c = 0; c < C; c++)
+      for (int x = 0; x < S; x++) Up[((size_t)root * C + c) * S + x] = pi[x];
+    for (int f = nn - 1; f >= 0; f--) {
+      if (first[f] < 0) continue;
+      for (int n = first[f]; n >= 0; n = next[n]) {
+        if (first[n] < 0) continue;
+        for (int c = 0; c < C; c++) {
+          const double* Upf = Up + ((size_t)f * C + c) * S;
+          for (int x = 0; x < S; x++) U[x] = Upf[x];
+          for (int m = first[f]; m >= 0; m = next[m])
+            if (m != n) {
+              const double* Mm = M + ((size_t)m * C + c) * S;
+              for (int x = 0; x < S; x++) U[x] *= Mm[x];
+            }
+          const double* Pn = P + ((size_t)n * C + c) * S2;
+          double* Upn = Up + ((size_t)n * C + c) * S;
+          for (int z = 0; z < S; z++) {
+            double s = 0;
+            for (int x = 0; x < S; x++) s += Pn[x * S + z] * U[x];
+            Upn[z] = s;
+          }
+        }
+      }
+    }
+    /* posteriors per state per rate, marginal ancestral states */
+    for (int n = 0; n < nn; n++) {
+      double bestv = -INFINITY, second = -INFINITY;
+      int best = 0;
+      if (first[n] < 0) {
+        const double* e = D + ((size_t)n * C) * S;
+        double se = 0;
+        for (int x = 0; x < S; x++) se += e[x];
+        for (int c = 0; c < C; c++)
+          for (int x = 0; x < S; x++) PP[((size_t)n * C + c) * S + x] = e[x] * probs[c] / se;
+        for (int x = 0; x < S; x++) {
+          if (e[x] > bestv) { second = bestv; bestv = e[x]; best = x; }
+          else if (e[x] > second) second = e[x];
+        }
+      } else {
+        for (int c = 0; c < C; c++)
+          for (int x = 0; x < S; x++)
+            PP[((size_t)n * C + c) * S + x] = Up[((size_t)n * C + c) * S + x] * D[((size_t)n * C + c) * S + x] * probs[c] / L;
+        for (int x = 0; x < S; x++) {
+          double s = 0;
+          for (int c = 0; c < C; c++) s += PP[((size_t)n * C + c) * S + x];
+          if (s > bestv) { second = bestv; bestv = s; best = x; }
+          else if (s > second) second = s;
+        }
+      }
+      st[n] = best;
+      if (anc) anc[(size_t)i * nn + n] = best;
+      if (margin) margin[(size_t)i * nn + n] = bestv > 0 ? (bestv - second) / bestv : 0.0;
+    }
+    if (post) memcpy(post + (size_t)i * vsz, PP, sizeof(double) * vsz);
+    double* ci = counts + (size_t)i * B * K;
+    double nrm = 0;
+    for (int b = 0; b < B; b++) {
+      int f = parent[b];
+      double tot = 0;
+      for (int k = 0; k < K; k++) {
+        double v = 0;
+        if (average) {
+          for (int c = 0; c < C; c++) {
+            const double* Nk = NC + (((size_t)b * (C + 1) + c) * K + k) * S2;
+            const double *pf = PP + ((size_t)f * C + c) * S, *pn = PP + ((size_t)b * C + c) * S;
+            for (int x = 0; x < S; x++) {
+              double s = 0;
+              for (int y = 0; y < S; y++) s += Nk[x * S + y] * pn[y];
+              v += pf[x] * s;
+            }
+          }
+        } else {
+          v = NC[(((size_t)b * (C + 1) + C) * K + k) * S2 + st[f] * S + st[b]];
+        }
+        ci[(size_t)b * K + k] = v;
+        tot += v;
+      }
+      nrm += tot * tot;
+    }
+    norm[i] = sqrt(nrm);
+  }
+  free(D); free(U); free(st); free(P); free(NC); free(Jtmp); free(lam); free(taxon_of); free(first); free(next);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ simulator (A.8; RNG scheme is this build's)
  * Bio++ draws from a global, time-seeded generator, so simulated alignments are not reproducible across
  * implementations; the product and this oracle share a counter-based scheme instead (Philox2x32-10, Random123):

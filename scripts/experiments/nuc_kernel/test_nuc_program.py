@@ -1,9 +1,10 @@
 """Host logic without a GPU: the program of the nucleotide mapping kernel (comap_amd/csrc/cmx_nuc.h) -- the tree cut into
-blocks of at most NB internal nodes, inside / outside visit records, operators -- is built and self-checked by
-cmx_debug_nuc_program for many tree shapes and block capacities.  The self-check (verify_nuc_program) executes the
-program in plain doubles exactly as the device does (block slots, block-root messages through "HBM", count rows
-accumulated over the rate classes) for a site with an unknown symbol in it and compares likelihood and every count with
-a direct pruning computation on the original (not binarised) tree."""
+blocks of at most NB internal nodes, one linear stream of visit packets, operators, leaf tables -- is built and
+self-checked by cmx_debug_nuc_program for many tree shapes and block capacities.  The self-check (verify_nuc_program)
+executes the stream in plain doubles exactly as the device does (block slots, block-root messages through "HBM", count
+rows accumulated over the rate classes, leaf masks read a block ahead, and every read the device issues one packet
+ahead DONE one packet ahead) for a site with unknown and ambiguous symbols in it and compares likelihood and every count
+with a direct pruning computation on the original (not binarised) tree."""
 import numpy as np
 import pytest
 
@@ -17,13 +18,15 @@ def _model(ncat=4):
 
 
 @pytest.mark.parametrize("ntaxa", [3, 4, 5, 9, 33, 64, 256, 320])
-@pytest.mark.parametrize("nb", [2, 3, 6, 10, 16])
+@pytest.mark.parametrize("nb", [2, 3, 6, 10, 13])
 def test_binary_trees(ntaxa, nb):
     Q, pi, rates, probs = _model()
     parent, blen, lot = sy.random_tree(ntaxa, 2000 + ntaxa)
     d = engine.debug_nuc_program(parent, blen, lot, Q, pi, rates, probs, block_capacity=nb)
     ninternal = len(parent) - ntaxa + 1          # + the pseudo node that splits the trifurcating root
-    assert d["inside_records"] == ninternal == d["outside_records"]
+    # packets: 4 classes x (phase 1: every node; phase 2: recomputation of all but the block roots + outside visits) and
+    # one leaf list per block and phase (the root block's masks survive from phase 1 to phase 2)
+    assert d["packets"] == 4 * (3 * ninternal - d["blocks"]) + 2 * d["blocks"] - 1
     assert d["blocks"] == d["roots"] + 1 and d["blocks"] >= -(-ninternal // nb)
     # greedy bottom-up cut: blocks are at least about half full on these trees
     assert d["blocks"] <= max(1, 2 * -(-ninternal // nb) + 1)
@@ -72,7 +75,7 @@ def test_caterpillar_and_star():
     # star tree: a chain of pseudo nodes under the root, no internal operator at all
     parent = np.array([n] * n + [-1], dtype=np.int32)
     d = engine.debug_nuc_program(parent, np.full(n + 1, 0.1), np.arange(n, dtype=np.int32), Q, pi, rates, probs, block_capacity=10)
-    assert d["inside_records"] == n - 1
+    assert d["applies"] == 0 and d["leaf_gathers"] > 3 * n
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -91,4 +94,4 @@ def test_rejects_protein_models_and_bad_capacity():
         engine.debug_nuc_program(parent, blen, lot, m["Q"], m["pi"], m["rates"], m["probs"])
     Q, pi, rates, probs = _model()
     with pytest.raises(engine.CmxError):
-        engine.debug_nuc_program(parent, blen, lot, Q, pi, rates, probs, block_capacity=1)
+        engine.debug_nuc_program(parent, blen, lot, Q, pi, rates, probs, block_capacity=14)

@@ -795,8 +795,85 @@ def test_noavg_mapping_matches_oracle(S, ntaxa, nsites, ncat):
     # back to the default: the averaged mapping again
     eng.set_mapping_options(True, True)
     rel_close(eng.map_sites(case["aln"])["counts"], avg["counts"], 1e-6, 1e-300)
-    with pytest.raises(engine.CmxError, match="joint"):
-        eng.set_mapping_options(True, False)
+
+
+@pytest.mark.parametrize("S,ntaxa,nsites,ncat", [(20, 9, 70, 4), (4, 12, 90, 4), (4, 6, 40, 2)])
+def test_marginal_mappings_match_oracle(S, ntaxa, nsites, ncat):
+    """nijt.joint = no (computeSubstitutionVectorsMarginal / ...NoAveragingMarginal, CoETools.cpp:399-405): the product
+    of the two ends' posteriors per state and rate weights N(x, y; r_c t_b); or N(x*, y*; t_b) at the two ends' marginal
+    ancestral states.  The oracle's restatement is pinned to those definitions by brute force
+    (tests/test_oracle_marginal.py); parity against the reference itself is unpinned."""
+    case = make_case(ntaxa, nsites, S, 400 + S, ncat=ncat)
+    case["aln"][2, ::7] = S                                   # some unknowns at a leaf
+    om = _omodel(case)
+    avg = oracle.map_sites(om, case["aln"])
+    eng = _engine(case)
+    # average = yes, joint = no
+    eng.set_mapping_options(average=True, joint=False)
+    g, o = eng.map_sites(case["aln"]), oracle.map_sites_marginal(om, case["aln"], True)
+    rel_close(g["counts"], o["counts"], 1e-6, 1e-14)
+    rel_close(g["norm"], o["norm"], 1e-6, 1e-14)
+    rel_close(g["logL"], avg["logL"], 1e-9)
+    assert np.array_equal(g["rate_class"], avg["rate_class"])
+    # average = no, joint = no: entries of N(t_b) at the marginal ancestral states; a state decided by less than 1e-9
+    # relative may fall the other way
+    eng.set_mapping_options(False, False)
+    g0, o0 = eng.map_sites(case["aln"]), oracle.map_sites_marginal(om, case["aln"], False)
+    parent = np.asarray(case["parent"])
+    clear = (o0["margin"][:, :-1] > 1e-9) & (o0["margin"][:, parent[:-1]] > 1e-9)     # node and father both clear
+    assert clear.mean() > 0.97
+    assert np.allclose(g0["counts"][clear], o0["counts"][clear], rtol=1e-6, atol=1e-12)
+    # the null follows the option: simulate -> map (variant) -> score
+    eng.set_mapping_options(True, False)
+    nl = eng.null_intra(engine.STAT_CORRELATION, 31, 0, 2, 24)
+    for r in range(2):
+        a0, _ = eng.simulate(31, (r * 2 + 0) * 24, 24)
+        a1, _ = eng.simulate(31, (r * 2 + 1) * 24, 24)
+        m0, m1 = eng.map_sites(a0), eng.map_sites(a1)
+        st = np.array([oracle.stat_pair(0, m0["counts"][j], m1["counts"][j]) for j in range(24)])
+        rel_close(nl["stat"][r * 24:(r + 1) * 24], st, 1e-9, 1e-12)
+    eng.set_mapping_options(True, True)
+    rel_close(eng.map_sites(case["aln"])["counts"], avg["counts"], 1e-6, 1e-300)
+
+
+def test_variant_mapping_on_a_side_stream_beside_the_null():
+    """with nijt.average = no the observed mapping (public entry point, side stream) and the null (engine's own
+    pipeline, main stream) may run at once -- each keeps its own scratch -- and give what they give one after the other"""
+    import torch
+    case = make_case(10, 300, 20, 55)
+    eng = _engine(case)
+    eng.set_mapping_options(False, True)
+    dev = torch.device("cuda:0")
+    T, n = case["aln"].shape
+    BK = eng.B * eng.K
+    d_aln = torch.from_numpy(case["aln"]).to(dev)
+    ram, nrep = 200, 3
+
+    def run(overlap):
+        counts = torch.zeros(BK, n, dtype=torch.float64, device=dev)
+        norm = torch.zeros(n, dtype=torch.float64, device=dev)
+        stat = torch.zeros(nrep * ram, dtype=torch.float64, device=dev)
+        nmin = torch.zeros(nrep * ram, dtype=torch.float64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        if overlap:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                eng.map_sites_dev(d_aln, counts=counts, norm=norm)
+            eng.null_intra_dev(engine.STAT_CORRELATION, 9, 0, nrep, ram, stat, nmin=nmin)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            eng.map_sites_dev(d_aln, counts=counts, norm=norm)
+            torch.cuda.synchronize()
+            eng.null_intra_dev(engine.STAT_CORRELATION, 9, 0, nrep, ram, stat, nmin=nmin)
+        torch.cuda.synchronize()
+        return counts.cpu().numpy(), norm.cpu().numpy(), stat.cpu().numpy(), nmin.cpu().numpy()
+
+    seq = run(False)
+    for _ in range(3):
+        ovl = run(True)
+        for a, b in zip(seq, ovl):
+            assert np.array_equal(a, b, equal_nan=True)
 
 
 def test_noavg_null_is_simulate_map_score():
@@ -878,3 +955,21 @@ def test_null_simulator_kernels_and_passes_agree_with_the_plain_simulator(tmp_pa
         subprocess.check_call([sys.executable, "-c", code, str(f)], env=env, cwd=ROOT)
         outs.append(np.load(f))
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
+
+
+def test_device_resident_handovers_equal_the_host_paths():
+    """the continuous-rate null (simulator -> mapping) and Mica's parametric bootstrap (simulator -> MI of
+    the (j, j) pairs -> norms) no longer cross PCIe between their stages; same bits as the paths through host memory"""
+    from comap_amd import mica
+    case = make_case(9, 10, 20, 41)
+    eng = _engine(case)
+    a = eng.null_intra_continuous(engine.STAT_CORRELATION, 5, 2, 5, 64, 0.5, 0.1)
+    b = eng.null_intra_continuous_via_host(engine.STAT_CORRELATION, 5, 2, 5, 64, 0.5, 0.1)
+    for k in ("stat", "nmin", "prmin", "rcmin"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    for norms in (False, True):
+        p = mica.parametric_null(eng, seed=77, nrep_cpu=3, nrep_ram=50, with_norms=norms)
+        q = mica.parametric_null_via_host(eng, seed=77, nrep_cpu=3, nrep_ram=50, with_norms=norms)
+        assert p.keys() == q.keys()
+        for k in p:
+            assert np.array_equal(p[k], q[k]), k
