@@ -369,8 +369,9 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
   if (nblocks * (size_t)ctx->hm.dC <= obs_waves && ctx->hm.dC > 1) {
     // small alignment: one (site block, class) per wave, classes summed by a second kernel (same arithmetic order)
     const size_t ntasks = nblocks * (size_t)ctx->hm.dC, BK = (size_t)ctx->hm.B * ctx->hm.K;
-    if ((s = scratch(ctx, "split_part", sizeof(double) * ntasks * BK * ks, (void**)&a.split_part)) != CMX_OK) return s;
-    if ((s = scratch(ctx, "split_lc", sizeof(double) * 4 * ntasks * ks, (void**)&a.split_lc)) != CMX_OK) return s;
+    // (per caller, like the workspaces: the public observed mapping and the engine's own pipelines may overlap on two streams)
+    if ((s = scratch(ctx, full_grid ? "split_part_null" : "split_part_obs", sizeof(double) * ntasks * BK * ks, (void**)&a.split_part)) != CMX_OK) return s;
+    if ((s = scratch(ctx, full_grid ? "split_lc_null" : "split_lc_obs", sizeof(double) * 4 * ntasks * ks, (void**)&a.split_lc)) != CMX_OK) return s;
     const int grid = (int)((ntasks + kWavesPerBlock - 1) / kWavesPerBlock);
     HIP_TRY(ctx, launch_map(a, kModeObservedSplit, grid, (hipStream_t)stream));
     HIP_TRY(ctx, launch_map_finalize(a, (hipStream_t)stream));
@@ -872,7 +873,9 @@ static cmx_status null_unfused_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const
     uint8_t *d_aln, *d_st;
     int32_t* d_cls;
     if ((s = scratch(ctx1, (tag + "_aln").c_str(), (size_t)c->hm.T * n, (void**)&d_aln)) != CMX_OK) return s;
-    if ((s = scratch(ctx1, (tag + "_st").c_str(), (size_t)c->hm.nn * rep_ram, (void**)&d_st)) != CMX_OK) return s;
+    // (node states share the alignment's row stride n in simulate_kernel: [nn][n], not [nn][rep_ram] -- sized for rep_ram
+    // this overflowed as soon as a call held more than one replicate)
+    if ((s = scratch(ctx1, (tag + "_st").c_str(), (size_t)c->hm.nn * n, (void**)&d_st)) != CMX_OK) return s;
     if ((s = scratch(ctx1, (tag + "_cls").c_str(), sizeof(int32_t) * rep_ram, (void**)&d_cls)) != CMX_OK) return s;
     if ((s = scratch(ctx1, (tag + "_cnt").c_str(), sizeof(double) * BK * n, (void**)&cnt[h])) != CMX_OK) return s;
     if ((s = scratch(ctx1, (tag + "_pr").c_str(), sizeof(double) * n, (void**)&pr[h])) != CMX_OK) return s;
@@ -1172,6 +1175,147 @@ cmx_status cmx_intra_rows(cmx_ctx* ctx, int kind, const double* params, const do
   return CMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ inter-gene rows
+cmx_status cmx_inter_rows_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts1, size_t n1, size_t ld1,
+                              const int32_t* d_rc1, const double* d_pr1, const double* d_nm1, const double* d_counts2, size_t n2,
+                              size_t ld2, const int32_t* d_rc2, const double* d_pr2, const double* d_nm2,
+                              const cmx_inter_filters* filters, cmx_pair_row* d_rows, size_t capacity, uint64_t* d_count, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
+  if (!d_counts1 || !d_counts2 || n1 == 0 || n2 == 0 || ld1 < n1 || ld2 < n2 || !d_rc1 || !d_pr1 || !d_nm1 || !d_rc2 || !d_pr2 ||
+      !d_nm2 || !d_count || (capacity && !d_rows) || n1 > 0x7fffffffull || n2 > 0x7fffffffull)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_inter_rows: bad arguments");
+  if (kind == CMX_STAT_EUCLIDIAN_DISTANCE) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_inter_rows: EuclidianDistance is a distance, not a statistic");
+  cmx_inter_filters f{0, 0, -1, 0, 0.0, 0.0, -1.0, 0.0, 0, 0};
+  if (filters) f = *filters;
+  if (f.independent_comparisons && n1 != n2)   // CoETools.cpp:745-749
+    return fail(ctx, CMX_ERR_INVALID, "When performing independant comparisons, the two datasets must have the same length.");
+  const HostModel& h = ctx->hm;
+  if (h.B < 2) return fail(ctx, CMX_ERR_INVALID, "cmx_inter_rows: need at least two branches");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(uint64_t), st));
+  unsigned long long* rowcount;
+  size_t tmp_bytes = 0;
+  void* tmp = nullptr;
+  if (f.independent_comparisons) {
+    // the n1 pairs (i, i): statistic of the diagonal, then the same filters and compaction
+    double* dstat;
+    if ((s = scratch(ctx, "inter_diag", sizeof(double) * n1, (void**)&dstat)) != CMX_OK) return s;
+    if (kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+      MiBounds mb;
+      uint32_t *c1, *c2;
+      uint8_t *b1, *b2;
+      size_t lx1, lx2;
+      if ((s = mi_bounds(ctx, params, &mb, stream)) != CMX_OK) return s;
+      if ((s = mi_classify(ctx, mb, d_counts1, n1, ld1, "1", &c1, &b1, &lx1, stream)) != CMX_OK) return s;
+      if ((s = mi_classify(ctx, mb, d_counts2, n2, ld2, "2", &c2, &b2, &lx2, stream)) != CMX_OK) return s;
+      HIP_TRY(ctx, launch_mi_pairs_diag(h.B, c1, b1, lx1, c2, b2, lx2, n1, dstat, st));
+    } else {
+      const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+      const double* d_mean = nullptr;
+      if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;
+      HIP_TRY(ctx, launch_pair_diag(kind, param, h.B, h.K, d_counts1, ld1, d_counts2, ld2, n1, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, dstat, nullptr, nullptr, nullptr, d_mean, st));
+    }
+    if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (n1 + 1), (void**)&rowcount)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_inter_rows(dstat, 1, n2, d_rc1, d_pr1, d_nm1, d_rc2, d_pr2, d_nm2, f, rowcount, nullptr, tmp_bytes, d_rows, capacity,
+                                   reinterpret_cast<unsigned long long*>(d_count), st, 0, n1, nullptr));
+    if ((s = scratch(ctx, "rows_scan", tmp_bytes ? tmp_bytes : 16, &tmp)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_inter_rows(dstat, 1, n2, d_rc1, d_pr1, d_nm1, d_rc2, d_pr2, d_nm2, f, rowcount, tmp, tmp_bytes, d_rows, capacity,
+                                   reinterpret_cast<unsigned long long*>(d_count), st, 0, n1, nullptr));
+    return CMX_OK;
+  }
+  // operands of both data sets once, then row blocks of data set 1 (dense scratch <= 256 MiB)
+  const bool mi = kind == CMX_STAT_DISCRETE_MI_BOUNDS;
+  const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  const double* d_mean = nullptr;
+  const int gk = kind == CMX_STAT_CORRECTED_CORRELATION ? CMX_STAT_CORRELATION : kind;
+  const int Bp = (h.B + 3) / 4 * 4;
+  const size_t ldx1 = (n1 + 15) / 16 * 16, ldx2 = (n2 + 15) / 16 * 16;
+  double *X1 = nullptr, *s1 = nullptr, *r1 = nullptr, *X2 = nullptr, *s2 = nullptr, *r2 = nullptr;
+  uint32_t *c1 = nullptr, *c2 = nullptr;
+  uint8_t *b1 = nullptr, *b2 = nullptr;
+  size_t lx1 = 0, lx2 = 0;
+  if (mi) {
+    MiBounds mb;
+    if ((s = mi_bounds(ctx, params, &mb, stream)) != CMX_OK) return s;
+    if ((s = mi_classify(ctx, mb, d_counts1, n1, ld1, "1", &c1, &b1, &lx1, stream)) != CMX_OK) return s;
+    if ((s = mi_classify(ctx, mb, d_counts2, n2, ld2, "2", &c2, &b2, &lx2, stream)) != CMX_OK) return s;
+  } else {
+    if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx1, (void**)&X1)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_s1", sizeof(double) * n1, (void**)&s1)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_r1", sizeof(double) * n1, (void**)&r1)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_X2", sizeof(double) * Bp * ldx2, (void**)&X2)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_s2", sizeof(double) * n2, (void**)&s2)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_r2", sizeof(double) * n2, (void**)&r2)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts1, n1, ld1, h.B, h.K, X1, ldx1, Bp, s1, r1, d_mean, st));
+    HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts2, n2, ld2, h.B, h.K, X2, ldx2, Bp, s2, r2, d_mean ? d_mean + h.B : nullptr, st));
+  }
+  size_t RB = ((size_t)256 << 20) / (8 * n2) / 64 * 64;
+  RB = std::max<size_t>(64, std::min<size_t>(RB, (n1 + 63) / 64 * 64));
+  double* blk;
+  if ((s = scratch(ctx, "blk_stat", sizeof(double) * RB * n2, (void**)&blk)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (RB + 1), (void**)&rowcount)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_inter_rows(blk, n2, n2, d_rc1, d_pr1, d_nm1, d_rc2, d_pr2, d_nm2, f, rowcount, nullptr, tmp_bytes, d_rows, capacity,
+                                 reinterpret_cast<unsigned long long*>(d_count), st, 0, RB, nullptr));
+  if ((s = scratch(ctx, "rows_scan", tmp_bytes ? tmp_bytes : 16, &tmp)) != CMX_OK) return s;
+  for (size_t i0 = 0; i0 < n1; i0 += RB) {
+    const size_t rb = std::min(RB, n1 - i0);
+    if (mi) HIP_TRY(ctx, launch_mi_pairs_block(h.B, c1 + i0, b1 + i0, rb, lx1, c2, b2, n2, lx2, 0, blk, n2, i0, st));
+    else HIP_TRY(ctx, launch_pair_gram(gk, h.B, Bp, X1 + i0, s1 + i0, r1 + i0, rb, ldx1, X2, s2, r2, n2, ldx2, 0, blk, n2, st));
+    HIP_TRY(ctx, launch_inter_rows(blk, n2, n2, d_rc1, d_pr1, d_nm1, d_rc2, d_pr2, d_nm2, f, rowcount, tmp, tmp_bytes, d_rows, capacity,
+                                   reinterpret_cast<unsigned long long*>(d_count), st, i0, rb, reinterpret_cast<unsigned long long*>(d_count)));
+  }
+  return CMX_OK;
+}
+
+cmx_status cmx_inter_rows(cmx_ctx* ctx, int kind, const double* params, const double* counts1, size_t n1, const int32_t* rate_class1,
+                          const double* post_rate1, const double* norm1, const double* counts2, size_t n2, const int32_t* rate_class2,
+                          const double* post_rate2, const double* norm2, const cmx_inter_filters* filters, cmx_pair_row* rows,
+                          size_t capacity, uint64_t* count) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (!counts1 || !counts2 || n1 == 0 || n2 == 0 || !rate_class1 || !post_rate1 || !norm1 || !rate_class2 || !post_rate2 || !norm2 ||
+      !count || (capacity && !rows))
+    return fail(ctx, CMX_ERR_INVALID, "cmx_inter_rows: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t BK = (size_t)ctx->hm.B * ctx->hm.K;
+  TmpDev tmp;
+  std::vector<double> bm;
+  double *d_c[2], *d_pr[2], *d_nm[2];
+  int32_t* d_rc[2];
+  const double* cs[2] = {counts1, counts2};
+  const size_t ns[2] = {n1, n2};
+  const int32_t* rcs[2] = {rate_class1, rate_class2};
+  const double *prs[2] = {post_rate1, post_rate2}, *nms[2] = {norm1, norm2};
+  for (int q = 0; q < 2; ++q) {
+    to_branch_major(cs[q], ns[q], BK, &bm);
+    HIP_TRY(ctx, tmp.alloc((void**)&d_c[q], bm.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(d_c[q], bm.data(), bm.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, tmp.alloc((void**)&d_pr[q], ns[q] * sizeof(double)));
+    HIP_TRY(ctx, tmp.alloc((void**)&d_nm[q], ns[q] * sizeof(double)));
+    HIP_TRY(ctx, tmp.alloc((void**)&d_rc[q], ns[q] * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemcpy(d_pr[q], prs[q], ns[q] * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_nm[q], nms[q], ns[q] * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_rc[q], rcs[q], ns[q] * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  cmx_pair_row* d_rows = nullptr;
+  uint64_t* d_count;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_count, sizeof(uint64_t)));
+  if (capacity) HIP_TRY(ctx, tmp.alloc((void**)&d_rows, capacity * sizeof(cmx_pair_row)));
+  if ((s = cmx_inter_rows_dev(ctx, kind, params, d_c[0], n1, n1, d_rc[0], d_pr[0], d_nm[0], d_c[1], n2, n2, d_rc[1], d_pr[1], d_nm[1],
+                              filters, d_rows, capacity, d_count, nullptr)) != CMX_OK)
+    return s;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(count, d_count, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  const size_t nw = std::min<size_t>((size_t)*count, capacity);
+  if (nw) HIP_TRY(ctx, hipMemcpy(rows, d_rows, nw * sizeof(cmx_pair_row), hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Mica MI
 cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* d_masks, const uint8_t* d_aln1,
                               size_t n1, size_t ld1, const uint8_t* d_aln2, size_t n2, size_t ld2, double* d_mi,
@@ -1323,6 +1467,84 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
   return CMX_OK;
 }
 
+
+// ---- Mica's bootstrap nulls.  Site indices of the non-parametric bootstrap (SiteContainerTools::sampleSites,
+// CoMap/Mica.cpp:426-430) come from the engine's counter RNG (cmx_kernels.hip philox_uniform: Philox2x32-10, key from the
+// seed, counter = (g, draw)), so that every binding -- this library's C++ adapter, the Python mirror, a Mica.cpp linked
+// against the C-ABI -- draws the same pairs: idx_h[r * rep_ram + j] = floor(u(seed, g = (r * 2 + h) * rep_ram + j, draw 0) * nsites).
+static double host_philox_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
+  uint32_t c0 = (uint32_t)g, c1 = ((uint32_t)(g >> 32) & 0x7fffu) | (draw << 15);
+  uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ 0x434d5832u;
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0;
+    c0 = (uint32_t)(p >> 32) ^ k ^ c1;
+    c1 = (uint32_t)p;
+    k += 0x9E3779B9u;
+  }
+  const uint64_t bits = (((uint64_t)c0 << 32) | c1) >> 11;
+  return (double)bits * (1.0 / 9007199254740992.0);
+}
+
+cmx_status cmx_mica_bootstrap_indices(uint64_t seed, size_t nsites, size_t nrep_cpu, size_t nrep_ram, int64_t* idx1, int64_t* idx2) {
+  if (nsites == 0 || !idx1 || !idx2 || (uint64_t)nrep_cpu * 2 * nrep_ram > (1ull << 47)) return CMX_ERR_INVALID;
+  for (size_t r = 0; r < nrep_cpu; ++r)
+    for (size_t j = 0; j < nrep_ram; ++j)
+      for (int h = 0; h < 2; ++h) {
+        size_t v = (size_t)(host_philox_uniform(seed, ((uint64_t)r * 2 + h) * nrep_ram + j, 0) * (double)nsites);
+        if (v >= nsites) v = nsites - 1;
+        (h ? idx2 : idx1)[r * nrep_ram + j] = (int64_t)v;
+      }
+  return CMX_OK;
+}
+
+// null.method = parametric-bootstrap (CoMap/Mica.cpp:469-548): per replicate two alignments of nrep_ram sites are simulated
+// under the context's model, column j of the one is scored against column j of the other (MI, joint entropy), and -- Mica's
+// `use_model` case -- both are mapped for their norms.  One simulation, one MI launch and one mapping over all replicates,
+// none of it leaving the device; only the null's columns come back.
+cmx_status cmx_mica_parametric_null(cmx_ctx* ctx, int nalpha, uint64_t seed, size_t nrep_cpu, size_t nrep_ram, double gamma_alpha,
+                                    double p_invariant, double* mi, double* hjoint, double* nmin) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if (nrep_cpu == 0 || nrep_ram == 0 || !mi || !hjoint) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_parametric_null: bad arguments");
+  if (nalpha != ctx->hm.S) return fail(ctx, CMX_ERR_INVALID, "cmx_mica_parametric_null: the alphabet is the model's");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = nrep_cpu * nrep_ram, T = (size_t)ctx->hm.T;
+  TmpDev tmp;
+  uint8_t* d_aln;
+  int64_t *d_i1, *d_i2;
+  double *d_mi, *d_hj, *d_norm = nullptr;
+  HIP_TRY(ctx, tmp.alloc((void**)&d_aln, T * 2 * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_i1, sizeof(int64_t) * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_i2, sizeof(int64_t) * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_mi, sizeof(double) * n));
+  HIP_TRY(ctx, tmp.alloc((void**)&d_hj, sizeof(double) * n));
+  // simulated-site index g = (rep * 2 + batch) * nrep_ram + j = its column in the [T][2 n] alignment
+  if (gamma_alpha > 0.0) s = cmx_simulate_continuous_dev(ctx, seed, 0, 2 * n, gamma_alpha, p_invariant, d_aln, 2 * n, nullptr, nullptr);
+  else s = cmx_simulate_dev(ctx, seed, 0, 2 * n, d_aln, 2 * n, nullptr, nullptr);
+  if (s != CMX_OK) return s;
+  std::vector<int64_t> i1(n), i2(n);
+  for (size_t q = 0; q < n; ++q) {
+    const size_t rep = q / nrep_ram, j = q % nrep_ram;
+    i1[q] = (int64_t)((rep * 2) * nrep_ram + j);
+    i2[q] = (int64_t)((rep * 2 + 1) * nrep_ram + j);
+  }
+  HIP_TRY(ctx, hipMemcpy(d_i1, i1.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_i2, i2.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice));
+  if ((s = cmx_mi_pairs_dev(ctx, nalpha, (int)T, nullptr, d_aln, 2 * n, 2 * n, nullptr, 0, 0, d_i1, d_i2, n, d_mi, d_hj, nullptr)) != CMX_OK) return s;
+  if (nmin) {
+    HIP_TRY(ctx, tmp.alloc((void**)&d_norm, sizeof(double) * 2 * n));
+    if ((s = map_sites_impl(ctx, d_aln, 2 * n, 2 * n, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_norm, nullptr, true)) != CMX_OK) return s;
+  }
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(mi, d_mi, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(hjoint, d_hj, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (nmin) {
+    std::vector<double> norm(2 * n);
+    HIP_TRY(ctx, hipMemcpy(norm.data(), d_norm, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < n; ++q) nmin[q] = std::min(norm[(size_t)i1[q]], norm[(size_t)i2[q]]);
+  }
+  return CMX_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ groups of sites
 cmx_status cmx_group_stats_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts, size_t n, size_t ldc,

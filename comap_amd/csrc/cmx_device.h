@@ -208,6 +208,11 @@ hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pv
                             unsigned long long* d_rowcount /*[n + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
                             size_t capacity, unsigned long long* d_count, hipStream_t stream, size_t irow0 = 0, size_t nrows = 0,
                             const unsigned long long* d_base = nullptr);
+hipError_t launch_inter_rows(const double* d_stat, size_t ldo, size_t n2, const int32_t* d_rc1, const double* d_pr1, const double* d_nm1,
+                             const int32_t* d_rc2, const double* d_pr2, const double* d_nm2, const cmx_inter_filters& f,
+                             unsigned long long* d_rowcount, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows, size_t capacity,
+                             unsigned long long* d_count, hipStream_t stream, size_t irow0, size_t nrows,
+                             const unsigned long long* d_base);
 hipError_t launch_mi_pairs(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t ld1, const uint8_t* d_aln2,
                            size_t ld2, const int64_t* d_idx1, const int64_t* d_idx2, size_t npairs, double* d_mi,
                            double* d_hj, hipStream_t stream);

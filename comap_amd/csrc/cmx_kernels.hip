@@ -1883,6 +1883,83 @@ hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pv
   return hipGetLastError();
 }
 
+// ---- rows of the inter-gene statistics file: CoETools::computeInterStats' pair loop (CoMap/CoETools.cpp:786-828) on the
+// device, the same two passes as pair_rows_kernel.  Row i of data set 1 against columns [0, n2) of data set 2, or against
+// column i alone (independant_comparisons, :796-797).  Filters: min rate class / rate per data set, max differences per
+// pair, |stat| >= statistic.min.  Nmin = min(norm1[i], norm2[j]); with f.reference_norm_quirk the reference's own column,
+// min(norms1[i], norms2[i]) (:803 reads norms2[i]; beyond the second data set's end the index is clamped where the
+// reference reads out of bounds).
+__device__ __forceinline__ bool inter_passes(const cmx_inter_filters& f, int ci, double ri, int cj, double rj, double st) {
+  if (cj < f.min_rate_class2 || rj < f.min_rate2) return false;
+  if (f.max_rate_class_diff >= 0 && abs(cj - ci) > f.max_rate_class_diff) return false;
+  if (f.max_rate_diff >= 0.0 && fabs(rj - ri) > f.max_rate_diff) return false;
+  return !(fabs(st) < f.min_statistic);
+}
+template <bool WRITE>
+__global__ __launch_bounds__(64) void inter_rows_kernel(const double* __restrict__ stat, size_t ldo, size_t n2,
+                                                        const int32_t* __restrict__ rc1, const double* __restrict__ pr1,
+                                                        const double* __restrict__ nm1, const int32_t* __restrict__ rc2,
+                                                        const double* __restrict__ pr2, const double* __restrict__ nm2,
+                                                        cmx_inter_filters f, unsigned long long* __restrict__ rowcount,
+                                                        cmx_pair_row* __restrict__ rows, size_t capacity, size_t irow0,
+                                                        const unsigned long long* __restrict__ base) {
+  const size_t il = blockIdx.x, i = irow0 + il;
+  const int lane = threadIdx.x;
+  const int ci = rc1[i];
+  const double ri = pr1[i];
+  unsigned long long run = WRITE ? rowcount[il] + (base ? *base : 0ull) : 0ull;
+  const bool diag = f.independent_comparisons != 0;
+  const size_t jb = diag ? i : 0, je = diag ? i + 1 : n2;
+  if (!(ci < f.min_rate_class1 || ri < f.min_rate1))
+    for (size_t j0 = jb; j0 < je; j0 += 64) {
+      const size_t j = j0 + lane;
+      bool ok = false;
+      double st = 0.0;
+      if (j < je) {
+        st = diag ? stat[il] : stat[il * ldo + j];
+        ok = inter_passes(f, ci, ri, rc2[j], pr2[j], st);
+      }
+      const unsigned long long m = __ballot(ok);
+      if (WRITE && ok) {
+        const unsigned long long pos = run + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < capacity) {
+          cmx_pair_row r;
+          r.i = (int32_t)i; r.j = (int32_t)j; r.stat = st;
+          r.rc_min = ci < rc2[j] ? ci : rc2[j];
+          r.pr_min = ri < pr2[j] ? ri : pr2[j];
+          const double nj = nm2[f.reference_norm_quirk ? (i < n2 ? i : n2 - 1) : j];
+          r.n_min = nm1[i] < nj ? nm1[i] : nj;
+          r.pvalue = __builtin_nan("");
+          r.nsim = 0;
+          rows[pos] = r;
+        }
+      }
+      run += __popcll(m);
+    }
+  if (!WRITE && lane == 0) rowcount[il] = run;
+}
+
+// rows irow0 .. irow0 + nrows - 1 of data set 1; d_stat: [nrows][ldo] (or [nrows] for independant comparisons); d_base
+// / d_count as in launch_pair_rows
+hipError_t launch_inter_rows(const double* d_stat, size_t ldo, size_t n2, const int32_t* d_rc1, const double* d_pr1, const double* d_nm1,
+                             const int32_t* d_rc2, const double* d_pr2, const double* d_nm2, const cmx_inter_filters& f,
+                             unsigned long long* d_rowcount, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows, size_t capacity,
+                             unsigned long long* d_count, hipStream_t stream, size_t irow0, size_t nrows,
+                             const unsigned long long* d_base) {
+  if (d_tmp == nullptr)
+    return rocprim::exclusive_scan(nullptr, tmp_bytes, d_rowcount, d_rowcount, 0ull, nrows, rocprim::plus<unsigned long long>(), stream);
+  hipLaunchKernelGGL((inter_rows_kernel<false>), dim3((unsigned)nrows), dim3(64), 0, stream, d_stat, ldo, n2, d_rc1, d_pr1, d_nm1, d_rc2,
+                     d_pr2, d_nm2, f, d_rowcount, d_rows, capacity, irow0, d_base);
+  hipError_t e = hipMemcpyAsync(d_rowcount + nrows, d_rowcount + nrows - 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) return e;
+  e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_rowcount, d_rowcount, 0ull, nrows, rocprim::plus<unsigned long long>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((inter_rows_kernel<true>), dim3((unsigned)nrows), dim3(64), 0, stream, d_stat, ldo, n2, d_rc1, d_pr1, d_nm1, d_rc2,
+                     d_pr2, d_nm2, f, d_rowcount, d_rows, capacity, irow0, d_base);
+  hipLaunchKernelGGL(pair_rows_total_kernel, dim3(1), dim3(64), 0, stream, d_rowcount, d_rowcount + nrows, nrows, d_count, d_base);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ Mica column MI
 // SiteTools::mutualInformation / jointEntropy / entropy (resolveUnknowns = true), natural log (Mica.cpp:93-95).
 // LDS-table kernel (the general path: any ambiguity code, fractional counts in fp64): one wave per (column i, 16 columns

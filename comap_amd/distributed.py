@@ -78,25 +78,42 @@ def row_shard(rank, world, n):
     return begin, end
 
 
-def mica_rectangle(engine, d_aln1, d_aln2, nalpha=20, group=None):
-    """Mica's N1 x N2 column-MI rectangle (Mica.cpp:349-361, 646-689) split by rows of the first alignment over the ranks:
-    every rank holds both alignments (they are small), computes MI / Hjoint of its contiguous block of columns of
-    alignment 1 against all of alignment 2 on its own GPU, and ONE all-reduce (sum) of the per-column MI sums gives every
-    rank the averages APC / RCW need (Mica.cpp:656-657: MI_i. MI_.j / MI_..).
+def mica_rectangle(engine, d_aln1, d_aln2=None, nalpha=20, group=None):
+    """Column MI split by blocks of columns of the first alignment over the ranks: every rank holds the alignments (they
+    are small), computes MI / Hjoint of its contiguous block of columns against all columns of the second on its own GPU,
+    and ONE all-reduce (sum) of the per-column MI sums gives every rank the averages APC / RCW need.
+
+    d_aln2 None -- the reference's case, one alignment against itself (Mica.cpp:346-361, 646-689): the averages follow
+    the reference, averageMI_i = sum over j != i of MI_ij / (n - 1) and fullAverageMI = the mean of those.
+    d_aln2 given -- an N1 x N2 rectangle between two alignments.  The reference has no such mode (its Mica reads one
+    alignment): this is an extension of this engine, and row_mean / col_mean / full_mean are then the plain means over
+    the rectangle, by this repo's own definition and not a reference-parity quantity.
+    A rank whose block is empty (world > N1) skips the engine call but still enters the all-reduce.
     -> dict(rows=(begin, end), mi, hjoint [rows_local, N2] CUDA, h1 [rows_local], h2 [N2], row_mean [rows_local],
             col_mean [N2], full_mean) -- APC_ij = row_mean[i] * col_mean[j] / full_mean."""
     import torch
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    n1, n2 = d_aln1.shape[1], d_aln2.shape[1]
+    intra = d_aln2 is None
+    other = d_aln1 if intra else d_aln2
+    n1, n2 = d_aln1.shape[1], other.shape[1]
     b, e = replicate_shard(rank, world, n1)
     dev = d_aln1.device
-    blk = d_aln1[:, b:e].contiguous()
-    mi = torch.empty((e - b, n2), dtype=torch.float64, device=dev)
-    hj = torch.empty_like(mi)
-    h1 = torch.empty(e - b, dtype=torch.float64, device=dev)
-    h2 = torch.empty(n2, dtype=torch.float64, device=dev)
-    engine.mi_columns_dev(blk, mi, hj, d_aln2, nalpha, None, h1, h2)
+    mi = torch.zeros((e - b, n2), dtype=torch.float64, device=dev)
+    hj = torch.zeros_like(mi)
+    h1 = torch.zeros(e - b, dtype=torch.float64, device=dev)
+    h2 = torch.zeros(n2, dtype=torch.float64, device=dev)
+    if e > b:
+        engine.mi_columns_dev(d_aln1[:, b:e].contiguous(), mi, hj, other, nalpha, None, h1, h2)
+    if intra:
+        # MI_ii (= H_i) is not part of the reference's averages
+        own = torch.arange(b, e, device=dev)
+        off = mi.clone()
+        off[own - b, own] = 0.0
+        col_sum, _ = combine_mica_sums(off.sum(dim=0), group)
+        col_mean = col_sum / (n1 - 1)
+        return dict(rows=(b, e), mi=mi, hjoint=hj, h1=h1, h2=h2, row_mean=off.sum(dim=1) / (n1 - 1), col_mean=col_mean,
+                    full_mean=col_mean.mean())
     col_sum, tot = combine_mica_sums(mi.sum(dim=0), group)
     return dict(rows=(b, e), mi=mi, hjoint=hj, h1=h1, h2=h2, row_mean=mi.mean(dim=1), col_mean=col_sum / n1,
                 full_mean=tot / (n1 * n2))

@@ -53,7 +53,7 @@ EXPORTS = [
     "cmx_simulate_continuous_dev", "cmx_null_intra_continuous", "cmx_null_intra_continuous_dev", "cmx_mi_pairs_dev",
     "cmx_pair_stats", "cmx_pair_stats_dev", "cmx_null_intra", "cmx_null_simulate_dev", "cmx_null_intra_dev", "cmx_null_inter",
     "cmx_null_inter_dev", "cmx_intra_pvalues", "cmx_intra_rows", "cmx_intra_rows_dev", "cmx_intra_rows_range_dev",
-    "cmx_intra_pvalues_dev", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
+    "cmx_intra_pvalues_dev", "cmx_inter_rows", "cmx_inter_rows_dev", "cmx_mica_bootstrap_indices", "cmx_mica_parametric_null", "cmx_mi_columns", "cmx_mi_columns_dev", "cmx_mi_pairs",
     "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_permutation_test_masks", "cmx_mica_permutation_test_masks_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
     "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups", "cmx_debug_candidate_cursor",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
@@ -66,6 +66,18 @@ DIST_BY_NAME = {"cor": DIST_CORRELATION, "Correlation": DIST_CORRELATION, "comp"
 LINK_BY_NAME = {"complete": LINK_COMPLETE, "single": LINK_SINGLE, "average": LINK_AVERAGE}
 CLUSTER_MAX_SITES = 5000
 MICA_MI, MICA_MIP, MICA_MIC = range(3)      # null.method_zscore.stat (Mica.cpp:551-559)
+
+
+def mica_bootstrap_indices(seed, nsites, nrep_cpu, nrep_ram):
+    """index1 / index2 of Mica's non-parametric bootstrap (SiteContainerTools::sampleSites, Mica.cpp:426-430) from the engine's
+    counter RNG (cmx_mica_bootstrap_indices; host-side, no GPU): [nrep_cpu * nrep_ram] each"""
+    lib = load_library()
+    n = nrep_cpu * nrep_ram
+    i1, i2 = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    st = lib.cmx_mica_bootstrap_indices(ctypes.c_uint64(seed), _sz(nsites), _sz(nrep_cpu), _sz(nrep_ram), _vp(i1), _vp(i2))
+    if st != 0:
+        raise CmxError(st, "cmx_mica_bootstrap_indices: bad arguments")
+    return i1, i2
 
 
 def label_substitution_weights(nstates):
@@ -107,6 +119,19 @@ class PairFilters(ctypes.Structure):
 
     def __init__(self, min_rate_class=0, max_rate_class_diff=-1, min_rate=0.0, max_rate_diff=-1.0, min_statistic=0.0):
         super().__init__(min_rate_class, max_rate_class_diff, min_rate, max_rate_diff, min_statistic)
+
+
+class InterFilters(ctypes.Structure):
+    """cmx_inter_filters: the filters of CoETools::computeInterStats (CoETools.cpp:755-812)."""
+    _fields_ = [("min_rate_class1", ctypes.c_int32), ("min_rate_class2", ctypes.c_int32), ("max_rate_class_diff", ctypes.c_int32),
+                ("independent_comparisons", ctypes.c_int32), ("min_rate1", ctypes.c_double), ("min_rate2", ctypes.c_double),
+                ("max_rate_diff", ctypes.c_double), ("min_statistic", ctypes.c_double), ("reference_norm_quirk", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+    def __init__(self, min_rate_class1=0, min_rate_class2=0, max_rate_class_diff=-1, independent_comparisons=False, min_rate1=0.0,
+                 min_rate2=0.0, max_rate_diff=-1.0, min_statistic=0.0, reference_norm_quirk=False):
+        super().__init__(min_rate_class1, min_rate_class2, max_rate_class_diff, int(independent_comparisons), min_rate1, min_rate2,
+                         max_rate_diff, min_statistic, int(reference_norm_quirk), 0)
 
 
 PAIR_ROW = np.dtype([("i", np.int32), ("j", np.int32), ("stat", np.float64), ("rc_min", np.int32), ("nsim", np.int32),
@@ -410,6 +435,25 @@ class Engine:
                                              ctypes.byref(f), _vp(rows), _sz(cap), ctypes.byref(count)))
         return rows[: min(cap, count.value)], count.value
 
+    def inter_rows(self, kind, m1, m2, filters=None, capacity=None, threshold=0.99, mean_vectors=None):
+        """rows of the inter-gene statistics file (CoETools::computeInterStats, CoETools.cpp:786-828), compacted on the
+        device.  m1 / m2: dicts with counts [N, B, K], rate_class, post_rate, norm (what map_sites returns)."""
+        c1 = _f64(m1["counts"]).reshape(len(m1["counts"]), self.B, self.K)
+        c2 = _f64(m2["counts"]).reshape(len(m2["counts"]), self.B, self.K)
+        n1, n2 = c1.shape[0], c2.shape[0]
+        f = filters if filters is not None else InterFilters()
+        cap = (n1 if f.independent_comparisons else n1 * n2) if capacity is None else int(capacity)
+        rows = np.zeros(max(cap, 1), dtype=PAIR_ROW)
+        count = ctypes.c_uint64(0)
+        params = _stat_params(kind, threshold, mean_vectors)
+        args = []
+        for m in (m1, m2):
+            args += [np.ascontiguousarray(m["rate_class"], dtype=np.int32), _f64(m["post_rate"]), _f64(m["norm"])]
+        self._check(self._lib.cmx_inter_rows(self._ctx, int(kind), _vp(params), _vp(c1), _sz(n1), _vp(args[0]), _vp(args[1]),
+                                             _vp(args[2]), _vp(c2), _sz(n2), _vp(args[3]), _vp(args[4]), _vp(args[5]),
+                                             ctypes.byref(f), _vp(rows), _sz(cap), ctypes.byref(count)))
+        return rows[: min(cap, count.value)], count.value
+
     def mi_columns(self, aln1, aln2=None, nalpha=20, masks=None):
         a1 = np.ascontiguousarray(aln1, dtype=np.uint8)
         T, n1 = a1.shape
@@ -434,6 +478,19 @@ class Engine:
                                            _vp(a1), _sz(n1), _vp(a2), _sz(0 if a2 is None else a2.shape[1]), _vp(i1),
                                            _vp(i2), _sz(len(i1)), _vp(mi), _vp(hj)))
         return dict(mi=mi, hjoint=hj)
+
+    def mica_parametric_null(self, seed, nrep_cpu, nrep_ram, with_norms=False, gamma_alpha=0.0, p_invariant=0.0):
+        """null.method = parametric-bootstrap (Mica.cpp:469-548) in one call (cmx_mica_parametric_null) -> dict(mi, hjoint[, nmin])"""
+        n = nrep_cpu * nrep_ram
+        mi, hj = np.zeros(n), np.zeros(n)
+        nm = np.zeros(n) if with_norms else None
+        self._check(self._lib.cmx_mica_parametric_null(self._ctx, int(self.S), ctypes.c_uint64(seed), _sz(nrep_cpu), _sz(nrep_ram),
+                                                       ctypes.c_double(gamma_alpha), ctypes.c_double(p_invariant), _vp(mi), _vp(hj),
+                                                       _vp(nm)))
+        out = dict(mi=mi, hjoint=hj)
+        if with_norms:
+            out["nmin"] = nm
+        return out
 
     # -- groups of sites / candidate-group test
     @staticmethod

@@ -14,11 +14,10 @@ import numpy as np
 
 
 def bootstrap_indices(seed, nsites, nrep_cpu, nrep_ram):
-    """index1 / index2 of SiteContainerTools::sampleSites (Mica.cpp:426-430), [nrep_cpu * nrep_ram] each."""
-    rng = np.random.Generator(np.random.Philox(key=int(seed)))
-    n = nrep_cpu * nrep_ram
-    idx = rng.integers(0, nsites, size=(nrep_cpu, 2, nrep_ram))
-    return idx[:, 0, :].reshape(n).astype(np.int64), idx[:, 1, :].reshape(n).astype(np.int64)
+    """index1 / index2 of SiteContainerTools::sampleSites (Mica.cpp:426-430), [nrep_cpu * nrep_ram] each: drawn behind the
+    C-ABI (cmx_mica_bootstrap_indices, the engine's counter RNG) so that the C++ adapter and this mirror agree."""
+    from .engine import mica_bootstrap_indices
+    return mica_bootstrap_indices(seed, nsites, nrep_cpu, nrep_ram)
 
 
 def bootstrap_null(engine, aln, entropy, seed, nrep_cpu=10, nrep_ram=100, nalpha=20, masks=None, norms=None):

@@ -268,6 +268,33 @@ cmx_status cmx_intra_rows(cmx_ctx* ctx, int kind, const double* params, const do
                           const double* null_stat, const double* null_nmin, size_t nnull, int nclasses,
                           const cmx_pair_filters* filters, cmx_pair_row* rows, size_t capacity, uint64_t* count);
 
+/* ---- the rows of the inter-gene statistics file: CoETools::computeInterStats' pair loop (CoMap/CoETools.cpp:786-828) for
+ * the rows of data set 1 against data set 2 -- statistic on the matrix cores a block of rows at a time, filters, rows
+ * compacted in the reference's (i, j) order; no N1 x N2 matrix leaves the device (or exists beyond a <= 256 MiB block).
+ * Both data sets: branch-major counts of the same branches, rate class / posterior rate / norm per site.  Rows carry
+ * pvalue NaN, nsim 0 (this path has no p-values in the reference either). */
+typedef struct cmx_inter_filters {
+  int32_t min_rate_class1, min_rate_class2; /* statistic.min_rate_class, .min_rate_class2 (CoETools.cpp:755-756) */
+  int32_t max_rate_class_diff;              /* < 0: off */
+  int32_t independent_comparisons;          /* independant_comparisons = yes: only the pairs (i, i), n1 == n2 (:744-748) */
+  double min_rate1, min_rate2;
+  double max_rate_diff;                     /* < 0: off */
+  double min_statistic;
+  int32_t reference_norm_quirk;             /* 0: Nmin = min(norm1[i], norm2[j]).  1: the reference's own column,
+                                               min(norms1[i], norms2[i]) -- CoETools.cpp:803 reads norms2[i] */
+  int32_t reserved;
+} cmx_inter_filters;
+cmx_status cmx_inter_rows_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts1, size_t n1, size_t ld1,
+                              const int32_t* d_rate_class1, const double* d_post_rate1, const double* d_norm1,
+                              const double* d_counts2, size_t n2, size_t ld2, const int32_t* d_rate_class2,
+                              const double* d_post_rate2, const double* d_norm2, const cmx_inter_filters* filters,
+                              cmx_pair_row* d_rows, size_t capacity, uint64_t* d_count, void* stream);
+/* host pointers, counts [N][B][K]; only the rows cross PCIe on the way back */
+cmx_status cmx_inter_rows(cmx_ctx* ctx, int kind, const double* params, const double* counts1, size_t n1,
+                          const int32_t* rate_class1, const double* post_rate1, const double* norm1, const double* counts2,
+                          size_t n2, const int32_t* rate_class2, const double* post_rate2, const double* norm2,
+                          const cmx_inter_filters* filters, cmx_pair_row* rows, size_t capacity, uint64_t* count);
+
 /* ---- Mica: mutual information between alignment columns over taxa (Mica.cpp:93-95, 349-361, 646-660).
  * aln2 == NULL: intra (filled for j > i, NaN elsewhere).  Outputs dense [n1][n2] (mi, hjoint) and per-column entropies;
  * nalpha = alphabet size.  Alignment codes >= nalpha index `masks` (bit a set = compatible with state a; masks == NULL:
@@ -290,6 +317,18 @@ cmx_status cmx_mi_pairs(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* mas
 cmx_status cmx_mi_pairs_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                             const uint8_t* d_aln2, size_t n2, size_t ld2, const int64_t* d_idx1, const int64_t* d_idx2, size_t npairs,
                             double* d_mi, double* d_hjoint, void* stream);
+
+/* Mica's bootstrap nulls.
+ * cmx_mica_bootstrap_indices (host-side only, no GPU): the site indices of null.method = nonparametric-bootstrap
+ * (SiteContainerTools::sampleSites, CoMap/Mica.cpp:426-430) from the engine's counter RNG, so that every binding draws the
+ * same pairs: idx_h[r * nrep_ram + j] = floor(u(seed, g = (r * 2 + h) * nrep_ram + j) * nsites).  Score them with cmx_mi_pairs.
+ * cmx_mica_parametric_null: null.method = parametric-bootstrap (Mica.cpp:469-548) -- per replicate two alignments of
+ * nrep_ram sites simulated under the context's model (gamma_alpha > 0: simulations.continuous = yes with that Gamma shape
+ * and p_invariant), column j against column j: mi, hjoint [nrep_cpu * nrep_ram]; nmin (may be NULL) = the smaller of the
+ * two simulated sites' norms (`use_model`).  Simulation, MI and mapping stay on the device. */
+cmx_status cmx_mica_bootstrap_indices(uint64_t seed, size_t nsites, size_t nrep_cpu, size_t nrep_ram, int64_t* idx1, int64_t* idx2);
+cmx_status cmx_mica_parametric_null(cmx_ctx* ctx, int nalpha, uint64_t seed, size_t nrep_cpu, size_t nrep_ram, double gamma_alpha,
+                                    double p_invariant, double* mi, double* hjoint, double* nmin);
 
 /* ---- Mica, after the all-pairs matrix (intra, n columns, upper triangle j > i is what is read):
  * cmx_mica_average_mi: averageMI[i] = sum_{j != i} MI(i,j) / (n-1) and fullAverageMI = mean(averageMI)

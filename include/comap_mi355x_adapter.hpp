@@ -153,7 +153,7 @@ class Engine {
 
   // nijt.average / nijt.joint (CoETools.cpp:393-406; "for benchmarking only" there).  average = no, joint = yes maps with
   // computeSubstitutionVectorsNoAveraging from here on (observed data and nulls; what nijt = Label with the MI statistic
-  // needs, CoETools.cpp:577-588); joint = no throws (the Marginal variants are not implemented).
+  // needs, CoETools.cpp:577-588); joint = no selects the two ...Marginal variants (CoETools.cpp:399-405).
   void setMappingOptions(bool average, bool joint) { check(cmx_set_mapping_options(ctx_, average ? 1 : 0, joint ? 1 : 0)); }
   // simulations.continuous = yes (CoMap.cpp:146, 213: seqSim->enableContinuousRates(true)): n simulated sites [taxon][site]
   // with global site indices g0 .. g0 + n - 1, every site with its own rate from the continuous Gamma(alpha, alpha)
@@ -169,6 +169,7 @@ class Engine {
   size_t getNumberOfBranches() const { return nbBranches_; }
   size_t getNumberOfSubstitutionTypes() const { return nbTypes_; }
   size_t getNumberOfTaxa() const { return nbTaxa_; }
+  int getNumberOfStates() const { return S_; }
   void check(cmx_status s) const {
     if (s != CMX_OK) throw Exception(cmx_last_error(ctx_));
   }
@@ -340,6 +341,9 @@ class CompensationDistance : public StatisticBasedDistance {
 
 // ------------------------------------------------------------------------------------------------ AnalysisTools
 struct NullDistributionRow { double stat; int32_t rcMin; double prMin, nMin; };  // columns of AnalysisTools.cpp:642
+// simulations.continuous = yes (CoMap.cpp:146, 213: seqSim->enableContinuousRates(true)): every simulated site draws its
+// rate from the continuous Gamma(alpha, alpha) (+ an invariant mass) instead of the discrete classes
+struct ContinuousRates { double gammaAlpha = 1.; double pInvariant = 0.; };
 
 class AnalysisTools {
  public:
@@ -363,7 +367,7 @@ class AnalysisTools {
   static void getNullDistributionIntraDR(const Engine& eng, const Statistic& statistic, uint64_t seed, size_t repCPU,
                                          size_t repRAM, std::vector<NullDistributionRow>* rows,
                                          std::vector<std::vector<double>>* simstats, const Domain* rateDomain,
-                                         size_t repBegin = 0) {
+                                         size_t repBegin = 0, const ContinuousRates* continuous = nullptr) {
     if (simstats && rateDomain && rateDomain->getSize() != simstats->size())
       throw Exception("AnalysisTools::getNullDistributionIntraDR. Input vector should be of same size as rate domain.");
     if (simstats && !rateDomain && simstats->size() != 1)
@@ -371,8 +375,12 @@ class AnalysisTools {
     const size_t n = repCPU * repRAM;
     Vdouble stat(n), pr(n), nm(n);
     std::vector<int32_t> rc(n);
-    eng.check(cmx_null_intra(eng.ctx(), statistic.kind(), statistic.params(), seed, repBegin, repBegin + repCPU, repRAM,
-                             nullptr, stat.data(), rc.data(), pr.data(), nm.data()));
+    if (continuous)   // simulator and mapping both on the device, the alignments never leave it
+      eng.check(cmx_null_intra_continuous(eng.ctx(), statistic.kind(), statistic.params(), seed, repBegin, repBegin + repCPU, repRAM,
+                                          continuous->gammaAlpha, continuous->pInvariant, stat.data(), rc.data(), pr.data(), nm.data()));
+    else
+      eng.check(cmx_null_intra(eng.ctx(), statistic.kind(), statistic.params(), seed, repBegin, repBegin + repCPU, repRAM,
+                               nullptr, stat.data(), rc.data(), pr.data(), nm.data()));
     for (size_t q = 0; q < n; ++q) {
       if (rows) rows->push_back({stat[q], rc[q], pr[q], nm[q]});
       if (simstats) {
@@ -436,7 +444,8 @@ class CoETools {
   static std::vector<IntraStatRow> computeIntraStats(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping,
                                                      const Statistic& statistic, bool computeNull, uint64_t seed,
                                                      size_t nbRepCPU = 100, size_t nbRepRAM = 1000,
-                                                     size_t nbRateClasses = 10, const PairFilters& f = PairFilters()) {
+                                                     size_t nbRateClasses = 10, const PairFilters& f = PairFilters(),
+                                                     const ContinuousRates* continuous = nullptr) {
     const size_t n = mapping.getNumberOfSites();
     const Vdouble norms = AnalysisTools::computeNorms(mapping);
     Vdouble ns, nm;
@@ -444,8 +453,12 @@ class CoETools {
       const size_t nn = nbRepCPU * nbRepRAM;
       ns.resize(nn);
       nm.resize(nn);
-      eng.check(cmx_null_intra(eng.ctx(), statistic.kind(), statistic.params(), seed, 0, nbRepCPU, nbRepRAM, nullptr,
-                               ns.data(), nullptr, nullptr, nm.data()));
+      if (continuous)   // simulations.continuous = yes
+        eng.check(cmx_null_intra_continuous(eng.ctx(), statistic.kind(), statistic.params(), seed, 0, nbRepCPU, nbRepRAM,
+                                            continuous->gammaAlpha, continuous->pInvariant, ns.data(), nullptr, nullptr, nm.data()));
+      else
+        eng.check(cmx_null_intra(eng.ctx(), statistic.kind(), statistic.params(), seed, 0, nbRepCPU, nbRepRAM, nullptr,
+                                 ns.data(), nullptr, nullptr, nm.data()));
     }
     // statistic, p-values, filters and the (i, j) ordering all happen on the device (cmx_intra_rows): only the rows
     // that the reference would write come back
@@ -468,41 +481,43 @@ class CoETools {
     return rows;
   }
 
-  // CoETools.cpp:732-832 (no p-values there: the reference leaves them to computePValues.R).  Nmin is
-  // min(norm1[i], norm2[j]); the reference reads norms2[i] at :803, which is not reproduced.
+  // CoETools.cpp:732-832 (no p-values there: the reference leaves them to computePValues.R): statistic, filters and the
+  // compaction of the surviving pairs run on the device (cmx_inter_rows), only the rows come back.  Nmin is
+  // min(norm1[i], norm2[j]); referenceNormQuirk = true reproduces the reference's own column, which reads norms2[i]
+  // (CoETools.cpp:803).
   static std::vector<IntraStatRow> computeInterStats(const Engine& eng, const ProbabilisticSubstitutionMapping& mapping1,
                                                      const ProbabilisticSubstitutionMapping& mapping2,
                                                      const Statistic& statistic, bool independentComparisons = false,
                                                      const PairFilters& f1 = PairFilters(),
-                                                     const PairFilters& f2 = PairFilters()) {
+                                                     const PairFilters& f2 = PairFilters(), bool referenceNormQuirk = false) {
     const size_t n1 = mapping1.getNumberOfSites(), n2 = mapping2.getNumberOfSites();
     if (independentComparisons && n1 != n2)
       throw Exception("When performing independant comparisons, the two datasets must have the same length.");
+    if (mapping1.getNumberOfBranches() != mapping2.getNumberOfBranches())
+      throw DimensionException("CoETools::computeInterStats.", mapping2.getNumberOfBranches(), mapping1.getNumberOfBranches());
     const Vdouble norms1 = AnalysisTools::computeNorms(mapping1), norms2 = AnalysisTools::computeNorms(mapping2);
-    const Vdouble stat = statistic.getValuesForAllPairs(eng, mapping1, mapping2);
-    std::vector<IntraStatRow> rows;
-    for (size_t i = 0; i < n1; i++) {
-      const int iClass = mapping1.rateClasses[i];
-      const double iRate = mapping1.posteriorRates[i];
-      if (iClass < f1.minRateClass || iRate < f1.minRate) continue;
-      const size_t begin = independentComparisons ? i : 0, end = independentComparisons ? i + 1 : n2;
-      for (size_t j = begin; j < end; j++) {
-        const int jClass = mapping2.rateClasses[j];
-        const double jRate = mapping2.posteriorRates[j];
-        if (jClass < f2.minRateClass || jRate < f2.minRate) continue;
-        if (f1.maxRateClassDiff >= 0 && std::abs(jClass - iClass) > f1.maxRateClassDiff) continue;
-        if (f1.maxRateDiff >= 0. && std::fabs(jRate - iRate) > f1.maxRateDiff) continue;
-        const double s = stat[i * n2 + j];
-        if (std::fabs(s) < f1.minStatistic) continue;
-        IntraStatRow r;
-        r.i = i; r.j = j; r.stat = s;
-        r.rcMin = std::min(iClass, jClass);
-        r.prMin = std::min(iRate, jRate);
-        r.nMin = std::min(norms1[i], norms2[j]);
-        r.pValue = std::numeric_limits<double>::quiet_NaN();
-        r.nSim = 0;
-        rows.push_back(r);
-      }
+    cmx_inter_filters f;
+    f.min_rate_class1 = f1.minRateClass; f.min_rate_class2 = f2.minRateClass;
+    f.max_rate_class_diff = f1.maxRateClassDiff;
+    f.independent_comparisons = independentComparisons ? 1 : 0;
+    f.min_rate1 = f1.minRate; f.min_rate2 = f2.minRate;
+    f.max_rate_diff = f1.maxRateDiff;
+    f.min_statistic = f1.minStatistic;
+    f.reference_norm_quirk = referenceNormQuirk ? 1 : 0;
+    f.reserved = 0;
+    const size_t cap = independentComparisons ? n1 : n1 * n2;
+    std::vector<cmx_pair_row> raw(cap ? cap : 1);
+    uint64_t count = 0;
+    eng.check(cmx_inter_rows(eng.ctx(), statistic.kind(), statistic.params(), mapping1.data(), n1, mapping1.rateClasses.data(),
+                             mapping1.posteriorRates.data(), norms1.data(), mapping2.data(), n2, mapping2.rateClasses.data(),
+                             mapping2.posteriorRates.data(), norms2.data(), &f, raw.data(), cap, &count));
+    std::vector<IntraStatRow> rows(count);
+    for (size_t q = 0; q < count; ++q) {
+      const cmx_pair_row& r = raw[q];
+      rows[q].i = (size_t)r.i; rows[q].j = (size_t)r.j; rows[q].stat = r.stat;
+      rows[q].rcMin = r.rc_min; rows[q].prMin = r.pr_min; rows[q].nMin = r.n_min;
+      rows[q].pValue = std::numeric_limits<double>::quiet_NaN();
+      rows[q].nSim = 0;
     }
     return rows;
   }
@@ -722,6 +737,155 @@ class ClusterTools {
   }
 };
 
+// ------------------------------------------------------------------------------------------------ Mica
+// CoMap/Mica.cpp on top of the C-ABI: all-pairs MI / joint entropy / entropies (one-hot Gram on the matrix cores),
+// averageMI -> APC / RCW (:346-363, :656-657), the four null methods (:399-632) and the p-value rule of :671-683.
+// The alignment is [taxon][site] state codes; codes >= alphabetSize index `masks` (bit a = compatible with state a),
+// as SiteTools::*(.., resolveUnknowns = true) resolves them.  An Engine WITH a model is Mica's `use_model` case: the
+// parametric bootstrap needs it, and norms (from CoETools::getVectors on the same engine) then bin the p-values
+// (:383-386) and add the Nmin column.
+class Mica {
+ public:
+  struct Options {
+    std::string nullMethod = "none";      // none | nonparametric-bootstrap | parametric-bootstrap | z-score | permutations (:370)
+    size_t nbRepCPU = 10, nbRepRAM = 100; // null.nb_rep_CPU / null.nb_rep_RAM (:415-416, :499-500)
+    size_t nbRateClasses = 10;            // null.nb_rate_classes (:390)
+    bool computePValues = true;           // null.compute_pvalues (:387; forced on for z-score, off for permutations)
+    std::string zScoreStat = "MIp";       // null.method_zscore.stat (:551): MI | MIp | MIc
+    size_t maxNbPermutations = 1000;      // null.max_number_of_permutations (:610)
+    bool continuousSim = false;           // simulations.continuous (:473), with the Gamma shape / invariant mass below
+    ContinuousRates continuous;
+    uint64_t seed = 0;                    // replaces Bio++'s global generator
+  };
+  struct NullRow { double mi, hjoint, hmin, nmin; };               // lines of null.output.file (:411-415, :494)
+  struct Row {                                                     // lines of output.file (:646-689)
+    size_t i, j;
+    double mi, apc, rcw, hjoint, hmin, nmin;
+    double permPValue; int32_t permNb;                             // Perm.p.value / Perm.nb
+    double bsPValue; int32_t bsNb;                                 // Bs.p.value (NaN == "NA") / Bs.nb
+  };
+  struct Result {
+    bool withModel = false, withPermutations = false, withPValues = false;
+    Vdouble entropy, averageMI;
+    double fullAverageMI = 0.;
+    std::vector<Row> rows;
+    std::vector<NullRow> null;                                     // bootstrap nulls only (the z-score null is the data itself)
+  };
+
+  // miTest of every pair (Mica.cpp:93-118): shuffles until 5 of them reach the observed MI or maxNbPermutations were done.
+  // pvalue / nbPermutations: [n (n - 1) / 2] in the reference's (i, j) order
+  static void miTest(const Engine& eng, const uint8_t* aln, size_t nbTaxa, size_t nbSites, int alphabetSize, const uint32_t* masks,
+                     size_t nbMasks, size_t maxNbPermutations, uint64_t seed, Vdouble& pvalue, std::vector<int32_t>& nbPermutations) {
+    const size_t np = nbSites * (nbSites - 1) / 2;
+    pvalue.assign(np, 0.);
+    nbPermutations.assign(np, 0);
+    eng.check(cmx_mica_permutation_test_masks(eng.ctx(), alphabetSize, (int)nbTaxa, masks, nbMasks, aln, nbSites,
+                                              (uint32_t)maxNbPermutations, seed, pvalue.data(), nbPermutations.data()));
+  }
+
+  static Result analyse(const Engine& eng, const uint8_t* aln, size_t nbTaxa, size_t nbSites, int alphabetSize,
+                        const uint32_t* masks, size_t nbMasks, const Vdouble* norms, const Options& opt) {
+    if (nbSites < 2) throw Exception("Mica: at least two sites are needed.");
+    const size_t n = nbSites;
+    Result res;
+    res.withModel = norms != nullptr;
+    if (norms && norms->size() != n) throw DimensionException("Mica::analyse: norms.", norms->size(), n);
+    // ---- all pairs at once (the reference computes every MI twice, :349-361 and :658)
+    Vdouble mi(n * n), hj(n * n);
+    res.entropy.assign(n, 0.);
+    eng.check(cmx_mi_columns(eng.ctx(), alphabetSize, (int)nbTaxa, masks, nbMasks, aln, n, nullptr, 0, mi.data(), hj.data(),
+                             res.entropy.data(), nullptr));
+    res.averageMI.assign(n, 0.);
+    eng.check(cmx_mica_average_mi(eng.ctx(), mi.data(), n, res.averageMI.data(), &res.fullAverageMI));
+    const Vdouble& key = norms ? *norms : res.entropy;             // what the p-values are binned on (:383-386)
+    // ---- null distribution
+    Vdouble nullStat, nullKey;
+    bool computePValues = false;
+    if (opt.nullMethod != "none") {
+      if (opt.nullMethod == "z-score") computePValues = true;
+      else if (opt.nullMethod == "permutations") computePValues = false;
+      else computePValues = opt.computePValues;
+      if (opt.nullMethod == "nonparametric-bootstrap") {
+        const size_t m = opt.nbRepCPU * opt.nbRepRAM;
+        std::vector<int64_t> i1(m), i2(m);
+        eng.check(cmx_mica_bootstrap_indices(opt.seed, n, opt.nbRepCPU, opt.nbRepRAM, i1.data(), i2.data()));
+        Vdouble bmi(m), bhj(m);
+        eng.check(cmx_mi_pairs(eng.ctx(), alphabetSize, (int)nbTaxa, masks, nbMasks, aln, n, nullptr, 0, i1.data(), i2.data(), m,
+                               bmi.data(), bhj.data()));
+        for (size_t q = 0; q < m; ++q) {
+          const double hm = std::min(res.entropy[i1[q]], res.entropy[i2[q]]);
+          const double nm = norms ? std::min((*norms)[i1[q]], (*norms)[i2[q]]) : std::numeric_limits<double>::quiet_NaN();
+          res.null.push_back({bmi[q], bhj[q], hm, nm});
+          nullStat.push_back(bmi[q]);
+          nullKey.push_back(norms ? nm : hm);
+        }
+      } else if (opt.nullMethod == "parametric-bootstrap") {
+        if (!norms) throw Exception("You need to specify a model of sequence evolution in order to use a parametric bootstrap approach!");
+        const size_t m = opt.nbRepCPU * opt.nbRepRAM;
+        Vdouble bmi(m), bhj(m), bnm(m);
+        eng.check(cmx_mica_parametric_null(eng.ctx(), alphabetSize, opt.seed, opt.nbRepCPU, opt.nbRepRAM,
+                                           opt.continuousSim ? opt.continuous.gammaAlpha : 0., opt.continuous.pInvariant, bmi.data(),
+                                           bhj.data(), bnm.data()));
+        for (size_t q = 0; q < m; ++q) {
+          // (Hmin of this file is min(entropy[i], entropy[j]) with the REPLICATE and site counters in the reference,
+          // :528 -- meaningless; reproduced where the indices exist, NaN beyond)
+          const size_t rep = q / opt.nbRepRAM, j = q % opt.nbRepRAM;
+          const double hm = (rep < n && j < n) ? std::min(res.entropy[rep], res.entropy[j]) : std::numeric_limits<double>::quiet_NaN();
+          res.null.push_back({bmi[q], bhj[q], hm, bnm[q]});
+        }
+        nullStat = bmi;
+        nullKey = bnm;
+      } else if (opt.nullMethod == "z-score") {
+        int which;
+        if (opt.zScoreStat == "MI") which = CMX_MICA_MI;
+        else if (opt.zScoreStat == "MIp") which = CMX_MICA_MIP;
+        else if (opt.zScoreStat == "MIc") which = CMX_MICA_MIC;
+        else throw Exception("Unkown statistic, should be 'MI', 'MIp' or 'MIc'.");
+        nullStat.assign(n * (n - 1) / 2, 0.);
+        nullKey.assign(n * (n - 1) / 2, 0.);
+        eng.check(cmx_mica_zscore_null(eng.ctx(), which, mi.data(), n, key.data(), nullStat.data(), nullKey.data()));
+      } else if (opt.nullMethod == "permutations") {
+        if (opt.maxNbPermutations == 0) throw Exception("Permutation number should be greater than 0!");
+      } else {
+        throw Exception("Unvalid null distribution method specified: " + opt.nullMethod);
+      }
+    }
+    // ---- p-values of :671-683 (same Domain(0, max key, nbRateClasses) binning and count as CoMap's; NaN == "NA")
+    Vdouble pv;
+    std::vector<int32_t> nsim;
+    if (computePValues) {
+      pv.assign(n * n, 0.);
+      nsim.assign(n * n, 0);
+      eng.check(cmx_intra_pvalues(eng.ctx(), mi.data(), key.data(), n, (int)opt.nbRateClasses, nullStat.data(), nullKey.data(),
+                                  nullStat.size(), pv.data(), nsim.data()));
+    }
+    Vdouble permP;
+    std::vector<int32_t> permN;
+    if (opt.nullMethod == "permutations") miTest(eng, aln, nbTaxa, n, alphabetSize, masks, nbMasks, opt.maxNbPermutations, opt.seed, permP, permN);
+    res.withPermutations = !permP.empty();
+    res.withPValues = computePValues;
+    // ---- the table (:646-689)
+    size_t q = 0;
+    for (size_t i = 0; i + 1 < n; ++i)
+      for (size_t j = i + 1; j < n; ++j, ++q) {
+        Row r;
+        r.i = i; r.j = j;
+        r.mi = mi[i * n + j];
+        r.apc = res.averageMI[i] * res.averageMI[j] / res.fullAverageMI;
+        r.rcw = res.averageMI[i] * res.averageMI[j] / 2.;
+        r.hjoint = hj[i * n + j];
+        r.hmin = std::min(res.entropy[i], res.entropy[j]);
+        r.nmin = norms ? std::min((*norms)[i], (*norms)[j]) : std::numeric_limits<double>::quiet_NaN();
+        r.permPValue = res.withPermutations ? permP[q] : std::numeric_limits<double>::quiet_NaN();
+        r.permNb = res.withPermutations ? permN[q] : 0;
+        r.bsPValue = computePValues ? pv[i * n + j] : std::numeric_limits<double>::quiet_NaN();
+        r.bsNb = computePValues ? nsim[i * n + j] : 0;
+        res.rows.push_back(r);
+      }
+    return res;
+  }
+};
+
 namespace io {
 // LegacySubstitutionMappingTools::writeToStream as called at CoETools.cpp:408-412 (format: one row per branch)
 inline void writeToStream(const ProbabilisticSubstitutionMapping& mapping, const Vdouble& branchLengths,
@@ -773,6 +937,35 @@ inline void writeGroups(const std::vector<Group>& groups, const std::vector<std:
 inline void writeNull(const std::vector<NullDistributionRow>& rows, std::ostream& out) {
   out << "Stat\tRCmin\tPRmin\tNmin" << std::endl;
   for (const NullDistributionRow& r : rows) out << r.stat << "\t" << r.rcMin << "\t" << r.prMin << "\t" << r.nMin << std::endl;
+}
+// Mica's output.file (Mica.cpp:634-690) and null.output.file (:411-415, :494, :534)
+inline void writeMica(const Mica::Result& res, const std::vector<int>& coordinates, std::ostream& out) {
+  out << "Group\tMI\tAPC\tRCW\tHjoint\tHmin";
+  if (res.withModel) out << "\tNmin";
+  if (res.withPermutations) out << "\tPerm.p.value\tPerm.nb";
+  if (res.withPValues) out << "\tBs.p.value\tBs.nb";
+  out << std::endl;
+  for (const Mica::Row& r : res.rows) {
+    out << "[" << coordinates[r.i] << ";" << coordinates[r.j] << "]\t" << r.mi << "\t" << r.apc << "\t" << r.rcw << "\t" << r.hjoint
+        << "\t" << r.hmin;
+    if (res.withModel) out << "\t" << r.nmin;
+    if (res.withPermutations) out << "\t" << r.permPValue << "\t" << r.permNb;
+    if (res.withPValues) {
+      if (std::isnan(r.bsPValue)) out << "\tNA\t0";
+      else out << "\t" << r.bsPValue << "\t" << r.bsNb;
+    }
+    out << std::endl;
+  }
+}
+inline void writeMicaNull(const Mica::Result& res, bool withNmin, std::ostream& out) {
+  out << "MI\tHjoint\tHmin";
+  if (withNmin) out << "\tNmin";
+  out << std::endl;
+  for (const Mica::NullRow& r : res.null) {
+    out << r.mi << "\t" << r.hjoint << "\t" << r.hmin;
+    if (withNmin) out << "\t" << r.nmin;
+    out << std::endl;
+  }
 }
 }  // namespace io
 

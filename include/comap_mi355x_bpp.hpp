@@ -49,6 +49,7 @@
 
 #include <fstream>
 #include <map>
+#include <tuple>
 
 // the reference's own scorer / domain classes (CoMap/Statistics.h, CoMap/Domain.h): the seams take them by reference
 #include "Statistics.h"
@@ -171,9 +172,8 @@ inline AlignmentView toArrays(const ::bpp::SiteContainerInterface& sites, const 
   return a;
 }
 
-// the engine behind a likelihood object + substitution count (one per (drtl, nijt) pair; the reference re-initialises
-// its likelihood for every simulated batch, AnalysisTools.cpp:592-593 -- the engine keeps tree, model and count
-// operators on the device instead)
+// the engine behind a likelihood object + substitution count (the reference re-initialises its likelihood for every
+// simulated batch, AnalysisTools.cpp:592-593 -- the engine keeps tree, model and count operators on the device instead)
 struct Seam {
   TreeView tree;
   cmx::Engine engine;
@@ -181,6 +181,67 @@ struct Seam {
       : tree(toArrays(dynamic_cast<const ::bpp::TreeTemplate<::bpp::Node>&>(drtl.tree()), drtl.data())),
         engine(tree.arrays, toArrays(drtl.substitutionModel(0, 0), *drtl.getRateDistribution(), nijt)) {}
 };
+
+// One Seam (= one cmx_ctx: host-side walk verification + a multi-GB device workspace) per (likelihood, substitution
+// count) pair and parameter state, kept for the life of the process: CoMap.cpp calls getVectors, computeIntraStats and
+// the null seams on the same pair in turn.  The fingerprint covers what a context depends on, so that an optimised or
+// re-parameterised likelihood gets a fresh context.
+inline Seam& seamFor(const ::bpp::DRTreeLikelihoodInterface& drtl, const ::bpp::SubstitutionCountInterface& nijt) {
+  struct Key {
+    const void *tl, *nijt;
+    std::vector<double> print;
+    bool operator<(const Key& o) const { return std::tie(tl, nijt, print) < std::tie(o.tl, o.nijt, o.print); }
+  };
+  static std::map<Key, std::unique_ptr<Seam>> cache;
+  Key k{&drtl, &nijt, {}};
+  for (const auto* n : dynamic_cast<const ::bpp::TreeTemplate<::bpp::Node>&>(drtl.tree()).getNodes())
+    k.print.push_back(n->hasFather() ? n->getDistanceToFather() : 0.);
+  const auto& model = drtl.substitutionModel(0, 0);
+  for (size_t x = 0; x < model.getNumberOfStates(); ++x) { k.print.push_back(model.freq(x)); k.print.push_back(model.Qij(x, (x + 1) % model.getNumberOfStates())); }
+  const auto& rDist = *drtl.getRateDistribution();
+  for (size_t c = 0; c < rDist.getNumberOfCategories(); ++c) { k.print.push_back(rDist.getCategory(c)); k.print.push_back(rDist.getProbability(c)); }
+  auto it = cache.find(k);
+  if (it == cache.end()) it = cache.emplace(std::move(k), std::make_unique<Seam>(drtl, nijt)).first;
+  return *it->second;
+}
+
+// ---- the caller's sequence simulator.  The engine simulates under the likelihood's own tree / model / rate distribution
+// with its counter-based generator; what a NonHomogeneousSequenceSimulator built from the same objects (CoMap.cpp:209-219)
+// adds is ONE switch, enableContinuousRates (CoMap.cpp:213, option simulations.continuous).  The legacy simulator keeps
+// that flag private, so the seams learn it from a registry: replace CoMap.cpp:213 by
+//     cmx::bpp::enableContinuousRates(*seqSim, continuousSim);
+// Any other kind of SequenceSimulatorInterface cannot be honoured and is refused -- never silently replaced.
+inline std::map<const void*, bool>& continuousRegistry() {
+  static std::map<const void*, bool> reg;
+  return reg;
+}
+inline void enableContinuousRates(::bpp::NonHomogeneousSequenceSimulator& seqSim, bool yn) {
+  seqSim.enableContinuousRates(yn);
+  continuousRegistry()[&seqSim] = yn;
+}
+// alpha (and the invariant mass) of Gamma(n, alpha) / Invariant(dist = Gamma(n, alpha), p): what the continuous draw needs
+inline cmx::ContinuousRates continuousRatesOf(const ::bpp::DiscreteDistributionInterface& rDist) {
+  cmx::ContinuousRates cr;
+  bool haveAlpha = false;
+  const auto& pl = rDist.getParameters();
+  for (size_t q = 0; q < pl.size(); ++q) {
+    const std::string name = pl[q].getName();
+    if (name.size() >= 5 && name.compare(name.size() - 5, 5, "alpha") == 0) { cr.gammaAlpha = pl[q].getValue(); haveAlpha = true; }
+    if (name == "p" || (name.size() >= 2 && name.compare(name.size() - 2, 2, ".p") == 0)) cr.pInvariant = pl[q].getValue();
+  }
+  if (!haveAlpha) throw cmx::Exception("cmx::bpp: simulations.continuous needs a Gamma rate distribution (no alpha parameter found)");
+  return cr;
+}
+// nullptr: the discrete simulator (the engine's default); otherwise the continuous-rate parameters
+inline std::unique_ptr<cmx::ContinuousRates> simulatorMode(const ::bpp::SequenceSimulatorInterface& seqSim,
+                                                           const ::bpp::DRTreeLikelihoodInterface& drtl) {
+  if (!dynamic_cast<const ::bpp::NonHomogeneousSequenceSimulator*>(&seqSim))
+    throw cmx::Exception("cmx::bpp: only a NonHomogeneousSequenceSimulator built from the likelihood's own tree, model and rate "
+                         "distribution (CoMap.cpp:209-219) can be replaced by the engine's simulator");
+  const auto it = continuousRegistry().find(&seqSim);
+  if (it == continuousRegistry().end() || !it->second) return nullptr;
+  return std::make_unique<cmx::ContinuousRates>(continuousRatesOf(*drtl.getRateDistribution()));
+}
 
 // reference Statistic object -> the engine's statistic (CoETools::getStatistic builds exactly these, CoETools.cpp:535-600)
 inline std::unique_ptr<cmx::Statistic> toEngineStatistic(const ::Statistic& statistic) {
@@ -243,16 +304,17 @@ class AnalysisTools {
     return n;
   }
 
-  // CoMap/AnalysisTools.h:248-260, body AnalysisTools.cpp:564-658.  `seqSim` is not used: the engine simulates under
-  // the likelihood's own tree / model / rates with its counter-based generator.  average = joint = true only
-  // (the other variants are "for benchmarking only", CoETools.cpp:393).
+  // CoMap/AnalysisTools.h:248-260, body AnalysisTools.cpp:564-658.  The engine simulates under the likelihood's own tree /
+  // model / rates with its counter-based generator; `seqSim` decides between discrete and continuous rates (simulatorMode
+  // above) and is refused when it is anything else.  average / joint select the mapping variant (AnalysisTools.cpp:598-633).
   static void getNullDistributionIntraDR(std::shared_ptr<::bpp::DRTreeLikelihoodInterface> drtl,
-                                         const ::bpp::SequenceSimulatorInterface& /*seqSim*/,
+                                         const ::bpp::SequenceSimulatorInterface& seqSim,
                                          std::shared_ptr<::bpp::SubstitutionCountInterface> nijt, const ::Statistic& statistic,
                                          std::ostream* out, ::bpp::VVdouble* simstats, const ::Domain* rateDomain, size_t repCPU,
                                          size_t repRAM, bool average, bool joint, bool verbose = true) {
-    if (!average || !joint) throw cmx::Exception("cmx::bpp: nijt.average=no / nijt.joint=no go through cmx_map_options (see INTEGRATION.md)");
-    Seam seam(*drtl, *nijt);
+    Seam& seam = seamFor(*drtl, *nijt);
+    seam.engine.setMappingOptions(average, joint);
+    const auto continuous = simulatorMode(seqSim, *drtl);
     const auto stat = toEngineStatistic(statistic);
     std::vector<cmx::NullDistributionRow> rows;
     std::unique_ptr<cmx::Domain> dom;
@@ -260,7 +322,7 @@ class AnalysisTools {
     cmx::VVdouble sims;
     if (simstats) sims = *simstats;
     cmx::AnalysisTools::getNullDistributionIntraDR(seam.engine, *stat, seedOf(drtl.get()), repCPU, repRAM, out ? &rows : nullptr,
-                                                   simstats ? &sims : nullptr, dom.get());
+                                                   simstats ? &sims : nullptr, dom.get(), 0, continuous.get());
     if (simstats) *simstats = sims;
     if (out) {
       *out << "Stat\tRCmin\tPRmin\tNmin" << std::endl;                 // AnalysisTools.cpp:580
@@ -272,14 +334,17 @@ class AnalysisTools {
   // CoMap/AnalysisTools.h:262-275, body AnalysisTools.cpp:662-735
   static void getNullDistributionInterDR(std::shared_ptr<::bpp::DRTreeLikelihoodInterface> drtl1,
                                          std::shared_ptr<::bpp::DRTreeLikelihoodInterface> drtl2,
-                                         const ::bpp::SequenceSimulatorInterface& /*seqSim1*/,
-                                         const ::bpp::SequenceSimulatorInterface& /*seqSim2*/,
+                                         const ::bpp::SequenceSimulatorInterface& seqSim1,
+                                         const ::bpp::SequenceSimulatorInterface& seqSim2,
                                          std::shared_ptr<::bpp::SubstitutionCountInterface> nijt1,
                                          std::shared_ptr<::bpp::SubstitutionCountInterface> nijt2, const ::Statistic& statistic,
                                          std::ostream& out, size_t repCPU, size_t repRAM, bool average, bool joint,
                                          bool verbose = true) {
-    if (!average || !joint) throw cmx::Exception("cmx::bpp: nijt.average=no / nijt.joint=no go through cmx_map_options (see INTEGRATION.md)");
-    Seam seam1(*drtl1, *nijt1), seam2(*drtl2, *nijt2);
+    Seam &seam1 = seamFor(*drtl1, *nijt1), &seam2 = seamFor(*drtl2, *nijt2);
+    seam1.engine.setMappingOptions(average, joint);
+    seam2.engine.setMappingOptions(average, joint);
+    if (simulatorMode(seqSim1, *drtl1) || simulatorMode(seqSim2, *drtl2))
+      throw cmx::Exception("cmx::bpp: simulations.continuous is not available for the two-data-set null (cmx_null_inter simulates with the discrete classes)");
     const auto stat = toEngineStatistic(statistic);
     std::vector<cmx::NullDistributionRow> rows;
     cmx::AnalysisTools::getNullDistributionInterDR(seam1.engine, seam2.engine, *stat, seedOf(drtl1.get()), repCPU, repRAM, &rows);
@@ -314,7 +379,7 @@ class CoETools {
     }
     const bool average = ApplicationTools::getBooleanParameter("nijt.average", params, true, "", true, 4);
     const bool joint = ApplicationTools::getBooleanParameter("nijt.joint", params, true, "", true, 4);
-    Seam seam(*drtl, *substitutionCount);
+    Seam& seam = seamFor(*drtl, *substitutionCount);
     seam.engine.setMappingOptions(average, joint);                       // CoETools.cpp:393-406
     const AlignmentView aln = toArrays(completeSites, drtl->substitutionModel(0, 0));
     const auto mapping = cmx::CoETools::getVectors(seam.engine, aln.codes.data(), aln.nbSites, aln.masks.data(), aln.masks.size());
@@ -367,13 +432,16 @@ class CoETools {
 
   // CoMap/CoETools.h:363-371, body CoETools.cpp:604-728: statistic of every pair of sites, filters, conditional
   // p-values; statistics.txt is written by the same writer the engine's tests pin to the reference's column layout.
-  static void computeIntraStats(const ::bpp::DRTreeLikelihoodInterface& tl, const ::bpp::SequenceSimulatorInterface& /*seqSim*/,
+  static void computeIntraStats(const ::bpp::DRTreeLikelihoodInterface& tl, const ::bpp::SequenceSimulatorInterface& seqSim,
                                 const ::bpp::SiteContainerInterface& completeSites, ::bpp::LegacyProbabilisticSubstitutionMapping& mapping,
                                 std::shared_ptr<::bpp::SubstitutionCountInterface> nijt, const ::Statistic& statistic, bool computeNull,
                                 std::map<std::string, std::string>& params) {
     const std::string path = ApplicationTools::getAFilePath("statistic.output.file", params, true, false);                      // CoETools.cpp:617
     std::ofstream statOut(path.c_str(), std::ios::out);
-    Seam seam(tl, *nijt);
+    Seam& seam = seamFor(tl, *nijt);
+    seam.engine.setMappingOptions(ApplicationTools::getBooleanParameter("nijt.average", params, true, "", true, 4),
+                                  ApplicationTools::getBooleanParameter("nijt.joint", params, true, "", true, 4));
+    const auto continuous = simulatorMode(seqSim, tl);                    // the null of CoETools.cpp:641-653 draws from seqSim
     cmx::ProbabilisticSubstitutionMapping m = fromBpp(mapping, seam.tree);
     const std::vector<size_t> classes = tl.getRateClassWithMaxPostProbPerSite();                                                // :669
     const ::bpp::Vdouble rates = tl.getPosteriorRatePerSite();                                                                  // :670
@@ -389,7 +457,8 @@ class CoETools {
     const size_t nbRepRAM = ApplicationTools::getParameter<size_t>("statistic.null.nb_rep_RAM", params, 1000);
     const unsigned nbRateClasses = ApplicationTools::getParameter<unsigned>("statistic.null.nb_rate_classes", params, 10);      // :638
     const auto stat = toEngineStatistic(statistic);
-    const auto rows = cmx::CoETools::computeIntraStats(seam.engine, m, *stat, computeNull, seedFrom(params), nbRepCPU, nbRepRAM, nbRateClasses, f);
+    const auto rows = cmx::CoETools::computeIntraStats(seam.engine, m, *stat, computeNull, seedFrom(params), nbRepCPU, nbRepRAM, nbRateClasses, f,
+                                                       continuous.get());
     std::vector<int> coordinates(completeSites.getNumberOfSites());
     for (size_t i = 0; i < coordinates.size(); ++i) coordinates[i] = completeSites.site(i).getCoordinate();
     cmx::io::writeIntraStats(rows, coordinates, computeNull, statOut);

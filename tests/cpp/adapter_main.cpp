@@ -6,6 +6,8 @@
 //   adapter_main cluster <input.bin> <method> <maxsize>   -> ClusterTools::cluster + getGroups + writeGroups of the observed data (GPU)
 //   adapter_main clusternull <input.bin> cor|euclidian <method> <nsites> <nrep> <maxsize>   -> null groups file (GPU)
 //   adapter_main candidates <input.bin> <omega> <minSim> <repRAM> <maxTrials> <seed>   -> candidate-group test (GPU)
+//   adapter_main mica <input.bin> <method> <withModel 0|1> <zstat> -> cmx::Mica::analyse: output.file to stdout, null.output.file to stderr (GPU)
+//   adapter_main inter <input.bin> <indep 0|1> <quirk 0|1> -> CoETools::computeInterStats of the alignment's two halves (GPU)
 //   adapter_main vec <input.bin>                     -> cmx::io::writeToStream of a mapping to stdout (host only);
 //      input.bin: int32 N, B; int32 coords[N]; f64 blen[B]; f64 counts[N*B] (site-major)
 // input.bin (little endian): int32 nn, T, S, C, N, repCPU, repRAM, nclasses; uint64 seed;
@@ -181,6 +183,61 @@ int main(int argc, char** argv) {
         std::cout << set[g].getStatisticValue() << " " << set.getN1ForGroup(g) << " " << set.getN2ForGroup(g) << " "
                   << set.getPValueForGroup(g) << "\n";
       std::cout << set.getNumberOfTrials() << " " << set.getNumberOfBatches() << "\n";
+      return 0;
+    }
+    if ((argc == 6 && std::strcmp(argv[1], "mica") == 0) || (argc == 5 && std::strcmp(argv[1], "inter") == 0)) {
+      std::ifstream in(argv[2], std::ios::binary);
+      int32_t h[8];
+      uint64_t seed;
+      rd(in, h, 8);
+      rd(in, &seed, 1);
+      const int nn = h[0], T = h[1], S = h[2], C = h[3], N = h[4];
+      cmx::TreeArrays t;
+      cmx::ModelArrays m;
+      t.parent.resize(nn); t.branchLengths.resize(nn); t.leafOfTaxon.resize(T);
+      rd(in, t.parent.data(), nn); rd(in, t.branchLengths.data(), nn); rd(in, t.leafOfTaxon.data(), T);
+      m.nbStates = S;
+      m.generator.resize(S * S); m.frequencies.resize(S); m.rates.resize(C); m.rateProbabilities.resize(C);
+      rd(in, m.generator.data(), S * S); rd(in, m.frequencies.data(), S); rd(in, m.rates.data(), C);
+      rd(in, m.rateProbabilities.data(), C);
+      std::vector<uint8_t> aln(static_cast<size_t>(T) * N);
+      rd(in, aln.data(), aln.size());
+      cmx::Engine eng(t, m, 0);
+      std::cout.precision(6);
+      if (std::strcmp(argv[1], "inter") == 0) {   // data set 1 = the first half of the columns, data set 2 = the second half
+        const int n1 = N / 2, n2 = N - n1;
+        std::vector<uint8_t> a1(static_cast<size_t>(T) * n1), a2(static_cast<size_t>(T) * n2);
+        for (int tx = 0; tx < T; ++tx) {
+          std::copy(aln.begin() + static_cast<size_t>(tx) * N, aln.begin() + static_cast<size_t>(tx) * N + n1, a1.begin() + static_cast<size_t>(tx) * n1);
+          std::copy(aln.begin() + static_cast<size_t>(tx) * N + n1, aln.begin() + static_cast<size_t>(tx + 1) * N, a2.begin() + static_cast<size_t>(tx) * n2);
+        }
+        auto m1 = cmx::CoETools::getVectors(eng, a1.data(), n1);
+        auto m2 = cmx::CoETools::getVectors(eng, a2.data(), n2);
+        cmx::CorrelationStatistic stat;
+        cmx::PairFilters f1, f2;
+        f1.minRateClass = 1; f2.minRate = 0.2; f1.minStatistic = 0.05;
+        const auto rows = cmx::CoETools::computeInterStats(eng, *m1, *m2, stat, std::atoi(argv[3]) != 0, f1, f2, std::atoi(argv[4]) != 0);
+        std::vector<int> c1(n1), c2(n2);
+        for (int i = 0; i < n1; ++i) c1[i] = 100 + i;
+        for (int i = 0; i < n2; ++i) c2[i] = 500 + i;
+        cmx::io::writeIntraStats(rows, c1, false, std::cout, &c2);
+        return 0;
+      }
+      cmx::Mica::Options opt;
+      opt.nullMethod = argv[3];
+      opt.nbRepCPU = h[5]; opt.nbRepRAM = h[6]; opt.nbRateClasses = h[7];
+      opt.seed = seed;
+      opt.zScoreStat = argv[5];
+      opt.maxNbPermutations = 200;
+      const bool withModel = std::atoi(argv[4]) != 0;
+      cmx::Vdouble norms;
+      if (withModel) norms = cmx::AnalysisTools::computeNorms(*cmx::CoETools::getVectors(eng, aln.data(), N));
+      const cmx::Mica::Result res = cmx::Mica::analyse(eng, aln.data(), T, N, S, nullptr, 0, withModel ? &norms : nullptr, opt);
+      std::vector<int> coords(N);
+      for (int i = 0; i < N; ++i) coords[i] = 10 + i;
+      cmx::io::writeMica(res, coords, std::cout);
+      std::cerr.precision(6);
+      if (!res.null.empty()) cmx::io::writeMicaNull(res, withModel, std::cerr);
       return 0;
     }
     if (argc == 3 && std::strcmp(argv[1], "vec") == 0) {

@@ -170,3 +170,61 @@ def test_two_rank_gloo_observed_rows_and_mica_rectangle():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_rows and ok_cols and ok_tot
+
+
+class _OracleColumns:
+    """stands where the engine stands in mica_rectangle (same method, same argument order), columns through the oracle:
+    there is no GPU in the CPU suite, and what is under test is the sharding, the skipped empty block and the averages"""
+
+    def mi_columns_dev(self, blk, mi, hj, other, nalpha, masks, h1, h2):
+        import oracle
+        assert blk.shape[1] > 0, "an empty block must not reach the engine"
+        r = oracle.mi_columns(blk.numpy(), other.numpy(), nalpha)
+        mi.copy_(torch.from_numpy(r["mi"])); hj.copy_(torch.from_numpy(r["hjoint"]))
+        h1.copy_(torch.from_numpy(r["h1"])); h2.copy_(torch.from_numpy(r["h2"]))
+
+
+def _worker_rectangle(rank, world, port, n1, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from comap_amd.distributed import mica_rectangle
+    rng = np.random.default_rng(11)
+    a1 = rng.integers(0, 20, size=(25, n1)).astype(np.uint8)
+    a2 = rng.integers(0, 20, size=(25, 6)).astype(np.uint8)
+    t1, t2 = torch.from_numpy(a1), torch.from_numpy(a2)
+    intra = mica_rectangle(_OracleColumns(), t1, None, 20)
+    rect = mica_rectangle(_OracleColumns(), t1, t2, 20)
+    parts = [None] * world
+    dist.all_gather_object(parts, (intra["rows"], intra["row_mean"].numpy(), rect["row_mean"].numpy()))
+    if rank == 0:
+        full = oracle.mi_columns(a1, a1, 20)["mi"]
+        avg, fullavg = oracle.mica_average_mi(full)          # Mica.cpp:346-363
+        fr = oracle.mi_columns(a1, a2, 20)["mi"]
+        ok = [np.allclose(np.concatenate([p[1] for p in parts]), avg, rtol=1e-13, atol=1e-15),
+              np.allclose(intra["col_mean"].numpy(), avg, rtol=1e-13, atol=1e-15),
+              abs(float(intra["full_mean"]) - fullavg) <= 1e-13 * abs(fullavg),
+              np.allclose(np.concatenate([p[2] for p in parts]), fr.mean(axis=1), rtol=1e-13),
+              np.allclose(rect["col_mean"].numpy(), fr.mean(axis=0), rtol=1e-13),
+              abs(float(rect["full_mean"]) - fr.mean()) <= 1e-13 * fr.mean(),
+              [p[0] for p in parts][0][0] == 0 and [p[0] for p in parts][-1][1] == n1]
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n1", [(2, 9), (3, 2)])     # (3, 2): one rank has no column of its own
+def test_gloo_mica_rectangle_shards_and_reference_averages(world, n1):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker_rectangle, args=(r, world, port, n1, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok), ok

@@ -973,3 +973,63 @@ def test_device_resident_handovers_equal_the_host_paths():
         assert p.keys() == q.keys()
         for k in p:
             assert np.array_equal(p[k], q[k]), k
+
+
+def _inter_rows_restated(stat, m1, m2, f):
+    """CoETools::computeInterStats' pair loop (CoETools.cpp:786-828) restated on a dense statistic matrix"""
+    out = []
+    n1, n2 = stat.shape
+    for i in range(n1):
+        ci, ri = int(m1["rate_class"][i]), m1["post_rate"][i]
+        if ci < f.min_rate_class1 or ri < f.min_rate1:
+            continue
+        js = [i] if f.independent_comparisons else range(n2)
+        for j in js:
+            cj, rj = int(m2["rate_class"][j]), m2["post_rate"][j]
+            if cj < f.min_rate_class2 or rj < f.min_rate2:
+                continue
+            if f.max_rate_class_diff >= 0 and abs(cj - ci) > f.max_rate_class_diff:
+                continue
+            if f.max_rate_diff >= 0 and abs(rj - ri) > f.max_rate_diff:
+                continue
+            st = stat[i, j]
+            if abs(st) < f.min_statistic:
+                continue
+            nj = m2["norm"][min(i, n2 - 1)] if f.reference_norm_quirk else m2["norm"][j]     # :803 reads norms2[i]
+            out.append((i, j, st, min(ci, cj), min(ri, rj), min(m1["norm"][i], nj)))
+    return out
+
+
+@pytest.mark.parametrize("kind", [engine.STAT_CORRELATION, engine.STAT_COMPENSATION, engine.STAT_DISCRETE_MI_BOUNDS])
+def test_inter_rows_on_the_device_match_the_reference_loop(kind):
+    """the inter-gene pair loop (filters of CoETools.cpp:786-812, independant comparisons, compaction) runs
+    on the device; the rows equal the reference's loop restated over the oracle's statistic, pair for pair"""
+    case = make_case(12, 150, 20, 88)
+    case2 = dict(case)
+    case2["blen"] = case["blen"] * 1.4
+    e1, e2 = _engine(case), _engine(case2)
+    m1 = e1.map_sites(case["aln"])
+    m2 = e2.map_sites(case["aln"][:, ::-1][:, :150 if kind != engine.STAT_CORRELATION else 97].copy())
+    thr = [0.0, 0.02, 0.2, 1.0, 100.0] if kind == engine.STAT_DISCRETE_MI_BOUNDS else 0.99
+    okind = oracle.ST_DISCRETE_MI if kind == engine.STAT_DISCRETE_MI_BOUNDS else kind
+    op = np.concatenate([[len(thr)], thr]) if kind == engine.STAT_DISCRETE_MI_BOUNDS else None
+    dense = oracle.pair_stats_inter(okind, m1["counts"], m2["counts"], params=op)
+    n2 = len(m2["norm"])
+    cases = [engine.InterFilters(),
+             engine.InterFilters(min_rate_class1=1, min_rate_class2=2, max_rate_class_diff=1, min_rate1=0.2, min_rate2=0.1,
+                                 max_rate_diff=1.5, min_statistic=0.05),
+             engine.InterFilters(reference_norm_quirk=True, min_statistic=0.1)]
+    if n2 == 150:
+        cases.append(engine.InterFilters(independent_comparisons=True, min_rate_class1=1))
+    for f in cases:
+        rows, count = e1.inter_rows(kind, m1, m2, f, threshold=thr)
+        want = _inter_rows_restated(dense, m1, m2, f)
+        assert count == len(want) == len(rows) and count > 0
+        assert [(int(r["i"]), int(r["j"])) for r in rows] == [(w[0], w[1]) for w in want]
+        rel_close(rows["stat"], [w[2] for w in want], 1e-6, 1e-12)
+        assert np.array_equal(rows["rc_min"], [w[3] for w in want])
+        rel_close(rows["pr_min"], [w[4] for w in want], 1e-12)
+        rel_close(rows["n_min"], [w[5] for w in want], 1e-12)
+        assert np.isnan(rows["pvalue"]).all() and (rows["nsim"] == 0).all()
+    with pytest.raises(engine.CmxError, match="same length"):
+        e1.inter_rows(kind, m1, {k: v[:60] for k, v in m2.items()}, engine.InterFilters(independent_comparisons=True), threshold=thr)
