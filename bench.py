@@ -176,7 +176,7 @@ def mica_leg(dev, steps, world=1, rank=0, gloo=False):
     out = dict(workload="cfg5: Mica MI, 5000 + 5000 columns x 256 taxa, protein alphabet, all 25e6 cross pairs",
                value=pairs / (ms * 1e-3), unit="column-pair MI/s", ms_per_step=ms, steps=steps, dtype="i8", n_gpus=world,
                parallelism=("single GPU" if world == 1 else f"rows of alignment 1 split x{world}, one all-reduce of the column sums"),
-               roofline=dict(bound="mfma", kernel="mica_mfma3_kernel (+ symbol bytes / column sums / row and column means)", achieved=tops,
+               roofline=dict(bound="mfma", kernel="mica_mfma4_kernel<8, plain> (+ symbol bytes / column sums / row and column means)", achieved=tops,
                              peak=INT8_PEAK_TOPS * world, unit="TOP/s", frac=tops / (INT8_PEAK_TOPS * world), traffic=None,
                              ops_per_pair_algorithmic=2.0 * A * A * T),
                max_identity_residual=ident, full_mean_mi=float(r["full_mean"]))

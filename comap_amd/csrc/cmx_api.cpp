@@ -1345,19 +1345,23 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
     w.Tp = (ntaxa + 31) / 32 * 32;
     const size_t hb = 32 * (size_t)w.Tp;
     if ((s = scratch(ctx, "mica_H1", hb * n1, (void**)&w.H1)) != CMX_OK) return s;
-    if ((s = scratch(ctx, "mica_C1", (size_t)w.Tp * n1, (void**)&w.C1)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "mica_C1", (size_t)w.Tp * (n1 + kMicaCodePad), (void**)&w.C1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_f1", n1, (void**)&w.flag1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_g1", n1, (void**)&w.gap1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_S1", sizeof(double) * n1, (void**)&w.S1)) != CMX_OK) return s;
     if (!intra) {
       if ((s = scratch(ctx, "mica_H2", hb * n2, (void**)&w.H2)) != CMX_OK) return s;
-      if ((s = scratch(ctx, "mica_C2", (size_t)w.Tp * n2, (void**)&w.C2)) != CMX_OK) return s;
+      if ((s = scratch(ctx, "mica_C2", (size_t)w.Tp * (n2 + kMicaCodePad), (void**)&w.C2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_f2", n2, (void**)&w.flag2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_g2", n2, (void**)&w.gap2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_S2", sizeof(double) * n2, (void**)&w.S2)) != CMX_OK) return s;
     }
-    if ((s = scratch(ctx, "mica_ftab", sizeof(double) * ((size_t)(ntaxa + 1) + (size_t)nalpha * nalpha * ntaxa + 1), (void**)&w.ftab)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "mica_ftab", sizeof(double) * ((size_t)(ntaxa + 1) + 2 * ((size_t)nalpha * nalpha * ntaxa + 1) + 2), (void**)&w.ftab)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_any", sizeof(int), (void**)&w.anyflag)) != CMX_OK) return s;
+    if (nalpha == 20) {   // block info of the four-wave kernel, padded to whole tiles of 12 columns
+      if ((s = scratch(ctx, "mica_info1", sizeof(unsigned) * ((n1 + 11) / 12 * 4 + 4), (void**)&w.info1)) != CMX_OK) return s;
+      if (!intra && (s = scratch(ctx, "mica_info2", sizeof(unsigned) * ((n2 + 11) / 12 * 4 + 4), (void**)&w.info2)) != CMX_OK) return s;
+    }
   }
   HIP_TRY(ctx, launch_mi_columns(nalpha, ntaxa, d_masks, d_aln1, n1, ld1, d_aln2, n2, ld2, intra ? 1 : 0, d_mi, d_hjoint,
                                  ldo, d_h1, intra ? nullptr : d_h2, mfma ? &w : nullptr, (hipStream_t)stream));

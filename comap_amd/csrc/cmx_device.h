@@ -217,16 +217,23 @@ hipError_t launch_mi_pairs(int A, int T, const uint32_t* d_masks, const uint8_t*
                            size_t ld2, const int64_t* d_idx1, const int64_t* d_idx2, size_t npairs, double* d_mi,
                            double* d_hj, hipStream_t stream);
 // scratch of the MFMA Mica path (all device pointers; H1 null = LDS-table kernel only)
+constexpr int kMicaLdsF2 = 4096;   // entries of f2 the weighted four-wave kernel keeps in LDS (m < 4096: cells of up to ten taxa)
+constexpr int kMicaCodePad = 12;   // columns of "no row" symbols behind the last column of C1 / C2 (the four-wave kernel reads whole tiles)
 struct MicaWork {
   int8_t *H1, *H2;         // one-hot [n][32][Tp] int8 (one-column-per-tile kernel)
-  uint8_t *C1, *C2;        // [n][Tp] one-hot row of each taxon (state, A = unknown, 255 = none): the packed protein kernel's operands
+  uint8_t *C1, *C2;        // [n + kMicaCodePad][Tp] one-hot row of each taxon (state, A = unknown, 255 = none): the packed protein kernel's operands
   uint8_t *flag1, *flag2;  // [n] column has ambiguous symbols other than "unknown" (-> LDS-table kernel)
   uint8_t *gap1, *gap2;    // [n] column has unknowns (gap / X / N: compatible with every state; handled on the matrix cores)
   double *S1, *S2;         // [n] sum_a f(count_a)
-  double* ftab;            // [T + 1] c ln c, then [A*A*T + 1] (m / A^2) ln(m / A^2) (pairs with unknowns)
+  double* ftab;            // [T + 1] c ln c, then [A*A*T + 1] f2[m] = (m / A^2) ln(m / A^2) (pairs with unknowns), then 0 and f2[M0 ..] again
   int* anyflag;            // some column of either alignment has ambiguous symbols
+  unsigned *info1, *info2;   // per block of three columns: not-served and has-unknowns bits (cmx_mica4.hip; NULL: not used)
   int Tp;                  // T rounded up to a multiple of 32 (taxa per MFMA step)
 };
+// cmx_mica4.hip: the four-wave protein kernel (unknowns included; partial ambiguity codes are not served)
+bool mica4_serves(int A, int Tp, size_t n1, size_t n2);
+hipError_t launch_mica4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,
+                        hipStream_t stream);
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
                              size_t ldo, double* d_h1, double* d_h2, const MicaWork* work, hipStream_t stream);

@@ -26,6 +26,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "cmx_device.h"
+#include "cmx_lanes.h"
 #include "cmx_pairstat.h"
 #include "cmx_walk.h"
 
@@ -161,20 +162,6 @@ __device__ __forceinline__ void wait_vm(int allowed) {
 // v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second one,
 // v_permlane16_swap does the same for the odd / even rows of 16 lanes: after swap(a, b) the sum a + b holds, in the
 // lanes that keep a's site group, own + partner's a, and in the others own + partner's b -- no LDS round trip.
-__device__ __forceinline__ void swap32(double& a, double& b) {
-  const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
-  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
-  a = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
-  b = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
-}
-__device__ __forceinline__ void swap16(double& a, double& b) {
-  const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
-  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
-  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
-  a = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
-  b = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
-}
 template <int NG>
 __device__ __forceinline__ double reduce_sites(const double (&p)[NG]) {
   if constexpr (NG == 4) {
@@ -2132,23 +2119,27 @@ constexpr int kMicaK = 32;   // taxa per MFMA step (v_mfma_i32_32x32x32_i8)
 // (pairs of that column go to the LDS-table kernel).  S[col] = sum_a f(count_a) with the fractional counts.
 __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, const uint32_t* __restrict__ masks,
                                                           const uint8_t* __restrict__ aln, size_t ld,
-                                                          int8_t* __restrict__ H, uint8_t* __restrict__ codes /*[n][Tp]: the one-hot row of each taxon, 255 = none*/,
+                                                          int8_t* __restrict__ H, uint8_t* __restrict__ codes /*[n][Tp]: the one-hot row of each taxon (state, A = unknown), 63 = none*/,
                                                           uint8_t* __restrict__ flag,
                                                           uint8_t* __restrict__ gap, double* __restrict__ S,
-                                                          int* __restrict__ anyflag) {
+                                                          int* __restrict__ anyflag, size_t n) {
   __shared__ int cnt[33];
   __shared__ int amb;
   const size_t i = blockIdx.x;
+  if (i >= n) {   // the columns of padding behind the last one (kMicaCodePad): "no row" everywhere
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) codes[i * (size_t)Tp + t] = 63;
+    return;
+  }
   const uint32_t full = (1u << A) - 1u;
   if (threadIdx.x < 33) cnt[threadIdx.x] = 0;
   if (threadIdx.x == 0) amb = 0;
   __syncthreads();
   for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
-    unsigned c = t < T ? aln[(size_t)t * ld + i] : 255u;
+    unsigned c = t < T ? aln[(size_t)t * ld + i] : 63u;
     if (t < T) {
       if (c >= (unsigned)A) {
         if ((masks[c] & full) == full) c = (unsigned)A;     // unknown: pseudo-state
-        else { amb = 1; c = 255u; }
+        else { amb = 1; c = 63u; }
       }
       if (c <= (unsigned)A) atomicAdd(&cnt[c], 1);
     }
@@ -2183,7 +2174,13 @@ __global__ void mica_ftable_kernel(int T, int A, double* __restrict__ f, int* __
   const int M = A * A * T;
   if (c <= M) {
     const double v = (double)c / (double)(A * A);
-    f[T + 1 + c] = c > 0 ? v * log(v) : 0.0;
+    const double fv = c > 0 ? v * log(v) : 0.0;
+    f[T + 1 + c] = fv;
+    // third table (cmx_mica4.hip): a zero, then f2[M0 ..], so that "m below M0" can be a load of entry 0
+    const int M0 = M + 1 < kMicaLdsF2 ? M + 1 : kMicaLdsF2;
+    double* hi = f + (T + 1) + (M + 1);
+    if (c == 0) hi[0] = 0.0;
+    if (c >= M0) hi[c - M0 + 1] = fv;
   }
 }
 
@@ -2192,12 +2189,6 @@ __global__ void mica_ftable_kernel(int T, int A, double* __restrict__ f, int* __
 // (four waves per SIMD) and one workgroup's barriers and table epilogue overlap the other's MFMAs.  The 12 operand tiles
 // of a k-step (64 lanes x 16 B each) go through LDS once per workgroup.
 constexpr int kMicaTileI = 8, kMicaTileJ = 4;
-template <int CTRL>
-__device__ __forceinline__ double mica_dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 template <int A>
 __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const int8_t* __restrict__ H1, size_t n1,
                                                            const uint8_t* __restrict__ flag1, const uint8_t* __restrict__ gap1,
@@ -2371,20 +2362,7 @@ __global__ __launch_bounds__(512, 2) void mica_mfma_kernel(int T, int Tp, const 
 // The epilogue sums f(count) per (column of the block row, column of the block column): an accumulator register's row
 // block is known at compile time up to the lane's half (rows + 4 in lanes >= 32), its column block from the lane.
 constexpr int kMica3I = 12, kMica3J = 6, kMicaP = 21;
-__device__ __forceinline__ double mica_reduce4(double p0, double p1, double p2, double p3) {
-  // totals over the wave of four values at once: lanes with lane >> 4 == r end with the total of value r
-  swap32(p0, p2);
-  swap32(p1, p3);
-  double k0 = p0 + p2, k1 = p1 + p3;
-  swap16(k0, k1);
-  double s = k0 + k1;
-  s += mica_dpp_f64<0x128>(s);   // row_ror:8
-  s += mica_dpp_f64<0x124>(s);   // row_ror:4
-  s += mica_dpp_f64<0x122>(s);   // row_ror:2
-  s += mica_dpp_f64<0x121>(s);   // row_ror:1
-  return s;
-}
-__global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const uint8_t* __restrict__ C1, size_t n1,
+__device__ __forceinline__ void mica3_tile(int T, int Tp, const uint8_t* __restrict__ C1, size_t n1,
                                                             const uint8_t* __restrict__ flag1, const uint8_t* __restrict__ gap1,
                                                             const double* __restrict__ S1,
                                                             const uint8_t* __restrict__ C2, size_t n2,
@@ -2392,7 +2370,7 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
                                                             const double* __restrict__ S2,
                                                             const double* __restrict__ ftab_g, int intra,
                                                             double* __restrict__ mi, double* __restrict__ hj, size_t ldo,
-                                                            unsigned ntx, unsigned ntiles, unsigned per_xcd) {
+                                                            unsigned ntx, unsigned tlin) {
   extern __shared__ __attribute__((aligned(16))) uint8_t mica_smem[];
   constexpr int A = 20, P = kMicaP;
   double* ftab = reinterpret_cast<double*>(mica_smem);                       // [T + 1]
@@ -2402,12 +2380,6 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
   double* Scol = reinterpret_cast<double*>(codes + (size_t)(kMica3I + kMica3J) * Tp);   // [18] S of the tile's columns (12 + 6)
   int* fcol = reinterpret_cast<int*>(Scol + 18);   // [18] bit 0 partial ambiguity codes, bit 1 unknowns, bit 2 past the end
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
-  // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8) and each XCD has its own L2:
-  // XCD x takes a contiguous run of the row-major tile order, so that the tiles which complete an output cache line (a
-  // tile writes 48-byte pieces of 12 rows) and re-read the same symbol columns meet in one L2.  At 5000 x 5000 x 256 the
-  // launch time did not change (6.31 ms either way): kept for the traffic, not for the time.
-  const unsigned tlin = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if ((blockIdx.x >> 3) >= per_xcd || tlin >= ntiles) return;
   const size_t i0 = (size_t)(tlin / ntx) * kMica3I, j0 = (size_t)(tlin % ntx) * kMica3J;
   if (intra && j0 + kMica3J <= i0 + 1) {   // no pair with j > i in this tile: only the NaN convention of the intra layout
     if (tid < kMica3I * kMica3J) {
@@ -2632,6 +2604,22 @@ __global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(int T, int Tp, const
   }
 }
 
+#define CMX_MICA3_PARAMS                                                                                                      \
+  int T, int Tp, const uint8_t *__restrict__ C1, size_t n1, const uint8_t *__restrict__ flag1, const uint8_t *__restrict__ gap1, \
+      const double *__restrict__ S1, const uint8_t *__restrict__ C2, size_t n2, const uint8_t *__restrict__ flag2,              \
+      const uint8_t *__restrict__ gap2, const double *__restrict__ S2, const double *__restrict__ ftab_g, int intra,             \
+      double *__restrict__ mi, double *__restrict__ hj, size_t ldo, unsigned ntx
+#define CMX_MICA3_ARGS T, Tp, C1, n1, flag1, gap1, S1, C2, n2, flag2, gap2, S2, ftab_g, intra, mi, hj, ldo, ntx
+// alignments of more than 256 taxa, and the A/B switch CMX_MICA_TILES=3 (up to 256 taxa: cmx_mica4.hip)
+__global__ __launch_bounds__(512, 4) void mica_mfma3_kernel(CMX_MICA3_PARAMS, unsigned ntiles, unsigned per_xcd) {
+  // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8) and each XCD has its own L2:
+  // XCD x takes a contiguous run of the row-major tile order, so that the tiles which complete an output cache line (a
+  // tile writes 48-byte pieces of 12 rows) and re-read the same symbol columns meet in one L2.  At 5000 x 5000 x 256 the
+  // launch time did not change (6.31 ms either way): kept for the traffic, not for the time.
+  const unsigned tlin = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tlin >= ntiles) return;
+  mica3_tile(CMX_MICA3_ARGS, tlin);
+}
 template <int A>
 __global__ void column_entropy_kernel(int T, const uint32_t* __restrict__ masks, const uint8_t* __restrict__ aln,
                                       size_t n, size_t ld, double* __restrict__ h) {
@@ -2661,6 +2649,12 @@ static bool mica_one_column_tiles() {
   return v;
 }
 
+// CMX_MICA_TILES=3: the eight-wave packed kernel for every tile (A/B timing of the four-wave kernel; same results)
+static bool mica_eight_wave_tiles() {
+  static const bool v = [] { const char* e = getenv("CMX_MICA_TILES"); return e && e[0] == '3'; }();
+  return v;
+}
+
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
                              size_t ldo, double* d_h1, double* d_h2, const MicaWork* work, hipStream_t stream) {
@@ -2675,11 +2669,11 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
     const int Tp = work->Tp;
     const bool needH = !(A == 20 && !mica_one_column_tiles());   // the packed protein kernel expands the symbol bytes itself
     hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)((A * A * T) / 256 + 1)), dim3(256), 0, stream, T, A, work->ftab, work->anyflag);
-    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n1), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, needH ? work->H1 : nullptr, work->C1, work->flag1,
-                       work->gap1, work->S1, work->anyflag);
+    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)(n1 + kMicaCodePad)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, needH ? work->H1 : nullptr, work->C1, work->flag1,
+                       work->gap1, work->S1, work->anyflag, n1);
     if (!intra)
-      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)n2), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln2, ld2, needH ? work->H2 : nullptr, work->C2,
-                         work->flag2, work->gap2, work->S2, work->anyflag);
+      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)(n2 + kMicaCodePad)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln2, ld2, needH ? work->H2 : nullptr, work->C2,
+                         work->flag2, work->gap2, work->S2, work->anyflag, n2);
     dim3 g2((unsigned)((n2 + kMicaTileJ - 1) / kMicaTileJ), (unsigned)((n1 + kMicaTileI - 1) / kMicaTileI));
     const size_t lds2 = (((size_t)(T + 1) * 8 + 15) & ~(size_t)15) + 2 * (kMicaTileI + kMicaTileJ) * 64 * sizeof(cmx_i4);
     if (A == 20 && !mica_one_column_tiles()) {
@@ -2687,10 +2681,14 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
       const unsigned ntiles = ntx * nty, per_xcd = (ntiles + 7) / 8;
       const size_t lds3 = lds2 + 2 * (kMica3I / 3 * 2 + kMica3J / 3 * 2) * 64 * sizeof(cmx_i4) + 16384 + (size_t)(kMica3I + kMica3J) * Tp + 18 * sizeof(double) + 20 * sizeof(int);
       if (lds3 > 64 * 1024) {
-        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&mica_mfma3_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&mica_mfma3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (ea != hipSuccess) return ea;
       }
+      if (mica4_serves(A, Tp, n1, n2) && work->info1 && !mica_eight_wave_tiles()) {
+        // up to 256 taxa: the four-wave kernel (cmx_mica4.hip), unknowns included
+        const hipError_t e4 = launch_mica4(T, work, n1, n2, intra, d_mi, d_hj, ldo, stream);
+        if (e4 != hipSuccess) return e4;
+      } else
       hipLaunchKernelGGL(mica_mfma3_kernel, dim3(8 * per_xcd), dim3(512), lds3, stream, T, Tp, work->C1, n1,
                          work->flag1, work->gap1, work->S1, intra ? work->C1 : work->C2, n2, intra ? work->flag1 : work->flag2,
                          intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo, ntx, ntiles, per_xcd);

@@ -1,0 +1,409 @@
+// Mica column MI for the protein alphabet, third arrangement (Mica.cpp:349-361, 646-689 -> per pair
+// SiteTools::mutualInformation / jointEntropy): the one-hot Gram of two symbol columns on v_mfma_i32_32x32x32_i8, with
+//
+//   * persistent workgroups of FOUR waves (one per SIMD), each walking a run of tiles of 12 columns of the first
+//     alignment x 3 columns of the second; wave w owns the 3 x 3 pairs of its block of three first-alignment columns;
+//   * the first alignment's operands held in REGISTERS for the whole run: three columns x 20 states = 60 of the 64 rows
+//     of a block (no pseudo-state row for the unknowns: see below), 8 k-steps x 2 row tiles x 4 registers, expanded
+//     once per run straight from the symbol bytes.  The k-loop reads only the second alignment's operands from LDS
+//     (2 ds_read_b128 per 4 MFMAs) -- the 8-wave kernel (cmx_kernels.hip, mica_mfma3_kernel) expanded all twelve operand
+//     tiles of every tile again, and its busiest SIMDs spent more issue cycles on that than on the matrix products;
+//   * the first operand's "one" is 8, the second's 1: an accumulator holds 8 x count, which IS the LDS address of
+//     f(count) (the table sits at LDS address 0) -- no shift and no add in front of the 64 lookups per lane;
+//   * the second alignment's symbol bytes of the NEXT tile are fetched while the current tile's products run and are
+//     expanded into the other operand buffer before the current tile's epilogue: one barrier per tile, no wait on memory;
+//   * 20 rows per column put the column boundaries on the accumulator registers' row quads (rows 20 and 60 fall between
+//     the two lane halves of a register, row 40 between registers): one select pair per tile column instead of eleven.
+//
+// UNKNOWNS (gap, X: symbols compatible with every state -- what real alignments are full of) take the same road in a second
+// instantiation (WEIGHTED).  The fractional counts of resolveUnknowns = true are c_ab = N_ab + (N_aG + N_Gb) / A + N_GG / A^2
+// = m / A^2 with the integer m = A^2 N_ab + A (N_aG + N_Gb) + N_GG, and m IS a Gram: the sum over the taxa of u_a(t) v_b(t)
+// with u, v = A where the symbol is the state and 1 where it is an unknown.  Expanded with those weights (20 and 1 fit a
+// byte) the accumulators hold m (8 m with the weights doubled on one side and quadrupled on the other), and the epilogue
+// looks f2[m] = (m / A^2) ln(m / A^2) up instead of f[N]: the first 4096 entries of that table sit in LDS (cells of up to
+// ten taxa: most of them), the rest is gathered from the table in global memory (L2-resident) by the registers that hold
+// such a cell -- the gather's descriptor starts at entry 4096, so the lanes below it fall out of its range and cost no
+// memory access.  No pseudo-state row, no dump of the accumulators to LDS, no per-pair gather of cells (the eight-wave
+// kernel's way).  The plain instantiation serves the (block, tile) combinations
+// without an unknown on either side, the weighted one the others; a tile nobody in the workgroup needs is not even fetched.
+//
+// Pairs with a column that carries PARTIAL ambiguity codes (B, Z, R, Y ...) are left to the LDS-table kernel
+// (launch_mi_columns).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "cmx_device.h"
+#include "cmx_lanes.h"
+
+namespace cmx {
+
+constexpr int kM4I = 12, kM4J = 3, kM4Rows = 20;
+constexpr unsigned kM4MaxChunk = 64;   // tiles per run: one lane of a wave per tile when the run's tile info is loaded
+
+// 16 symbols (four dwords) against one state.  Symbols and states are < 64 (the codes use 63 for "no row", 20 for the
+// unknown), so 0x80 - (symbol ^ state) has bit 7 set exactly where they match and no byte borrows.
+// plain: bytes `one` where they match (SHIFT / MASK move bit 7 to the one's place)
+template <int SHIFT, unsigned MASK>
+__device__ __forceinline__ cmx_i4 m4_expand(const cmx_i4 sy, unsigned srow) {
+  cmx_i4 oh;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) oh[d] = (int)(((0x80808080u - ((unsigned)sy[d] ^ srow)) >> SHIFT) & MASK);
+  return oh;
+}
+// weighted: UNIT x A (A = 20) where the symbol is the state, UNIT where it is the unknown; `live` = 0 for the padding rows.
+// UNIT is 2 on the first side and 4 on the second, so that the accumulators hold 8 m, the byte offset of f2[m]
+template <unsigned UNIT>
+__device__ __forceinline__ cmx_i4 m4_expand_weighted(const cmx_i4 sy, unsigned srow, unsigned live) {
+  cmx_i4 oh;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    // 20 UNIT = 5 x (4 UNIT): the match bit moved to the place of 4 UNIT, OR itself two places higher (bytes do not carry)
+    const unsigned eq = ((0x80808080u - ((unsigned)sy[d] ^ srow)) >> (UNIT == 2 ? 4 : 3)) & (0x01010101u * (4u * UNIT));
+    const unsigned un = ((0x80808080u - ((unsigned)sy[d] ^ 0x14141414u)) >> (UNIT == 2 ? 6 : 5)) & (live * UNIT);
+    oh[d] = (int)((eq << 2) | eq | un);
+  }
+  return oh;
+}
+
+// per block of three columns (block k = columns 3k .. 3k + 2): bits 0..2 column not served here (partial ambiguity codes
+// or past the end), bits 3..5 column has unknowns
+__global__ void mica_blockinfo_kernel(const uint8_t* __restrict__ flag, const uint8_t* __restrict__ gap, size_t n, size_t nblocks,
+                                      unsigned* __restrict__ info) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nblocks) return;
+  unsigned v = 0;
+  for (int c = 0; c < 3; ++c) {
+    const size_t i = 3 * k + c;
+    if (i >= n || flag[i]) v |= 1u << c;
+    else if (gap[i]) v |= 8u << c;
+  }
+  info[k] = v;
+}
+
+template <int KS, bool WEIGHTED>   // k-steps of 32 taxa: Tp <= 32 KS
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mica_mfma4_kernel(
+    int T, int Tp, const uint8_t* __restrict__ C1, size_t n1, const unsigned* __restrict__ info1, const double* __restrict__ S1,
+    const uint8_t* __restrict__ C2, size_t n2, const unsigned* __restrict__ info2, const double* __restrict__ S2,
+    const double* __restrict__ ftab_g, int intra, double* __restrict__ mi, double* __restrict__ hj, size_t ldo, unsigned nJ,
+    unsigned chunk, unsigned nchunks, unsigned nruns) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t m4_smem[];   // the kernel's only LDS object: LDS address 0
+  constexpr int NQ = 2 * KS;            // operand tiles of the second alignment per tile: 2 column tiles x KS k-steps
+  constexpr int SPT = NQ / 4;           // slots per thread
+  // LDS address 0: plain f[0 .. T]; weighted f2[0 .. M0) followed by one zero entry (what a cell >= M0 reads there)
+  const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
+  const size_t ftab_bytes = ((size_t)(WEIGHTED ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15;
+  cmx_i4* ops = reinterpret_cast<cmx_i4*>(m4_smem + ftab_bytes);                 // [2][NQ][64]
+  double* s2t = reinterpret_cast<double*>(ops + 2 * NQ * 64);                     // [2][4] S of the tile's columns
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool hi = lane >= 32;
+  const int cl = lane & 31;
+  if (WEIGHTED)
+    for (int c = tid; c <= M0; c += 256) reinterpret_cast<double*>(m4_smem)[c] = c < M0 ? ftab_g[T + 1 + c] : 0.0;
+  else
+    for (int c = tid; c <= T; c += 256) reinterpret_cast<double*>(m4_smem)[c] = ftab_g[c];
+  const unsigned M8 = 8u * (unsigned)M0;
+  const double lnT = log((double)T), invT = 1.0 / (double)T;
+  const int nks = Tp / 32;
+  // the second alignment's symbol bytes through a buffer descriptor: lane offset in a VGPR, tile offset in an SGPR
+  const __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(C2), 0, 0x7fffffff, 0x00020000);
+  // f2[m] for m >= M0: the third table holds a zero and then f2[M0 ..]; byte offset max(8 m - (8 M0 - 8), 0)
+  const char* f2hi = reinterpret_cast<const char*>(ftab_g + (T + 1) + (400 * T + 1));
+  // this thread's slots of the second alignment's operand tiles: q = w + 4 m -> column tile q / KS, k-step q % KS;
+  // packed column 32 (q / KS) + cl = column C / 20 of the tile, state C % 20 (C >= 60: padding)
+  unsigned bsrow[SPT], boff[SPT];
+#pragma unroll
+  for (int m = 0; m < SPT; ++m) {
+    const int q = w + 4 * m, C = 32 * (q / KS) + cl;
+    bsrow[m] = (C < 60 ? (unsigned)(C % kM4Rows) : 31u) * 0x01010101u;
+    boff[m] = (unsigned)((C < 60 ? C / kM4Rows : 2) * Tp + 32 * (q % KS) + 16 * (lane >> 5));   // from the tile's first column
+  }
+  // first alignment: row tile ii, packed row 32 ii + cl
+  unsigned asrow[2];
+  int acol[2];
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    const int R = 32 * ii + cl;
+    asrow[ii] = (R < 60 ? (unsigned)(R % kM4Rows) : 31u) * 0x01010101u;
+    acol[ii] = R < 60 ? R / kM4Rows : 2;
+  }
+  const int r4 = lane >> 4;
+  for (unsigned run = blockIdx.x; run < nruns; run += gridDim.x) {
+    const unsigned I = run / nchunks, ch = run % nchunks;
+    const size_t i0 = (size_t)I * kM4I;
+    unsigned jt0 = ch * chunk;
+    const unsigned jt1 = jt0 + chunk < nJ ? jt0 + chunk : nJ;
+    __syncthreads();   // the previous run's reads of the operand buffers and tile scalars are done (and the table is in LDS)
+    if (intra) {
+      // tiles J < 4 I hold no pair with j > i: only the NaN convention of the intra layout (the plain instantiation's job)
+      const unsigned first = 4 * I, jn = first < jt1 ? first : jt1;
+      if (!WEIGHTED)
+        for (size_t e = (size_t)jt0 * (kM4I * kM4J) + tid; e < (size_t)jn * (kM4I * kM4J); e += 256) {
+          const size_t jt = e / (kM4I * kM4J), p = e % (kM4I * kM4J), i = i0 + p / kM4J, j = jt * kM4J + p % kM4J;
+          if (i < n1 && j < n2 && !((info1[i / 3] >> (i % 3)) & 1) && !((info2[j / 3] >> (j % 3)) & 1)) {
+            mi[i * ldo + j] = __builtin_nan("");
+            hj[i * ldo + j] = __builtin_nan("");
+          }
+        }
+      if (jt0 < first) jt0 = first;
+    }
+    if (jt0 >= jt1) continue;
+    // who needs what: this wave's block, the workgroup's four blocks, the run's tiles (one lane per tile, chunk <= 64)
+    const unsigned inf1 = __builtin_amdgcn_readfirstlane(info1[(size_t)I * (kM4I / 3) + w]);   // (info arrays are padded to whole tiles)
+    const int bad1 = inf1 & 7;
+    const bool gapA = (inf1 >> 3) != 0;
+    unsigned anyA = 0, allA = 1;   // over the workgroup's blocks that are served at all: some / all have unknowns
+#pragma unroll
+    for (int k = 0; k < kM4I / 3; ++k) {
+      const unsigned v = info1[(size_t)I * (kM4I / 3) + k];
+      if ((v & 7) != 7) {
+        anyA |= (v >> 3) != 0;
+        allA &= (v >> 3) != 0;
+      }
+    }
+    const unsigned tinfo = jt0 + lane < jt1 ? info2[jt0 + lane] : 7u;
+    // a tile is walked by the workgroup if some (block, tile) combination in it is this instantiation's
+    const bool tile_mine = (tinfo & 7) != 7 && (WEIGHTED ? ((tinfo >> 3) != 0 || anyA) : ((tinfo >> 3) == 0 && !allA));
+    unsigned long long need = __ballot(tile_mine);
+    if (need == 0) continue;
+    double s1v[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const size_t i = i0 + 3 * w + a;
+      s1v[a] = S1[i < n1 ? i : n1 - 1];
+    }
+    cmx_i4 areg[2][KS];
+    {
+      cmx_i4 raw[2][KS];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        // (the symbol arrays carry twelve columns of padding behind the last one: no clamp)
+        const uint8_t* src = C1 + (i0 + 3 * w + acol[ii]) * (size_t)Tp + 16 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          raw[ii][ks] = ks < nks ? *reinterpret_cast<const cmx_i4*>(src + 32 * ks) : cmx_i4{0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f};
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          areg[ii][ks] = WEIGHTED ? m4_expand_weighted<2>(raw[ii][ks], asrow[ii], asrow[ii] == 0x1f1f1f1fu ? 0u : 0x01010101u)
+                                  : m4_expand<4, 0x08080808u>(raw[ii][ks], asrow[ii]);
+    }
+    cmx_i4 braw[SPT];
+    double s2r = 0.0;
+    auto fetch = [&](unsigned jt) {
+      const unsigned soff = jt * (unsigned)(kM4J * Tp);   // uniform
+#pragma unroll
+      for (int m = 0; m < SPT; ++m)
+        braw[m] = (w + 4 * m) % KS < nks ? __builtin_bit_cast(cmx_i4, __builtin_amdgcn_raw_buffer_load_b128(rc2, boff[m], soff, 0))
+                                         : cmx_i4{0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f};
+      if (tid < kM4J) {
+        const size_t j = (size_t)jt * kM4J + tid;
+        s2r = S2[j < n2 ? j : n2 - 1];
+      }
+    };
+    auto expand = [&](int buf) {
+#pragma unroll
+      for (int m = 0; m < SPT; ++m)
+        ops[(buf * NQ + w + 4 * m) * 64 + lane] = WEIGHTED ? m4_expand_weighted<4>(braw[m], bsrow[m], bsrow[m] == 0x1f1f1f1fu ? 0u : 0x01010101u)
+                                                           : m4_expand<7, 0x01010101u>(braw[m], bsrow[m]);
+      if (tid < kM4J) s2t[4 * buf + tid] = s2r;
+    };
+    unsigned jt = jt0 + (unsigned)__builtin_ctzll(need);
+    need &= need - 1;
+    fetch(jt);
+    expand(0);
+    int buf = 0;
+    for (;;) {
+      __syncthreads();   // this tile's operands and scalars are in LDS; every wave is done with the other buffer
+      const bool more = need != 0;
+      const unsigned jn = more ? jt0 + (unsigned)__builtin_ctzll(need) : 0u;
+      need &= need - 1;
+      if (more) fetch(jn);
+      const unsigned inf2 = __builtin_amdgcn_readlane(tinfo, jt - jt0);
+      const int bad2 = inf2 & 7;
+      const bool gapB = (inf2 >> 3) != 0;
+      const bool work = bad1 != 7 && bad2 != 7 && (gapA || gapB) == WEIGHTED;    // wave-uniform
+      cmx_i16v acc[2][2];   // written by the first k-step (C operand 0)
+      if (work) {
+        const cmx_i16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const cmx_i4* ob = ops + buf * NQ * 64 + lane;
+        cmx_i4 nb0 = ob[0], nb1 = ob[KS * 64];   // operands one k-step ahead of the products, not all sixteen at once
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const cmx_i4 bb0 = nb0, bb1 = nb1;
+          if (ks + 1 < KS) {
+            nb0 = ob[(ks + 1) * 64];
+            nb1 = ob[(KS + ks + 1) * 64];
+          }
+          asm volatile("" ::: "memory");
+          acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][ks], bb0, ks ? acc[0][0] : zero, 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[1][ks], bb0, ks ? acc[1][0] : zero, 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][ks], bb1, ks ? acc[0][1] : zero, 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[1][ks], bb1, ks ? acc[1][1] : zero, 0, 0, 0);
+        }
+      }
+      if (more) expand(buf ^ 1);
+      if (work) {
+        // per lane: sums by (column a of the wave's block, column tile jj).  Register v of tile (ii, jj) is packed row
+        // R0 = 32 ii + 8 (v / 4) + v % 4 in the lower lane half and R0 + 4 in the upper one, packed column 32 jj + cl.
+        // Rows 16..19 | 20..23 are the one register quad whose halves belong to different columns (0 | 1); rows 60..63
+        // are padding (count 0, f = 0).
+        double pa[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, pm[2] = {0.0, 0.0};
+        // (the table's address in a scalar register pair for the gathers' inline asm, whatever the allocator did with it)
+        // It is moved back by 8 M0 - 8 bytes: the accumulator itself (8 m) is then the gather's offset, entry 8 M0 the first real one
+        const unsigned long long f2hi_a = (unsigned long long)f2hi - (M8 - 8u);
+        const unsigned long long f2hi_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(f2hi_a >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((unsigned)f2hi_a);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            constexpr int NB = WEIGHTED ? 8 : 16;   // lookups in flight at a time
+            static_assert(!WEIGHTED || NB == 8, "the wait below names eight registers");
+#pragma unroll
+            for (int v0 = 0; v0 < 16; v0 += NB) {
+              double val[NB];
+#pragma unroll
+              for (int v = 0; v < NB; ++v) asm volatile("" : "+v"(acc[ii][jj][v0 + v]));   // no address arithmetic ahead of its batch
+#pragma unroll
+              for (int v = 0; v < NB; ++v) {
+                // plain: the accumulator is 8 x count = the LDS address of f(count).  weighted: it is 8 m, the LDS address of
+                // f2[m] for m < M0; larger cells read the zero behind the table here and their value from global memory below
+                const unsigned a8 = (unsigned)acc[ii][jj][v0 + v];
+                val[v] = *reinterpret_cast<const __attribute__((address_space(3))) double*>(static_cast<uintptr_t>(WEIGHTED ? (a8 < M8 ? a8 : M8) : a8));
+              }
+              if (WEIGHTED) {
+                // cells of M0 or more: gathered from the third table by the lanes that hold one, under their own EXEC mask (a
+                // register without such a cell issues nothing to the texture unit).  Inline asm: written as a branch or a
+                // per-lane `if`, the compiler spilled 100 - 230 registers around the sixteen regions per tile.
+                double big[NB];
+#pragma unroll
+                for (int v = 0; v < NB; ++v) {
+                  big[v] = 0.0;
+                  unsigned long long sv;
+                  asm volatile("v_cmp_le_u32_e32 vcc, %[m8], %[a]\n\t"
+                               "s_and_saveexec_b64 %[sv], vcc\n\t"
+                               "global_load_dwordx2 %[b], %[a], %[base]\n\t"
+                               "s_mov_b64 exec, %[sv]"
+                               : [b] "+v"(big[v]), [sv] "=&s"(sv)
+                               : [a] "v"(acc[ii][jj][v0 + v]), [m8] "s"(M8), [base] "s"(f2hi_u)
+                               : "vcc", "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(big[0]), "+v"(big[1]), "+v"(big[2]), "+v"(big[3]), "+v"(big[4]), "+v"(big[5]), "+v"(big[6]), "+v"(big[7])::"memory");
+#pragma unroll
+                for (int v = 0; v < NB; ++v) val[v] += big[v];
+              }
+#pragma unroll
+              for (int v = 0; v < NB; ++v) {
+                const int R0 = 32 * ii + 8 * ((v0 + v) / 4) + (v0 + v) % 4, a0 = R0 / kM4Rows, a1 = (R0 + 4) / kM4Rows;
+                if (a0 == a1 || a1 == 3) pa[a0][jj] += val[v];
+                else pm[jj] += val[v];    // a0 == 0, a1 == 1
+              }
+              asm volatile("" ::: "memory");
+            }
+          }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          pa[0][jj] += hi ? 0.0 : pm[jj];
+          pa[1][jj] += hi ? pm[jj] : 0.0;
+        }
+        // by column b of the tile: column tile 0 holds packed columns 0..31 (b = 0 for cl < 20, else 1), tile 1 holds
+        // 32..63 (b = 1 for cl < 8, else 2; packed columns 60..63 are padding)
+        double t[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          t[3 * a + 0] = cl < 20 ? pa[a][0] : 0.0;
+          t[3 * a + 1] = (cl >= 20 ? pa[a][0] : 0.0) + (cl < 8 ? pa[a][1] : 0.0);
+          t[3 * a + 2] = cl >= 8 ? pa[a][1] : 0.0;
+        }
+        double sres[3];   // lanes with lane >> 4 == r hold pair 4 g + r in sres[g] (pair = 3 a + b)
+        sres[0] = mica_reduce4(t[0], t[1], t[2], t[3]);
+        sres[1] = mica_reduce4(t[4], t[5], t[6], t[7]);
+        sres[2] = mica_reduce4(t[8], 0.0, 0.0, 0.0);
+        if ((lane & 15) == 0) {
+          const size_t j0 = (size_t)jt * kM4J;
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const int pr = 4 * g + r4;
+            if (pr < 9) {
+              const int a = pr / 3, b = pr % 3;
+              if (!((bad1 >> a) & 1) && !((bad2 >> b) & 1)) {
+                const size_t i = i0 + 3 * w + a, j = j0 + b;
+                const bool valid = !intra || j > i;
+                const double s = sres[g];
+                const double sa = a == 0 ? s1v[0] : (a == 1 ? s1v[1] : s1v[2]);
+                mi[i * ldo + j] = valid ? lnT + (s - sa - s2t[4 * buf + b]) * invT : __builtin_nan("");
+                hj[i * ldo + j] = valid ? lnT - s * invT : __builtin_nan("");
+              }
+            }
+          }
+        }
+      }
+      if (!more) break;
+      buf ^= 1;
+      jt = jn;
+    }
+  }
+}
+
+size_t mica4_lds_bytes(int T, int KS, bool weighted) {
+  const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
+  return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 8 * sizeof(double);
+}
+
+template <int KS, bool WEIGHTED>
+static hipError_t launch_mica4_one(int T, int Tp, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj,
+                                   size_t ldo, unsigned nJ, unsigned chunk, unsigned nchunks, unsigned nruns, unsigned grid,
+                                   hipStream_t stream) {
+  const size_t lds = mica4_lds_bytes(T, KS, WEIGHTED);
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mica_mfma4_kernel<KS, WEIGHTED>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((mica_mfma4_kernel<KS, WEIGHTED>), dim3(grid < nruns ? grid : nruns), dim3(256), lds, stream, T, Tp, wk->C1, n1,
+                     wk->info1, wk->S1, intra ? wk->C1 : wk->C2, n2, intra ? wk->info1 : wk->info2, intra ? wk->S1 : wk->S2, wk->ftab,
+                     intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns);
+  return hipGetLastError();
+}
+
+template <int KS>
+static hipError_t launch_mica4_ks(int T, int Tp, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj,
+                                  size_t ldo, unsigned chunk, unsigned grid, hipStream_t stream) {
+  const unsigned nJ = (unsigned)((n2 + kM4J - 1) / kM4J), nI = (unsigned)((n1 + kM4I - 1) / kM4I);
+  const unsigned nchunks = (nJ + chunk - 1) / chunk, nruns = nI * nchunks;
+  // block info, padded to whole tiles (blocks past the end: all three columns "not served")
+  const size_t nb1 = (size_t)nI * (kM4I / 3), nb2 = nJ;
+  hipLaunchKernelGGL(mica_blockinfo_kernel, dim3((unsigned)((nb1 + 255) / 256)), dim3(256), 0, stream, wk->flag1, wk->gap1, n1, nb1, wk->info1);
+  if (!intra)
+    hipLaunchKernelGGL(mica_blockinfo_kernel, dim3((unsigned)((nb2 + 255) / 256)), dim3(256), 0, stream, wk->flag2, wk->gap2, n2, nb2, wk->info2);
+  hipError_t e = launch_mica4_one<KS, false>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns, grid, stream);
+  if (e == hipSuccess) e = launch_mica4_one<KS, true>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns, grid, stream);
+  return e;
+}
+
+// proteins, Tp <= 256 (eight k-steps of operand registers), byte offsets within 31 bits; the caller serves the pairs with
+// partial ambiguity codes
+bool mica4_serves(int A, int Tp, size_t n1, size_t n2) {
+  return A == 20 && Tp <= 256 && (std::max(n1, n2) + kMicaCodePad) * (size_t)Tp < 0x7fffffffull;
+}
+
+hipError_t launch_mica4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,
+                        hipStream_t stream) {
+  static const unsigned chunk = [] {
+    const char* e = getenv("CMX_MICA4_CHUNK");
+    const unsigned c = e ? (unsigned)atoi(e) : 32u;
+    return c < 1 ? 1u : (c > kM4MaxChunk ? kM4MaxChunk : c);
+  }();
+  // two workgroups per CU at a time (254 registers): a multiple of 512
+  static const unsigned grid = [] { const char* e = getenv("CMX_MICA4_GRID"); return e ? (unsigned)atoi(e) : 1024u; }();
+  const int Tp = wk->Tp;
+  if (Tp <= 64) return launch_mica4_ks<2>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
+  if (Tp <= 128) return launch_mica4_ks<4>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
+  return launch_mica4_ks<8>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
+}
+
+}  // namespace cmx

@@ -1049,3 +1049,37 @@ def test_inter_rows_on_the_device_match_the_reference_loop(kind):
         assert np.isnan(rows["pvalue"]).all() and (rows["nsim"] == 0).all()
     with pytest.raises(engine.CmxError, match="same length"):
         e1.inter_rows(kind, m1, {k: v[:60] for k, v in m2.items()}, engine.InterFilters(independent_comparisons=True), threshold=thr)
+
+
+@pytest.mark.parametrize("T,n1,n2", [(40, 50, 77), (100, 37, 205), (256, 130, 260), (300, 40, 50)])
+def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
+    """The protein path up to 256 taxa (cmx_mica4.hip: plain and weighted instantiation, operand registers for 2 / 4 / 8
+    k-steps) and above (eight-wave kernel): column counts that are no multiple of the 12 x 3 tile, runs longer than one
+    chunk of tiles (n2 = 205, 260), columns with unknowns scattered so that blocks and tiles mix clean and gapped
+    columns, some columns all unknown, one column with a partial ambiguity code; rectangle and intra layout."""
+    rng = np.random.default_rng(T + n1)
+    A = 20
+    masks = oracle.default_masks(A).copy()
+    masks[A + 1] = 0b101                                    # partial ambiguity: two states
+    base = rng.integers(0, A, size=(T, 1))
+
+    def draw(n, p):
+        a = np.where(rng.random((T, n)) < p, base, rng.integers(0, A, size=(T, n))).astype(np.uint8)
+        gapped = rng.random(n) < 0.3
+        a[(rng.random((T, n)) < 0.2) & gapped[None, :]] = A   # unknowns in 30 % of the columns
+        a[:, n // 2] = A                                       # a column of unknowns only
+        return a
+
+    a1, a2 = draw(n1, 0.6), draw(n2, 0.4)
+    a1[rng.integers(0, T, 3), 7] = A + 1
+    eng = engine.Engine()
+    g = eng.mi_columns(a1, a2, A, masks=masks[: A + 2])
+    o = oracle.mi_columns(a1, a2, A, masks)
+    rel_close(g["mi"], o["mi"], 1e-6, 1e-10)
+    rel_close(g["hjoint"], o["hjoint"], 1e-6, 1e-10)
+    gi = eng.mi_columns(a2, None, A, masks=masks[: A + 2])
+    oi = oracle.mi_columns(a2, a2, A, masks)
+    iu = np.triu_indices(n2, 1)
+    rel_close(gi["mi"][iu], oi["mi"][iu], 1e-6, 1e-10)
+    rel_close(gi["hjoint"][iu], oi["hjoint"][iu], 1e-6, 1e-10)
+    assert np.isnan(gi["mi"][np.tril_indices(n2)]).all() and np.isnan(gi["hjoint"][np.tril_indices(n2)]).all()
