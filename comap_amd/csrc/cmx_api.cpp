@@ -712,7 +712,6 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
     return null_unfused_dev(ctx, ctx, kind, params, seed, rep_begin, rep_end, rep_ram, d_supplied, d_stat, d_rcmin, d_prmin, d_nmin, stream);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-#ifndef CMX_FUSED_SIM
   if (!d_supplied) {
     // simulate first, at full occupancy, then map the alignments as "supplied" ones: the same draws, the same results
     // as a simulator inside the mapping waves (round 1; 7.8 % of the launch there, latency nobody could hide).  The
@@ -737,7 +736,6 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
     if ((s = cmx_null_simulate_dev(ctx, seed, rep_begin, rep_end, rep_ram, d_aln, stream)) != CMX_OK) return s;
     d_supplied = d_aln;
   }
-#endif
   MapArgs a{};
   a.m = ctx->dm; a.ws = ctx->ws;
   a.nsites = (rep_end - rep_begin) * rep_ram;

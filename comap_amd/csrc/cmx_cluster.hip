@@ -23,9 +23,6 @@ namespace cmx {
 
 namespace {
 
-#ifndef HC_ABLATE
-#define HC_ABLATE 0   // timing diagnostics only (wrong results): 1 no column store, 2 no matrix stores, 3 no matrix traffic
-#endif
 #ifndef HC_THREADS
 #define HC_THREADS 512
 #endif
@@ -259,27 +256,16 @@ __global__ __launch_bounds__(kHcThreads) void hclust_kernel(HcArgs a) {
     for (int t = 0; t < PER; ++t) {
       const int k = tid + t * kHcThreads;
       const bool on = k < n && k != i && k != j && cid[k < n ? k : 0] >= 0;
-      {
-#if HC_ABLATE < 3
-        xi[t] = on ? rowi[k] : 0.0;
-        xj[t] = on ? rowj[k] : 0.0;
-#else
-        xi[t] = 1.0 + (double)((k * 7919 + step * 104729) & 1023);
-        xj[t] = 2.0 + (double)((k * 104729 + step * 7919) & 1023);
-#endif
-      }
+      xi[t] = on ? rowi[k] : 0.0;
+      xj[t] = on ? rowj[k] : 0.0;
     }
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
       const int k = tid + t * kHcThreads;
       if (k >= n || k == i || k == j || cid[k] < 0) continue;
       const double nw = linkage_update<LINK>(xi[t], xj[t], ni, nj);
-#if HC_ABLATE < 2
       D[(size_t)i * ld + k] = nw;
-#endif
-#if HC_ABLATE < 1
       coli[(unsigned)k * ld32] = nw;
-#endif
       if (k > i) {
         if (key_less(nw, k, cv, cc)) { cv = nw; cc = k; }
         if (k < j && nn[k] == j) nn[k] = kStale;                     // its neighbour disappears; the bound stands

@@ -16,7 +16,7 @@
 //   DESIGN.md 4.1 has the full description and the measurements.
 //   MODE == kModeNull: map (x2 batches) -> per-pair statistic of AnalysisTools::getNullDistributionIntraDR
 //   (CoMap/AnalysisTools.cpp:587-653) per wave, on alignments simulated beforehand by simulate_lds_kernel /
-//   simulate_blocked_kernel at full occupancy (round 1 simulated inside the mapping wave: CMX_FUSED_SIM builds).
+//   simulate_blocked_kernel at full occupancy (round 1 simulated inside the mapping wave).
 // pair_gram_kernel: all-pairs statistic as X.X^T on v_mfma_f64_16x16x4_f64 with per-statistic epilogues
 //   (CoMap/Statistics.h:164-329; loops CoMap/CoETools.cpp:672-692, 786-810).
 // mica_mfma_kernel: column mutual information as a one-hot Gram on v_mfma_i32_32x32x32_i8 (CoMap/Mica.cpp:349-361).
@@ -37,10 +37,6 @@ typedef double d8 __attribute__((ext_vector_type(8)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-#ifndef CMX_ABLATE
-#define CMX_ABLATE 0  // diagnostic builds (wrong results, timing only): 1 no leaf gathers, 2 no workspace vectors,
-                      // 3 no matrix products, 4 = 1 + 2, 5 no vector stores, 6 no vector loads, 8 no wait for the staged operator, 9 = 1 + 2 + 3, 10 = 8 + 9
-#endif
 
 // Every edge of the tree applies one SxS operator that is the same for all 64 lanes: a matrix-vector product on
 // internal edges, a row gather by observed symbol on leaf edges.  The sequence of operators of a class pass is known
@@ -214,11 +210,6 @@ template <int S, bool TR, int NG, bool DIAG>
 __device__ __forceinline__ void matvec_stage(const uint8_t* buf, int lane, const double (&x)[S / 4 * NG],
                                              double (&y)[S / 4 * NG]) {
   static_assert(S % 4 == 0, "state count must be a multiple of 4");
-  if (CMX_ABLATE == 3 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
-#pragma unroll
-    for (int i = 0; i < S / 4 * NG; ++i) y[i] = x[i] * 0.5;
-    return;
-  }
   constexpr int NT = DIAG ? S / 4 : (S / 4) * (S / 4);
   // element (row r, column c) of a packed tile sits at (4 r + c) * 8; the A slot of lane l is row l & 3, column l >> 4
   // (transposed product: the transposed tile, i.e. row l >> 4, column l & 3)
@@ -252,16 +243,6 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     part[g] = 0.0;
-    if (CMX_ABLATE == 1 || CMX_ABLATE == 4 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
-#pragma unroll
-      for (int sb = 0; sb < NB; ++sb) {
-        const double v = 0.05 + 0.001 * code[g];
-        if (MODE == LEAF_SET) out[sb * NG + g] = v;
-        else if (MODE == LEAF_MUL) out[sb * NG + g] = v * in[sb * NG + g];
-        else part[g] = __builtin_fma(in[sb * NG + g], v, part[g]);
-      }
-      continue;
-    }
     double v[NB];
 #pragma unroll
     for (int sb = 0; sb < NB; ++sb) v[sb] = r[g][sb];
@@ -281,11 +262,6 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
 // wave-instruction, the same image in HBM and (for prefetched vectors) in LDS.
 template <int S>
 __device__ __forceinline__ void load_vec(const double* p /* slice base + 2*lane */, double (&v)[S]) {
-  if (CMX_ABLATE == 2 || CMX_ABLATE == 4 || CMX_ABLATE == 6 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
-#pragma unroll
-    for (int i = 0; i < S; ++i) v[i] = 0.9;
-    return;
-  }
 #pragma unroll
   for (int i = 0; i < S / 2; ++i) {
     const d2 t = *reinterpret_cast<const d2*>(p + (size_t)i * 2 * kWave);
@@ -295,10 +271,6 @@ __device__ __forceinline__ void load_vec(const double* p /* slice base + 2*lane 
 }
 template <int S>
 __device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
-  if (CMX_ABLATE == 2 || CMX_ABLATE == 4 || CMX_ABLATE == 5 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) {
-    asm volatile("" ::"v"(v[0]), "v"(v[S - 1]));
-    return;
-  }
 #pragma unroll
   for (int i = 0; i < S / 2; ++i) {
     d2 t;
@@ -311,7 +283,6 @@ __device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
 // asynchronous HBM -> LDS copy of one workspace vector (S/2 LDS-DMA instructions, no VGPR destination)
 template <int S>
 __device__ __forceinline__ void prefetch_vec_lds(const double* p /* slice base + 2*lane */, uint8_t* lds /* wave-uniform */) {
-  if (CMX_ABLATE == 2 || CMX_ABLATE == 4 || CMX_ABLATE == 6 || (CMX_ABLATE == 9 || CMX_ABLATE == 10)) return;
   constexpr int R = S / 2;
   const uint32_t l = lds_addr(lds);
 #pragma unroll
@@ -388,20 +359,9 @@ struct ConstModel {
 // code issued and knows about (DMA rows, vector stores); an asynchronous transfer remembers vs right after its issue,
 // and "wait for X" is s_waitcnt vmcnt(vs - X_seq): VMEM completes in order, so the instructions issued after X may stay
 // in flight.  Instructions that are not counted only make the wait stricter.
-// CMX_TIMING builds (scripts/build_ablations.sh "t"): wave 0 accumulates s_memtime deltas per phase and prints them
-#ifdef CMX_TIMING
-#define CMX_TIC() const long long tic_ = (long long)__builtin_readcyclecounter()
-#define CMX_TOC(slot) os.tm[slot] += (long long)__builtin_readcyclecounter() - tic_; os.tn[slot] += 1
-#else
-#define CMX_TIC() do {} while (0)
-#define CMX_TOC(slot) do {} while (0)
-#endif
-enum { TM_OPWAIT = 0, TM_POPWAIT = 1, TM_MV = 2, TM_LEAF = 3, TM_LOAD = 4, TM_STORE = 5, TM_PASS = 6, TM_SIM = 7, TM_OPB = 8, TM_EPI = 9, TM_N = 10 };
+// (The phase timers, the ablation switches and the round-1 fused-simulator arrangement that produced the figures quoted in
+// DESIGN.md were stripped from this file in round 3: scripts/experiments/ablations/README.md names the tagged source.)
 struct OpState {
-#ifdef CMX_TIMING
-  long long tm[TM_N];
-  long long tn[TM_N];
-#endif
   int pre_mat, pre_tx;  // op-stream entry of the NEXT op, loaded one op early (its latency hides behind the current op)
   unsigned par;      // stage buffer / code slot of the current operator op
   unsigned vs;       // counted VMEM instructions issued so far
@@ -488,7 +448,7 @@ struct DevWalk {
       os.pre_mat = cm.msched[2 * i2];
       os.pre_tx = cm.msched[2 * i2 + 1];
     }
-    { CMX_TIC(); if (CMX_ABLATE != 8 && CMX_ABLATE != 10) wait_vm<S, VL>((int)(os.vs - os.cur_seq + issued)); CMX_TOC(TM_OPWAIT); }
+    wait_vm<S, VL>((int)(os.vs - os.cur_seq + issued));
     os.vs += issued;
     nseq = os.vs;
     return stage + os.par * MatStage<S>::BYTES;
@@ -502,18 +462,16 @@ struct DevWalk {
   __device__ __forceinline__ void mv(int, int) {
     unsigned nseq;
     const uint8_t* buf = op_begin(nseq);
-    { CMX_TIC(); matvec_stage<S, TR, NG, (FUSE > 1 && S / FUSE == 4)>(buf, vlane(), reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1])); CMX_TOC(TM_MV); }
+    matvec_stage<S, TR, NG, (FUSE > 1 && S / FUSE == 4)>(buf, vlane(), reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1]));
     op_end(nseq);
   }
   template <int MODE, int SRC, int DST>
   __device__ __forceinline__ double leaf(void) {
     unsigned nseq;
     const uint8_t* buf = op_begin(nseq);
-    CMX_TIC();
     const int vl = vlane();
     const double tot = leaf_apply<S, MODE, NG>(buf, cslot + os.par * kCodeSlotBytes + 4 * (vl & 15), vl, reg<SRC>(), reg<DST>());
     asm volatile("" :: "v"(tot), "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1]));
-    CMX_TOC(TM_LEAF);
     op_end(nseq);
     return tot;
   }
@@ -530,17 +488,13 @@ struct DevWalk {
   // instruction this code issues so that the counted waits of the operator stream let them stay in flight.
   template <int D>
   __device__ __forceinline__ void load(int arr, int slot) {
-    CMX_TIC();
     load_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vlane(), reg<D>());
     os.vs += VL / 2;
-    CMX_TOC(TM_LOAD);
   }
   template <int SRC>
   __device__ __forceinline__ void store(int arr, int slot) {
-    CMX_TIC();
     store_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vlane(), reg<SRC>());
     os.vs += VL / 2;
-    CMX_TOC(TM_STORE);
   }
   template <int D, int SRC> __device__ __forceinline__ void mov() {
 #pragma unroll
@@ -642,7 +596,6 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     }
   }
   for (int c = c_begin; c < c_end; ++c) {
-    CMX_TIC();
     // operators of this class and of the class of the pass that follows (its first operator is requested by our last op)
     be.mat_c = m.MAT + (size_t)c * m.MC * MatStage<S>::UNIT;
     be.mat_after = m.MAT + (size_t)((c + 1 < c_end) ? c + 1 : c_after) * m.MC * MatStage<S>::UNIT;
@@ -669,7 +622,6 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
         }
       }
     }
-    CMX_TOC(TM_PASS);
   }
   if (!finalize) {   // class-split mode: the pass's sums, its best class and that class's weight
     L_out = Lsum;
@@ -681,7 +633,6 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   // ---------------- sum the classes in class order, divide by the site likelihood, norm (computeNormForSite)
   // Rows r = b*K + k are taken sixteen at a time and classes four at a time so that 64 independent loads are in flight
   // (this phase is pure L2 latency); the sums run in the same order as a plain (b, k, c) loop nest.
-  CMX_TIC();
   double nrm = 0.0, tot = 0.0;
   const int BK = m.B * K;
   int kk = 0;  // r % K
@@ -721,7 +672,6 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       }
     }
   }
-  CMX_TOC(TM_EPI);
   L_out = Lsum;
   pr_out = prsum / Lsum;
   rc_out = bestc;
@@ -756,10 +706,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   const size_t nblocks = (a.nsites + kSites - 1) / kSites;
   // request the first op's operator (class 0, entry 0); every op then requests the next one
   OpState os;
-#ifdef CMX_TIMING
-  for (int q = 0; q < TM_N; ++q) { os.tm[q] = 0; os.tn[q] = 0; }
-  const long long tk0_ = (long long)__builtin_readcyclecounter();
-#endif
   os.par = 0;
   {
     const int c0 = (MODE == kModeObservedSplit) ? wave % m.C : 0;   // class of this wave's first pass
@@ -813,82 +759,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
         const size_t rep_local = s / a.rep_ram, j = s % a.rep_ram;
         const uint8_t* gbase;
         size_t gstride;
-#ifdef CMX_FUSED_SIM   // round 1's arrangement (the simulator inside the mapping wave), kept for A/B builds only
-        if (a.supplied) {
-          gbase = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
-          gstride = a.rep_ram;
-        } else {
-          const size_t rep = a.rep_begin + rep_local;
-          uint8_t* al = a.ws.aln + (size_t)wave * m.T * kSites + sidx;
-          gbase = al;
-          gstride = kSites;
-          CMX_TIC();
-          const uint64_t g = ((uint64_t)rep * 2 + h) * (uint64_t)a.rep_ram + j;
-          const int S0 = S / FUSE;
-          const int c = draw_index(philox_uniform(a.seed, g, 0), cm.cum_probs, m.C0);
-          // states of the nodes: in LDS when nn * 64 bytes fit the wave's share, else in HBM
-          const bool st_lds = a.lds_per_wave >= map_lds_fixed<S>() + m.nn * kSites;
-          uint8_t* stl = cmx_smem + lds_off + map_lds_fixed<S>() + sidx;
-          uint8_t* stg = a.ws.st + (size_t)wave * m.nn * kSites + sidx;
-          const uint8_t x0 = (uint8_t)draw_index(philox_uniform(a.seed, g, 1), cm.cum_pi, S0);
-          if (st_lds) stl[(size_t)m.root * kSites] = x0; else stg[(size_t)m.root * kSites] = x0;
-          // Nodes are drawn level by level, four at a time (m.simg: host-built groups of nodes of equal depth, padded by
-          // repetition): the draws of a group do not depend on each other, so their table reads -- lane-divergent
-          // gathers, two dependent round trips to L2 per node -- overlap instead of forming one serial chain of 2(nn-1).
-          for (int gi = 0; gi < m.nsimg; ++gi) {
-            cmx_i16 q;   // [0..3] node, [4..7] its parent, [8..11] its taxon or -1
-            sload_rec((cmx_cint)m.simg + gi * 16, q);
-            int x[4], idx[4];
-            double u[4];
-            size_t row[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) x[jj] = st_lds ? stl[(size_t)q[4 + jj] * kSites] : stg[(size_t)q[4 + jj] * kSites];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) u[jj] = philox_uniform(a.seed, g, 2u + (uint32_t)q[jj]);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              row[jj] = ((size_t)c * m.nn + q[jj]) * S0 + x[jj];
-              idx[jj] = m.CPG[row[jj] * 32 + (int)(u[jj] * 32.0)];
-            }
-            bool any;
-            do {   // the same index as draw_guided, the four searches advancing together -- and four running sums per
-                   // search and round trip: the loop runs until the slowest of the wave's 256 searches is done, and one
-                   // sum per trip made that 4-5 dependent L2 gathers per group (487 -> 478 ms at the target, same box).
-                   // Tried on top and slower: groups of eight nodes (480 -> 507 ms: registers), the next group's random
-                   // numbers computed under this group's gathers (488 -> 528 ms: the copies of the group state)
-              double cv[4][4];
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) cv[jj][d] = m.CP[row[jj] * S0 + idx[jj] + d];   // the table is padded by 4 sums
-              any = false;
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) {
-                bool go = true;
-                int adv = 0;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                  go = go && idx[jj] + d < S0 - 1 && u[jj] >= cv[jj][d];
-                  adv += go ? 1 : 0;
-                }
-                idx[jj] += adv;
-                any |= adv == 4;
-              }
-            } while (any);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              if (st_lds) stl[(size_t)q[jj] * kSites] = (uint8_t)idx[jj]; else stg[(size_t)q[jj] * kSites] = (uint8_t)idx[jj];
-              if (q[8 + jj] >= 0) al[(size_t)q[8 + jj] * kSites] = (uint8_t)idx[jj];
-            }
-          }
-          CMX_TOC(TM_SIM);
-        }
-#else
         // the alignments were simulated by simulate_lds_kernel / simulate_blocked_kernel (cmx_null_simulate_dev) or
         // supplied by the caller: [replicate][batch][taxon][rep_ram]
         gbase = a.supplied + ((rep_local * 2 + h) * (size_t)m.T) * a.rep_ram + j;
         gstride = a.rep_ram;
-#endif
         double L, pr, nrm;
         int rc;
         map_sites_wave<S, FUSE, NG>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
@@ -905,14 +779,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last op left an operator DMA in flight
-#ifdef CMX_TIMING
-  if (MODE == kModeNull && lane == 0 && (wave == 0 || wave == 777)) {
-    const long long tot_ = (long long)__builtin_readcyclecounter() - tk0_;
-    printf("wave %d total %lld | opwait %lld/%lld loadwait %lld/%lld mv %lld/%lld leaf %lld/%lld load %lld/%lld store %lld/%lld pass %lld/%lld sim %lld/%lld epi %lld/%lld\n",
-           wave, tot_, os.tm[0], os.tn[0], os.tm[1], os.tn[1], os.tm[2], os.tn[2], os.tm[3], os.tn[3], os.tm[4], os.tn[4],
-           os.tm[5], os.tn[5], os.tm[6], os.tn[6], os.tm[7], os.tn[7], os.tm[9], os.tn[9]);
-  }
-#endif
 }
 
 // LDS per mapping wave: operator stage buffers + symbol slots, plus (null mode) the simulator's node states when
@@ -921,12 +787,8 @@ int map_lds_per_wave(int S, int nn, int mode) {
   const int fixed = S == 20 ? map_lds_fixed<20>() : (S == 16 ? map_lds_fixed<16>() : map_lds_fixed<4>());
   const int share = 160 * 1024 / map_waves_per_simd(S) / kWavesPerBlock;
   const int states = (nn * map_sites_per_wave(S) + 15) / 16 * 16;
-#ifdef CMX_FUSED_SIM
-  return (mode == kModeNull && fixed + states <= share) ? fixed + states : fixed;
-#else
   (void)share; (void)states; (void)mode;   // the node states of a simulator inside the wave: not needed any more
   return fixed;
-#endif
 }
 
 hipError_t launch_map(const MapArgs& a_in, int mode, int grid_blocks, hipStream_t stream) {
@@ -950,16 +812,11 @@ hipError_t launch_map(const MapArgs& a_in, int mode, int grid_blocks, hipStream_
     else if (mode == kModeObservedSplit) CMX_LAUNCH(S_, kModeObservedSplit, F_); \
     else CMX_LAUNCH(S_, kModeNull, F_);                                     \
   } while (0)
-#ifdef CMX_PROBE   // register-allocation experiments: one instantiation only (make probe)
-  if (a.m.S == 20 && a.m.fuse == 1) CMX_LAUNCH(20, kModeNull, 1);
-  else return hipErrorInvalidValue;
-#else
   if (a.m.S == 20 && a.m.fuse == 1) CMX_LAUNCH_MODES(20, 1);
   else if (a.m.S == 20 && a.m.fuse == 5) CMX_LAUNCH_MODES(20, 5);
   else if (a.m.S == 16 && a.m.fuse == 4) CMX_LAUNCH_MODES(16, 4);
   else if (a.m.S == 4 && a.m.fuse == 1) CMX_LAUNCH_MODES(4, 1);
   else return hipErrorInvalidValue;
-#endif
 #undef CMX_LAUNCH_MODES
 #undef CMX_LAUNCH
   return hipGetLastError();
@@ -2452,11 +2309,7 @@ __device__ __forceinline__ void mica3_tile(int T, int Tp, const uint8_t* __restr
             for (int d = 0; d < 4; ++d) {
               const unsigned x = (unsigned)sy[d] ^ srow[u];
               const unsigned t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 where the byte of x is zero
-#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 3   // timing only: no one-hot expansion
-              oh[d] = sy[d];
-#else
               oh[d] = (int)(t >> 7);
-#endif
             }
             ops[((buf + h) * NOP + q) * 64 + l0 + u] = oh;
           }
@@ -2475,11 +2328,7 @@ __device__ __forceinline__ void mica3_tile(int T, int Tp, const uint8_t* __restr
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 2   // timing only: no matrix products
-          for (int jj = 0; jj < 2; ++jj) acc[ii][jj][0] += a[ii][0] ^ b[jj][1];
-#else
           for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ii], b[jj], acc[ii][jj], 0, 0, 0);
-#endif
       }
     }
     buf ^= 2;
@@ -2497,15 +2346,7 @@ __device__ __forceinline__ void mica3_tile(int T, int Tp, const uint8_t* __restr
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int R0 = 32 * ii + 8 * (v / 4) + v % 4, a0 = R0 / P, a1 = (R0 + 4) / P;
-#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 1   // timing only: no table lookups
-        const double val = (double)acc[ii][jj][v];
-#else
-#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 1   // timing only: no table lookups
-        const double val = (double)acc[ii][jj][v];
-#else
         const double val = ftab[acc[ii][jj][v]];
-#endif
-#endif
         if (a0 == a1) {
           pa[a0][jj] += val;
         } else {
@@ -2590,13 +2431,7 @@ __device__ __forceinline__ void mica3_tile(int T, int Tp, const uint8_t* __restr
           const size_t i = i0 + ci, j = j0 + (cj - kMica3I);
           const bool valid = !intra || j > i;
           const double s = sres[g];
-#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 4   // timing only: one store per tile
-          if (ci + cj == 0)
-#endif
           mi[i * ldo + j] = valid ? lnT + (s - Scol[ci] - Scol[cj]) * invT : __builtin_nan("");
-#if defined(CMX_MICA_ABLATE) && CMX_MICA_ABLATE == 4
-          if (ci + cj == 0)
-#endif
           hj[i * ldo + j] = valid ? lnT - s * invT : __builtin_nan("");
         }
       }
@@ -2628,13 +2463,20 @@ __global__ void column_entropy_kernel(int T, const uint32_t* __restrict__ masks,
   double p[A];
 #pragma unroll
   for (int a = 0; a < A; ++a) p[a] = 0.0;
-  for (int t = 0; t < T; ++t) {
-    const unsigned c = aln[(size_t)t * ld + i];
-    const uint32_t m = c < (unsigned)A ? (1u << c) : masks[c];
-    const double w = 1.0 / (double)__popc(m);
+  for (int t0 = 0; t0 < T; t0 += 16) {   // sixteen symbols in flight: one thread walks a whole column, the loop is all load latency
+    unsigned cs[16];
 #pragma unroll
-    for (int a = 0; a < A; ++a)
-      if ((m >> a) & 1u) p[a] += w;
+    for (int u = 0; u < 16; ++u) cs[u] = t0 + u < T ? aln[(size_t)(t0 + u) * ld + i] : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const unsigned c = cs[u];
+      if (c == 0xffffffffu) continue;
+      const uint32_t m = c < (unsigned)A ? (1u << c) : masks[c];
+      const double w = 1.0 / (double)__popc(m);
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+        if ((m >> a) & 1u) p[a] += w;
+    }
   }
   double s = 0.0;
 #pragma unroll
@@ -2706,13 +2548,13 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
   if (A == 20) {
     hipLaunchKernelGGL((mi_columns_kernel<20>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, n1, ld1, d_aln2, n2,
                        ld2, intra, d_mi, d_hj, ldo, f1, f2, anyf);
-    if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
-    if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
+    if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
+    if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<20>), dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
   } else if (A == 4) {
     hipLaunchKernelGGL((mi_columns_kernel<4>), grid, dim3(64), lds, stream, T, d_masks, d_aln1, n1, ld1, d_aln2, n2,
                        ld2, intra, d_mi, d_hj, ldo, f1, f2, anyf);
-    if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
-    if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
+    if (d_h1) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, stream, T, d_masks, d_aln1, n1, ld1, d_h1);
+    if (d_h2) hipLaunchKernelGGL((column_entropy_kernel<4>), dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, stream, T, d_masks, d_aln2, n2, ld2, d_h2);
   } else {
     return hipErrorInvalidValue;
   }
