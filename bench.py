@@ -304,14 +304,16 @@ def main():
     # `achieved` / `frac` follow SURVEY 8(d): ALGORITHMIC flops (7 B C S^2 per site, leaf edges counted as dense
     # products) / time / peak.  `frac_executed` counts only the matrix products the kernel issues (leaf edges are row
     # gathers, sibling messages are stored instead of recomputed): the matrix pipe's duty, always lower.
-    # (4-state models: map_nuc_kernel applies its 4x4 operators with v_fma_f64 -- the fp64 vector roof equals the matrix
-    # one -- and `executed` counts operator applications + the 8 flops behind each leaf-table gather.)
     sim_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_sim]))
-    kname = f"map_kernel<{eng.S},null>" if eng.S != 4 or os.environ.get("CMX_NUC_LEGACY") == "1" else "map_nuc_kernel<null>"
+    kname = f"map_kernel<{eng.S},null>"
     roofline = dict(bound="mfma", kernel=kname, achieved=achieved, peak=FP64_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
                     launch_ms=null_ms, simulate_ms=sim_ms, sites_per_launch=sites_per_launch, flops_per_site_algorithmic=alg,
                     flops_per_site_executed=exe, achieved_executed=ach_exe, frac_executed=ach_exe / FP64_PEAK_TFLOPS)
+    # what is left of a step besides the simulator and the null's mapping launch: at N = 1 the observed stage (null sort +
+    # index, Gram, p-value lookup, filters, compacted rows; the observed alignment's mapping runs beside the null); at N > 1
+    # the all-gather too
+    roofline["rest_of_step_ms"] = ms_per_step - null_ms - sim_ms
     for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
         try:
             t = json.load(open(tf))

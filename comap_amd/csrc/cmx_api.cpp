@@ -946,11 +946,10 @@ cmx_status cmx_null_inter(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* 
 // The null distribution as the p-value kernel wants it (CoETools.cpp:636-652): Domain(0, max norm, nclasses) classes of
 // the null pairs' min norms, every class sorted ascending, classes laid out one after the other; hist = class sizes.
 static cmx_status prepare_null(cmx_ctx* ctx, const double* d_norms, size_t n, int nclasses, const double* d_null_stat,
-                               const double* d_null_nmin, size_t nnull, hipStream_t st, double** maxnorm_out, double** sorted_out,
-                               uint32_t** hist_out) {
+                               const double* d_null_nmin, size_t nnull, hipStream_t st, NullTable* out) {
   cmx_status s;
-  double *maxnorm, *sa, *sb;
-  uint32_t *ca, *cb, *hist;
+  double *maxnorm, *sa, *sb, *top;
+  uint32_t *ca, *cb, *hist, *off;
   const size_t nn = nnull ? nnull : 1;
   if ((s = scratch(ctx, "pv_max", sizeof(double), (void**)&maxnorm)) != CMX_OK) return s;
   if ((s = scratch(ctx, "pv_sa", sizeof(double) * nn, (void**)&sa)) != CMX_OK) return s;
@@ -958,6 +957,8 @@ static cmx_status prepare_null(cmx_ctx* ctx, const double* d_norms, size_t n, in
   if ((s = scratch(ctx, "pv_ca", sizeof(uint32_t) * nn, (void**)&ca)) != CMX_OK) return s;
   if ((s = scratch(ctx, "pv_cb", sizeof(uint32_t) * nn, (void**)&cb)) != CMX_OK) return s;
   if ((s = scratch(ctx, "pv_hist", sizeof(uint32_t) * 66, (void**)&hist)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_off", sizeof(uint32_t) * 66, (void**)&off)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_top", sizeof(double) * (nn / kNullTopStride + 2), (void**)&top)) != CMX_OK) return s;
   HIP_TRY(ctx, launch_max_reduce(d_norms, n, maxnorm, st));
   HIP_TRY(ctx, launch_null_classify(d_null_stat, d_null_nmin, nnull, maxnorm, nclasses, ca, hist, st));
   if (nnull > 0) {
@@ -968,7 +969,8 @@ static cmx_status prepare_null(cmx_ctx* ctx, const double* d_norms, size_t n, in
     if ((s = scratch(ctx, "pv_sorttmp", tmp_bytes, &tmp)) != CMX_OK) return s;
     HIP_TRY(ctx, sort_null_by_class(tmp, tmp_bytes, sa, sb, ca, cb, nnull, st));
   }
-  *maxnorm_out = maxnorm; *sorted_out = sa; *hist_out = hist;
+  HIP_TRY(ctx, launch_null_index(sa, hist, nclasses, nnull, off, top, st));
+  *out = NullTable{sa, hist, off, top, maxnorm, nclasses};
   return CMX_OK;
 }
 
@@ -982,10 +984,9 @@ cmx_status cmx_intra_pvalues_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo,
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   cmx_status s;
-  double *maxnorm, *sa;
-  uint32_t* hist;
-  if ((s = prepare_null(ctx, d_norms, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &maxnorm, &sa, &hist)) != CMX_OK) return s;
-  HIP_TRY(ctx, launch_pvalues(d_stat, ldo, d_norms, n, maxnorm, nclasses, sa, hist, d_pvalue, d_nsim, st));
+  NullTable nt;
+  if ((s = prepare_null(ctx, d_norms, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &nt)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_pvalues(d_stat, ldo, d_norms, n, nt, d_pvalue, d_nsim, st));
   return CMX_OK;
 }
 
@@ -1089,24 +1090,18 @@ cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params
     if ((s = scratch(ctx, "pair_r1", sizeof(double) * n, (void**)&rv)) != CMX_OK) return s;
     HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts, n, ldc, h.B, h.K, X, ldx, Bp, sv, rv, d_mean, st));
   }
-  double *maxnorm = nullptr, *sorted = nullptr;
-  uint32_t* hist = nullptr;
-  if (with_null && (s = prepare_null(ctx, d_norm, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &maxnorm, &sorted, &hist)) != CMX_OK)
-    return s;
-  // row blocks: a multiple of 64 rows (Gram tiles), dense scratch (f64 statistic + f64 p-value + i32 Nsim) <= 256 MiB
-  size_t RB = ((size_t)256 << 20) / (20 * n) / 64 * 64;
+  NullTable nt{};
+  if (with_null && (s = prepare_null(ctx, d_norm, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &nt)) != CMX_OK) return s;
+  // row blocks: a multiple of 64 rows (Gram tiles), dense scratch (the f64 statistic; the p-values are looked up by the
+  // pass that writes the rows, for the pairs it writes) <= 256 MiB
+  size_t RB = ((size_t)256 << 20) / (8 * n) / 64 * 64;
   RB = std::max<size_t>(64, std::min<size_t>(RB, (row_end - row_begin + 63) / 64 * 64));
-  double *blk_stat, *blk_pv = nullptr;
-  int32_t* blk_ns = nullptr;
+  double* blk_stat;
   unsigned long long* rowcount;
   if ((s = scratch(ctx, "blk_stat", sizeof(double) * RB * n, (void**)&blk_stat)) != CMX_OK) return s;
-  if (with_null) {
-    if ((s = scratch(ctx, "blk_pv", sizeof(double) * RB * n, (void**)&blk_pv)) != CMX_OK) return s;
-    if ((s = scratch(ctx, "blk_ns", sizeof(int32_t) * RB * n, (void**)&blk_ns)) != CMX_OK) return s;
-  }
   if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (RB + 1), (void**)&rowcount)) != CMX_OK) return s;
   size_t tmp_bytes = 0;
-  HIP_TRY(ctx, launch_pair_rows(blk_stat, n, blk_pv, blk_ns, n, d_rate_class, d_post_rate, d_norm, f, rowcount, nullptr, tmp_bytes,
+  HIP_TRY(ctx, launch_pair_rows(blk_stat, n, nullptr, nullptr, n, d_rate_class, d_post_rate, d_norm, f, rowcount, nullptr, tmp_bytes,
                                 d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), st, 0, RB));
   void* tmp = nullptr;
   if ((s = scratch(ctx, "rows_scan", tmp_bytes ? tmp_bytes : 16, &tmp)) != CMX_OK) return s;
@@ -1115,10 +1110,9 @@ cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params
     if (gk == CMX_STAT_EUCLIDIAN_DISTANCE) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_intra_rows_range: EuclidianDistance is a distance, not a statistic");
     if (mcls) HIP_TRY(ctx, launch_mi_pairs_block(h.B, mcls + i0, mbad + i0, rb, mldx, mcls, mbad, n, mldx, 2, blk_stat, n, i0, st));
     else HIP_TRY(ctx, launch_pair_gram(gk, h.B, Bp, X + i0, sv + i0, rv + i0, rb, ldx, X, sv, rv, n, ldx, 2, blk_stat, n, st, 1, 0, 0, 0, i0));
-    if (with_null) HIP_TRY(ctx, launch_pvalues(blk_stat, n, d_norm, n, maxnorm, nclasses, sorted, hist, blk_pv, blk_ns, st, i0, rb));
-    HIP_TRY(ctx, launch_pair_rows(blk_stat, n, blk_pv, blk_ns, n, d_rate_class, d_post_rate, d_norm, f, rowcount, tmp, tmp_bytes,
+    HIP_TRY(ctx, launch_pair_rows(blk_stat, n, nullptr, nullptr, n, d_rate_class, d_post_rate, d_norm, f, rowcount, tmp, tmp_bytes,
                                   d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), st, i0, rb,
-                                  reinterpret_cast<unsigned long long*>(d_count)));
+                                  reinterpret_cast<unsigned long long*>(d_count), with_null ? &nt : nullptr));
   }
   return CMX_OK;
 }

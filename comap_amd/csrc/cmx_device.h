@@ -198,8 +198,20 @@ hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const d
 hipError_t launch_max_reduce(const double* d_x, size_t n, double* d_out, hipStream_t stream);
 hipError_t launch_null_classify(const double* d_stat, const double* d_nmin, size_t nnull, const double* d_maxnorm,
                                 int nclasses, uint32_t* d_cls, uint32_t* d_hist, hipStream_t stream);
-hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norms, size_t n, const double* d_maxnorm,
-                          int nclasses, const double* d_sorted, const uint32_t* d_hist, double* d_pvalue,
+// The null distribution prepared for p-value lookups: statistics sorted by (class, value), the classes' sizes and
+// offsets, and `top` = every 64th sorted value (the first level of the two-level lower bound; 1/64 of the null: L2-resident)
+constexpr int kNullTopStride = 64;
+struct NullTable {
+  const double* sorted;     // [nnull] ascending inside each class, classes in order
+  const uint32_t* hist;     // [nclasses + 1] class sizes (last: values without a class)
+  const uint32_t* off;      // [nclasses + 1] class offsets in `sorted`
+  const double* top;        // [ceil(nnull / 64)] sorted[64 t]
+  const double* maxnorm;    // upper bound of the Domain of the norms
+  int nclasses;
+};
+hipError_t launch_null_index(const double* d_sorted, const uint32_t* d_hist, int nclasses, size_t nnull, uint32_t* d_off, double* d_top,
+                             hipStream_t stream);
+hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norms, size_t n, const NullTable& nt, double* d_pvalue,
                           int32_t* d_nsim, hipStream_t stream, size_t irow0 = 0, size_t nrows = 0);
 hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in, double* d_stat_tmp, uint32_t* d_cls_in,
                               uint32_t* d_cls_tmp, size_t n, hipStream_t stream);
@@ -207,7 +219,7 @@ hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pv
                             const int32_t* d_rc, const double* d_pr, const double* d_norm, const cmx_pair_filters& f,
                             unsigned long long* d_rowcount /*[n + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
                             size_t capacity, unsigned long long* d_count, hipStream_t stream, size_t irow0 = 0, size_t nrows = 0,
-                            const unsigned long long* d_base = nullptr);
+                            const unsigned long long* d_base = nullptr, const NullTable* d_inline_null = nullptr);
 hipError_t launch_inter_rows(const double* d_stat, size_t ldo, size_t n2, const int32_t* d_rc1, const double* d_pr1, const double* d_nm1,
                              const int32_t* d_rc2, const double* d_pr2, const double* d_nm2, const cmx_inter_filters& f,
                              unsigned long long* d_rowcount, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows, size_t capacity,

@@ -1603,44 +1603,63 @@ hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in,
 }
 
 // p = (nsim - #{null < stat} + 1) / (nsim + 1), strict '<' (CoETools.cpp:712-717); the reference scans linearly,
-// the sorted class makes it a lower_bound.  hist[c] = class sizes; classes are laid out in order in `sorted`.
-__global__ void pvalue_kernel(const double* __restrict__ stat, size_t ldo, const double* __restrict__ norms, size_t n,
-                              const double* __restrict__ maxnorm, int nclasses, const double* __restrict__ sorted,
-                              const uint32_t* __restrict__ hist, double* __restrict__ pvalue, int32_t* __restrict__ nsim,
-                              size_t irow0) {
-  __shared__ uint32_t off[66];
-  if (threadIdx.x == 0) {
-    uint32_t o = 0;
-    for (int c = 0; c <= nclasses && c < 65; ++c) { off[c] = o; o += hist[c]; }
+// the sorted class makes it a lower bound.  Two levels: first among every 64th value of the class (`top`, 1/64 of the
+// null: it stays in the L2 where the plain binary search sent its last dozen probes of every pair to the Infinity Cache /
+// HBM), then inside the one stretch of at most 63 values that is left.  Same count as the plain search.
+__device__ __forceinline__ void null_pvalue(const NullTable& nt, double ni, double nj, double st, double* pvalue, int32_t* nsim) {
+  const double mn = ni < nj ? ni : nj;
+  const int cat = domain_index(*nt.maxnorm, nt.nclasses, mn);
+  if (cat < 0) { *pvalue = __builtin_nan(""); *nsim = 0; return; }
+  const uint32_t a = nt.off[cat], ns = nt.hist[cat], b = a + ns;
+  // first t in [T0, T1) with top[t] >= st: everything up to 64 (t - 1) is < st, everything from 64 t on is >= st
+  const uint32_t T0 = (a + kNullTopStride - 1) / kNullTopStride, T1 = ns ? (b - 1) / kNullTopStride + 1 : T0;
+  uint32_t lo = T0, hi = T1 > T0 ? T1 : T0;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (nt.top[mid] < st) lo = mid + 1; else hi = mid;
   }
-  __syncthreads();
+  uint32_t l2 = lo > T0 ? kNullTopStride * (lo - 1) + 1 : a, h2 = lo < T1 ? kNullTopStride * lo : b;
+  if (T1 <= T0) { l2 = a; h2 = b; }   // the class holds no sampled position
+  while (l2 < h2) {
+    const uint32_t mid = (l2 + h2) >> 1;
+    if (nt.sorted[mid] < st) l2 = mid + 1; else h2 = mid;
+  }
+  const uint32_t below = l2 - a;
+  *pvalue = (double)(ns - below + 1) / (double)(ns + 1);
+  *nsim = (int32_t)ns;
+}
+__global__ void pvalue_kernel(const double* __restrict__ stat, size_t ldo, const double* __restrict__ norms, size_t n, const NullTable nt,
+                              double* __restrict__ pvalue, int32_t* __restrict__ nsim, size_t irow0) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = irow0 + blockIdx.y;          // row of the full matrix; the arrays hold rows irow0 ..
   if (j >= n) return;
   const size_t o = (size_t)blockIdx.y * ldo + j;
   if (j <= i) { pvalue[o] = __builtin_nan(""); nsim[o] = 0; return; }
-  const double ni = norms[i], nj = norms[j];
-  const double mn = ni < nj ? ni : nj;
-  const int cat = domain_index(*maxnorm, nclasses, mn);
-  if (cat < 0) { pvalue[o] = __builtin_nan(""); nsim[o] = 0; return; }
-  const uint32_t lo0 = off[cat], ns = hist[cat];
-  const double st = stat[o];
-  uint32_t lo = 0, hi = ns;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (sorted[lo0 + mid] < st) lo = mid + 1; else hi = mid;
-  }
-  pvalue[o] = (double)(ns - lo + 1) / (double)(ns + 1);
-  nsim[o] = (int32_t)ns;
+  null_pvalue(nt, norms[i], norms[j], stat[o], pvalue + o, nsim + o);
 }
 
-hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norms, size_t n, const double* d_maxnorm,
-                          int nclasses, const double* d_sorted, const uint32_t* d_hist, double* d_pvalue,
+hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norms, size_t n, const NullTable& nt, double* d_pvalue,
                           int32_t* d_nsim, hipStream_t stream, size_t irow0, size_t nrows) {
   if (nrows == 0) nrows = n;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)nrows);
-  hipLaunchKernelGGL(pvalue_kernel, grid, dim3(256), 0, stream, d_stat, ldo, d_norms, n, d_maxnorm, nclasses, d_sorted,
-                     d_hist, d_pvalue, d_nsim, irow0);
+  hipLaunchKernelGGL(pvalue_kernel, grid, dim3(256), 0, stream, d_stat, ldo, d_norms, n, nt, d_pvalue, d_nsim, irow0);
+  return hipGetLastError();
+}
+
+// class offsets and the sampled first level of the sorted null
+__global__ void null_index_kernel(const double* __restrict__ sorted, const uint32_t* __restrict__ hist, int nclasses, size_t nnull,
+                                  uint32_t* __restrict__ off, double* __restrict__ top) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    uint32_t o = 0;
+    for (int c = 0; c <= nclasses; ++c) { off[c] = o; o += hist[c]; }
+  }
+  if (t * kNullTopStride < nnull) top[t] = sorted[t * kNullTopStride];
+}
+hipError_t launch_null_index(const double* d_sorted, const uint32_t* d_hist, int nclasses, size_t nnull, uint32_t* d_off, double* d_top,
+                             hipStream_t stream) {
+  const size_t nt = (nnull + kNullTopStride - 1) / kNullTopStride;
+  hipLaunchKernelGGL(null_index_kernel, dim3((unsigned)(nt / 256 + 1)), dim3(256), 0, stream, d_sorted, d_hist, nclasses, nnull, d_off, d_top);
   return hipGetLastError();
 }
 
@@ -1660,7 +1679,7 @@ __global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict_
                                                        const double* __restrict__ norm, cmx_pair_filters f,
                                                        unsigned long long* __restrict__ rowcount /* counts, then offsets */,
                                                        cmx_pair_row* __restrict__ rows, size_t capacity, size_t irow0,
-                                                       const unsigned long long* __restrict__ base) {
+                                                       const unsigned long long* __restrict__ base, const NullTable nt) {
   // stat / pvalue / nsim hold rows irow0 .. of the full matrix (local row = blockIdx.x); rows are appended after *base
   const size_t il = blockIdx.x, i = irow0 + il;
   const int lane = threadIdx.x;
@@ -1688,6 +1707,7 @@ __global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict_
           r.n_min = norm[i] < norm[j] ? norm[i] : norm[j];
           r.pvalue = pvalue ? pvalue[il * ldo + j] : __builtin_nan("");
           r.nsim = nsim ? nsim[il * ldo + j] : 0;
+          if (nt.sorted) null_pvalue(nt, norm[i], norm[j], st, &r.pvalue, &r.nsim);   // only for the pairs that are written
           rows[pos] = r;
         }
       }
@@ -1708,20 +1728,22 @@ hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pv
                             const int32_t* d_rc, const double* d_pr, const double* d_norm, const cmx_pair_filters& f,
                             unsigned long long* d_rowcount /*[nrows + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
                             size_t capacity, unsigned long long* d_count, hipStream_t stream, size_t irow0, size_t nrows,
-                            const unsigned long long* d_base) {
+                            const unsigned long long* d_base, const NullTable* d_inline_null) {
+  // d_inline_null: the write pass looks the p-values up itself (no dense p-value / Nsim block, no pvalue_kernel)
+  const NullTable nt = d_inline_null ? *d_inline_null : NullTable{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (nrows == 0) nrows = n;
   if (d_tmp == nullptr) {
     return rocprim::exclusive_scan(nullptr, tmp_bytes, d_rowcount, d_rowcount, 0ull, nrows, rocprim::plus<unsigned long long>(), stream);
   }
   hipLaunchKernelGGL((pair_rows_kernel<false>), dim3((unsigned)nrows), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
-                     d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base);
+                     d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base, nt);
   // keep the last row's count (the scan overwrites it) to form the total
   hipError_t e = hipMemcpyAsync(d_rowcount + nrows, d_rowcount + nrows - 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) return e;
   e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_rowcount, d_rowcount, 0ull, nrows, rocprim::plus<unsigned long long>(), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((pair_rows_kernel<true>), dim3((unsigned)nrows), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
-                     d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base);
+                     d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base, nt);
   // (after the writes: d_count may be the very word d_base points to)
   hipLaunchKernelGGL(pair_rows_total_kernel, dim3(1), dim3(64), 0, stream, d_rowcount, d_rowcount + nrows, nrows, d_count, d_base);
   return hipGetLastError();

@@ -1083,3 +1083,47 @@ def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
     rel_close(gi["mi"][iu], oi["mi"][iu], 1e-6, 1e-10)
     rel_close(gi["hjoint"][iu], oi["hjoint"][iu], 1e-6, 1e-10)
     assert np.isnan(gi["mi"][np.tril_indices(n2)]).all() and np.isnan(gi["hjoint"][np.tril_indices(n2)]).all()
+
+
+def test_pvalues_two_level_lookup_is_the_linear_count():
+    """The p-value lookup goes through a sampled first level (every 64th sorted null value) and a last stretch of at most
+    63 values; the count must be the reference's linear scan with strict '<' (CoETools.cpp:712-717) for classes whose
+    sizes are no multiple of 64, classes smaller than the sampling stride, an empty class, heavy ties, statistics below
+    and above every null value -- in the dense call and in the pass that writes the compacted rows."""
+    rng = np.random.default_rng(77)
+    n, ncls, nnull = 120, 7, 200_003
+    norms = np.concatenate([rng.uniform(0.0, 5.0, n - 1), [5.0]])
+    width = 5.0 / ncls
+    null_nmin = rng.uniform(0.0, 5.0, nnull)
+    null_nmin[(null_nmin >= 2 * width) & (null_nmin < 3 * width)] = 0.1 * width     # class 2 stays empty
+    small = np.flatnonzero((null_nmin >= 4 * width) & (null_nmin < 5 * width))
+    null_nmin[small[37:]] = 5 * width + 0.01                                         # class 4 keeps 37 values
+    null_stat = np.round(rng.normal(0.0, 0.3, nnull), 3)                             # three decimals: ties everywhere
+    null_stat[rng.integers(0, nnull, 50)] = np.nan                                   # dropped from their class
+    stat = np.round(rng.normal(0.0, 0.35, (n, n)), 3)
+    stat = np.triu(stat, 1) + np.triu(stat, 1).T
+    stat[0, 1] = stat[1, 0] = -9.0
+    stat[0, 2] = stat[2, 0] = 9.0
+    eng = engine.Engine()
+    pv, ns = eng.intra_pvalues(stat, norms, ncls, null_stat, null_nmin)
+    opv, ons = oracle.intra_pvalues(stat, norms, ncls, null_stat, null_nmin)
+    iu = np.triu_indices(n, 1)
+    assert np.array_equal(ns[iu], ons[iu])
+    assert np.array_equal(pv[iu], opv[iu], equal_nan=True)
+    assert set(np.unique(ons[iu])) >= {0, 37}
+    # the row writer (cmx_intra_rows_range_dev) looks the same values up itself, for the pairs it writes
+    import torch
+    from test_gpu_fullsize import _rows_range
+    case = make_case(9, n, 20, 5)
+    e2 = _engine(case)
+    m = e2.map_sites(case["aln"])
+    scale = float(m["norm"].max()) / 5.0
+    dev = torch.device("cuda:0")
+    cbm = torch.from_numpy(np.ascontiguousarray(m["counts"].reshape(n, -1).T)).to(dev)
+    rc, pr, nm = (torch.from_numpy(m[k]).to(dev) for k in ("rate_class", "post_rate", "norm"))
+    rows = _rows_range(e2, cbm, rc, pr, nm, torch.from_numpy(null_stat).to(dev), torch.from_numpy(null_nmin * scale).to(dev), ncls,
+                       engine.STAT_CORRELATION, 0, n)
+    assert len(rows) == n * (n - 1) // 2
+    st = e2.pair_stats(engine.STAT_CORRELATION, m["counts"])
+    opv2, ons2 = oracle.intra_pvalues(st, m["norm"], ncls, null_stat, null_nmin * scale)
+    assert np.array_equal(rows["nsim"], ons2[iu]) and np.array_equal(rows["pvalue"], opv2[iu], equal_nan=True)
