@@ -180,6 +180,16 @@ def mica_leg(dev, steps, world=1, rank=0, gloo=False):
                              peak=INT8_PEAK_TOPS * world, unit="TOP/s", frac=tops / (INT8_PEAK_TOPS * world), traffic=None,
                              ops_per_pair_algorithmic=2.0 * A * A * T),
                max_identity_residual=ident, full_mean_mi=float(r["full_mean"]))
+    # HBM bytes per call of the dominant kernel from the PMC passes, only if they were taken on these device sources
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
+        try:
+            t = json.load(open(tf))
+            if t.get("kernel_source_sha") == kernel_source_sha() and "mica_cfg5" in t:
+                out["roofline"]["traffic"] = t["mica_cfg5"] / world
+                out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
+                break
+        except Exception:
+            pass
     if world == 1:
         import oracle
         ns = 300

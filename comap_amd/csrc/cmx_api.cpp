@@ -46,6 +46,12 @@ struct cmx_ctx {
   bool leaf_rows_custom = false;   // the leaf operators' ambiguity rows were built from a caller's mask table
   bool map_average = true;         // nijt.average (cmx_set_mapping_options); false: the no-averaging mapping of cmx_variants.hip
   bool map_joint = true;           // nijt.joint; false: the ...Marginal variants of cmx_variants.hip
+  // Mica's permutation test: host-side sources of its asynchronous table uploads (they must outlive the copies, also
+  // when a later call fails), and which (L, taxa, shift) the fixed-point table F on the device was built for
+  std::vector<long long> perm_dF_host, perm_F_host;
+  std::vector<uint8_t> perm_tab_host;
+  unsigned long long perm_F_L = 0;
+  int perm_F_T = 0, perm_F_sh = -1;
   const double *va_P = nullptr, *va_N1 = nullptr, *va_NC = nullptr;   // their operators, uploaded at first use
   const int *va_first = nullptr, *va_next = nullptr;
   mutable std::string err;
@@ -1932,22 +1938,27 @@ cmx_status cmx_mica_permutation_test_masks_dev(cmx_ctx* ctx, int nalpha, int nta
   if ((s = scratch(ctx, "perm_bad", 2 * sizeof(int), (void**)&d_bad)) != CMX_OK) return s;
   if ((s = scratch(ctx, "perm_dF", sizeof(long long) * ntaxa, (void**)&d_dF)) != CMX_OK) return s;
   // resolved pairs: F[c] = round(c ln c * 2^40); the kernel accumulates F[c+1] - F[c] per increment of a joint count
-  std::vector<long long> dF(ntaxa);
+  // (sources owned by the context: a failing call further down must not free memory an upload still reads)
+  std::vector<long long>& dF = ctx->perm_dF_host;
+  dF.assign(ntaxa, 0);
   long long prev = 0;
   for (int c = 1; c <= ntaxa; ++c) {
     const long long f = std::llround((double)c * std::log((double)c) * 1099511627776.0);
     dF[c - 1] = f - prev;
     prev = f;
   }
+  ctx->perm_tab_host.assign(256 + 64 * sizeof(uint32_t), 0);
+  std::memcpy(ctx->perm_tab_host.data(), pc.emap, 256);
+  std::memcpy(ctx->perm_tab_host.data() + 256, pc.emask, 32 * sizeof(uint32_t));
+  std::memcpy(ctx->perm_tab_host.data() + 256 + 32 * sizeof(uint32_t), pc.ewgt, 32 * sizeof(uint32_t));
   HIP_TRY(ctx, hipMemcpyAsync(d_dF, dF.data(), sizeof(long long) * ntaxa, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(d_emap, pc.emap, 256, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(d_tab, pc.emask, sizeof(uint32_t) * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(d_tab + 32, pc.ewgt, sizeof(uint32_t) * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_emap, ctx->perm_tab_host.data(), 256, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tab, ctx->perm_tab_host.data() + 256, sizeof(uint32_t) * 64, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 2 * sizeof(int), st));
   HIP_TRY(ctx, launch_mica_colcount(d_aln, ntaxa, n, ld, nalpha, d_emap, d_cnt, d_ext, d_hasamb, d_bad, st));
   int bad[2] = {0, 0};
   HIP_TRY(ctx, hipMemcpyAsync(bad, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));   // also: dF and the code tables have been read from this frame
+  HIP_TRY(ctx, hipStreamSynchronize(st));   // the one host decision of this call: are there pairs with unknowns at all
   int cus = 0;
   HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
   const size_t npairs = pair_end - pair_begin;
@@ -1958,14 +1969,22 @@ cmx_status cmx_mica_permutation_test_masks_dev(cmx_ctx* ctx, int nalpha, int nta
       return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_mica_permutation_test: " + std::to_string(ntaxa) + " taxa with " + std::to_string(bad[1]) +
                                             " distinct ambiguity codes in one column do not fit the LDS");
     const size_t M = (size_t)pc.L * pc.L * (size_t)ntaxa;
-    std::vector<long long> F(M + 1, 0);
-    const double scale = std::ldexp(1.0, pc.sh);
-    for (size_t m = 1; m <= M; ++m) F[m] = std::llround((double)m * std::log((double)m) * scale);
     long long* d_F;
     uint16_t* d_order;
     if ((s = scratch(ctx, "perm_F", sizeof(long long) * (M + 1), (void**)&d_F)) != CMX_OK) return s;
     if ((s = scratch(ctx, "perm_order", sizeof(uint16_t) * n * (size_t)ntaxa, (void**)&d_order)) != CMX_OK) return s;
-    HIP_TRY(ctx, hipMemcpyAsync(d_F, F.data(), sizeof(long long) * (M + 1), hipMemcpyHostToDevice, st));
+    // F[m] = round(m ln m 2^sh), up to 2^26 entries with a logarithm each: built once per (L, taxa, shift) and kept on the
+    // device -- a caller that shards the pairs over several calls pays for it once.  (Built on the host with the oracle's
+    // logarithm so that the fixed-point sums, and with them every tie, are the oracle's.)
+    if (ctx->perm_F_L != pc.L || ctx->perm_F_T != ntaxa || ctx->perm_F_sh != pc.sh || ctx->perm_F_host.size() != M + 1) {
+      ctx->perm_F_sh = -1;
+      std::vector<long long>& F = ctx->perm_F_host;
+      F.assign(M + 1, 0);
+      const double scale = std::ldexp(1.0, pc.sh);
+      for (size_t m = 1; m <= M; ++m) F[m] = std::llround((double)m * std::log((double)m) * scale);
+      HIP_TRY(ctx, hipMemcpyAsync(d_F, F.data(), sizeof(long long) * (M + 1), hipMemcpyHostToDevice, st));
+      ctx->perm_F_L = pc.L; ctx->perm_F_T = ntaxa; ctx->perm_F_sh = pc.sh;
+    }
     HIP_TRY(ctx, launch_mica_colorder(d_aln, ntaxa, n, ld, nalpha, d_emap, d_ext, d_order, st));
     if (!mica_perm_opening_fits(ntaxa, nalpha)) {
       HIP_TRY(ctx, hipMemsetAsync(d_nperm, 0xFF, sizeof(int32_t) * npairs, st));   // -1: undecided, no hits (resolved pairs)
@@ -1973,7 +1992,6 @@ cmx_status cmx_mica_permutation_test_masks_dev(cmx_ctx* ctx, int nalpha, int nta
     }
     HIP_TRY(ctx, launch_mica_perm_general(d_aln, ntaxa, n, ld, nalpha, d_emap, d_ext, d_order, d_hasamb, d_tab, d_tab + 32, d_F, pc.L,
                                           bad[1], max_perm, seed, pair_begin, pair_end, d_pvalue, d_nperm, cus, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));   // F lives in this frame
   }
   HIP_TRY(ctx, launch_mica_perm(d_aln, ntaxa, n, ld, nalpha, d_cnt, d_hasamb, d_dF, preset, max_perm, seed, pair_begin, pair_end,
                                 d_pvalue, d_nperm, cus, st));

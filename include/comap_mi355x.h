@@ -391,7 +391,12 @@ cmx_status cmx_debug_candidate_cursor(size_t ngroups, const int64_t* offsets, co
  * symbol with k compatible states adds 1/k to each.  `masks` is a HOST table indexed by alignment code (bit a =
  * compatible with state a), as for cmx_mi_columns; codes >= nalpha without an entry (and masks == NULL) are unknowns.
  * Partial ambiguity codes must be < 31.  Pairs of fully resolved columns take the same path, and give the same
- * results, with or without a mask table. */
+ * results, with or without a mask table.
+ * A column WITHOUT ANY resolved symbol (gaps / unknowns only) is treated like a constant column: pvalue 1, nperm 0.
+ * (Whether Bio++'s SiteTools::isConstant(site, true) says the same of such a site could not be checked: bpp-seq is not
+ * in the reference tree.  Its MI with any column is 0 either way.)
+ * The call blocks the host once (it has to learn whether any pair carries unknowns); the fixed-point table of the
+ * unknowns' path is built once per (alphabet, ambiguity codes, ntaxa) and kept by the context. */
 cmx_status cmx_mica_permutation_test_masks_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_t* masks, size_t nmasks,
                                                const uint8_t* d_aln, size_t n, size_t ld, uint32_t max_perm, uint64_t seed,
                                                size_t pair_begin, size_t pair_end, double* d_pvalue, int32_t* d_nperm,
