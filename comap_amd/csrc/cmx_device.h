@@ -14,7 +14,12 @@ constexpr int kWavesPerBlock = 4;   // mapping kernels: 4 independent waves per 
 // operator: row S+a = sum of the rows of the states compatible with ambiguity id a (filled per call from the caller's
 // mask table, default "every state").  A = 12 for nucleotides (IUPAC + gap), 4 for proteins (B, Z, J, X/gap).
 constexpr int max_ambig(int S) { return S == 4 ? 12 : 4; }
-constexpr int mat_unit(int S) { return (S + max_ambig(S)) * S; }   // doubles per device matrix
+// A transposed leaf operator is read row by row, the row named by a site's symbol: sixteen sites of a lane group read
+// sixteen rows at once.  With rows of S doubles (40 dwords for S = 20, 32 for the class-fused 16) rows 8 (2) apart fall
+// on the same LDS banks -- 61 % of the mapping kernel's LDS cycles were bank conflicts.  One double of padding per row
+// (42 / 34 dwords) moves the period to 32 rows: no two rows of an operator share a bank.
+constexpr int leaf_row_stride(int S) { return S + 1; }             // doubles per row of a transposed leaf operator
+constexpr int mat_unit(int S) { return (S + max_ambig(S)) * leaf_row_stride(S); }   // doubles per device matrix
 #ifndef CMX_WAVES_PER_SIMD
 #define CMX_WAVES_PER_SIMD 2       // resident mapping waves per SIMD for 20 states (1: 512-register budget, 2: 256)
 #endif

@@ -224,7 +224,7 @@ struct Numeric {
     const int tx = hm.taxon_of[leaf];
     return staged(which < 0 ? hm.NI + hm.NI * hm.K + tx : hm.NI + hm.NI * hm.K + hm.T + which * hm.T + tx, tx);
   }
-  double leafrow(int mat, int leaf, int X) const { return blk[(size_t)mat * MU + (size_t)code[hm.taxon_of[leaf]] * dS + (X % 4) * NB + X / 4]; }
+  double leafrow(int mat, int leaf, int X) const { return blk[(size_t)mat * MU + (size_t)code[hm.taxon_of[leaf]] * leaf_row_stride(dS) + (X % 4) * NB + X / 4]; }
   double packed(int mat, int r, int c) const { return blk[(size_t)mat * MU + ((size_t)(r / 4) * NB + c / 4) * 16 + (r % 4) * 4 + c % 4]; }
   void count_row(int row, double v) {
     if (row < 0 || row >= hm.B * hm.K) return fail("count row out of range");
@@ -608,7 +608,7 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
                 // Columns are stored state-in-tile major (X % 4) * (dS / 4) + X / 4: the values one lane of the
                 // matrix-core layout needs from a row are contiguous.
                 const int X = g * S + x, pos = (X % 4) * (dS / 4) + X / 4;
-                lt[(size_t)z * dS + pos] = M ? weight(g, which) * M[(size_t)x * S + z] : (which < 0 && x == z ? 1.0 : 0.0);
+                lt[(size_t)z * leaf_row_stride(dS) + pos] = M ? weight(g, which) * M[(size_t)x * S + z] : (which < 0 && x == z ? 1.0 : 0.0);
               }
           }
         }

@@ -238,7 +238,7 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
   for (int g = 0; g < NG; ++g) {
     const unsigned row = code[g] < (unsigned)MatStage<S>::NROW ? code[g] : (unsigned)(MatStage<S>::NROW - 1);
     // rows are stored state-in-tile major: state 4 sb + s4 at position s4 * NB + sb (cmx_host_model.cpp)
-    r[g] = reinterpret_cast<const double*>(buf + row * (S * 8)) + (lane >> 4) * NB;
+    r[g] = reinterpret_cast<const double*>(buf + row * (leaf_row_stride(S) * 8)) + (lane >> 4) * NB;
   }
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -868,7 +868,7 @@ hipError_t launch_map_finalize(const MapArgs& a, hipStream_t stream) {
 // (what the DR likelihood's leaf initialisation does for B/Z/X/gap).  One thread per (class, leaf operator, a, x);
 // a row has `rowlen` values (= S0, or S0 * fuse for the class-fused nucleotide layout).
 __global__ void extend_leaf_rows_kernel(double* MAT, int C, int MC, int first_leaf, int nleaf, int S0, int rowlen, int A,
-                                        int unit, const uint32_t* __restrict__ masks) {
+                                        int unit, int stride /* doubles between rows: leaf_row_stride */, const uint32_t* __restrict__ masks) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)C * nleaf * A * rowlen;
   if (i >= total) return;
@@ -880,15 +880,15 @@ __global__ void extend_leaf_rows_kernel(double* MAT, int C, int MC, int first_le
   const uint32_t mk = masks ? masks[S0 + a] : 0xffffffffu;
   double v = 0.0;
   for (int z = 0; z < S0; ++z)
-    if ((mk >> z) & 1u) v += M[(size_t)z * rowlen + x];
-  M[(size_t)(S0 + a) * rowlen + x] = v;
+    if ((mk >> z) & 1u) v += M[(size_t)z * stride + x];
+  M[(size_t)(S0 + a) * stride + x] = v;
 }
 
 hipError_t launch_extend_leaf_rows(const DevModel& m, const uint32_t* d_masks, hipStream_t stream) {
   const int A = max_ambig(m.S0), nleaf = m.T + m.K * m.T;
   const size_t total = (size_t)m.C * nleaf * A * m.S;
   hipLaunchKernelGGL(extend_leaf_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, m.MAT, m.C, m.MC,
-                     m.NI + m.NI * m.K, nleaf, m.S0, m.S, A, mat_unit(m.S), d_masks);
+                     m.NI + m.NI * m.K, nleaf, m.S0, m.S, A, mat_unit(m.S), leaf_row_stride(m.S), d_masks);
   return hipGetLastError();
 }
 
