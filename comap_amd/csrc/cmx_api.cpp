@@ -1342,13 +1342,14 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
     cmx_status s;
     w.Tp = (ntaxa + 31) / 32 * 32;
     const size_t hb = 32 * (size_t)w.Tp;
-    if ((s = scratch(ctx, "mica_H1", hb * n1, (void**)&w.H1)) != CMX_OK) return s;
+    const bool needH = mica_needs_onehot(nalpha);   // 32 Tp bytes per column: only where a kernel reads them
+    if ((s = scratch(ctx, "mica_H1", needH ? hb * n1 : 16, (void**)&w.H1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_C1", (size_t)w.Tp * (n1 + kMicaCodePad), (void**)&w.C1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_f1", n1, (void**)&w.flag1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_g1", n1, (void**)&w.gap1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_S1", sizeof(double) * n1, (void**)&w.S1)) != CMX_OK) return s;
     if (!intra) {
-      if ((s = scratch(ctx, "mica_H2", hb * n2, (void**)&w.H2)) != CMX_OK) return s;
+      if ((s = scratch(ctx, "mica_H2", needH ? hb * n2 : 16, (void**)&w.H2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_C2", (size_t)w.Tp * (n2 + kMicaCodePad), (void**)&w.C2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_f2", n2, (void**)&w.flag2)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_g2", n2, (void**)&w.gap2)) != CMX_OK) return s;

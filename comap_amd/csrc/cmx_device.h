@@ -247,6 +247,7 @@ struct MicaWork {
   unsigned *info1, *info2;   // per block of three columns: not-served and has-unknowns bits (cmx_mica4.hip; NULL: not used)
   int Tp;                  // T rounded up to a multiple of 32 (taxa per MFMA step)
 };
+bool mica_needs_onehot(int A);   // whether launch_mi_columns reads MicaWork::H1 / H2 for this alphabet
 // cmx_mica4.hip: the four-wave protein kernel (unknowns included; partial ambiguity codes are not served)
 bool mica4_serves(int A, int Tp, size_t n1, size_t n2);
 hipError_t launch_mica4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,

@@ -2519,6 +2519,9 @@ static bool mica_eight_wave_tiles() {
   return v;
 }
 
+// the one-hot matrices H [n][32][Tp] are operands of the one-column-per-tile kernel only (DNA, and CMX_MICA_TILES=1)
+bool mica_needs_onehot(int A) { return !(A == 20 && !mica_one_column_tiles()); }
+
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
                              size_t ldo, double* d_h1, double* d_h2, const MicaWork* work, hipStream_t stream) {
@@ -2531,7 +2534,7 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
   const uint8_t *f1 = nullptr, *f2 = nullptr;
   if (work && work->H1) {
     const int Tp = work->Tp;
-    const bool needH = !(A == 20 && !mica_one_column_tiles());   // the packed protein kernel expands the symbol bytes itself
+    const bool needH = mica_needs_onehot(A);   // the packed protein kernels expand the symbol bytes themselves
     hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)((A * A * T) / 256 + 1)), dim3(256), 0, stream, T, A, work->ftab, work->anyflag);
     hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)(n1 + kMicaCodePad)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, needH ? work->H1 : nullptr, work->C1, work->flag1,
                        work->gap1, work->S1, work->anyflag, n1);

@@ -22,10 +22,11 @@
 // byte) the accumulators hold m (8 m with the weights doubled on one side and quadrupled on the other), and the epilogue
 // looks f2[m] = (m / A^2) ln(m / A^2) up instead of f[N]: the first 4096 entries of that table sit in LDS (cells of up to
 // ten taxa: most of them), the rest is gathered from the table in global memory (L2-resident) by the registers that hold
-// such a cell -- the gather's descriptor starts at entry 4096, so the lanes below it fall out of its range and cost no
-// memory access.  No pseudo-state row, no dump of the accumulators to LDS, no per-pair gather of cells (the eight-wave
-// kernel's way).  The plain instantiation serves the (block, tile) combinations
-// without an unknown on either side, the weighted one the others; a tile nobody in the workgroup needs is not even fetched.
+// such a cell, under their own EXEC mask (a copy of the table's tail behind a zero entry serves them).  No pseudo-state
+// row, no dump of the accumulators to LDS, no per-pair gather of cells (the eight-wave kernel's way).  The plain
+// instantiation walks the tiles where neither the workgroup's twelve first-alignment columns nor the tile's three carry
+// an unknown, the weighted one all the others (it is exact for pairs without unknowns too); a tile that is not an
+// instantiation's is not even fetched by it.
 //
 // Pairs with a column that carries PARTIAL ambiguity codes (B, Z, R, Y ...) are left to the LDS-table kernel
 // (launch_mi_columns).
@@ -151,19 +152,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // who needs what: this wave's block, the workgroup's four blocks, the run's tiles (one lane per tile, chunk <= 64)
     const unsigned inf1 = __builtin_amdgcn_readfirstlane(info1[(size_t)I * (kM4I / 3) + w]);   // (info arrays are padded to whole tiles)
     const int bad1 = inf1 & 7;
-    const bool gapA = (inf1 >> 3) != 0;
-    unsigned anyA = 0, allA = 1;   // over the workgroup's blocks that are served at all: some / all have unknowns
+    unsigned anyA = 0;   // some block of the workgroup (that is served at all) has unknowns
 #pragma unroll
     for (int k = 0; k < kM4I / 3; ++k) {
       const unsigned v = info1[(size_t)I * (kM4I / 3) + k];
-      if ((v & 7) != 7) {
-        anyA |= (v >> 3) != 0;
-        allA &= (v >> 3) != 0;
-      }
+      if ((v & 7) != 7) anyA |= (v >> 3) != 0;
     }
     const unsigned tinfo = jt0 + lane < jt1 ? info2[jt0 + lane] : 7u;
-    // a tile is walked by the workgroup if some (block, tile) combination in it is this instantiation's
-    const bool tile_mine = (tinfo & 7) != 7 && (WEIGHTED ? ((tinfo >> 3) != 0 || anyA) : ((tinfo >> 3) == 0 && !allA));
+    // Every tile is walked by exactly one instantiation, with all four waves at work: the plain one where neither the
+    // workgroup's twelve columns nor the tile's three carry an unknown, the weighted one everywhere else (it is exact for
+    // the pairs without unknowns too: f2[400 N] = f[N]).  Splitting by (block, tile) instead made both instantiations walk
+    // most tiles of a partly gapped alignment with some waves idle: 9.0 ms at 10 % gapped columns, more than with all of them.
+    const bool tile_mine = (tinfo & 7) != 7 && (((tinfo >> 3) != 0 || anyA) == WEIGHTED);
     unsigned long long need = __ballot(tile_mine);
     if (need == 0) continue;
     double s1v[3];
@@ -223,8 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (more) fetch(jn);
       const unsigned inf2 = __builtin_amdgcn_readlane(tinfo, jt - jt0);
       const int bad2 = inf2 & 7;
-      const bool gapB = (inf2 >> 3) != 0;
-      const bool work = bad1 != 7 && bad2 != 7 && (gapA || gapB) == WEIGHTED;    // wave-uniform
+      const bool work = bad1 != 7 && bad2 != 7;    // wave-uniform (the tile is this instantiation's: see tile_mine)
       cmx_i16v acc[2][2];   // written by the first k-step (C operand 0)
       if (work) {
         const cmx_i16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
