@@ -275,25 +275,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               }
               if (WEIGHTED) {
                 // cells of M0 or more: gathered from the third table by the lanes that hold one, under their own EXEC mask (a
-                // register without such a cell issues nothing to the texture unit).  Inline asm: written as a branch or a
-                // per-lane `if`, the compiler spilled 100 - 230 registers around the sixteen regions per tile.
-                double big[NB];
+                // register without such a cell issues nothing to the texture unit), straight over the zero those lanes read
+                // from LDS -- `val` is an operand of the asm, so the compiler has the LDS value land first.  Inline asm:
+                // written as a branch or a per-lane `if`, the compiler spilled 100 - 230 registers around the 64 regions.
 #pragma unroll
                 for (int v = 0; v < NB; ++v) {
-                  big[v] = 0.0;
                   unsigned long long sv;
                   asm volatile("v_cmp_le_u32_e32 vcc, %[m8], %[a]\n\t"
                                "s_and_saveexec_b64 %[sv], vcc\n\t"
                                "global_load_dwordx2 %[b], %[a], %[base]\n\t"
                                "s_mov_b64 exec, %[sv]"
-                               : [b] "+v"(big[v]), [sv] "=&s"(sv)
+                               : [b] "+v"(val[v]), [sv] "=&s"(sv)
                                : [a] "v"(acc[ii][jj][v0 + v]), [m8] "s"(M8), [base] "s"(f2hi_u)
                                : "vcc", "memory");
                 }
                 asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(big[0]), "+v"(big[1]), "+v"(big[2]), "+v"(big[3]), "+v"(big[4]), "+v"(big[5]), "+v"(big[6]), "+v"(big[7])::"memory");
-#pragma unroll
-                for (int v = 0; v < NB; ++v) val[v] += big[v];
+                             : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7])::"memory");
               }
 #pragma unroll
               for (int v = 0; v < NB; ++v) {
