@@ -53,6 +53,7 @@ struct cmx_ctx {
   unsigned long long perm_F_L = 0;
   int perm_F_T = 0, perm_F_sh = -1;
   const double *va_P = nullptr, *va_N1 = nullptr, *va_NC = nullptr;   // their operators, uploaded at first use
+  const double *va_PN = nullptr, *va_pi = nullptr;                     // plain path: joint counts and frequencies, padded
   const int *va_first = nullptr, *va_next = nullptr;
   mutable std::string err;
 };
@@ -175,6 +176,15 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     d.S = h.dS; d.C = h.dC; d.S0 = h.S; d.C0 = h.C; d.fuse = h.fuse; d.K = h.K; d.nn = h.nn; d.B = h.B; d.T = h.T; d.NI = h.NI; d.NIW = h.NIW; d.NV = h.NV; d.root = h.root;
 #define UP(field) if ((s = upload(ctx, h.field, &d.field)) != CMX_OK) return s
     UP(taxon_of); UP(parent);
+    if (h.plain) {
+      // alphabets other than 4 / 20 states: simulator tables and tree only; the sites are mapped by the plain kernels of
+      // cmx_variants.hip on scratch buffers (map_plain below), no operator stream, no per-wave workspaces
+      UP(simg); UP(simord);
+      d.nsimg = (int)(h.simg.size() / 16);
+      UP(eigV); UP(eigVi); UP(eigLam); UP(model_of); UP(blen);
+      UP(CP); UP(CPG); UP(pi); UP(rates); UP(probs); UP(cum_pi); UP(cum_probs);
+      return CMX_OK;
+    }
     {
       const double* mat = nullptr;
       if ((s = upload(ctx, h.MAT, &mat)) != CMX_OK) return s;
@@ -313,34 +323,59 @@ cmx_status cmx_synchronize(cmx_ctx* ctx) {
 // full_grid names the caller as in map_sites_impl: the engine's own null / clustering / candidate pipelines (true) and the
 // public observed-alignment mapping (false) may run on two streams at once, so each has its own scratch -- the averaged
 // path keeps ws and ws_obs apart for the same reason.
+// S x S matrices padded with zeros to SP x SP (the plain path's kernels run at kPlainStates states)
+static std::vector<double> pad_mats(const std::vector<double>& m, int S, int SP) {
+  if (S == SP) return m;
+  const size_t nm = m.size() / ((size_t)S * S);
+  std::vector<double> o(nm * (size_t)SP * SP, 0.0);
+  for (size_t q = 0; q < nm; ++q)
+    for (int x = 0; x < S; ++x)
+      for (int y = 0; y < S; ++y) o[(q * SP + x) * SP + y] = m[(q * S + x) * S + y];
+  return o;
+}
+
+// plain: the caller is map_plain (alphabets other than 4 / 20 states): every mapping option, the default one included, and
+// the site scalars come from these kernels
 static cmx_status map_variant(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsites, size_t ld, const uint32_t* d_masks,
-                              double* d_counts, size_t ldc, double* d_norm, void* stream, bool full_grid) {
-  if ((ctx->map_average && ctx->map_joint) || (!d_counts && !d_norm)) return CMX_OK;
+                              double* d_counts, size_t ldc, double* d_norm, void* stream, bool full_grid,
+                              double* d_logL = nullptr, double* d_post_rate = nullptr, int32_t* d_rate_class = nullptr) {
   const HostModel& h = ctx->hm;
+  const bool scalars = h.plain && (d_logL || d_post_rate || d_rate_class);
+  if (!h.plain && ((ctx->map_average && ctx->map_joint) || (!d_counts && !d_norm))) return CMX_OK;
+  if (h.plain && !d_counts && !d_norm && !scalars) return CMX_OK;
+  const int SD = h.plain ? kPlainStates : h.S;   // device states
   cmx_status s;
   if (!ctx->va_P) {
-    if ((s = upload(ctx, h.P, &ctx->va_P)) != CMX_OK) return s;
-    if ((s = upload(ctx, h.N1, &ctx->va_N1)) != CMX_OK) return s;
-    if ((s = upload(ctx, h.NC, &ctx->va_NC)) != CMX_OK) return s;
+    if ((s = upload(ctx, pad_mats(h.P, h.S, SD), &ctx->va_P)) != CMX_OK) return s;
+    if ((s = upload(ctx, pad_mats(h.N1, h.S, SD), &ctx->va_N1)) != CMX_OK) return s;
+    if ((s = upload(ctx, pad_mats(h.NC, h.S, SD), &ctx->va_NC)) != CMX_OK) return s;
     if ((s = upload(ctx, h.first_child, &ctx->va_first)) != CMX_OK) return s;
     if ((s = upload(ctx, h.next_sib, &ctx->va_next)) != CMX_OK) return s;
+    if (h.plain) {
+      std::vector<double> pi(SD, 0.0);
+      std::copy(h.pi.begin(), h.pi.end(), pi.begin());
+      if ((s = upload(ctx, pad_mats(h.PN, h.S, SD), &ctx->va_PN)) != CMX_OK) return s;
+      if ((s = upload(ctx, pi, &ctx->va_pi)) != CMX_OK) return s;
+    }
   }
-  if (!d_counts) {   // only the norms were asked for: they still need the counts
+  const bool want_counts = d_counts || d_norm;
+  if (!d_counts && want_counts) {   // only the norms were asked for: they still need the counts
     if ((s = scratch(ctx, full_grid ? "va_counts_null" : "va_counts_obs", sizeof(double) * (size_t)h.B * h.K * nsites, (void**)&d_counts)) != CMX_OK) return s;
     ldc = nsites;
   }
   NoAvgArgs a{};
-  a.S = h.S; a.C = h.C; a.K = h.K; a.nn = h.nn; a.B = h.B; a.root = h.root;
-  a.mode = ctx->map_joint ? kVariantNoAvg : (ctx->map_average ? kVariantMarginal : kVariantNoAvgMarginal);
+  a.S = SD; a.Sreal = h.S; a.C = h.C; a.K = h.K; a.nn = h.nn; a.B = h.B; a.root = h.root;
+  a.mode = ctx->map_joint ? (ctx->map_average ? kVariantJoint : kVariantNoAvg) : (ctx->map_average ? kVariantMarginal : kVariantNoAvgMarginal);
   a.first_child = ctx->va_first; a.next_sib = ctx->va_next; a.taxon_of = ctx->dm.taxon_of; a.parent = ctx->dm.parent;
-  a.P = ctx->va_P; a.N1 = ctx->va_N1; a.NC = ctx->va_NC; a.pi = ctx->dm.pi; a.probs = ctx->dm.probs;
+  a.P = ctx->va_P; a.N1 = ctx->va_N1; a.NC = ctx->va_NC; a.PN = ctx->va_PN; a.pi = h.plain ? ctx->va_pi : ctx->dm.pi; a.probs = ctx->dm.probs;
+  a.rates = ctx->dm.rates; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.masks = d_masks; a.aln = d_aln; a.ld = ld;
   // sites per pass: per-node vectors of a pass stay under 1 GiB
-  const size_t per_site = sizeof(double) * noavg_scratch_doubles(h.S, h.C, h.nn, 1);
+  const size_t per_site = sizeof(double) * noavg_scratch_doubles(SD, h.C, h.nn, 1);
   a.chunk = std::max<size_t>(256, std::min<size_t>(nsites, ((size_t)1 << 30) / per_site / 256 * 256));
   a.counts = d_counts; a.ldc = ldc;
   double* buf;
-  if ((s = scratch(ctx, full_grid ? "va_nodes_null" : "va_nodes_obs", sizeof(double) * noavg_scratch_doubles(h.S, h.C, h.nn, a.chunk), (void**)&buf)) != CMX_OK) return s;
+  if ((s = scratch(ctx, full_grid ? "va_nodes_null" : "va_nodes_obs", sizeof(double) * noavg_scratch_doubles(SD, h.C, h.nn, a.chunk), (void**)&buf)) != CMX_OK) return s;
   HIP_TRY(ctx, launch_map_noavg(a, nsites, buf, d_norm, (hipStream_t)stream));
   return CMX_OK;
 }
@@ -358,6 +393,12 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
   if (!d_aln || nsites == 0 || ld < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: bad alignment arguments");
   if (d_counts && ldc < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: ldc < nsites");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->hm.plain) {
+    // alphabets other than 4 / 20 states (codon models): likelihood, rates and every mapping option from the plain kernels.
+    // No mask table: every code >= nstates is an unknown.
+    if (d_masks) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_map_sites: no ambiguity table for alphabets other than 4 / 20 states (codes >= nstates are unknowns)");
+    return map_variant(ctx, d_aln, nsites, ld, d_masks, d_counts, ldc, d_norm, stream, full_grid, d_logL, d_post_rate, d_rate_class);
+  }
   const int max_blocks = full_grid ? ctx->grid_blocks : ctx->obs_blocks;
   MapArgs a{};
   a.m = ctx->dm; a.ws = full_grid ? ctx->ws : ctx->ws_obs;
@@ -402,6 +443,8 @@ cmx_status cmx_map_sites(cmx_ctx* ctx, const uint8_t* aln, size_t nsites, size_t
   if (s != CMX_OK) return s;
   if (!aln || nsites == 0 || ld < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: bad alignment arguments");
   const HostModel& h = ctx->hm;
+  if (masks && h.plain)
+    return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_map_sites: no ambiguity table for alphabets other than 4 / 20 states (codes >= nstates are unknowns)");
   if (masks && nmasks > (size_t)(h.S + max_ambig(h.S)))
     return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_map_sites: at most " + std::to_string(max_ambig(h.S)) +
                                               " ambiguity ids (codes >= nstates) are supported for this alphabet");
@@ -711,7 +754,7 @@ cmx_status cmx_null_intra_dev(cmx_ctx* ctx, int kind, const double* params, uint
   if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
   if (rep_end <= rep_begin || rep_ram == 0 || !d_stat) return fail(ctx, CMX_ERR_INVALID, "cmx_null_intra: bad arguments");
   if ((s = rng_range(ctx, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_intra")) != CMX_OK) return s;
-  if (!ctx->map_average || !ctx->map_joint || kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+  if (!ctx->map_average || !ctx->map_joint || kind == CMX_STAT_DISCRETE_MI_BOUNDS || ctx->hm.plain) {
     // nijt.average = no (AnalysisTools.cpp:598-610): the fused kernel only knows the averaged mapping; and a statistic that
     // needs a joint table per pair cannot be evaluated per lane inside the mapping wave.  The same simulate -> map ->
     // score sequence then runs unfused, which is what the two-data-set null does with both sides equal.

@@ -143,9 +143,17 @@ hipError_t launch_mi_group(int B, const uint32_t* d_cls, const uint8_t* d_bad, s
                            const int32_t* d_sites, size_t ngroups, double* d_out, hipStream_t stream);
 // nijt.average = no (cmx_variants.hip): the no-averaging mapping as plain kernels over a global scratch
 // mode: which LegacySubstitutionMappingTools function (CoETools.cpp:395-405)
-enum { kVariantNoAvg = 0 /* NoAveraging */, kVariantMarginal = 1 /* Marginal */, kVariantNoAvgMarginal = 2 /* NoAveragingMarginal */ };
+// kVariantJoint: the default mapping (computeSubstitutionVectors: averaged, joint) for the alphabets the matrix-core walk
+// does not serve
+enum { kVariantNoAvg = 0 /* NoAveraging */, kVariantMarginal = 1 /* Marginal */, kVariantNoAvgMarginal = 2 /* NoAveragingMarginal */,
+       kVariantJoint = 3 };
 struct NoAvgArgs {
   int S, C, K, nn, B, root, mode;
+  int Sreal;              // states of the alphabet; < S on the plain path, whose operators are padded with zeros to S = 64
+  const double* PN;       // [C][B][K][S*S] joint counts P o N^k (kVariantJoint)
+  const double* rates;    // [C] (site scalars)
+  double *logL, *post_rate;   // [ld...] per site, optional: likelihood, posterior rate, rate class (plain path)
+  int32_t* rate_class;
   const int *first_child, *next_sib, *taxon_of, *parent;
   const double* P;        // [C][B][S*S] row-major transition matrices
   const double* N1;       // [B][K][S*S] conditional counts at the branch length itself

@@ -359,10 +359,11 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   if (!model || !tree) return "model and tree are required";
   const int S = model->nstates, C = model->nclasses;
   const int K = (model->nmodels > 0 ? model->Bks : model->Bk) ? model->ntypes : 1;
-  if (S != 4 && S != 20) {
+  if (S < 2 || S > kPlainStates) {
     *code = CMX_ERR_UNSUPPORTED;
-    return "nstates must be 4 (nucleotides) or 20 (proteins); got " + std::to_string(S);
+    return "nstates must be between 2 and " + std::to_string(kPlainStates) + " (4 and 20 run on the matrix cores, the others on the plain kernels); got " + std::to_string(S);
   }
+  hm->plain = S != 4 && S != 20;
   if (C < 1 || C > 64) return "nclasses out of range";
   if (K < 1 || K > 64) return "ntypes out of range";
   if (!model->rates || !model->probs) return "rates and probs are required";
@@ -408,8 +409,10 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   }
   if (nchild[nn - 1] < 2) return "the root needs at least two children";
   hm->NI = (int)hm->int_post.size();
-  build_records(hm);
-  record_walk(hm);
+  if (!hm->plain) {
+    build_records(hm);
+    record_walk(hm);
+  }
   {  // simulator: nodes by depth, four of a level at a time (a level's draws only need the level above); a short group is
      // padded by repeating its last node (drawing a node twice gives the same state twice)
     std::vector<int> depth(nn, 0);
@@ -564,14 +567,14 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   //   [.., + T)                  P of leaf edges transposed, [z][x] = P[x][z] (per-lane row gather by observed symbol)
   //   [.., + K*T)                P o N^k of leaf edges transposed, index k*T + taxon
   const int NI = hm->NI;
-  const int MC = NI + NI * K + T + K * T;
+  const int MC = hm->plain ? 0 : NI + NI * K + T + K * T;
   hm->MC = MC;
   hm->fuse = (S == 4 && C >= 4) ? (C == 4 ? 4 : 5) : 1;
   const int F = hm->fuse;
   const int dS = S * F, dC = (C + F - 1) / F;
   hm->dS = dS;
   hm->dC = dC;
-  const size_t MU = (size_t)mat_unit(dS);   // doubles per device matrix: dS*dS plus max_ambig(dS) extra leaf rows
+  const size_t MU = hm->plain ? 0 : (size_t)mat_unit(dS);   // doubles per device matrix: dS*dS plus max_ambig(dS) extra leaf rows
   const size_t dS2 = (size_t)dS * dS;
   hm->MAT.assign((size_t)dC * MC * MU, 0.0);
   hm->CP.assign((size_t)C * nn * S2 + 4, 0.0);   // + 4: the fused simulator reads four running sums at a time
@@ -585,7 +588,7 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
       }
     }
   Mat dense(dS2);
-  for (int dc = 0; dc < dC; ++dc) {
+  for (int dc = 0; dc < (hm->plain ? 0 : dC); ++dc) {
     double* blk = &hm->MAT[(size_t)dc * MC * MU];
     for (int b = 0; b < B; ++b) {
       // operator of edge b for device class dc: diagonal blocks g = 0..F-1 <-> true class dc*F + g (classes beyond C
@@ -639,7 +642,7 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
       hm->CPG[r * 32 + k] = (uint8_t)st;
     }
   }
-  {
+  if (!hm->plain) {
     const std::string bad = verify_walk(*hm);
     if (!bad.empty()) return bad;
   }

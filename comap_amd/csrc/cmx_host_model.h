@@ -12,6 +12,8 @@
 
 namespace cmx {
 
+constexpr int kPlainStates = 64;   // device state count of the plain path (alphabets other than 4 / 20 states, up to 64)
+
 struct HostModel {
   int S = 0, C = 0, K = 0, nn = 0, B = 0, T = 0, NI = 0, root = 0;
   // Device view.  Nucleotide models with >= 4 rate classes are mapped `fuse` classes at a time: the per-class 4-vectors
@@ -19,6 +21,9 @@ struct HostModel {
   // one dS x dS operator (class probabilities folded into the count operators), so that one pass of the 20-state
   // machinery does the work of `fuse` class passes.  Otherwise dS = S, dC = C, fuse = 1.
   int dS = 0, dC = 0, fuse = 1;
+  // Alphabets other than 4 / 20 states (codon models, CoETools.cpp:95-100): no matrix-core walk is built for them; the
+  // plain kernels of cmx_variants.hip map their sites with the states padded to kPlainStates (operators padded with zeros).
+  bool plain = false;
   std::vector<int> parent, first_child, next_sib, taxon_of, slot, int_post;
   std::vector<double> blen, pi, rates, probs, cum_pi, cum_probs;
   std::vector<double> P;    // [C][B][S*S] row-major (x -> y)

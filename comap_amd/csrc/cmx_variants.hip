@@ -18,6 +18,8 @@
 
 namespace cmx {
 
+constexpr int kPlainStatesDev = 64;   // == kPlainStates (cmx_host_model.h): padded state count of the plain path
+
 namespace {
 
 template <int S>
@@ -28,15 +30,20 @@ __global__ __launch_bounds__(256) void noavg_inside_kernel(const NoAvgArgs a) {
   const size_t ch = a.chunk;
   double* Dc = a.D + (size_t)c * nn * S * ch;
   double* Mc = a.M + (size_t)c * nn * S * ch;
-  const uint32_t all = (1u << S) - 1u;
+  const uint32_t all = S >= 32 ? 0xffffffffu : ((1u << (S & 31)) - 1u);
   for (int n = 0; n < nn; ++n) {
     double d[S];
     if (a.first_child[n] < 0) {
       const unsigned code = a.aln[(size_t)a.taxon_of[n] * a.ld + a.site0 + j];
-      const unsigned row = code < (unsigned)(S + max_ambig(S)) ? code : (unsigned)(S + max_ambig(S) - 1);
-      const uint32_t m = code < (unsigned)S ? (1u << code) : (a.masks ? a.masks[row] : all);
+      if constexpr (S > 32) {   // plain path (padded states): no mask table, every code >= Sreal is an unknown
 #pragma unroll
-      for (int x = 0; x < S; ++x) d[x] = (double)((m >> x) & 1u);
+        for (int x = 0; x < S; ++x) d[x] = code < (unsigned)a.Sreal ? (double)((unsigned)x == code) : (double)(x < a.Sreal);
+      } else {
+        const unsigned row = code < (unsigned)(S + max_ambig(S)) ? code : (unsigned)(S + max_ambig(S) - 1);
+        const uint32_t m = code < (unsigned)S ? (1u << code) : (a.masks ? a.masks[row] : all);
+#pragma unroll
+        for (int x = 0; x < S; ++x) d[x] = (double)((m >> x) & 1u);
+      }
     } else {
 #pragma unroll
       for (int x = 0; x < S; ++x) d[x] = 1.0;
@@ -187,6 +194,61 @@ __global__ __launch_bounds__(256) void marginal_kernel(const NoAvgArgs a) {
     a.counts[((size_t)b * a.K + k) * a.ldc + a.site0 + j] = a.N1[((size_t)b * a.K + k) * S * S + xs * S + ys];
 }
 
+// ---- the default mapping (computeSubstitutionVectors: nijt.average = yes, nijt.joint = yes) on the same per-node vectors,
+// for the alphabets the matrix-core walk does not serve (codon models, CoETools.cpp:95-100):
+//   count(b, i, k) = sum_c p_c sum_xy U_b(i,c,x) (P o N^k)_c,b(x,y) D_n(i,c,y) / L_i
+// One thread per (site, branch).
+template <int S>
+__global__ __launch_bounds__(256) void joint_kernel(const NoAvgArgs a) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.nsites) return;
+  const int b = blockIdx.y, nn = a.nn, C = a.C;
+  const size_t ch = a.chunk;
+  double L = 0.0;
+  for (int c = 0; c < C; ++c) {
+    double s = 0.0;
+    for (int x = 0; x < S; ++x) s += a.pi[x] * a.D[(((size_t)c * nn + a.root) * S + x) * ch + j];
+    L += a.probs[c] * s;
+  }
+  for (int k = 0; k < a.K; ++k) {
+    double v = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const double* PNk = a.PN + (((size_t)c * a.B + b) * a.K + k) * S * S;
+      double d[S];
+#pragma unroll
+      for (int y = 0; y < S; ++y) d[y] = a.D[(((size_t)c * nn + b) * S + y) * ch + j];
+      double vc = 0.0;
+      for (int x = 0; x < S; ++x) {
+        double s = 0.0;
+#pragma unroll
+        for (int y = 0; y < S; ++y) s += PNk[x * S + y] * d[y];
+        vc += a.U[(((size_t)c * nn + b) * S + x) * ch + j] * s;
+      }
+      v += a.probs[c] * vc;
+    }
+    a.counts[((size_t)b * a.K + k) * a.ldc + a.site0 + j] = v / L;
+  }
+}
+// site scalars of the plain path: log-likelihood, posterior rate, rate class with the largest posterior (first maximum)
+template <int S>
+__global__ __launch_bounds__(256) void site_scalars_kernel(const NoAvgArgs a) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.nsites) return;
+  double L = 0.0, pr = 0.0, best = -1.0;
+  int bc = 0;
+  for (int c = 0; c < a.C; ++c) {
+    double s = 0.0;
+    for (int x = 0; x < S; ++x) s += a.pi[x] * a.D[(((size_t)c * a.nn + a.root) * S + x) * a.chunk + j];
+    const double w = a.probs[c] * s;
+    L += w;
+    pr += a.rates[c] * w;
+    if (w > best) { best = w; bc = c; }
+  }
+  if (a.logL) a.logL[a.site0 + j] = log(L);
+  if (a.post_rate) a.post_rate[a.site0 + j] = pr / L;
+  if (a.rate_class) a.rate_class[a.site0 + j] = bc;
+}
+
 // computeNormForSite over the (branch-major) counts: sqrt(sum_b (sum_k count)^2), branches in order
 __global__ __launch_bounds__(256) void counts_norm_kernel(const double* __restrict__ counts, size_t ldc, int B, int K, size_t n,
                                                           double* __restrict__ norm) {
@@ -222,11 +284,20 @@ hipError_t launch_map_noavg(NoAvgArgs a, size_t nsites_total, double* scratch, d
       hipLaunchKernelGGL(noavg_outside_kernel<4>, dim3(gx, a.C), dim3(256), 0, stream, a);
       if (a.mode == kVariantNoAvg) hipLaunchKernelGGL(noavg_pick_kernel<4>, dim3(gx, a.B), dim3(256), 0, stream, a);
       else hipLaunchKernelGGL(marginal_kernel<4>, dim3(gx, a.B), dim3(256), 0, stream, a);
+    } else if (a.S == kPlainStatesDev) {
+      hipLaunchKernelGGL(noavg_inside_kernel<kPlainStatesDev>, dim3(gx, a.C), dim3(256), 0, stream, a);
+      if (a.logL || a.post_rate || a.rate_class) hipLaunchKernelGGL(site_scalars_kernel<kPlainStatesDev>, dim3(gx), dim3(256), 0, stream, a);
+      if (a.counts) {
+        hipLaunchKernelGGL(noavg_outside_kernel<kPlainStatesDev>, dim3(gx, a.C), dim3(256), 0, stream, a);
+        if (a.mode == kVariantJoint) hipLaunchKernelGGL(joint_kernel<kPlainStatesDev>, dim3(gx, a.B), dim3(256), 0, stream, a);
+        else if (a.mode == kVariantNoAvg) hipLaunchKernelGGL(noavg_pick_kernel<kPlainStatesDev>, dim3(gx, a.B), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(marginal_kernel<kPlainStatesDev>, dim3(gx, a.B), dim3(256), 0, stream, a);
+      }
     } else {
       return hipErrorInvalidValue;
     }
   }
-  if (d_norm)
+  if (d_norm && a.counts)
     hipLaunchKernelGGL(counts_norm_kernel, dim3((unsigned)((nsites_total + 255) / 256)), dim3(256), 0, stream, a.counts, a.ldc, a.B,
                        a.K, nsites_total, d_norm);
   return hipGetLastError();

@@ -38,7 +38,7 @@ typedef struct cmx_ctx cmx_ctx;
 typedef enum {
   CMX_OK = 0,
   CMX_ERR_INVALID = -1,      /* bad argument (reference: bpp::Exception / DimensionException) */
-  CMX_ERR_UNSUPPORTED = -2,  /* e.g. nstates not in {4, 20} */
+  CMX_ERR_UNSUPPORTED = -2,  /* e.g. nstates > 64 */
   CMX_ERR_DEVICE = -3,       /* HIP error; no CPU fallback exists */
   CMX_ERR_NOMEM = -4
 } cmx_status;
@@ -71,7 +71,9 @@ typedef enum {
 } cmx_count_method;
 
 typedef struct {
-  int32_t nstates;             /* S: 4 or 20 */
+  int32_t nstates;             /* S: 4 and 20 run on the matrix cores; any other S in 2..64 (codon alphabets,
+                                * CoETools.cpp:95-100) on plain kernels: same results API, no ambiguity table (every
+                                * code >= S is an unknown), every null through the unfused sequence */
   int32_t nclasses;            /* C: discrete rate classes */
   int32_t ntypes;              /* K: substitution types (1 for the total register) */
   const double* Q;             /* [S*S] row-major generator, reversible w.r.t. pi */

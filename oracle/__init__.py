@@ -70,6 +70,9 @@ class Model:
 
 def default_masks(S):
     m = np.zeros(256, dtype=np.uint32)
+    if S > 32:          # no mask table for alphabets of more than 32 states: every code >= S is an unknown (oracle.c)
+        m[:] = 0xFFFFFFFF
+        return m
     m[:S] = 1 << np.arange(S, dtype=np.uint32)
     m[S:] = (1 << S) - 1
     return m

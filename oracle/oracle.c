@@ -19,11 +19,20 @@
  *
  * Conventions: tree nodes in post-order, root last, parent[root] = -1; branch b == node id of the branch's
  * lower node (row order of the reference .vec files).  Alignment codes: aln[t*N + i] (taxon-major);
- * code < S is a state, otherwise an index into masks[] (bit z set <=> state z compatible).
+ * code < S is a state, otherwise an index into masks[] (bit z set <=> state z compatible).  Alphabets of more than 32
+ * states (codon models, CoETools.cpp:95-100) have no mask table: every code >= S is an unknown, compatible with all.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+/* leaf initialisation of the DR likelihood: 1 where state x is compatible with the observed code */
+static inline double leaf_compatible(const uint32_t* masks, int S, unsigned code, int x) {
+  if (code < (unsigned)S) return (unsigned)x == code ? 1.0 : 0.0;
+  if (S > 32) return 1.0;
+  return (double)((masks[code] >> x) & 1u);
+}
+
 #include <string.h>
 
 #define IDX3(a, b, c, nb, nc) (((size_t)(a) * (nb) + (b)) * (nc) + (c))
@@ -234,8 +243,7 @@ int orc_map_sites(int nn, const int* parent, const double* blen, int T, const in
         double* Dn = D + ((size_t)n * C + c) * S;
         if (first[n] < 0) {
           uint8_t code = aln[(size_t)taxon_of[n] * N + i];
-          uint32_t m = code < S ? (1u << code) : masks[code];
-          for (int x = 0; x < S; x++) Dn[x] = (m >> x) & 1u;
+          for (int x = 0; x < S; x++) Dn[x] = leaf_compatible(masks, S, code, x);
         } else {
           for (int x = 0; x < S; x++) Dn[x] = 1.0;
           for (int e = first[n]; e >= 0; e = next[e]) {
@@ -383,8 +391,7 @@ int orc_map_sites_noavg(int nn, const int* parent, const double* blen, int T, co
         double* Dn = D + ((size_t)n * C + c) * S;
         if (first[n] < 0) {
           uint8_t code = aln[(size_t)taxon_of[n] * N + i];
-          uint32_t m = code < S ? (1u << code) : masks[code];
-          for (int x = 0; x < S; x++) Dn[x] = (m >> x) & 1u;
+          for (int x = 0; x < S; x++) Dn[x] = leaf_compatible(masks, S, code, x);
         } else {
           for (int x = 0; x < S; x++) Dn[x] = 1.0;
           for (int e = first[n]; e >= 0; e = next[e]) {
@@ -523,8 +530,7 @@ int orc_map_sites_marginal(int nn, const int* parent, const double* blen, int T,
         double* Dn = D + ((size_t)n * C + c) * S;
         if (first[n] < 0) {
           uint8_t code = aln[(size_t)taxon_of[n] * N + i];
-          uint32_t m = code < S ? (1u << code) : masks[code];
-          for (int x = 0; x < S; x++) Dn[x] = (m >> x) & 1u;
+          for (int x = 0; x < S; x++) Dn[x] = leaf_compatible(masks, S, code, x);
         } else {
           for (int x = 0; x < S; x++) Dn[x] = 1.0;
           for (int e = first[n]; e >= 0; e = next[e]) {

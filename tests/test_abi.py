@@ -38,8 +38,8 @@ def _tiny():
 def test_model_validation_errors_come_before_any_device_work():
     parent, blen, lot, m = _tiny()
     with pytest.raises(engine.CmxError) as e:
-        engine.Engine(parent, blen, lot, np.eye(5) - 1, np.full(5, 0.2), m["rates"], m["probs"])
-    assert e.value.status == -2 and "nstates" in str(e.value)            # CMX_ERR_UNSUPPORTED
+        engine.Engine(parent, blen, lot, np.eye(65) - 1, np.full(65, 1 / 65), m["rates"], m["probs"])
+    assert e.value.status == -2 and "nstates" in str(e.value)            # CMX_ERR_UNSUPPORTED: more than 64 states
     bad_parent = parent.copy()
     bad_parent[0], bad_parent[1] = 0, 0
     with pytest.raises(engine.CmxError) as e:

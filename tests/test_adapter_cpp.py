@@ -41,13 +41,13 @@ def test_domain_matches_oracle(adapter_exe):
 
 def test_errors_surface_as_exceptions(adapter_exe, tmp_path):
     bad = tmp_path / "bad.bin"
-    # S = 5 is rejected by the engine -> cmx::Exception -> exit code 1 (reference: bpp::Exception caught in main)
-    nn, T, S, C, N = 4, 3, 5, 1, 1
+    # S = 65 is rejected by the engine -> cmx::Exception -> exit code 1 (reference: bpp::Exception caught in main)
+    nn, T, S, C, N = 4, 3, 65, 1, 1
     with open(bad, "wb") as f:
         f.write(struct.pack("<8i", nn, T, S, C, N, 1, 1, 1) + struct.pack("<Q", 1))
         f.write(np.array([3, 3, 3, -1], dtype=np.int32).tobytes() + np.ones(4).tobytes())
         f.write(np.array([0, 1, 2], dtype=np.int32).tobytes())
-        f.write(np.zeros(S * S).tobytes() + np.full(S, 0.2).tobytes() + np.ones(1).tobytes() + np.ones(1).tobytes())
+        f.write(np.zeros(S * S).tobytes() + np.full(S, 1.0 / S).tobytes() + np.ones(1).tobytes() + np.ones(1).tobytes())
         f.write(bytes(T * N))
     r = subprocess.run([adapter_exe, "run", str(bad), str(tmp_path / "o.bin")], capture_output=True, text=True)
     assert r.returncode == 1 and "nstates" in r.stderr
