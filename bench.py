@@ -206,8 +206,8 @@ def mica_leg(dev, steps, world=1, rank=0, gloo=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)   # 10 x 0.47 s: one slow step (a busy host core) weighs a tenth
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mica", action="store_true")
