@@ -1402,7 +1402,15 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
     if ((s = scratch(ctx, "mica_any", sizeof(int), (void**)&w.anyflag)) != CMX_OK) return s;
     if (nalpha == 20) {   // block info of the four-wave kernel, padded to whole tiles of 12 columns
       if ((s = scratch(ctx, "mica_info1", sizeof(unsigned) * ((n1 + 11) / 12 * 4 + 4), (void**)&w.info1)) != CMX_OK) return s;
-      if (!intra && (s = scratch(ctx, "mica_info2", sizeof(unsigned) * ((n2 + 11) / 12 * 4 + 4), (void**)&w.info2)) != CMX_OK) return s;
+      if ((s = scratch(ctx, "mica_order1", sizeof(unsigned) * n1, (void**)&w.order1)) != CMX_OK) return s;
+      if ((s = scratch(ctx, "mica_Cs1", (size_t)w.Tp * (n1 + kMicaCodePad), (void**)&w.Cs1)) != CMX_OK) return s;
+      if ((s = scratch(ctx, "mica_Ss1", sizeof(double) * n1, (void**)&w.Ss1)) != CMX_OK) return s;
+      if (!intra) {
+        if ((s = scratch(ctx, "mica_info2", sizeof(unsigned) * ((n2 + 11) / 12 * 4 + 4), (void**)&w.info2)) != CMX_OK) return s;
+        if ((s = scratch(ctx, "mica_order2", sizeof(unsigned) * n2, (void**)&w.order2)) != CMX_OK) return s;
+        if ((s = scratch(ctx, "mica_Cs2", (size_t)w.Tp * (n2 + kMicaCodePad), (void**)&w.Cs2)) != CMX_OK) return s;
+        if ((s = scratch(ctx, "mica_Ss2", sizeof(double) * n2, (void**)&w.Ss2)) != CMX_OK) return s;
+      }
     }
   }
   HIP_TRY(ctx, launch_mi_columns(nalpha, ntaxa, d_masks, d_aln1, n1, ld1, d_aln2, n2, ld2, intra ? 1 : 0, d_mi, d_hjoint,

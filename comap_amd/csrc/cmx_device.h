@@ -252,7 +252,10 @@ struct MicaWork {
   double *S1, *S2;         // [n] sum_a f(count_a)
   double* ftab;            // [T + 1] c ln c, then [A*A*T + 1] f2[m] = (m / A^2) ln(m / A^2) (pairs with unknowns), then 0 and f2[M0 ..] again
   int* anyflag;            // some column of either alignment has ambiguous symbols
-  unsigned *info1, *info2;   // per block of three columns: not-served and has-unknowns bits (cmx_mica4.hip; NULL: not used)
+  unsigned *info1, *info2;   // per block of three SORTED columns: not-served and has-unknowns bits (cmx_mica4.hip; NULL: not used)
+  unsigned *order1, *order2; // [n] original column of a sorted position (columns without unknowns first, stable)
+  uint8_t *Cs1, *Cs2;        // [n + kMicaCodePad][Tp] symbol bytes in sorted order
+  double *Ss1, *Ss2;         // [n] column sums in sorted order
   int Tp;                  // T rounded up to a multiple of 32 (taxa per MFMA step)
 };
 bool mica_needs_onehot(int A);   // whether launch_mi_columns reads MicaWork::H1 / H2 for this alphabet

@@ -28,6 +28,9 @@
 // an unknown, the weighted one all the others (it is exact for pairs without unknowns too); a tile that is not an
 // instantiation's is not even fetched by it.
 //
+// The columns are tiled in SORTED order (those without unknowns first: mica_sort_columns_kernel below) and every result is
+// written at its original (i, j).
+//
 // Pairs with a column that carries PARTIAL ambiguity codes (B, Z, R, Y ...) are left to the LDS-table kernel
 // (launch_mi_columns).
 #include <hip/hip_runtime.h>
@@ -67,27 +70,94 @@ __device__ __forceinline__ cmx_i4 m4_expand_weighted(const cmx_i4 sy, unsigned s
   return oh;
 }
 
-// per block of three columns (block k = columns 3k .. 3k + 2): bits 0..2 column not served here (partial ambiguity codes
-// or past the end), bits 3..5 column has unknowns
-__global__ void mica_blockinfo_kernel(const uint8_t* __restrict__ flag, const uint8_t* __restrict__ gap, size_t n, size_t nblocks,
-                                      unsigned* __restrict__ info) {
+// ---- columns sorted by "has unknowns" before tiling.  A tile is the plain instantiation's only if none of its 15 columns
+// carries an unknown: with unknowns in a tenth of the columns, scattered, that is one tile in five.  A STABLE partition
+// (columns without unknowns first, the others behind them, each group in its original order -- neighbours stay
+// neighbours, so a tile's three output columns still share cache lines) makes the blocks homogeneous but one.
+// order[k] = original column at sorted position k.  One workgroup: a scan over n flags.
+__global__ __launch_bounds__(1024) void mica_sort_columns_kernel(const uint8_t* __restrict__ gap, size_t n, unsigned* __restrict__ order) {
+  __shared__ unsigned wsum[16], base[2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // first pass: number of columns without unknowns
+  unsigned cnt = 0;
+  for (size_t i = tid; i < n; i += 1024) cnt += gap[i] ? 0u : 1u;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0) wsum[w] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned t = 0;
+    for (int k = 0; k < 16; ++k) t += wsum[k];
+    base[0] = 0;        // next position among the columns without unknowns
+    base[1] = t;        // next position among the others
+  }
+  __syncthreads();
+  for (size_t i0 = 0; i0 < n; i0 += 1024) {
+    const size_t i = i0 + tid;
+    const bool in = i < n, g = in && gap[i] != 0, c = in && !g;
+    const unsigned long long mc = __ballot(c), mg = __ballot(g);
+    if (lane == 0) { wsum[w] = (unsigned)__popcll(mc); }
+    __syncthreads();
+    unsigned offc = 0, totc = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) offc += wsum[k]; totc += wsum[k]; }
+    // (the others: position in the chunk minus the clean ones before it)
+    const unsigned before = (unsigned)(64 * w + lane), cleanb = offc + (unsigned)__popcll(mc & ((1ull << lane) - 1ull));
+    if (c) order[base[0] + cleanb] = (unsigned)i;
+    if (g) order[base[1] + (before - cleanb) - 0u] = (unsigned)i;
+    (void)mg;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned inchunk = (unsigned)((n - i0) < 1024 ? (n - i0) : 1024);
+      base[0] += totc;
+      base[1] += inchunk - totc;
+    }
+    __syncthreads();
+  }
+}
+// symbol bytes and column sums in sorted order, the padding columns behind them ("no row" everywhere)
+__global__ __launch_bounds__(256) void mica_gather_columns_kernel(const unsigned* __restrict__ order, size_t n, int Tp,
+                                                                  const uint8_t* __restrict__ C, const double* __restrict__ S,
+                                                                  uint8_t* __restrict__ Cs, double* __restrict__ Ss) {
+  const size_t k = blockIdx.x;
+  if (k >= n) {
+    for (int t = threadIdx.x; t < Tp; t += 256) Cs[k * (size_t)Tp + t] = 63;
+    return;
+  }
+  const size_t i = order[k];
+  for (int t = threadIdx.x; t < Tp / 16; t += 256)
+    reinterpret_cast<cmx_i4*>(Cs + k * (size_t)Tp)[t] = reinterpret_cast<const cmx_i4*>(C + i * (size_t)Tp)[t];
+  if (threadIdx.x == 0) Ss[k] = S[i];
+}
+// per block of three SORTED columns (block k = sorted positions 3k .. 3k + 2): bits 0..2 column not served here (partial
+// ambiguity codes or past the end), bits 3..5 column has unknowns
+__global__ void mica_blockinfo_kernel(const unsigned* __restrict__ order, const uint8_t* __restrict__ flag, const uint8_t* __restrict__ gap,
+                                      size_t n, size_t nblocks, unsigned* __restrict__ info) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nblocks) return;
   unsigned v = 0;
   for (int c = 0; c < 3; ++c) {
-    const size_t i = 3 * k + c;
-    if (i >= n || flag[i]) v |= 1u << c;
-    else if (gap[i]) v |= 8u << c;
+    const size_t p = 3 * k + c;
+    if (p >= n || flag[order[p]]) v |= 1u << c;
+    else if (gap[order[p]]) v |= 8u << c;
   }
   info[k] = v;
+}
+// intra layout: NaN wherever j <= i (the kernels below write each unordered pair once, at (min, max) of its columns)
+__global__ void mica_nan_lower_kernel(size_t n, double* __restrict__ mi, double* __restrict__ hj, size_t ldo) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j <= i && j < n) {
+    mi[i * ldo + j] = __builtin_nan("");
+    hj[i * ldo + j] = __builtin_nan("");
+  }
 }
 
 template <int KS, bool WEIGHTED>   // k-steps of 32 taxa: Tp <= 32 KS
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mica_mfma4_kernel(
     int T, int Tp, const uint8_t* __restrict__ C1, size_t n1, const unsigned* __restrict__ info1, const double* __restrict__ S1,
     const uint8_t* __restrict__ C2, size_t n2, const unsigned* __restrict__ info2, const double* __restrict__ S2,
-    const double* __restrict__ ftab_g, int intra, double* __restrict__ mi, double* __restrict__ hj, size_t ldo, unsigned nJ,
-    unsigned chunk, unsigned nchunks, unsigned nruns) {
+    const unsigned* __restrict__ order1, const unsigned* __restrict__ order2, const double* __restrict__ ftab_g, int intra,
+    double* __restrict__ mi, double* __restrict__ hj, size_t ldo, unsigned nJ, unsigned chunk, unsigned nchunks, unsigned nruns) {
+  // C1 / C2 / S1 / S2 / info1 / info2 are in SORTED column order (mica_sort_columns_kernel); order1 / order2 name the
+  // original column of a sorted position, which is where the results go
   extern __shared__ __attribute__((aligned(16))) uint8_t m4_smem[];   // the kernel's only LDS object: LDS address 0
   constexpr int NQ = 2 * KS;            // operand tiles of the second alignment per tile: 2 column tiles x KS k-steps
   constexpr int SPT = NQ / 4;           // slots per thread
@@ -96,6 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const size_t ftab_bytes = ((size_t)(WEIGHTED ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15;
   cmx_i4* ops = reinterpret_cast<cmx_i4*>(m4_smem + ftab_bytes);                 // [2][NQ][64]
   double* s2t = reinterpret_cast<double*>(ops + 2 * NQ * 64);                     // [2][4] S of the tile's columns
+  unsigned* j2t = reinterpret_cast<unsigned*>(s2t + 8);                           // [2][4] their original column indices
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool hi = lane >= 32;
   const int cl = lane & 31;
@@ -136,16 +207,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned jt1 = jt0 + chunk < nJ ? jt0 + chunk : nJ;
     __syncthreads();   // the previous run's reads of the operand buffers and tile scalars are done (and the table is in LDS)
     if (intra) {
-      // tiles J < 4 I hold no pair with j > i: only the NaN convention of the intra layout (the plain instantiation's job)
-      const unsigned first = 4 * I, jn = first < jt1 ? first : jt1;
-      if (!WEIGHTED)
-        for (size_t e = (size_t)jt0 * (kM4I * kM4J) + tid; e < (size_t)jn * (kM4I * kM4J); e += 256) {
-          const size_t jt = e / (kM4I * kM4J), p = e % (kM4I * kM4J), i = i0 + p / kM4J, j = jt * kM4J + p % kM4J;
-          if (i < n1 && j < n2 && !((info1[i / 3] >> (i % 3)) & 1) && !((info2[j / 3] >> (j % 3)) & 1)) {
-            mi[i * ldo + j] = __builtin_nan("");
-            hj[i * ldo + j] = __builtin_nan("");
-          }
-        }
+      // tiles J < 4 I hold no pair with a later second column (sorted positions): each unordered pair is computed once
+      const unsigned first = 4 * I;
       if (jt0 < first) jt0 = first;
     }
     if (jt0 >= jt1) continue;
@@ -167,10 +230,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned long long need = __ballot(tile_mine);
     if (need == 0) continue;
     double s1v[3];
+    unsigned i1v[3];   // original columns of the wave's three
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const size_t i = i0 + 3 * w + a;
-      s1v[a] = S1[i < n1 ? i : n1 - 1];
+      const size_t i = i0 + 3 * w + a, ic = i < n1 ? i : n1 - 1;
+      s1v[a] = S1[ic];
+      i1v[a] = order1[ic];
     }
     cmx_i4 areg[2][KS];
     {
@@ -192,6 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     cmx_i4 braw[SPT];
     double s2r = 0.0;
+    unsigned j2r = 0;
     auto fetch = [&](unsigned jt) {
       const unsigned soff = jt * (unsigned)(kM4J * Tp);   // uniform
 #pragma unroll
@@ -199,8 +265,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         braw[m] = (w + 4 * m) % KS < nks ? __builtin_bit_cast(cmx_i4, __builtin_amdgcn_raw_buffer_load_b128(rc2, boff[m], soff, 0))
                                          : cmx_i4{0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f};
       if (tid < kM4J) {
-        const size_t j = (size_t)jt * kM4J + tid;
-        s2r = S2[j < n2 ? j : n2 - 1];
+        const size_t j = (size_t)jt * kM4J + tid, jc = j < n2 ? j : n2 - 1;
+        s2r = S2[jc];
+        j2r = order2[jc];
       }
     };
     auto expand = [&](int buf) {
@@ -208,7 +275,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int m = 0; m < SPT; ++m)
         ops[(buf * NQ + w + 4 * m) * 64 + lane] = WEIGHTED ? m4_expand_weighted<4>(braw[m], bsrow[m], bsrow[m] == 0x1f1f1f1fu ? 0u : 0x01010101u)
                                                            : m4_expand<7, 0x01010101u>(braw[m], bsrow[m]);
-      if (tid < kM4J) s2t[4 * buf + tid] = s2r;
+      if (tid < kM4J) {
+        s2t[4 * buf + tid] = s2r;
+        j2t[4 * buf + tid] = j2r;
+      }
     };
     unsigned jt = jt0 + (unsigned)__builtin_ctzll(need);
     need &= need - 1;
@@ -326,13 +396,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int pr = 4 * g + r4;
             if (pr < 9) {
               const int a = pr / 3, b = pr % 3;
-              if (!((bad1 >> a) & 1) && !((bad2 >> b) & 1)) {
-                const size_t i = i0 + 3 * w + a, j = j0 + b;
-                const bool valid = !intra || j > i;
+              // intra: the pair is this tile's if its second column comes later in SORTED order; it is written at (smaller,
+              // larger) ORIGINAL column (MI and the joint entropy are symmetric; j <= i holds NaN, mica_nan_lower_kernel)
+              if (!((bad1 >> a) & 1) && !((bad2 >> b) & 1) && (!intra || j0 + b > i0 + 3 * w + a)) {
+                const size_t oi = a == 0 ? i1v[0] : (a == 1 ? i1v[1] : i1v[2]), oj = j2t[4 * buf + b];
+                const size_t i = intra && oj < oi ? oj : oi, j = intra && oj < oi ? oi : oj;
                 const double s = sres[g];
                 const double sa = a == 0 ? s1v[0] : (a == 1 ? s1v[1] : s1v[2]);
-                mi[i * ldo + j] = valid ? lnT + (s - sa - s2t[4 * buf + b]) * invT : __builtin_nan("");
-                hj[i * ldo + j] = valid ? lnT - s * invT : __builtin_nan("");
+                mi[i * ldo + j] = lnT + (s - sa - s2t[4 * buf + b]) * invT;
+                hj[i * ldo + j] = lnT - s * invT;
               }
             }
           }
@@ -347,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 size_t mica4_lds_bytes(int T, int KS, bool weighted) {
   const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
-  return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 8 * sizeof(double);
+  return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 8 * sizeof(double) + 8 * sizeof(unsigned);
 }
 
 template <int KS, bool WEIGHTED>
@@ -360,9 +432,9 @@ static hipError_t launch_mica4_one(int T, int Tp, const MicaWork* wk, size_t n1,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((mica_mfma4_kernel<KS, WEIGHTED>), dim3(grid < nruns ? grid : nruns), dim3(256), lds, stream, T, Tp, wk->C1, n1,
-                     wk->info1, wk->S1, intra ? wk->C1 : wk->C2, n2, intra ? wk->info1 : wk->info2, intra ? wk->S1 : wk->S2, wk->ftab,
-                     intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns);
+  hipLaunchKernelGGL((mica_mfma4_kernel<KS, WEIGHTED>), dim3(grid < nruns ? grid : nruns), dim3(256), lds, stream, T, Tp, wk->Cs1, n1,
+                     wk->info1, wk->Ss1, intra ? wk->Cs1 : wk->Cs2, n2, intra ? wk->info1 : wk->info2, intra ? wk->Ss1 : wk->Ss2,
+                     wk->order1, intra ? wk->order1 : wk->order2, wk->ftab, intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns);
   return hipGetLastError();
 }
 
@@ -373,9 +445,20 @@ static hipError_t launch_mica4_ks(int T, int Tp, const MicaWork* wk, size_t n1, 
   const unsigned nchunks = (nJ + chunk - 1) / chunk, nruns = nI * nchunks;
   // block info, padded to whole tiles (blocks past the end: all three columns "not served")
   const size_t nb1 = (size_t)nI * (kM4I / 3), nb2 = nJ;
-  hipLaunchKernelGGL(mica_blockinfo_kernel, dim3((unsigned)((nb1 + 255) / 256)), dim3(256), 0, stream, wk->flag1, wk->gap1, n1, nb1, wk->info1);
-  if (!intra)
-    hipLaunchKernelGGL(mica_blockinfo_kernel, dim3((unsigned)((nb2 + 255) / 256)), dim3(256), 0, stream, wk->flag2, wk->gap2, n2, nb2, wk->info2);
+  hipLaunchKernelGGL(mica_sort_columns_kernel, dim3(1), dim3(1024), 0, stream, wk->gap1, n1, wk->order1);
+  hipLaunchKernelGGL(mica_gather_columns_kernel, dim3((unsigned)(n1 + kMicaCodePad)), dim3(256), 0, stream, wk->order1, n1, Tp, wk->C1, wk->S1,
+                     wk->Cs1, wk->Ss1);
+  hipLaunchKernelGGL(mica_blockinfo_kernel, dim3((unsigned)((nb1 + 255) / 256)), dim3(256), 0, stream, wk->order1, wk->flag1, wk->gap1, n1, nb1,
+                     wk->info1);
+  if (!intra) {
+    hipLaunchKernelGGL(mica_sort_columns_kernel, dim3(1), dim3(1024), 0, stream, wk->gap2, n2, wk->order2);
+    hipLaunchKernelGGL(mica_gather_columns_kernel, dim3((unsigned)(n2 + kMicaCodePad)), dim3(256), 0, stream, wk->order2, n2, Tp, wk->C2, wk->S2,
+                       wk->Cs2, wk->Ss2);
+    hipLaunchKernelGGL(mica_blockinfo_kernel, dim3((unsigned)((nb2 + 255) / 256)), dim3(256), 0, stream, wk->order2, wk->flag2, wk->gap2, n2, nb2,
+                       wk->info2);
+  } else {
+    hipLaunchKernelGGL(mica_nan_lower_kernel, dim3((unsigned)((n1 + 255) / 256), (unsigned)n1), dim3(256), 0, stream, n1, d_mi, d_hj, ldo);
+  }
   hipError_t e = launch_mica4_one<KS, false>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns, grid, stream);
   if (e == hipSuccess) e = launch_mica4_one<KS, true>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns, grid, stream);
   return e;
