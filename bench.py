@@ -342,6 +342,9 @@ def main():
         roofline["hbm_achieved_TBps"] = hbm_tbs
         roofline["hbm_frac"] = hbm_tbs / HBM_PEAK_TBPS
         roofline["nearest_roof"] = ("hbm" if roofline["hbm_frac"] > roofline["frac_executed"] else "fp64")
+        roofline["note"] = ("bound / achieved / frac price the ALGORITHMIC flops of SURVEY 8(d) (leaf edges as dense products); the kernel "
+                            "executes frac_executed of the fp64 peak in matrix products and moves `traffic` bytes = hbm_frac of the 8 TB/s "
+                            "HBM spec (its per-site intermediate state and the operator stream, DESIGN.md 4.1)")
 
     out = dict(metric="site-pair coevolution statistics/s (incl. null sims)", value=value,
                unit="site-pair statistics/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
