@@ -1385,7 +1385,7 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
     cmx_status s;
     w.Tp = (ntaxa + 31) / 32 * 32;
     const size_t hb = 32 * (size_t)w.Tp;
-    const bool needH = mica_needs_onehot(nalpha);   // 32 Tp bytes per column: only where a kernel reads them
+    const bool needH = mica_needs_onehot(nalpha, w.Tp);   // 32 Tp bytes per column: only where a kernel reads them
     if ((s = scratch(ctx, "mica_H1", needH ? hb * n1 : 16, (void**)&w.H1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_C1", (size_t)w.Tp * (n1 + kMicaCodePad), (void**)&w.C1)) != CMX_OK) return s;
     if ((s = scratch(ctx, "mica_f1", n1, (void**)&w.flag1)) != CMX_OK) return s;

@@ -243,7 +243,7 @@ hipError_t launch_mi_pairs(int A, int T, const uint32_t* d_masks, const uint8_t*
                            double* d_hj, hipStream_t stream);
 // scratch of the MFMA Mica path (all device pointers; H1 null = LDS-table kernel only)
 constexpr int kMicaLdsF2 = 4096;   // entries of f2 the weighted four-wave kernel keeps in LDS (m < 4096: cells of up to ten taxa)
-constexpr int kMicaCodePad = 12;   // columns of "no row" symbols behind the last column of C1 / C2 (the four-wave kernel reads whole tiles)
+constexpr int kMicaCodePad = 64;   // columns of "no row" symbols behind the last column of C1 / C2 (the four-wave kernels read whole tiles: 12 / 64 columns)
 struct MicaWork {
   int8_t *H1, *H2;         // one-hot [n][32][Tp] int8 (one-column-per-tile kernel)
   uint8_t *C1, *C2;        // [n + kMicaCodePad][Tp] one-hot row of each taxon (state, A = unknown, 255 = none): the packed protein kernel's operands
@@ -258,11 +258,15 @@ struct MicaWork {
   double *Ss1, *Ss2;         // [n] column sums in sorted order
   int Tp;                  // T rounded up to a multiple of 32 (taxa per MFMA step)
 };
-bool mica_needs_onehot(int A);   // whether launch_mi_columns reads MicaWork::H1 / H2 for this alphabet
+bool mica_needs_onehot(int A, int Tp);   // whether launch_mi_columns reads MicaWork::H1 / H2 for this alphabet
 // cmx_mica4.hip: the four-wave protein kernel (unknowns included; partial ambiguity codes are not served)
 bool mica4_serves(int A, int Tp, size_t n1, size_t n2);
 hipError_t launch_mica4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,
                         hipStream_t stream);
+// the four-wave nucleotide kernel (unknowns included; partial ambiguity codes are not served)
+bool mica_dna4_serves(int A, int Tp, size_t n1, size_t n2);
+hipError_t launch_mica_dna4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,
+                            hipStream_t stream);
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
                              size_t ldo, double* d_h1, double* d_h2, const MicaWork* work, hipStream_t stream);

@@ -2520,7 +2520,7 @@ static bool mica_eight_wave_tiles() {
 }
 
 // the one-hot matrices H [n][32][Tp] are operands of the one-column-per-tile kernel only (DNA, and CMX_MICA_TILES=1)
-bool mica_needs_onehot(int A) { return !(A == 20 && !mica_one_column_tiles()); }
+bool mica_needs_onehot(int A, int Tp) { return mica_one_column_tiles() || !(A == 20 || (A == 4 && Tp <= 256)); }
 
 hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_t* d_aln1, size_t n1, size_t ld1,
                              const uint8_t* d_aln2, size_t n2, size_t ld2, int intra, double* d_mi, double* d_hj,
@@ -2534,7 +2534,7 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
   const uint8_t *f1 = nullptr, *f2 = nullptr;
   if (work && work->H1) {
     const int Tp = work->Tp;
-    const bool needH = mica_needs_onehot(A);   // the packed protein kernels expand the symbol bytes themselves
+    const bool needH = mica_needs_onehot(A, Tp);   // the packed protein kernels expand the symbol bytes themselves
     hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)((A * A * T) / 256 + 1)), dim3(256), 0, stream, T, A, work->ftab, work->anyflag);
     hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)(n1 + kMicaCodePad)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, needH ? work->H1 : nullptr, work->C1, work->flag1,
                        work->gap1, work->S1, work->anyflag, n1);
@@ -2563,7 +2563,12 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
       hipLaunchKernelGGL(mica_mfma_kernel<20>, g2, dim3(512), lds2, stream, T, Tp, work->H1, n1,
                          work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
                          intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);
-    else
+    else if (A == 4 && Tp <= 256 && !mica_one_column_tiles()) {
+      // up to 256 taxa: the four-wave nucleotide kernel (cmx_mica4.hip), unknowns included (no one-hot matrices exist here)
+      if (!mica_dna4_serves(A, Tp, n1, n2)) return hipErrorInvalidValue;
+      const hipError_t e4 = launch_mica_dna4(T, work, n1, n2, intra, d_mi, d_hj, ldo, stream);
+      if (e4 != hipSuccess) return e4;
+    } else
       hipLaunchKernelGGL(mica_mfma_kernel<4>, g2, dim3(512), lds2, stream, T, Tp, work->H1, n1,
                          work->flag1, work->gap1, work->S1, intra ? work->H1 : work->H2, n2, intra ? work->flag1 : work->flag2,
                          intra ? work->gap1 : work->gap2, intra ? work->S1 : work->S2, work->ftab, intra, d_mi, d_hj, ldo);

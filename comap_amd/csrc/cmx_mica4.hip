@@ -417,6 +417,203 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---- nucleotides.  Four states: SIXTEEN columns share a 64-row block, a wave's 64 x 64 accumulator block is the Gram of
+// 16 x 16 column pairs (nine for proteins), and the table of the weighted form -- m = 16 N_ab + 4 (N_aG + N_Gb) + N_GG <= 16 T,
+// 4 097 entries at 256 taxa -- fits the LDS whole: ONE instantiation serves columns with and without unknowns (weights 8 / 2
+// on the first side, 16 / 4 on the second: the accumulator is 8 m, the LDS address of f2[m]), nothing is gathered from
+// global memory, nothing needs sorting.  A workgroup's tile is 64 columns of the first alignment x 16 of the second =
+// 1 024 pairs.  Epilogue per lane: the four state rows of a first-alignment column are four consecutive accumulator
+// registers (4 lookups, 3 adds), the four states of a second-alignment column are four neighbouring lanes (two DPP adds
+// within the quad); sixteen sums per lane, 256 pairs per wave, stored as 128-byte row pieces.  The one-column-per-tile
+// kernel this replaces (cmx_kernels.hip, mica_mfma_kernel<4>) used 5 of 32 rows of every operand tile: 12.2 ms for
+// 5 000 x 5 000 columns x 256 taxa.
+constexpr int kD4I = 64, kD4J = 16;
+template <unsigned KNOWN, unsigned UNK>
+__device__ __forceinline__ cmx_i4 d4_expand(const cmx_i4 sy, unsigned srow) {
+  cmx_i4 oh;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const unsigned eq = ((0x80808080u - ((unsigned)sy[d] ^ srow)) >> 7) & 0x01010101u;
+    const unsigned un = ((0x80808080u - ((unsigned)sy[d] ^ 0x04040404u)) >> 7) & 0x01010101u;
+    oh[d] = (int)(eq * KNOWN + un * UNK);   // bytes do not carry: at most KNOWN (a symbol is a state or the unknown)
+  }
+  return oh;
+}
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mica_dna4_kernel(
+    int T, int Tp, const uint8_t* __restrict__ C1, size_t n1, const uint8_t* __restrict__ flag1, const double* __restrict__ S1,
+    const uint8_t* __restrict__ C2, size_t n2, const uint8_t* __restrict__ flag2, const double* __restrict__ S2,
+    const double* __restrict__ ftab_g, int intra, double* __restrict__ mi, double* __restrict__ hj, size_t ldo, unsigned nJ,
+    unsigned chunk, unsigned nchunks, unsigned nruns) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t d4_smem[];   // the kernel's only LDS object: LDS address 0
+  constexpr int NQ = 2 * KS, SPT = NQ / 4;
+  const int M = 16 * T + 1;                                             // entries of f2
+  const size_t tab_bytes = ((size_t)M * 8 + 15) & ~(size_t)15;
+  cmx_i4* ops = reinterpret_cast<cmx_i4*>(d4_smem + tab_bytes);         // [2][NQ][64]
+  double* s1t = reinterpret_cast<double*>(ops + 2 * NQ * 64);           // [64] S of the workgroup's first-alignment columns
+  double* s2t = s1t + kD4I;                                             // [2][16] S of the tile's columns
+  int* ok1 = reinterpret_cast<int*>(s2t + 2 * kD4J);                    // [64] column is served (inside, no partial ambiguity code)
+  int* ok2 = ok1 + kD4I;                                                // [2][16]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, cl = lane & 31;
+  for (int c = tid; c < M; c += 256) reinterpret_cast<double*>(d4_smem)[c] = ftab_g[T + 1 + c];
+  const double lnT = log((double)T), invT = 1.0 / (double)T;
+  const int nks = Tp / 32;
+  const __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(C2), 0, 0x7fffffff, 0x00020000);
+  unsigned bsrow[SPT], boff[SPT];
+#pragma unroll
+  for (int m = 0; m < SPT; ++m) {
+    const int q = w + 4 * m, C = 32 * (q / KS) + cl;     // packed column C: column C / 4 of the tile, state C % 4
+    bsrow[m] = (unsigned)(C % 4) * 0x01010101u;
+    boff[m] = (unsigned)((C / 4) * Tp + 32 * (q % KS) + 16 * hi);
+  }
+  for (unsigned run = blockIdx.x; run < nruns; run += gridDim.x) {
+    const unsigned I = run / nchunks, ch = run % nchunks;
+    const size_t i0 = (size_t)I * kD4I;
+    unsigned jt0 = ch * chunk;
+    const unsigned jt1 = jt0 + chunk < nJ ? jt0 + chunk : nJ;
+    __syncthreads();   // the previous run's reads of LDS are done (and the table is in LDS)
+    if (intra && jt0 < 4 * I) jt0 = 4 * I;   // tiles J < 4 I hold no pair with j > i (mica_nan_lower_kernel wrote their NaN)
+    if (jt0 >= jt1) continue;
+    if (tid < kD4I) {
+      const size_t i = i0 + tid;
+      s1t[tid] = S1[i < n1 ? i : n1 - 1];
+      ok1[tid] = i < n1 && !flag1[i];
+    }
+    // the wave's sixteen columns of the first alignment, expanded once per run: row tile ii, packed row 32 ii + cl
+    cmx_i4 areg[2][KS];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int R = 32 * ii + cl;
+      const uint8_t* src = C1 + (i0 + 16 * w + R / 4) * (size_t)Tp + 16 * hi;   // (64 columns of padding behind the last one)
+      const unsigned srow = (unsigned)(R % 4) * 0x01010101u;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const cmx_i4 raw = ks < nks ? *reinterpret_cast<const cmx_i4*>(src + 32 * ks) : cmx_i4{0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f};
+        areg[ii][ks] = d4_expand<8, 2>(raw, srow);
+      }
+    }
+    cmx_i4 braw[SPT];
+    double s2r = 0.0;
+    int ok2r = 0;
+    auto fetch = [&](unsigned jt) {
+      const unsigned soff = jt * (unsigned)(kD4J * Tp);
+#pragma unroll
+      for (int m = 0; m < SPT; ++m)
+        braw[m] = (w + 4 * m) % KS < nks ? __builtin_bit_cast(cmx_i4, __builtin_amdgcn_raw_buffer_load_b128(rc2, boff[m], soff, 0))
+                                         : cmx_i4{0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f};
+      if (tid < kD4J) {
+        const size_t j = (size_t)jt * kD4J + tid;
+        s2r = S2[j < n2 ? j : n2 - 1];
+        ok2r = j < n2 && !flag2[j < n2 ? j : n2 - 1];
+      }
+    };
+    auto expand = [&](int buf) {
+#pragma unroll
+      for (int m = 0; m < SPT; ++m) ops[(buf * NQ + w + 4 * m) * 64 + lane] = d4_expand<16, 4>(braw[m], bsrow[m]);
+      if (tid < kD4J) {
+        s2t[kD4J * buf + tid] = s2r;
+        ok2[kD4J * buf + tid] = ok2r;
+      }
+    };
+    fetch(jt0);
+    expand(0);
+    int buf = 0;
+    for (unsigned jt = jt0; jt < jt1; ++jt) {
+      __syncthreads();   // this tile's operands and scalars (and, in the first tile, the run's) are in LDS
+      const bool more = jt + 1 < jt1;
+      if (more) fetch(jt + 1);
+      cmx_i16v acc[2][2];
+      {
+        const cmx_i16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const cmx_i4* ob = ops + buf * NQ * 64 + lane;
+        cmx_i4 nb0 = ob[0], nb1 = ob[KS * 64];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const cmx_i4 bb0 = nb0, bb1 = nb1;
+          if (ks + 1 < KS) {
+            nb0 = ob[(ks + 1) * 64];
+            nb1 = ob[(KS + ks + 1) * 64];
+          }
+          asm volatile("" ::: "memory");
+          acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][ks], bb0, ks ? acc[0][0] : zero, 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[1][ks], bb0, ks ? acc[1][0] : zero, 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][ks], bb1, ks ? acc[0][1] : zero, 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[1][ks], bb1, ks ? acc[1][1] : zero, 0, 0, 0);
+        }
+      }
+      if (more) expand(buf ^ 1);
+      // Register v of accumulator tile (ii, jj) is packed row 32 ii + 8 (v / 4) + v % 4 (+ 4 in the upper lane half), packed
+      // column 32 jj + cl: registers 4 vq .. 4 vq + 3 are the four states of first-alignment column 8 ii + 2 vq + hi, lanes
+      // 4 k .. 4 k + 3 the four states of second-alignment column 8 jj + k.
+      const size_t j0 = (size_t)jt * kD4J;
+      const int sel = cl & 3;            // lanes 0 / 1 of a quad store the pair of column tile 0 / 1
+      const int b = 8 * (sel & 1) + (cl >> 2);
+      const size_t j = j0 + b;
+      const bool okj = sel < 2 && ok2[kD4J * buf + b] != 0;
+      const double s2v = s2t[kD4J * buf + b];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int vq = 0; vq < 4; ++vq) {
+          double ps[2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            double v4[4];
+#pragma unroll
+            for (int vs = 0; vs < 4; ++vs)   // the accumulator is 8 m = the LDS address of f2[m]
+              v4[vs] = *reinterpret_cast<const __attribute__((address_space(3))) double*>(static_cast<uintptr_t>((unsigned)acc[ii][jj][4 * vq + vs]));
+            double s4 = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+            s4 += mica_dpp_f64<0xB1>(s4);   // quad_perm [1, 0, 3, 2]
+            s4 += mica_dpp_f64<0x4E>(s4);   // quad_perm [2, 3, 0, 1]
+            ps[jj] = s4;
+          }
+          const int al = 16 * w + 8 * ii + 2 * vq + hi;   // column of the workgroup's 64
+          const size_t i = i0 + al;
+          if (okj && ok1[al] != 0 && (!intra || j > i)) {
+            const double sp = sel ? ps[1] : ps[0];
+            mi[i * ldo + j] = lnT + (sp - s1t[al] - s2v) * invT;
+            hj[i * ldo + j] = lnT - sp * invT;
+          }
+        }
+      buf ^= 1;
+    }
+  }
+}
+
+size_t mica_dna4_lds_bytes(int T, int KS) {
+  return (((size_t)(16 * T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + (kD4I + 2 * kD4J) * sizeof(double) +
+         (kD4I + 2 * kD4J) * sizeof(int);
+}
+template <int KS>
+static hipError_t launch_mica_dna4_ks(int T, int Tp, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj,
+                                      size_t ldo, unsigned chunk, unsigned grid, hipStream_t stream) {
+  const size_t lds = mica_dna4_lds_bytes(T, KS);
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mica_dna4_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const unsigned nJ = (unsigned)((n2 + kD4J - 1) / kD4J), nI = (unsigned)((n1 + kD4I - 1) / kD4I);
+  const unsigned nchunks = (nJ + chunk - 1) / chunk, nruns = nI * nchunks;
+  if (intra) hipLaunchKernelGGL(mica_nan_lower_kernel, dim3((unsigned)((n1 + 255) / 256), (unsigned)n1), dim3(256), 0, stream, n1, d_mi, d_hj, ldo);
+  hipLaunchKernelGGL(mica_dna4_kernel<KS>, dim3(grid < nruns ? grid : nruns), dim3(256), lds, stream, T, Tp, wk->C1, n1, wk->flag1, wk->S1,
+                     intra ? wk->C1 : wk->C2, n2, intra ? wk->flag1 : wk->flag2, intra ? wk->S1 : wk->S2, wk->ftab, intra, d_mi, d_hj, ldo, nJ,
+                     chunk, nchunks, nruns);
+  return hipGetLastError();
+}
+// nucleotides, Tp <= 256 (eight k-steps of operand registers; the whole weighted table in LDS), byte offsets within 31 bits
+bool mica_dna4_serves(int A, int Tp, size_t n1, size_t n2) {
+  return A == 4 && Tp <= 256 && (std::max(n1, n2) + kMicaCodePad) * (size_t)Tp < 0x7fffffffull;
+}
+hipError_t launch_mica_dna4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,
+                            hipStream_t stream) {
+  const unsigned chunk = 16, grid = 512;   // 16 tiles of 64 x 16 columns per run; two workgroups per CU
+  const int Tp = wk->Tp;
+  if (Tp <= 64) return launch_mica_dna4_ks<2>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
+  if (Tp <= 128) return launch_mica_dna4_ks<4>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
+  return launch_mica_dna4_ks<8>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
+}
+
 size_t mica4_lds_bytes(int T, int KS, bool weighted) {
   const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
   return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 8 * sizeof(double) + 8 * sizeof(unsigned);

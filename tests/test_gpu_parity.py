@@ -1127,3 +1127,37 @@ def test_pvalues_two_level_lookup_is_the_linear_count():
     st = e2.pair_stats(engine.STAT_CORRELATION, m["counts"])
     opv2, ons2 = oracle.intra_pvalues(st, m["norm"], ncls, null_stat, null_nmin * scale)
     assert np.array_equal(rows["nsim"], ons2[iu]) and np.array_equal(rows["pvalue"], opv2[iu], equal_nan=True)
+
+
+@pytest.mark.parametrize("T,n1,n2", [(40, 70, 33), (100, 130, 300), (256, 200, 129), (300, 40, 50)])
+def test_mica_four_wave_nucleotide_kernel_against_oracle(T, n1, n2):
+    """Nucleotides up to 256 taxa (cmx_mica4.hip, mica_dna4_kernel: sixteen columns per 64-row block, the weighted table
+    whole in LDS, one instantiation for columns with and without unknowns) and above (one-column-per-tile kernel): column
+    counts that are no multiple of the 64 x 16 tile, several runs, unknowns in a third of the columns, a column of unknowns
+    only, a column with a partial ambiguity code (R = A or G); rectangle and intra layout."""
+    rng = np.random.default_rng(T + n2)
+    A = 4
+    masks = oracle.default_masks(A).copy()
+    masks[A + 1] = 0b0101                                    # R: two states
+    base = rng.integers(0, A, size=(T, 1))
+
+    def draw(n, p):
+        a = np.where(rng.random((T, n)) < p, base, rng.integers(0, A, size=(T, n))).astype(np.uint8)
+        gapped = rng.random(n) < 0.33
+        a[(rng.random((T, n)) < 0.2) & gapped[None, :]] = A
+        a[:, n // 2] = A
+        return a
+
+    a1, a2 = draw(n1, 0.6), draw(n2, 0.4)
+    a1[rng.integers(0, T, 3), 5] = A + 1
+    eng = engine.Engine()
+    g = eng.mi_columns(a1, a2, A, masks=masks[: A + 2])
+    o = oracle.mi_columns(a1, a2, A, masks)
+    rel_close(g["mi"], o["mi"], 1e-6, 1e-10)
+    rel_close(g["hjoint"], o["hjoint"], 1e-6, 1e-10)
+    gi = eng.mi_columns(a2, None, A, masks=masks[: A + 2])
+    oi = oracle.mi_columns(a2, a2, A, masks)
+    iu = np.triu_indices(n2, 1)
+    rel_close(gi["mi"][iu], oi["mi"][iu], 1e-6, 1e-10)
+    rel_close(gi["hjoint"][iu], oi["hjoint"][iu], 1e-6, 1e-10)
+    assert np.isnan(gi["mi"][np.tril_indices(n2)]).all() and np.isnan(gi["hjoint"][np.tril_indices(n2)]).all()
