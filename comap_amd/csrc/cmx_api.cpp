@@ -997,8 +997,9 @@ cmx_status cmx_null_inter(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const double* 
 static cmx_status prepare_null(cmx_ctx* ctx, const double* d_norms, size_t n, int nclasses, const double* d_null_stat,
                                const double* d_null_nmin, size_t nnull, hipStream_t st, NullTable* out) {
   cmx_status s;
-  double *maxnorm, *sa, *sb, *top;
-  uint32_t *ca, *cb, *hist, *off;
+  double *maxnorm, *sa, *sb;
+  uint32_t *ca, *cb, *hist, *bins;
+  NullClass* cls;
   const size_t nn = nnull ? nnull : 1;
   if ((s = scratch(ctx, "pv_max", sizeof(double), (void**)&maxnorm)) != CMX_OK) return s;
   if ((s = scratch(ctx, "pv_sa", sizeof(double) * nn, (void**)&sa)) != CMX_OK) return s;
@@ -1006,8 +1007,8 @@ static cmx_status prepare_null(cmx_ctx* ctx, const double* d_norms, size_t n, in
   if ((s = scratch(ctx, "pv_ca", sizeof(uint32_t) * nn, (void**)&ca)) != CMX_OK) return s;
   if ((s = scratch(ctx, "pv_cb", sizeof(uint32_t) * nn, (void**)&cb)) != CMX_OK) return s;
   if ((s = scratch(ctx, "pv_hist", sizeof(uint32_t) * 66, (void**)&hist)) != CMX_OK) return s;
-  if ((s = scratch(ctx, "pv_off", sizeof(uint32_t) * 66, (void**)&off)) != CMX_OK) return s;
-  if ((s = scratch(ctx, "pv_top", sizeof(double) * (nn / kNullTopStride + 2), (void**)&top)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_cls", sizeof(NullClass) * 66, (void**)&cls)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pv_bins", sizeof(uint32_t) * ((nn >> kNullBinShift) + 2 * 66), (void**)&bins)) != CMX_OK) return s;
   HIP_TRY(ctx, launch_max_reduce(d_norms, n, maxnorm, st));
   HIP_TRY(ctx, launch_null_classify(d_null_stat, d_null_nmin, nnull, maxnorm, nclasses, ca, hist, st));
   if (nnull > 0) {
@@ -1018,8 +1019,8 @@ static cmx_status prepare_null(cmx_ctx* ctx, const double* d_norms, size_t n, in
     if ((s = scratch(ctx, "pv_sorttmp", tmp_bytes, &tmp)) != CMX_OK) return s;
     HIP_TRY(ctx, sort_null_by_class(tmp, tmp_bytes, sa, sb, ca, cb, nnull, st));
   }
-  HIP_TRY(ctx, launch_null_index(sa, hist, nclasses, nnull, off, top, st));
-  *out = NullTable{sa, hist, off, top, maxnorm, nclasses};
+  HIP_TRY(ctx, launch_null_index(sa, hist, nclasses, nnull, cls, bins, st));
+  *out = NullTable{sa, cls, bins, maxnorm, nclasses};
   return CMX_OK;
 }
 
@@ -1082,7 +1083,7 @@ cmx_status cmx_intra_rows_dev(cmx_ctx* ctx, const double* d_stat, size_t ldo, co
   if (filters) f = *filters;
   unsigned long long* rowcount;
   cmx_status s;
-  if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (n + 1), (void**)&rowcount)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (n * kPairRowSegs + 1), (void**)&rowcount)) != CMX_OK) return s;
   size_t tmp_bytes = 0;
   HIP_TRY(ctx, launch_pair_rows(d_stat, ldo, d_pvalue, d_nsim, n, d_rate_class, d_post_rate, d_norm, f, rowcount, nullptr,
                                 tmp_bytes, d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), (hipStream_t)stream));
@@ -1148,7 +1149,7 @@ cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params
   double* blk_stat;
   unsigned long long* rowcount;
   if ((s = scratch(ctx, "blk_stat", sizeof(double) * RB * n, (void**)&blk_stat)) != CMX_OK) return s;
-  if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (RB + 1), (void**)&rowcount)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "rows_count", sizeof(unsigned long long) * (RB * kPairRowSegs + 1), (void**)&rowcount)) != CMX_OK) return s;
   size_t tmp_bytes = 0;
   HIP_TRY(ctx, launch_pair_rows(blk_stat, n, nullptr, nullptr, n, d_rate_class, d_post_rate, d_norm, f, rowcount, nullptr, tmp_bytes,
                                 d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), st, 0, RB));

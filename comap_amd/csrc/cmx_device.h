@@ -211,19 +211,25 @@ hipError_t launch_pair_gram(int kind, int B, int Bp, const double* d_X1, const d
 hipError_t launch_max_reduce(const double* d_x, size_t n, double* d_out, hipStream_t stream);
 hipError_t launch_null_classify(const double* d_stat, const double* d_nmin, size_t nnull, const double* d_maxnorm,
                                 int nclasses, uint32_t* d_cls, uint32_t* d_hist, hipStream_t stream);
-// The null distribution prepared for p-value lookups: statistics sorted by (class, value), the classes' sizes and
-// offsets, and `top` = every 64th sorted value (the first level of the two-level lower bound; 1/64 of the null: L2-resident)
-constexpr int kNullTopStride = 64;
+// The null distribution prepared for p-value lookups: statistics sorted by (class, value), and per class a table of
+// bins of equal width in the statistic's value, one bin per kNullBinSize sorted values: bins[b] = index of the first value
+// of the class that falls into bin b or later.  A lookup computes its bin and searches the few values inside it.
+constexpr int kNullBinShift = 3, kNullBinSize = 1 << kNullBinShift;
+constexpr int kPairRowSegs = 8;   // waves per row in the pair-row passes (pair_rows_kernel)
+struct NullClass {
+  uint32_t off, ns;         // the class's stretch of `sorted`
+  uint32_t nb, boff;        // number of bins (>= 1), and where its nb + 1 entries start in `bins`
+  double lo, scale;         // bin of v = clamp(floor((v - lo) * scale), 0, nb - 1)
+};
 struct NullTable {
   const double* sorted;     // [nnull] ascending inside each class, classes in order
-  const uint32_t* hist;     // [nclasses + 1] class sizes (last: values without a class)
-  const uint32_t* off;      // [nclasses + 1] class offsets in `sorted`
-  const double* top;        // [ceil(nnull / 64)] sorted[64 t]
+  const NullClass* cls;     // [nclasses]
+  const uint32_t* bins;     // [(nnull >> kNullBinShift) + 2 * nclasses + 2]
   const double* maxnorm;    // upper bound of the Domain of the norms
   int nclasses;
 };
-hipError_t launch_null_index(const double* d_sorted, const uint32_t* d_hist, int nclasses, size_t nnull, uint32_t* d_off, double* d_top,
-                             hipStream_t stream);
+hipError_t launch_null_index(const double* d_sorted, const uint32_t* d_hist, int nclasses, size_t nnull, NullClass* d_cls,
+                             uint32_t* d_bins, hipStream_t stream);
 hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norms, size_t n, const NullTable& nt, double* d_pvalue,
                           int32_t* d_nsim, hipStream_t stream, size_t irow0 = 0, size_t nrows = 0);
 hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in, double* d_stat_tmp, uint32_t* d_cls_in,

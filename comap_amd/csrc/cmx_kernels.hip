@@ -1603,30 +1603,33 @@ hipError_t sort_null_by_class(void* d_tmp, size_t& tmp_bytes, double* d_stat_in,
 }
 
 // p = (nsim - #{null < stat} + 1) / (nsim + 1), strict '<' (CoETools.cpp:712-717); the reference scans linearly,
-// the sorted class makes it a lower bound.  Two levels: first among every 64th value of the class (`top`, 1/64 of the
-// null: it stays in the L2 where the plain binary search sent its last dozen probes of every pair to the Infinity Cache /
-// HBM), then inside the one stretch of at most 63 values that is left.  Same count as the plain search.
+// the sorted class makes it a lower bound.  The bin of the statistic (equal-width bins in its value, one per eight sorted
+// values of the class) bounds the search to the handful of values inside that bin: two loads for the bin and about four
+// for the search, where a binary search over a class of 10^6 values sends twenty divergent loads per pair through the
+// vector cache.  null_bin is monotone in v, in the table's construction and here alike, so the count is the same.
+__device__ __forceinline__ uint32_t null_bin(double v, const NullClass& c) {
+  const double x = (v - c.lo) * c.scale;
+  if (!(x > 0.0)) return 0u;             // below the first bin, or not a number
+  return x >= (double)(c.nb - 1) ? c.nb - 1 : (uint32_t)x;
+}
 __device__ __forceinline__ void null_pvalue(const NullTable& nt, double ni, double nj, double st, double* pvalue, int32_t* nsim) {
   const double mn = ni < nj ? ni : nj;
   const int cat = domain_index(*nt.maxnorm, nt.nclasses, mn);
   if (cat < 0) { *pvalue = __builtin_nan(""); *nsim = 0; return; }
-  const uint32_t a = nt.off[cat], ns = nt.hist[cat], b = a + ns;
-  // first t in [T0, T1) with top[t] >= st: everything up to 64 (t - 1) is < st, everything from 64 t on is >= st
-  const uint32_t T0 = (a + kNullTopStride - 1) / kNullTopStride, T1 = ns ? (b - 1) / kNullTopStride + 1 : T0;
-  uint32_t lo = T0, hi = T1 > T0 ? T1 : T0;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (nt.top[mid] < st) lo = mid + 1; else hi = mid;
+  const NullClass c = nt.cls[cat];
+  uint32_t l2 = c.off, h2 = c.off + c.ns;
+  if (c.nb > 1) {
+    const uint32_t* bs = nt.bins + c.boff + null_bin(st, c);
+    l2 = bs[0];
+    h2 = bs[1];
   }
-  uint32_t l2 = lo > T0 ? kNullTopStride * (lo - 1) + 1 : a, h2 = lo < T1 ? kNullTopStride * lo : b;
-  if (T1 <= T0) { l2 = a; h2 = b; }   // the class holds no sampled position
   while (l2 < h2) {
     const uint32_t mid = (l2 + h2) >> 1;
     if (nt.sorted[mid] < st) l2 = mid + 1; else h2 = mid;
   }
-  const uint32_t below = l2 - a;
-  *pvalue = (double)(ns - below + 1) / (double)(ns + 1);
-  *nsim = (int32_t)ns;
+  const uint32_t below = l2 - c.off;
+  *pvalue = (double)(c.ns - below + 1) / (double)(c.ns + 1);
+  *nsim = (int32_t)c.ns;
 }
 __global__ void pvalue_kernel(const double* __restrict__ stat, size_t ldo, const double* __restrict__ norms, size_t n, const NullTable nt,
                               double* __restrict__ pvalue, int32_t* __restrict__ nsim, size_t irow0) {
@@ -1646,32 +1649,63 @@ hipError_t launch_pvalues(const double* d_stat, size_t ldo, const double* d_norm
   return hipGetLastError();
 }
 
-// class offsets and the sampled first level of the sorted null
-__global__ void null_index_kernel(const double* __restrict__ sorted, const uint32_t* __restrict__ hist, int nclasses, size_t nnull,
-                                  uint32_t* __restrict__ off, double* __restrict__ top) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) {
-    uint32_t o = 0;
-    for (int c = 0; c <= nclasses; ++c) { off[c] = o; o += hist[c]; }
+// class offsets and bin ranges: the bins span the class's values between its 1/64 and 63/64 quantiles (the tails fall
+// into the first and last bin), so that a few extreme values do not stretch them
+__global__ void null_classes_kernel(const double* __restrict__ sorted, const uint32_t* __restrict__ hist, int nclasses,
+                                    NullClass* __restrict__ cls) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t o = 0;
+  for (int k = 0; k < nclasses; ++k) {
+    NullClass c;
+    c.off = o; c.ns = hist[k]; c.nb = 1; c.boff = (o >> kNullBinShift) + 2 * (uint32_t)k; c.lo = 0.0; c.scale = 0.0;
+    if (c.ns >= 64) {
+      const double qlo = sorted[o + (c.ns >> 6)], qhi = sorted[o + c.ns - 1 - (c.ns >> 6)];
+      const uint32_t nb = c.ns >> kNullBinShift;
+      const double scale = (double)nb / (qhi - qlo);
+      if (qhi > qlo && scale > 0.0 && scale < 1.0e300 && qlo > -1.0e300) { c.nb = nb; c.lo = qlo; c.scale = scale; }
+    }
+    cls[k] = c;
+    o += c.ns;
   }
-  if (t * kNullTopStride < nnull) top[t] = sorted[t * kNullTopStride];
 }
-hipError_t launch_null_index(const double* d_sorted, const uint32_t* d_hist, int nclasses, size_t nnull, uint32_t* d_off, double* d_top,
-                             hipStream_t stream) {
-  const size_t nt = (nnull + kNullTopStride - 1) / kNullTopStride;
-  hipLaunchKernelGGL(null_index_kernel, dim3((unsigned)(nt / 256 + 1)), dim3(256), 0, stream, d_sorted, d_hist, nclasses, nnull, d_off, d_top);
+// bins[b] = first position of the class whose value's bin is >= b, for b = 0 .. nb (bins[nb] = the class's end): one
+// thread per bin searches the class (a thread per sorted value filling the bins up to its own is cheaper on a smooth
+// null and serial on one with gaps)
+__global__ void null_bins_kernel(const double* __restrict__ sorted, const NullClass* __restrict__ cls, uint32_t* __restrict__ bins) {
+  const NullClass c = cls[blockIdx.y];
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c.nb <= 1 || b > c.nb) return;
+  uint32_t lo = c.off, hi = c.off + c.ns;
+  if (b == 0) hi = lo;
+  if (b == c.nb) lo = hi;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (null_bin(sorted[mid], c) < b) lo = mid + 1; else hi = mid;
+  }
+  bins[c.boff + b] = lo;
+}
+hipError_t launch_null_index(const double* d_sorted, const uint32_t* d_hist, int nclasses, size_t nnull, NullClass* d_cls,
+                             uint32_t* d_bins, hipStream_t stream) {
+  hipLaunchKernelGGL(null_classes_kernel, dim3(1), dim3(64), 0, stream, d_sorted, d_hist, nclasses, d_cls);
+  if (nnull)   // (the classes' sizes live on the device: the grid covers the largest number of bins any class can have)
+    hipLaunchKernelGGL(null_bins_kernel, dim3((unsigned)((nnull >> kNullBinShift) / 256 + 1), (unsigned)nclasses), dim3(256), 0, stream,
+                       d_sorted, d_cls, d_bins);
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ compacted pair rows
-// CoETools.cpp:672-724 as two passes of one wave per row i: count the pairs (i, j > i) that pass the filters, exclusive
-// scan of the row counts (rocPRIM), then write the rows at their final position -- the reference's (i, j) order.
+// CoETools.cpp:672-724 as two passes of kPairRowSegs waves per row i: count the pairs (i, j > i) that pass the filters,
+// exclusive scan of the counts (rocPRIM), then write the rows at their final position -- the reference's (i, j) order.
 __device__ __forceinline__ bool pair_passes(const cmx_pair_filters& f, int ci, double ri, int cj, double rj, double st) {
   if (cj < f.min_rate_class || rj < f.min_rate) return false;
   if (f.max_rate_class_diff >= 0 && abs(cj - ci) > f.max_rate_class_diff) return false;
   if (f.max_rate_diff >= 0.0 && fabs(rj - ri) > f.max_rate_diff) return false;
   return !(fabs(st) < f.min_statistic);
 }
+static_assert(sizeof(cmx_pair_row) == 48 && offsetof(cmx_pair_row, stat) == 8 && offsetof(cmx_pair_row, rc_min) == 16 &&
+                  offsetof(cmx_pair_row, nsim) == 20 && offsetof(cmx_pair_row, pr_min) == 24 &&
+                  offsetof(cmx_pair_row, n_min) == 32 && offsetof(cmx_pair_row, pvalue) == 40,
+              "pair_rows_kernel packs a row as three 16-byte words");
 template <bool WRITE>
 __global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict__ stat, size_t ldo,
                                                        const double* __restrict__ pvalue, const int32_t* __restrict__ nsim,
@@ -1680,26 +1714,36 @@ __global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict_
                                                        unsigned long long* __restrict__ rowcount /* counts, then offsets */,
                                                        cmx_pair_row* __restrict__ rows, size_t capacity, size_t irow0,
                                                        const unsigned long long* __restrict__ base, const NullTable nt) {
-  // stat / pvalue / nsim hold rows irow0 .. of the full matrix (local row = blockIdx.x); rows are appended after *base
-  const size_t il = blockIdx.x, i = irow0 + il;
+  // stat / pvalue / nsim hold rows irow0 .. of the full matrix (local row = blockIdx.x / kPairRowSegs); rows are appended
+  // after *base.  A row's columns i + 1 .. n - 1 are cut into kPairRowSegs runs of whole 64-column steps, one wave each
+  // (one wave per row leaves a 1677-row block of the 25000-site job at 6 waves per CU, all waiting on their loads); the
+  // counting pass counts per run, so the runs of a row, and the rows, still land in (i, j) order.
+  const size_t il = blockIdx.x / kPairRowSegs, i = irow0 + il;
   const int lane = threadIdx.x;
   const int ci = rc[i];
   const double ri = pr[i];
-  unsigned long long run = WRITE ? rowcount[il] + (base ? *base : 0ull) : 0ull;
+  const size_t seg = ((n - i - 1 + kPairRowSegs - 1) / kPairRowSegs + 63) / 64 * 64;
+  const size_t jb = i + 1 + (blockIdx.x % kPairRowSegs) * seg, je = jb + seg < n ? jb + seg : n;
+  unsigned long long run = WRITE ? rowcount[blockIdx.x] + (base ? *base : 0ull) : 0ull;
   const bool row_ok = !(ci < f.min_rate_class || ri < f.min_rate);
+  // the passing pairs of one 64-column step are packed in LDS and leave as one contiguous run of 16-byte stores (a
+  // 48-byte row per lane is a 48-byte-strided store otherwise); a rows buffer that is not 16-byte aligned gets the rows
+  // one per lane
+  __shared__ cmx_i4 stage[WRITE ? 64 * 3 : 1];
+  const bool packed = ((uintptr_t)rows & 15) == 0;
   if (row_ok)
-    for (size_t j0 = i + 1; j0 < n; j0 += 64) {
+    for (size_t j0 = jb; j0 < je; j0 += 64) {
       const size_t j = j0 + lane;
       bool ok = false;
       double st = 0.0;
-      if (j < n) {
+      if (j < je) {
         st = stat[il * ldo + j];
         ok = pair_passes(f, ci, ri, rc[j], pr[j], st);
       }
       const unsigned long long m = __ballot(ok);
-      if (WRITE && ok) {
-        const unsigned long long pos = run + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < capacity) {
+      if (WRITE && m && run < capacity) {
+        const int slot = __popcll(m & ((1ull << lane) - 1ull));
+        if (ok) {
           cmx_pair_row r;
           r.i = (int32_t)i; r.j = (int32_t)j; r.stat = st;
           r.rc_min = ci < rc[j] ? ci : rc[j];
@@ -1708,12 +1752,28 @@ __global__ __launch_bounds__(64) void pair_rows_kernel(const double* __restrict_
           r.pvalue = pvalue ? pvalue[il * ldo + j] : __builtin_nan("");
           r.nsim = nsim ? nsim[il * ldo + j] : 0;
           if (nt.sorted) null_pvalue(nt, norm[i], norm[j], st, &r.pvalue, &r.nsim);   // only for the pairs that are written
-          rows[pos] = r;
+          if (packed) {
+            const long long s8 = __double_as_longlong(r.stat), p8 = __double_as_longlong(r.pr_min),
+                            n8 = __double_as_longlong(r.n_min), v8 = __double_as_longlong(r.pvalue);
+            stage[3 * slot + 0] = cmx_i4{r.i, r.j, (int)s8, (int)(s8 >> 32)};
+            stage[3 * slot + 1] = cmx_i4{r.rc_min, r.nsim, (int)p8, (int)(p8 >> 32)};
+            stage[3 * slot + 2] = cmx_i4{(int)n8, (int)(n8 >> 32), (int)v8, (int)(v8 >> 32)};
+          } else if (run + slot < capacity) {
+            rows[run + slot] = r;
+          }
+        }
+        if (packed) {
+          const unsigned long long room = capacity - run, cnt = (unsigned long long)__popcll(m);
+          const int nq = 3 * (int)(cnt < room ? cnt : room);
+          cmx_i4* dst = reinterpret_cast<cmx_i4*>(rows + run);
+#pragma unroll
+          for (int q = lane; q < 192; q += 64)
+            if (q < nq) dst[q] = stage[q];
         }
       }
       run += __popcll(m);
     }
-  if (!WRITE && lane == 0) rowcount[il] = run;
+  if (!WRITE && lane == 0) rowcount[blockIdx.x] = run;
 }
 
 __global__ void pair_rows_total_kernel(const unsigned long long* __restrict__ offsets, const unsigned long long* __restrict__ last_count,
@@ -1726,26 +1786,27 @@ __global__ void pair_rows_total_kernel(const unsigned long long* __restrict__ of
 // total, so that consecutive row blocks fill one array in the reference's (i, j) order.
 hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pvalue, const int32_t* d_nsim, size_t n,
                             const int32_t* d_rc, const double* d_pr, const double* d_norm, const cmx_pair_filters& f,
-                            unsigned long long* d_rowcount /*[nrows + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
+                            unsigned long long* d_rowcount /*[nrows * kPairRowSegs + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
                             size_t capacity, unsigned long long* d_count, hipStream_t stream, size_t irow0, size_t nrows,
                             const unsigned long long* d_base, const NullTable* d_inline_null) {
   // d_inline_null: the write pass looks the p-values up itself (no dense p-value / Nsim block, no pvalue_kernel)
-  const NullTable nt = d_inline_null ? *d_inline_null : NullTable{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  const NullTable nt = d_inline_null ? *d_inline_null : NullTable{nullptr, nullptr, nullptr, nullptr, 0};
   if (nrows == 0) nrows = n;
+  const size_t nruns = nrows * kPairRowSegs;
   if (d_tmp == nullptr) {
-    return rocprim::exclusive_scan(nullptr, tmp_bytes, d_rowcount, d_rowcount, 0ull, nrows, rocprim::plus<unsigned long long>(), stream);
+    return rocprim::exclusive_scan(nullptr, tmp_bytes, d_rowcount, d_rowcount, 0ull, nruns, rocprim::plus<unsigned long long>(), stream);
   }
-  hipLaunchKernelGGL((pair_rows_kernel<false>), dim3((unsigned)nrows), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
+  hipLaunchKernelGGL((pair_rows_kernel<false>), dim3((unsigned)nruns), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
                      d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base, nt);
   // keep the last row's count (the scan overwrites it) to form the total
-  hipError_t e = hipMemcpyAsync(d_rowcount + nrows, d_rowcount + nrows - 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
+  hipError_t e = hipMemcpyAsync(d_rowcount + nruns, d_rowcount + nruns - 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) return e;
-  e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_rowcount, d_rowcount, 0ull, nrows, rocprim::plus<unsigned long long>(), stream);
+  e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_rowcount, d_rowcount, 0ull, nruns, rocprim::plus<unsigned long long>(), stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((pair_rows_kernel<true>), dim3((unsigned)nrows), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
+  hipLaunchKernelGGL((pair_rows_kernel<true>), dim3((unsigned)nruns), dim3(64), 0, stream, d_stat, ldo, d_pvalue, d_nsim, n, d_rc,
                      d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base, nt);
   // (after the writes: d_count may be the very word d_base points to)
-  hipLaunchKernelGGL(pair_rows_total_kernel, dim3(1), dim3(64), 0, stream, d_rowcount, d_rowcount + nrows, nrows, d_count, d_base);
+  hipLaunchKernelGGL(pair_rows_total_kernel, dim3(1), dim3(64), 0, stream, d_rowcount, d_rowcount + nruns, nruns, d_count, d_base);
   return hipGetLastError();
 }
 

@@ -115,17 +115,17 @@ def test_configuration4_dna_10000x256_compensation_properties():
     rel_close(st[:16, :16][np.triu_indices(16, 1)], oracle.pair_stats_intra(1, c[:16])[np.triu_indices(16, 1)], 1e-6, 1e-12)
 
 
-def _rows_range(eng, counts_bm, rc, pr, norm, ns, nm, nclasses, kind, a, b, filters=None):
+def _rows_range(eng, counts_bm, rc, pr, norm, ns, nm, nclasses, kind, a, b, filters=None, offset=0, cap=None):
     import torch
     from comap_amd.pipeline import sum_pairs
     dev = counts_bm.device
     n = norm.shape[0]
-    cap = max(sum_pairs(n, a, b), 1)
-    rows = torch.zeros(cap * engine.PAIR_ROW.itemsize, dtype=torch.uint8, device=dev)
+    cap = max(sum_pairs(n, a, b), 1) if cap is None else cap
+    rows = torch.zeros(cap * engine.PAIR_ROW.itemsize + offset, dtype=torch.uint8, device=dev)[offset:]
     count = torch.zeros(1, dtype=torch.int64, device=dev)
     eng.intra_rows_range_dev(kind, counts_bm, rc, pr, norm, ns, nm, nclasses, rows, count, a, b, filters)
     torch.cuda.synchronize()
-    k = int(count.item())
+    k = min(int(count.item()), cap)
     return np.frombuffer(rows[: k * engine.PAIR_ROW.itemsize].cpu().numpy().tobytes(), dtype=engine.PAIR_ROW).copy()
 
 
@@ -156,6 +156,12 @@ def test_rows_range_equals_dense_path_and_concatenates():
         assert np.array_equal(np.concatenate(parts).tobytes(), full.tobytes())
         shards = [_rows_range(eng, cbm, rc, pr, nm, ns, nn, 10, 0, *row_shard(q, 3, 1500), flt) for q in range(3)]
         assert np.array_equal(np.concatenate(shards).tobytes(), full.tobytes())
+        # a rows buffer that is only 8-byte aligned (rows leave one per lane instead of packed), and one that is too
+        # small (the first `capacity` rows are written, the rest dropped)
+        assert _rows_range(eng, cbm, rc, pr, nm, ns, nn, 10, 0, 0, 1500, flt, offset=8).tobytes() == full.tobytes()
+        for off in (0, 8):
+            short = _rows_range(eng, cbm, rc, pr, nm, ns, nn, 10, 0, 0, 1500, flt, offset=off, cap=len(full) - 37)
+            assert short.tobytes() == full[: len(full) - 37].tobytes()
 
 
 def test_configuration4_pair_stage_all_10000_sites_through_row_ranges():

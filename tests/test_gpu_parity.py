@@ -1085,11 +1085,12 @@ def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
     assert np.isnan(gi["mi"][np.tril_indices(n2)]).all() and np.isnan(gi["hjoint"][np.tril_indices(n2)]).all()
 
 
-def test_pvalues_two_level_lookup_is_the_linear_count():
-    """The p-value lookup goes through a sampled first level (every 64th sorted null value) and a last stretch of at most
-    63 values; the count must be the reference's linear scan with strict '<' (CoETools.cpp:712-717) for classes whose
-    sizes are no multiple of 64, classes smaller than the sampling stride, an empty class, heavy ties, statistics below
-    and above every null value -- in the dense call and in the pass that writes the compacted rows."""
+def test_pvalues_binned_lookup_is_the_linear_count():
+    """The p-value lookup finds the bin of the statistic (equal-width bins between the class's 1/64 and 63/64 quantiles,
+    one per eight sorted null values) and searches inside it; the count must be the reference's linear scan with strict
+    '<' (CoETools.cpp:712-717) for classes whose sizes are no multiple of the bin size, classes too small for bins, an
+    empty class, heavy ties, statistics below and above every null value -- in the dense call and in the pass that
+    writes the compacted rows."""
     rng = np.random.default_rng(77)
     n, ncls, nnull = 120, 7, 200_003
     norms = np.concatenate([rng.uniform(0.0, 5.0, n - 1), [5.0]])
@@ -1127,6 +1128,54 @@ def test_pvalues_two_level_lookup_is_the_linear_count():
     st = e2.pair_stats(engine.STAT_CORRELATION, m["counts"])
     opv2, ons2 = oracle.intra_pvalues(st, m["norm"], ncls, null_stat, null_nmin * scale)
     assert np.array_equal(rows["nsim"], ons2[iu]) and np.array_equal(rows["pvalue"], opv2[iu], equal_nan=True)
+
+
+@pytest.mark.parametrize("dist", ["continuous", "outliers", "few_values", "constant", "two_clusters"])
+def test_pvalues_binned_lookup_on_awkward_null_distributions(dist):
+    """The bins are cut in the statistic's value, so the shapes that stress them: a continuous null (every bin a
+    handful of values), infinite and huge outliers (the tails fall into the first and last bin), a statistic that takes
+    six values (most bins empty, a few hold a sixth of the class), a constant null (no bins at all), two far clusters
+    (one thread fills the empty bins between them).  Always the linear count of the oracle."""
+    rng = np.random.default_rng(len(dist))
+    n, ncls, nnull = 90, 4, 150_001
+    norms = np.concatenate([rng.uniform(0.0, 3.0, n - 1), [3.0]])
+    null_nmin = rng.uniform(0.0, 3.0, nnull)
+    stat = rng.normal(0.0, 0.4, (n, n))
+    if dist == "continuous":
+        null_stat = rng.normal(0.0, 0.3, nnull)
+    elif dist == "outliers":
+        null_stat = rng.normal(0.0, 0.3, nnull)
+        null_stat[rng.integers(0, nnull, 40)] = np.inf
+        null_stat[rng.integers(0, nnull, 40)] = -np.inf
+        null_stat[rng.integers(0, nnull, 40)] = 1.0e308
+        null_stat[rng.integers(0, nnull, 40)] = -1.0e308
+        stat[3, 4] = np.inf
+        stat[5, 6] = -np.inf
+        stat[7, 8] = 1.0e308
+    elif dist == "few_values":
+        null_stat = rng.integers(0, 6, nnull).astype(np.float64)
+        stat = rng.integers(-1, 8, (n, n)).astype(np.float64)
+        stat[::3] += 0.5
+    elif dist == "constant":
+        null_stat = np.full(nnull, 0.25)
+        stat[2, 3] = 0.25
+    else:
+        null_stat = np.where(rng.random(nnull) < 0.5, rng.normal(-50.0, 0.01, nnull), rng.normal(70.0, 0.01, nnull))
+        stat = np.where(rng.random((n, n)) < 0.5, rng.normal(-50.0, 0.02, (n, n)), rng.normal(70.0, 0.02, (n, n)))
+        stat[1, 2] = 0.0
+    stat = np.triu(stat, 1) + np.triu(stat, 1).T
+    # the statistic equal to a null value, and one ulp either side of it
+    v = null_stat[np.isfinite(null_stat)][:20]
+    stat[0, 1:21] = v
+    stat[1, 2:22] = np.nextafter(v, np.inf)
+    stat[2, 3:23] = np.nextafter(v, -np.inf)
+    stat = np.triu(stat, 1) + np.triu(stat, 1).T
+    eng = engine.Engine()
+    pv, ns = eng.intra_pvalues(stat, norms, ncls, null_stat, null_nmin)
+    opv, ons = oracle.intra_pvalues(stat, norms, ncls, null_stat, null_nmin)
+    iu = np.triu_indices(n, 1)
+    assert np.array_equal(ns[iu], ons[iu])
+    assert np.array_equal(pv[iu], opv[iu], equal_nan=True)
 
 
 @pytest.mark.parametrize("T,n1,n2", [(40, 70, 33), (100, 130, 300), (256, 200, 129), (300, 40, 50)])
