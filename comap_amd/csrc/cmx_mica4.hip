@@ -43,6 +43,9 @@
 namespace cmx {
 
 constexpr int kM4I = 12, kM4J = 3, kM4Rows = 20;
+// The cells of a pair sum to 400 T, so at most 400 T / M0 <= 25 of them reach M0 = 4096 at T <= 256: a wave's nine pairs
+// queue at most 225 cells per tile.
+constexpr int kM4Corr = 12, kM4QCap = 232;
 constexpr unsigned kM4MaxChunk = 64;   // tiles per run: one lane of a wave per tile when the run's tile info is loaded
 
 // 16 symbols (four dwords) against one state.  Symbols and states are < 64 (the codes use 63 for "no row", 20 for the
@@ -167,12 +170,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   cmx_i4* ops = reinterpret_cast<cmx_i4*>(m4_smem + ftab_bytes);                 // [2][NQ][64]
   double* s2t = reinterpret_cast<double*>(ops + 2 * NQ * 64);                     // [2][4] S of the tile's columns
   unsigned* j2t = reinterpret_cast<unsigned*>(s2t + 8);                           // [2][4] their original column indices
+  // weighted: per wave the sums of its nine pairs' cells of M0 or more (gathered from global memory at the end of a tile),
+  // and the queue of those cells
+  double* corr = reinterpret_cast<double*>(j2t + 8);                              // [4][kM4Corr]
+  unsigned* bigq = reinterpret_cast<unsigned*>(corr + 4 * kM4Corr);               // [4][kM4QCap]
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool hi = lane >= 32;
   const int cl = lane & 31;
-  if (WEIGHTED)
+  if (WEIGHTED) {
     for (int c = tid; c <= M0; c += 256) reinterpret_cast<double*>(m4_smem)[c] = c < M0 ? ftab_g[T + 1 + c] : 0.0;
-  else
+    if (tid < 4 * kM4Corr) corr[tid] = 0.0;
+  } else
     for (int c = tid; c <= T; c += 256) reinterpret_cast<double*>(m4_smem)[c] = ftab_g[c];
   const unsigned M8 = 8u * (unsigned)M0;
   const double lnT = log((double)T), invT = 1.0 / (double)T;
@@ -319,18 +327,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // R0 = 32 ii + 8 (v / 4) + v % 4 in the lower lane half and R0 + 4 in the upper one, packed column 32 jj + cl.
         // Rows 16..19 | 20..23 are the one register quad whose halves belong to different columns (0 | 1); rows 60..63
         // are padding (count 0, f = 0).
-        double pa[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, pm[2] = {0.0, 0.0};
-        // (the table's address in a scalar register pair for the gathers' inline asm, whatever the allocator did with it)
-        // It is moved back by 8 M0 - 8 bytes: the accumulator itself (8 m) is then the gather's offset, entry 8 M0 the first real one
+        // the third table moved back by 8 M0 - 8 bytes: the accumulator itself (8 m) is then the gather's offset, entry 8 M0 the first real one
         const unsigned long long f2hi_a = (unsigned long long)f2hi - (M8 - 8u);
         const unsigned long long f2hi_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(f2hi_a >> 32)) << 32) |
                                           (unsigned)__builtin_amdgcn_readfirstlane((unsigned)f2hi_a);
+        const unsigned corrb = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<const uint8_t*>(corr) - m4_smem) + 8u * kM4Corr * (unsigned)w);
+        double pa[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, pm[2] = {0.0, 0.0};
+        // weighted, cells of M0 or more: they read the zero behind the LDS table, and the lanes that hold one queue
+        // (8 m, pair) in the wave's LDS queue -- a compare and a branch per register, the rest only where some lane has
+        // one.  (Gathering them on the spot under the lanes' EXEC mask cost a global-memory round trip per eight registers,
+        // with nothing to do meanwhile: 43 % of the registers hold such a cell in some lane.)  Inline asm: written as a
+        // branch or a per-lane `if`, the compiler spilled 100 - 230 registers around the 64 regions.
+        // (m4_smem is LDS address 0: the queue's LDS byte address is its offset)
+        unsigned qp = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<const uint8_t*>(bigq) - m4_smem) + 4u * kM4QCap * (unsigned)w);
+        const unsigned qbeg = qp;
+        // pair of a cell = 3 a + b: b by the lane's packed column (tile 0: columns 0..19 | 20..31, tile 1: 32..39 | 40..59)
+        unsigned btag[2] = {cl < 20 ? 0u : 1u, cl < 8 ? 1u : 2u}, hi3 = hi ? 3u : 0u;
+        asm volatile("" : "+v"(btag[0]), "+v"(btag[1]), "+v"(hi3));   // (or 64 loop-invariant sums stay live across the tiles)
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             constexpr int NB = WEIGHTED ? 8 : 16;   // lookups in flight at a time
-            static_assert(!WEIGHTED || NB == 8, "the wait below names eight registers");
 #pragma unroll
             for (int v0 = 0; v0 < 16; v0 += NB) {
               double val[NB];
@@ -339,28 +357,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
               for (int v = 0; v < NB; ++v) {
                 // plain: the accumulator is 8 x count = the LDS address of f(count).  weighted: it is 8 m, the LDS address of
-                // f2[m] for m < M0; larger cells read the zero behind the table here and their value from global memory below
+                // f2[m] for m < M0
                 const unsigned a8 = (unsigned)acc[ii][jj][v0 + v];
                 val[v] = *reinterpret_cast<const __attribute__((address_space(3))) double*>(static_cast<uintptr_t>(WEIGHTED ? (a8 < M8 ? a8 : M8) : a8));
               }
               if (WEIGHTED) {
-                // cells of M0 or more: gathered from the third table by the lanes that hold one, under their own EXEC mask (a
-                // register without such a cell issues nothing to the texture unit), straight over the zero those lanes read
-                // from LDS -- `val` is an operand of the asm, so the compiler has the LDS value land first.  Inline asm:
-                // written as a branch or a per-lane `if`, the compiler spilled 100 - 230 registers around the 64 regions.
 #pragma unroll
                 for (int v = 0; v < NB; ++v) {
+                  const int R0 = 32 * ii + 8 * ((v0 + v) / 4) + (v0 + v) % 4, a0 = R0 / kM4Rows, a1 = (R0 + 4) / kM4Rows;
+                  // (rows 60..63 are padding: never large)
+                  const bool mixed = !(a0 == a1 || a1 == 3);   // a0 == 0, a1 == 1
+                  const unsigned tag = mixed ? btag[jj] + hi3 : btag[jj];
                   unsigned long long sv;
+                  unsigned t, e, cnt;
                   asm volatile("v_cmp_le_u32_e32 vcc, %[m8], %[a]\n\t"
+                               "s_cbranch_vccz .Lmq%=\n\t"
+                               "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                               "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                               "v_lshl_add_u32 %[t], %[t], 2, %[qp]\n\t"
+                               "v_lshl_or_b32 %[e], %[a], 1, %[tag]\n\t"
+                               "v_add_u32_e32 %[e], %[a3], %[e]\n\t"
                                "s_and_saveexec_b64 %[sv], vcc\n\t"
-                               "global_load_dwordx2 %[b], %[a], %[base]\n\t"
-                               "s_mov_b64 exec, %[sv]"
-                               : [b] "+v"(val[v]), [sv] "=&s"(sv)
-                               : [a] "v"(acc[ii][jj][v0 + v]), [m8] "s"(M8), [base] "s"(f2hi_u)
-                               : "vcc", "memory");
+                               "ds_write_b32 %[t], %[e]\n\t"
+                               "s_mov_b64 exec, %[sv]\n\t"
+                               "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                               "s_lshl2_add_u32 %[qp], %[cnt], %[qp]\n"
+                               ".Lmq%=:"
+                               : [qp] "+s"(qp), [t] "=&v"(t), [e] "=&v"(e), [sv] "=&s"(sv), [cnt] "=&s"(cnt)
+                               : [a] "v"(acc[ii][jj][v0 + v]), [m8] "s"(M8), [tag] "v"(tag), [a3] "n"(mixed ? 0 : 3 * a0)
+                               : "vcc", "scc", "memory");
                 }
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7])::"memory");
               }
 #pragma unroll
               for (int v = 0; v < NB; ++v) {
@@ -371,6 +397,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               asm volatile("" ::: "memory");
             }
           }
+        // the queued cells: one gather for (nearly always) all of them, in flight during the reductions below.  Straight-line
+        // asm under an EXEC mask (no lanes when the queue is empty), for the register allocator's sake as above.
+        const unsigned nq = WEIGHTED ? (qp - qbeg) >> 2 : 0u;
+        unsigned ge = 0;
+        double gv = 0.0;
+        if (WEIGHTED) {
+          unsigned long long sv;
+          unsigned t;
+          asm volatile("v_cmp_gt_u32_e32 vcc, %[nq], %[lane]\n\t"
+                       "s_and_saveexec_b64 %[sv], vcc\n\t"
+                       "v_lshl_add_u32 %[t], %[lane], 2, %[qb]\n\t"
+                       "ds_read_b32 %[e], %[t]\n\t"
+                       "s_waitcnt lgkmcnt(0)\n\t"
+                       "v_lshrrev_b32_e32 %[t], 1, %[e]\n\t"
+                       "v_and_b32_e32 %[t], 0xfffffff8, %[t]\n\t"
+                       "global_load_dwordx2 %[g], %[t], %[base]\n\t"
+                       "s_mov_b64 exec, %[sv]"
+                       : [e] "+v"(ge), [g] "+v"(gv), [t] "=&v"(t), [sv] "=&s"(sv)
+                       : [nq] "s"(nq), [lane] "v"(lane), [qb] "s"(qbeg), [base] "s"(f2hi_u)
+                       : "vcc", "memory");
+        }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           pa[0][jj] += hi ? 0.0 : pm[jj];
@@ -389,6 +436,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         sres[0] = mica_reduce4(t[0], t[1], t[2], t[3]);
         sres[1] = mica_reduce4(t[4], t[5], t[6], t[7]);
         sres[2] = mica_reduce4(t[8], 0.0, 0.0, 0.0);
+        if (WEIGHTED) {
+          // the gathered values into the wave's per-pair sums (LDS atomics of one wave: program order, lane order); beyond
+          // the first 64 queued cells (rare) a loop of the same steps with the round trip exposed
+          unsigned long long sv;
+          unsigned t, e2, sq;
+          double g2;
+          asm volatile("v_cmp_gt_u32_e32 vcc, %[nq], %[lane]\n\t"
+                       "s_and_saveexec_b64 %[sv], vcc\n\t"
+                       "v_and_b32_e32 %[t], 15, %[e]\n\t"
+                       "v_lshl_add_u32 %[t], %[t], 3, %[cb]\n\t"
+                       "s_waitcnt vmcnt(0)\n\t"
+                       "ds_add_f64 %[t], %[g]\n\t"
+                       "s_mov_b64 exec, %[sv]\n\t"
+                       "s_movk_i32 %[sq], 64\n"
+                       ".Lmr%=:\n\t"
+                       "s_cmp_ge_u32 %[sq], %[nq]\n\t"
+                       "s_cbranch_scc1 .Lmd%=\n\t"
+                       "v_add_u32_e32 %[t], %[sq], %[lane]\n\t"
+                       "v_cmp_gt_u32_e32 vcc, %[nq], %[t]\n\t"
+                       "s_and_saveexec_b64 %[sv], vcc\n\t"
+                       "v_lshl_add_u32 %[t], %[t], 2, %[qb]\n\t"
+                       "ds_read_b32 %[e2], %[t]\n\t"
+                       "s_waitcnt lgkmcnt(0)\n\t"
+                       "v_lshrrev_b32_e32 %[t], 1, %[e2]\n\t"
+                       "v_and_b32_e32 %[t], 0xfffffff8, %[t]\n\t"
+                       "global_load_dwordx2 %[g2], %[t], %[base]\n\t"
+                       "v_and_b32_e32 %[e2], 15, %[e2]\n\t"
+                       "v_lshl_add_u32 %[e2], %[e2], 3, %[cb]\n\t"
+                       "s_waitcnt vmcnt(0)\n\t"
+                       "ds_add_f64 %[e2], %[g2]\n\t"
+                       "s_mov_b64 exec, %[sv]\n\t"
+                       "s_add_u32 %[sq], %[sq], 64\n\t"
+                       "s_branch .Lmr%=\n"
+                       ".Lmd%=:"
+                       : [t] "=&v"(t), [e2] "=&v"(e2), [g2] "=&v"(g2), [sv] "=&s"(sv), [sq] "=&s"(sq), "+v"(sres[0]), "+v"(sres[1]), "+v"(sres[2])
+                       : [nq] "s"(nq), [lane] "v"(lane), [e] "v"(ge), [g] "v"(gv), [cb] "s"(corrb), [qb] "s"(qbeg), [base] "s"(f2hi_u)
+                       : "vcc", "scc", "memory");
+        }
         if ((lane & 15) == 0) {
           const size_t j0 = (size_t)jt * kM4J;
 #pragma unroll
@@ -401,7 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               if (!((bad1 >> a) & 1) && !((bad2 >> b) & 1) && (!intra || j0 + b > i0 + 3 * w + a)) {
                 const size_t oi = a == 0 ? i1v[0] : (a == 1 ? i1v[1] : i1v[2]), oj = j2t[4 * buf + b];
                 const size_t i = intra && oj < oi ? oj : oi, j = intra && oj < oi ? oi : oj;
-                const double s = sres[g];
+                const double s = WEIGHTED ? sres[g] + corr[kM4Corr * w + pr] : sres[g];
                 const double sa = a == 0 ? s1v[0] : (a == 1 ? s1v[1] : s1v[2]);
                 mi[i * ldo + j] = lnT + (s - sa - s2t[4 * buf + b]) * invT;
                 hj[i * ldo + j] = lnT - s * invT;
@@ -409,6 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
           }
         }
+        if (WEIGHTED && lane < kM4Corr) corr[kM4Corr * w + lane] = 0.0;   // (after the reads above: one wave, LDS in order)
       }
       if (!more) break;
       buf ^= 1;
@@ -416,7 +502,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
 }
-
 // ---- nucleotides.  Four states: SIXTEEN columns share a 64-row block, a wave's 64 x 64 accumulator block is the Gram of
 // 16 x 16 column pairs (nine for proteins), and the table of the weighted form -- m = 16 N_ab + 4 (N_aG + N_Gb) + N_GG <= 16 T,
 // 4 097 entries at 256 taxa -- fits the LDS whole: ONE instantiation serves columns with and without unknowns (weights 8 / 2
@@ -616,7 +701,8 @@ hipError_t launch_mica_dna4(int T, const MicaWork* wk, size_t n1, size_t n2, int
 
 size_t mica4_lds_bytes(int T, int KS, bool weighted) {
   const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
-  return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 8 * sizeof(double) + 8 * sizeof(unsigned);
+  return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 8 * sizeof(double) + 8 * sizeof(unsigned) +
+         (weighted ? 4 * kM4Corr * sizeof(double) + 4 * kM4QCap * sizeof(unsigned) : 0);
 }
 
 template <int KS, bool WEIGHTED>

@@ -1085,6 +1085,32 @@ def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
     assert np.isnan(gi["mi"][np.tril_indices(n2)]).all() and np.isnan(gi["hjoint"][np.tril_indices(n2)]).all()
 
 
+def test_mica_weighted_kernel_queue_of_large_cells_beyond_one_wave():
+    """The weighted instantiation looks cells below 4 096 / 400 = 10.24 taxa up in LDS and queues the larger ones per wave
+    for one gather at the end of the tile.  Here every pair of columns has twenty cells of 12 or 13 taxa (the columns are
+    the same partition of the 256 taxa into twenty blocks, states permuted per column) and every column two unknowns: a
+    wave's nine pairs queue 180 cells per tile, three rounds of its 64 lanes (the bound is 225)."""
+    rng = np.random.default_rng(5)
+    A, T, n1, n2 = 20, 256, 26, 11
+    block = (np.arange(T) * A // T).astype(np.uint8)
+
+    def draw(n):
+        a = np.stack([rng.permutation(A).astype(np.uint8)[block] for _ in range(n)], axis=1)
+        for c in range(n):
+            a[rng.choice(T, 2, replace=False), c] = A
+        return np.ascontiguousarray(a)
+
+    a1, a2 = draw(n1), draw(n2)
+    eng = engine.Engine()
+    g = eng.mi_columns(a1, a2, A)
+    o = oracle.mi_columns(a1, a2, A, oracle.default_masks(A))
+    rel_close(g["mi"], o["mi"], 1e-6, 1e-10)
+    rel_close(g["hjoint"], o["hjoint"], 1e-6, 1e-10)
+    assert o["mi"].min() > 2.5          # (nearly the full ln 20: the cells are what the test says)
+    g2 = eng.mi_columns(a1, a2, A)
+    assert np.array_equal(g["mi"], g2["mi"]) and np.array_equal(g["hjoint"], g2["hjoint"])   # same bits run to run
+
+
 def test_pvalues_binned_lookup_is_the_linear_count():
     """The p-value lookup finds the bin of the statistic (equal-width bins between the class's 1/64 and 63/64 quantiles,
     one per eight sorted null values) and searches inside it; the count must be the reference's linear scan with strict
