@@ -46,10 +46,15 @@ constexpr int kM4I = 12, kM4J = 3, kM4Rows = 20;
 // The cells of a pair sum to 400 T, so at most 400 T / M0 <= 25 of them reach M0 = 4096 at T <= 256: a wave's nine pairs
 // queue at most 225 cells per tile.
 constexpr int kM4Corr = 12, kM4QCap = 232;
+// Symbol codes of the SORTED column arrays the protein kernels read (mica_gather_columns_kernel recodes them): states
+// 0..19, "no row" 31 (padding taxa and columns), the unknown 32 -- a bit of its own, so that the weighted expansion
+// takes its unit from the symbol byte with a shift and a mask; 30 is the state of the padding rows (matches nothing)
+constexpr unsigned kM4None = 31u, kM4Unknown = 32u, kM4PadRow = 30u;
+constexpr unsigned kM4NoneX4 = kM4None * 0x01010101u, kM4PadRowX4 = kM4PadRow * 0x01010101u;
 constexpr unsigned kM4MaxChunk = 64;   // tiles per run: one lane of a wave per tile when the run's tile info is loaded
 
-// 16 symbols (four dwords) against one state.  Symbols and states are < 64 (the codes use 63 for "no row", 20 for the
-// unknown), so 0x80 - (symbol ^ state) has bit 7 set exactly where they match and no byte borrows.
+// 16 symbols (four dwords) against one state.  Symbols and states are < 64, so 0x80 - (symbol ^ state) has bit 7 set
+// exactly where they match and no byte borrows.
 // plain: bytes `one` where they match (SHIFT / MASK move bit 7 to the one's place)
 template <int SHIFT, unsigned MASK>
 __device__ __forceinline__ cmx_i4 m4_expand(const cmx_i4 sy, unsigned srow) {
@@ -62,13 +67,15 @@ __device__ __forceinline__ cmx_i4 m4_expand(const cmx_i4 sy, unsigned srow) {
 // UNIT is 2 on the first side and 4 on the second, so that the accumulators hold 8 m, the byte offset of f2[m]
 template <unsigned UNIT>
 __device__ __forceinline__ cmx_i4 m4_expand_weighted(const cmx_i4 sy, unsigned srow, unsigned live) {
+  static_assert(kM4Unknown == 32u, "the unknown's bit is bit 5");
   cmx_i4 oh;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    // 20 UNIT = 5 x (4 UNIT): the match bit moved to the place of 4 UNIT, OR itself two places higher (bytes do not carry)
+    // 20 UNIT = 5 x (4 UNIT): the match bit moved to the place of 4 UNIT, OR itself two places higher (bytes do not
+    // carry); the unknown's bit 5 moved to the place of UNIT: seven instructions per dword (ten with the unknown compared
+    // like a state)
     const unsigned eq = ((0x80808080u - ((unsigned)sy[d] ^ srow)) >> (UNIT == 2 ? 4 : 3)) & (0x01010101u * (4u * UNIT));
-    const unsigned un = ((0x80808080u - ((unsigned)sy[d] ^ 0x14141414u)) >> (UNIT == 2 ? 6 : 5)) & (live * UNIT);
-    oh[d] = (int)((eq << 2) | eq | un);
+    oh[d] = (int)((((unsigned)sy[d] >> (UNIT == 2 ? 4 : 3)) & (live * UNIT)) | ((eq << 2) | eq));
   }
   return oh;
 }
@@ -122,12 +129,21 @@ __global__ __launch_bounds__(256) void mica_gather_columns_kernel(const unsigned
                                                                   uint8_t* __restrict__ Cs, double* __restrict__ Ss) {
   const size_t k = blockIdx.x;
   if (k >= n) {
-    for (int t = threadIdx.x; t < Tp; t += 256) Cs[k * (size_t)Tp + t] = 63;
+    for (int t = threadIdx.x; t < Tp; t += 256) Cs[k * (size_t)Tp + t] = (uint8_t)kM4None;
     return;
   }
   const size_t i = order[k];
-  for (int t = threadIdx.x; t < Tp / 16; t += 256)
-    reinterpret_cast<cmx_i4*>(Cs + k * (size_t)Tp)[t] = reinterpret_cast<const cmx_i4*>(C + i * (size_t)Tp)[t];
+  for (int t = threadIdx.x; t < Tp / 16; t += 256) {
+    // mica_onehot_kernel's codes (unknown = 20, no row = 63) -> this file's (kM4Unknown, kM4None)
+    cmx_i4 x = reinterpret_cast<const cmx_i4*>(C + i * (size_t)Tp)[t];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const unsigned v = (unsigned)x[d];
+      const unsigned isu = ((0x80808080u - (v ^ 0x14141414u)) >> 7) & 0x01010101u, isn = ((0x80808080u - (v ^ 0x3f3f3f3fu)) >> 7) & 0x01010101u;
+      x[d] = (int)(v ^ (isu * (20u ^ kM4Unknown)) ^ (isn * (63u ^ kM4None)));
+    }
+    reinterpret_cast<cmx_i4*>(Cs + k * (size_t)Tp)[t] = x;
+  }
   if (threadIdx.x == 0) Ss[k] = S[i];
 }
 // per block of three SORTED columns (block k = sorted positions 3k .. 3k + 2): bits 0..2 column not served here (partial
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int m = 0; m < SPT; ++m) {
     const int q = w + 4 * m, C = 32 * (q / KS) + cl;
-    bsrow[m] = (C < 60 ? (unsigned)(C % kM4Rows) : 31u) * 0x01010101u;
+    bsrow[m] = (C < 60 ? (unsigned)(C % kM4Rows) : kM4PadRow) * 0x01010101u;
     boff[m] = (unsigned)((C < 60 ? C / kM4Rows : 2) * Tp + 32 * (q % KS) + 16 * (lane >> 5));   // from the tile's first column
   }
   // first alignment: row tile ii, packed row 32 ii + cl
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii) {
     const int R = 32 * ii + cl;
-    asrow[ii] = (R < 60 ? (unsigned)(R % kM4Rows) : 31u) * 0x01010101u;
+    asrow[ii] = (R < 60 ? (unsigned)(R % kM4Rows) : kM4PadRow) * 0x01010101u;
     acol[ii] = R < 60 ? R / kM4Rows : 2;
   }
   const int r4 = lane >> 4;
@@ -254,13 +270,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const uint8_t* src = C1 + (i0 + 3 * w + acol[ii]) * (size_t)Tp + 16 * (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          raw[ii][ks] = ks < nks ? *reinterpret_cast<const cmx_i4*>(src + 32 * ks) : cmx_i4{0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f};
+          raw[ii][ks] = ks < nks ? *reinterpret_cast<const cmx_i4*>(src + 32 * ks) : cmx_i4{(int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4};
       }
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          areg[ii][ks] = WEIGHTED ? m4_expand_weighted<2>(raw[ii][ks], asrow[ii], asrow[ii] == 0x1f1f1f1fu ? 0u : 0x01010101u)
+          areg[ii][ks] = WEIGHTED ? m4_expand_weighted<2>(raw[ii][ks], asrow[ii], asrow[ii] == kM4PadRowX4 ? 0u : 0x01010101u)
                                   : m4_expand<4, 0x08080808u>(raw[ii][ks], asrow[ii]);
     }
     cmx_i4 braw[SPT];
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int m = 0; m < SPT; ++m)
         braw[m] = (w + 4 * m) % KS < nks ? __builtin_bit_cast(cmx_i4, __builtin_amdgcn_raw_buffer_load_b128(rc2, boff[m], soff, 0))
-                                         : cmx_i4{0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f, 0x3f3f3f3f};
+                                         : cmx_i4{(int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4};
       if (tid < kM4J) {
         const size_t j = (size_t)jt * kM4J + tid, jc = j < n2 ? j : n2 - 1;
         s2r = S2[jc];
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto expand = [&](int buf) {
 #pragma unroll
       for (int m = 0; m < SPT; ++m)
-        ops[(buf * NQ + w + 4 * m) * 64 + lane] = WEIGHTED ? m4_expand_weighted<4>(braw[m], bsrow[m], bsrow[m] == 0x1f1f1f1fu ? 0u : 0x01010101u)
+        ops[(buf * NQ + w + 4 * m) * 64 + lane] = WEIGHTED ? m4_expand_weighted<4>(braw[m], bsrow[m], bsrow[m] == kM4PadRowX4 ? 0u : 0x01010101u)
                                                            : m4_expand<7, 0x01010101u>(braw[m], bsrow[m]);
       if (tid < kM4J) {
         s2t[4 * buf + tid] = s2r;
