@@ -734,7 +734,9 @@ cmx_status cmx_null_simulate_dev(cmx_ctx* ctx, uint64_t seed, size_t rep_begin, 
   if ((s = rng_range(ctx, (uint64_t)rep_end * 2 * rep_ram, "cmx_null_simulate")) != CMX_OK) return s;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t nsites = (rep_end - rep_begin) * 2 * rep_ram;
-  const size_t chunk = std::min<size_t>(nsites, (size_t)1 << 21);
+  // node states of a pass: nn bytes per site, up to 4 GiB -- one pass for the 2 * 10^7 sites of the target's null (nine
+  // passes of 2^21 sites left nine tails of half-empty CUs)
+  const size_t chunk = std::min<size_t>(nsites, std::max<size_t>((size_t)1 << 21, (((size_t)4 << 30) / (size_t)ctx->hm.nn) & ~(size_t)1023));
   uint8_t* d_states;
   if ((s = scratch(ctx, "null_states", (size_t)ctx->hm.nn * chunk, (void**)&d_states)) != CMX_OK) return s;
   HIP_TRY(ctx, launch_simulate_blocked(ctx->dm, seed, (uint64_t)rep_begin * 2 * rep_ram, nsites, rep_ram, d_aln, d_states, chunk,

@@ -1072,9 +1072,10 @@ __global__ __launch_bounds__(256) void simulate_blocked_kernel(const DevModel m,
 // (four per thread), node by node, parents first: the node's C * S rows (12.8 KB for proteins) and guide bytes are copied
 // into LDS once per workgroup, double-buffered (global -> registers while the current node is drawn, registers -> LDS
 // behind a barrier), and every search runs on LDS.  Same draws, same states as simulate_kernel.
+constexpr int kSimStep = 2;        // running sums per search and LDS round trip in simulate_lds_kernel
 constexpr int kSimLdsChunks = 8;   // 16-byte pieces of a node's tables per thread (256 threads): up to 32 KiB per buffer
-template <int SPT>
-__global__ __launch_bounds__(256) void simulate_lds_kernel(const DevModel m, uint64_t seed, uint64_t g0, size_t s0, size_t n,
+template <int SPT, int NCH /* 16-byte pieces of a node's tables per thread */, int NT /* threads */, int WAVES>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void simulate_lds_kernel(const DevModel m, uint64_t seed, uint64_t g0, size_t s0, size_t n,
                                                            size_t blk, uint8_t* __restrict__ aln, uint8_t* __restrict__ states) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sim_smem[];
   const int S0 = m.S0, C0 = m.C0, tid = threadIdx.x;
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(256) void simulate_lds_kernel(const DevModel m, uin
   bool on[SPT];
 #pragma unroll
   for (int k = 0; k < SPT; ++k) {
-    j[k] = ((size_t)blockIdx.x * SPT + k) * 256 + tid;
+    j[k] = ((size_t)blockIdx.x * SPT + k) * NT + tid;
     on[k] = j[k] < n;
     const size_t jj = on[k] ? j[k] : n - 1, s = s0 + jj;
     j[k] = jj;
@@ -1110,43 +1111,74 @@ __global__ __launch_bounds__(256) void simulate_lds_kernel(const DevModel m, uin
   // tables of the first node
   const cmx_cint ord = (cmx_cint)m.simord;
   int buf = 0;
-  for (int q = tid; q < nch; q += 256)
+  for (int q = tid; q < nch; q += NT)
     reinterpret_cast<cmx_i4*>(sim_smem)[q] = (q * 16 < tabb + guib) ? *piece_src(ord[0], q) : cmx_i4{0, 0, 0, 0};
   __syncthreads();
   // nodes level by level (m.simord): the parent's state was written a whole level ago, not by the previous iteration
   for (int it = 0; it < m.nn - 1; ++it) {
     const int node = ord[it];
     const bool more = it + 1 < m.nn - 1;
-    cmx_i4 nxt[kSimLdsChunks];
+    cmx_i4 nxt[NCH];
     if (more) {
       const int nnode = ord[it + 1];
 #pragma unroll
-      for (int i = 0; i < kSimLdsChunks; ++i) {
-        const int q = tid + 256 * i;
+      for (int i = 0; i < NCH; ++i) {
+        const int q = tid + NT * i;
         if (q < nch && q * 16 < tabb + guib) nxt[i] = *piece_src(nnode, q);
       }
     }
     const double* T_ = reinterpret_cast<const double*>(sim_smem + (size_t)buf * bufb);
     const uint8_t* G_ = sim_smem + (size_t)buf * bufb + tabb;
     const int par = m.parent[node], tx = m.taxon_of[node];
+    // the SPT searches side by side: parents' states, uniforms, guide bytes, then kSimStep running sums per search and round
+    // trip (a `while (u >= cum[idx]) ++idx` per site is a chain of dependent LDS reads under a divergent branch: 36
+    // branches and 110 scalar instructions per wave and draw).  Reads past a row's end stay inside the buffer (the guide
+    // bytes follow the sums) and are not counted.
+    int x[SPT], idx[SPT];
+    double u[SPT];
+    const double* cum[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) x[k] = states[(size_t)par * n + j[k]];
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) u[k] = philox_uniform(seed, g[k], 2u + (uint32_t)node);
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
-      const int x = states[(size_t)par * n + j[k]];
-      const double u = philox_uniform(seed, g[k], 2u + (uint32_t)node);
-      const int row = cls[k] * S0 + x;
-      int idx = G_[row * 32 + (int)(u * 32.0)];
-      const double* cum = T_ + row * S0;
-      while (idx < S0 - 1 && u >= cum[idx]) ++idx;
-      if (on[k]) {
-        states[(size_t)node * n + j[k]] = (uint8_t)idx;
-        if (tx >= 0) out[k][(size_t)tx * blk] = (uint8_t)idx;
-      }
+      const int row = cls[k] * S0 + x[k];
+      idx[k] = G_[row * 32 + (int)(u[k] * 32.0)];
+      cum[k] = T_ + row * S0;
     }
+    bool any;
+    do {
+      double cv[SPT][kSimStep];
+#pragma unroll
+      for (int k = 0; k < SPT; ++k)
+#pragma unroll
+        for (int d = 0; d < kSimStep; ++d) cv[k][d] = cum[k][idx[k] + d];
+      any = false;
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        bool go = true;
+        int adv = 0;
+#pragma unroll
+        for (int d = 0; d < kSimStep; ++d) {
+          go = go && idx[k] + d < S0 - 1 && u[k] >= cv[k][d];
+          adv += go ? 1 : 0;
+        }
+        idx[k] += adv;
+        any |= adv == kSimStep;
+      }
+    } while (any);
+#pragma unroll
+    for (int k = 0; k < SPT; ++k)
+      if (on[k]) {
+        states[(size_t)node * n + j[k]] = (uint8_t)idx[k];
+        if (tx >= 0) out[k][(size_t)tx * blk] = (uint8_t)idx[k];
+      }
     if (more) {
       __syncthreads();   // nobody reads the other buffer any more (it held the previous node)
 #pragma unroll
-      for (int i = 0; i < kSimLdsChunks; ++i) {
-        const int q = tid + 256 * i;
+      for (int i = 0; i < NCH; ++i) {
+        const int q = tid + NT * i;
         if (q < nch && q * 16 < tabb + guib) reinterpret_cast<cmx_i4*>(sim_smem + (size_t)(buf ^ 1) * bufb)[q] = nxt[i];
       }
       __syncthreads();
@@ -1168,9 +1200,17 @@ hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0
     // tables in LDS, four sites per thread (a node's tables are copied once per 1 024 sites), when that fills the chip
     // several times over; below that (cfg3: 500 000 sites = 488 such workgroups on 256 CUs) its two barriers per node are
     // a floor of ~1 ms and the gather kernel, one thread per site and no barrier, is quicker
-    if (lds && n >= (size_t)256 * 4 * 2048)
-      hipLaunchKernelGGL(simulate_lds_kernel<4>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 2 * bufb, stream, m, seed, g0, s0, n,
-                         blk, d_aln, d_states);
+    if (lds && n >= (size_t)256 * 4 * 2048) {
+      // 512 threads with two sites each: 56 registers = eight waves per SIMD (the kernel is bound by vector issue -- half of
+      // it Philox's quarter-rate multiplies -- once enough waves hide the LDS round trips: four sites per thread at three
+      // waves per SIMD 14.8 ms per target step, at five 11.6, this shape 10.2)
+      if (bufb <= (size_t)2 * 512 * 16)
+        hipLaunchKernelGGL((simulate_lds_kernel<2, 2, 512, 8>), dim3((unsigned)((n + 1023) / 1024)), dim3(512), 2 * bufb, stream, m, seed, g0, s0,
+                           n, blk, d_aln, d_states);
+      else
+        hipLaunchKernelGGL((simulate_lds_kernel<4, kSimLdsChunks, 256, 4>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 2 * bufb, stream, m,
+                           seed, g0, s0, n, blk, d_aln, d_states);
+    }
     else
       hipLaunchKernelGGL(simulate_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m, seed, g0, s0, n, blk,
                          d_aln, d_states);

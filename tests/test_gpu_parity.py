@@ -941,13 +941,15 @@ def test_null_simulator_kernels_and_passes_agree_with_the_plain_simulator(tmp_pa
     eng = _engine(case)
     dev = torch.device("cuda:0")
     T = len(case["lot"])
-    for rb, re, ram in ((3, 5, 700), (0, 2, 600_000)):        # 2 800 sites (gather kernel); 2.4 M sites (LDS-table kernel)
+    case6 = make_case(8, 10, 20, 6, ncat=6)                     # six classes: a node's tables exceed 16 KB (the other LDS shape)
+    for e, rb, re, ram in ((eng, 3, 5, 700), (eng, 0, 2, 600_000), (_engine(case6), 1, 3, 550_001)):
+        # 2 800 sites (gather kernel); 2.4 M and 2.2 M sites (LDS-table kernel, 512 x 2 and 256 x 4 sites per workgroup)
         n = (re - rb) * 2 * ram
         buf = torch.empty(n * T, dtype=torch.uint8, device=dev)
-        eng.null_simulate_dev(77, rb, re, ram, buf)
+        e.null_simulate_dev(77, rb, re, ram, buf)
         torch.cuda.synchronize()
         got = buf.cpu().numpy().reshape(re - rb, 2, T, ram)
-        want, _ = eng.simulate(77, rb * 2 * ram, n)              # [T, n], column s <-> g = rb * 2 * ram + s
+        want, _ = e.simulate(77, rb * 2 * ram, n)                # [T, n], column s <-> g = rb * 2 * ram + s
         want = want.reshape(T, re - rb, 2, ram).transpose(1, 2, 0, 3)
         assert np.array_equal(got, want)
     code = textwrap.dedent("""
