@@ -1197,10 +1197,11 @@ hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0
   const bool lds = !gather && m.S0 > 4 && bufb <= (size_t)kSimLdsChunks * 256 * 16;
   for (size_t s0 = 0; s0 < nsites; s0 += chunk) {
     const size_t n = std::min(chunk, nsites - s0);
-    // tables in LDS, four sites per thread (a node's tables are copied once per 1 024 sites), when that fills the chip
-    // several times over; below that (cfg3: 500 000 sites = 488 such workgroups on 256 CUs) its two barriers per node are
-    // a floor of ~1 ms and the gather kernel, one thread per site and no barrier, is quicker
-    if (lds && n >= (size_t)256 * 4 * 2048) {
+    // tables in LDS (a node's tables are copied once per 1 024 sites) from about two workgroups per CU on (cfg3's 500 000
+    // sites: 0.61 ms against the gather kernel's 0.66); a workgroup's walk over the nodes with two barriers each takes
+    // ~0.6 ms however few there are, so below that the gather kernel, one thread per site and no barrier, is quicker
+    static const size_t lds_min = [] { const char* e = getenv("CMX_SIM_LDS_MIN"); return e ? (size_t)atoll(e) : (size_t)450000; }();   // (override: A/B timing)
+    if (lds && n >= lds_min) {
       // 512 threads with two sites each: 56 registers = eight waves per SIMD (the kernel is bound by vector issue -- half of
       // it Philox's quarter-rate multiplies -- once enough waves hide the LDS round trips: four sites per thread at three
       // waves per SIMD 14.8 ms per target step, at five 11.6, this shape 10.2)
