@@ -300,3 +300,35 @@ def test_mica_unknowns_at_size_mixed_tiles_and_intra_layout():
         blk = m[i0:i0 + 8, j0:j0 + 8]
         keep = np.add.outer(np.arange(i0, i0 + 8), np.zeros(8, int)) < np.add.outer(np.zeros(8, int), np.arange(j0, j0 + 8))
         assert np.max(np.abs(o["mi"][keep] - blk[keep])) < 1e-11
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 65, 130])
+def test_rows_of_tiny_alignments_and_tiny_nulls(n):
+    """The row passes cut a row into eight runs of whole 64-column steps and the p-value lookup cuts a class into bins:
+    alignments of one, two and three sites (zero, one, three pairs: most runs empty), one and two 64-column steps per row,
+    a null of seven values (no bins at all), an empty null, a capacity of zero (count only) -- all against the dense
+    oracle path."""
+    eng, om, aln = _protein_case(max(n, 8))
+    r = eng.map_sites(aln)
+    r = {k: v[:n] for k, v in r.items()}
+    st = oracle.pair_stats_intra(0, r["counts"]) if n > 1 else np.zeros((1, 1))
+    iu = np.triu_indices(n, 1)
+    rng = np.random.default_rng(n)
+    for nnull in (0, 7, 900):
+        ns = rng.normal(0.0, 0.3, nnull)
+        nm = rng.uniform(0.0, float(r["norm"].max()), nnull)
+        rows, cnt = eng.intra_rows(0, r["counts"], r["rate_class"], r["post_rate"], r["norm"], ns if nnull else None, nm if nnull else None, 3)
+        assert cnt == n * (n - 1) // 2 == len(rows)
+        assert np.array_equal(rows["i"], iu[0]) and np.array_equal(rows["j"], iu[1])
+        if n > 1:
+            rel_close(rows["stat"], st[iu], 1e-9, 1e-12)
+            if nnull:
+                opv, ons = oracle.intra_pvalues(st, r["norm"], 3, ns, nm)
+                # (the statistic differs from the oracle's in the last bits: compare the counts where no null value is that close)
+                assert np.array_equal(rows["nsim"], ons[iu])
+                far = np.array([np.min(np.abs(ns - v)) > 1e-9 for v in rows["stat"]])
+                assert np.array_equal(rows["pvalue"][far], opv[iu][far], equal_nan=True)
+            else:
+                assert np.isnan(rows["pvalue"]).all() and (rows["nsim"] == 0).all()
+        none, cnt0 = eng.intra_rows(0, r["counts"], r["rate_class"], r["post_rate"], r["norm"], capacity=0)
+        assert cnt0 == cnt and len(none) == 0
