@@ -1108,6 +1108,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     cls[k] = draw_index(philox_uniform(seed, g[k], 0), m.cum_probs, C0);
     if (on[k]) states[(size_t)m.root * n + jj] = (uint8_t)draw_index(philox_uniform(seed, g[k], 1), m.cum_pi, S0);
   }
+  // this thread's pieces of a node's tables: where they start for node 0, and the node's stride (sums: S0 * S0 doubles,
+  // guides: S0 * 32 bytes) -- loop-invariant, so that the node loop adds one 24-bit product instead of dividing and
+  // multiplying per node (quarter-rate 32-bit multiplies were a quarter of the loop's vector cycles)
+  const uint8_t* psrc[NCH];
+  unsigned pstride[NCH];
+  bool pok[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int q = tid + NT * i;
+    pok[i] = q < nch && q * 16 < tabb + guib;
+    psrc[i] = reinterpret_cast<const uint8_t*>(piece_src(0, pok[i] ? q : 0));
+    pstride[i] = (unsigned)(q * 16 < tabb ? S0 * rowb : S0 * 32);
+  }
+  int crow[SPT];
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) crow[k] = cls[k] * S0;
   // tables of the first node
   const cmx_cint ord = (cmx_cint)m.simord;
   int buf = 0;
@@ -1123,13 +1139,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
       const int nnode = ord[it + 1];
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int q = tid + NT * i;
-        if (q < nch && q * 16 < tabb + guib) nxt[i] = *piece_src(nnode, q);
+        if (pok[i]) nxt[i] = *reinterpret_cast<const cmx_i4*>(psrc[i] + __umul24((unsigned)nnode, pstride[i]));
       }
     }
     const double* T_ = reinterpret_cast<const double*>(sim_smem + (size_t)buf * bufb);
     const uint8_t* G_ = sim_smem + (size_t)buf * bufb + tabb;
-    const int par = m.parent[node], tx = m.taxon_of[node];
+    const int par = ((cmx_cint)m.parent)[node], tx = ((cmx_cint)m.taxon_of)[node];   // scalar loads: the products with n and blk stay scalar
     // the SPT searches side by side: parents' states, uniforms, guide bytes, then kSimStep running sums per search and round
     // trip (a `while (u >= cum[idx]) ++idx` per site is a chain of dependent LDS reads under a divergent branch: 36
     // branches and 110 scalar instructions per wave and draw).  Reads past a row's end stay inside the buffer (the guide
@@ -1143,9 +1158,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     for (int k = 0; k < SPT; ++k) u[k] = philox_uniform(seed, g[k], 2u + (uint32_t)node);
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
-      const int row = cls[k] * S0 + x[k];
+      const int row = crow[k] + x[k];
       idx[k] = G_[row * 32 + (int)(u[k] * 32.0)];
-      cum[k] = T_ + row * S0;
+      cum[k] = T_ + __mul24(row, S0);
     }
     bool any;
     do {
