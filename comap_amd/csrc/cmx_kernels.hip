@@ -299,22 +299,39 @@ __device__ __forceinline__ void read_vec_lds(const uint8_t* lds /* wave-uniform 
   }
 }
 
-// Philox2x32-10 (Random123): counter = (g_lo, g_hi[14:0] | draw << 15), key = seed_lo ^ seed_hi * 0x9E3779B9 ^ 'CMX2';
-// the 64 output bits give one 53-bit uniform.  Same scheme as oracle/oracle.c (DESIGN.md "RNG").  One 32 x 32 -> 64
-// multiply per round: the 4x32 variant (two per round, 128 output bits of which one draw uses 64) cost the fused null
-// kernel 4.7 % of its time in quarter-rate integer multiplies.  g < 2^47, draw < 2^17.
-__device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
+// Philox2x32-10 (Random123): counter = (g_lo, g_hi[14:0] | draw << 15), key = seed_lo ^ seed_hi * 0x9E3779B9 ^ 'CMX2'.
+// Same scheme as oracle/oracle.c (DESIGN.md "RNG").  One 32 x 32 -> 64 multiply per round: the 4x32 variant (two per
+// round, 128 output bits) cost the fused null kernel 4.7 % of its time in quarter-rate integer multiplies.
+// g < 2^47, draw < 2^17.
+//   draw 0 (rate class / continuous rate) and 1 (root state): counter from the site's g, the 64 output bits give one
+//   53-bit uniform (philox_uniform);
+//   draw 2 + node (state at the lower end of a branch): the sites 2k and 2k + 1 SHARE the call with counter g >> 1 and
+//   take its first and second output word as a 32-bit uniform (philox_node_uniform): the node draws are 99 % of a
+//   simulation's calls, a category's probability is resolved to 2^-32 either way, and a thread that holds both sites of
+//   a pair (simulate_lds_kernel) makes one call for two draws.
+__device__ __forceinline__ void philox_words(uint64_t seed, uint64_t g, uint32_t draw, uint32_t& w0, uint32_t& w1) {
   uint32_t c0 = (uint32_t)g, c1 = ((uint32_t)(g >> 32) & 0x7fffu) | (draw << 15);
   uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ 0x434d5832u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0;   // one v_mad_u64_u32 instead of v_mul_hi + v_mul_lo
-    c0 = (uint32_t)(p >> 32) ^ k ^ c1;
+    c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p >> 32), k, c1, 0x96);   // three-way xor in one v_bitop3_b32
     c1 = (uint32_t)p;
     k += 0x9E3779B9u;
   }
+  w0 = c0;
+  w1 = c1;
+}
+__device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
+  uint32_t c0, c1;
+  philox_words(seed, g, draw, c0, c1);
   const uint64_t bits = (((uint64_t)c0 << 32) | c1) >> 11;
   return (double)bits * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double philox_node_uniform(uint64_t seed, uint64_t g, uint32_t node) {
+  uint32_t w0, w1;
+  philox_words(seed, g >> 1, 2u + node, w0, w1);
+  return (double)((g & 1) ? w1 : w0) * (1.0 / 4294967296.0);
 }
 
 template <class CumPtr>
@@ -989,7 +1006,7 @@ __global__ void simulate_kernel(const DevModel m, uint64_t seed, uint64_t g0, si
   for (int node = m.nn - 2; node >= 0; --node) {
     const int x = states[(size_t)m.parent[node] * ld + j];
     const size_t row = ((size_t)c * m.nn + node) * S + x;
-    const int y = draw_guided(philox_uniform(seed, g, 2u + (uint32_t)node), m.CP + row * S, m.CPG + row * 32, S);
+    const int y = draw_guided(philox_node_uniform(seed, g, (uint32_t)node), m.CP + row * S, m.CPG + row * 32, S);
     states[(size_t)node * ld + j] = (uint8_t)y;
     const int tx = m.taxon_of[node];
     if (tx >= 0) aln[(size_t)tx * ld + j] = (uint8_t)y;
@@ -1031,7 +1048,7 @@ __global__ __launch_bounds__(256) void simulate_blocked_kernel(const DevModel m,
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) x[jj] = states[(size_t)q[4 + jj] * n + j];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) u[jj] = philox_uniform(seed, g, 2u + (uint32_t)q[jj]);
+    for (int jj = 0; jj < 4; ++jj) u[jj] = philox_node_uniform(seed, g, (uint32_t)q[jj]);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       row[jj] = ((size_t)c * m.nn + q[jj]) * S0 + x[jj];
@@ -1099,7 +1116,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
   bool on[SPT];
 #pragma unroll
   for (int k = 0; k < SPT; ++k) {
-    j[k] = ((size_t)blockIdx.x * SPT + k) * NT + tid;
+    // a thread's sites are neighbours: sites 2 q and 2 q + 1 share a Philox call for their node draws (g0 + s0 is even:
+    // launch_simulate_blocked checks it), and their states are neighbouring bytes
+    j[k] = (size_t)blockIdx.x * SPT * NT + (size_t)(SPT * tid + k);
     on[k] = j[k] < n;
     const size_t jj = on[k] ? j[k] : n - 1, s = s0 + jj;
     j[k] = jj;
@@ -1155,7 +1174,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 #pragma unroll
     for (int k = 0; k < SPT; ++k) x[k] = states[(size_t)par * n + j[k]];
 #pragma unroll
-    for (int k = 0; k < SPT; ++k) u[k] = philox_uniform(seed, g[k], 2u + (uint32_t)node);
+    for (int k = 0; k < SPT; k += 2) {
+      // (g[k] is even and g[k + 1] its neighbour -- or g[k] again, the clamped slot behind the last site of an odd n)
+      uint32_t w0, w1;
+      philox_words(seed, g[k] >> 1, 2u + (uint32_t)node, w0, w1);
+      u[k] = (double)((g[k] & 1) ? w1 : w0) * (1.0 / 4294967296.0);
+      if (k + 1 < SPT) {
+        u[k + 1] = (double)((g[k + 1] & 1) ? w1 : w0) * (1.0 / 4294967296.0);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
       const int row = crow[k] + x[k];
@@ -1216,7 +1243,7 @@ hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0
     // sites: 0.61 ms against the gather kernel's 0.66); a workgroup's walk over the nodes with two barriers each takes
     // ~0.6 ms however few there are, so below that the gather kernel, one thread per site and no barrier, is quicker
     static const size_t lds_min = [] { const char* e = getenv("CMX_SIM_LDS_MIN"); return e ? (size_t)atoll(e) : (size_t)450000; }();   // (override: A/B timing)
-    if (lds && n >= lds_min) {
+    if (lds && n >= lds_min && ((g0 + s0) & 1) == 0) {   // (the LDS kernel pairs the sites 2 k, 2 k + 1 of the global numbering)
       // 512 threads with two sites each: 56 registers = eight waves per SIMD (the kernel is bound by vector issue -- half of
       // it Philox's quarter-rate multiplies -- once enough waves hide the LDS round trips: four sites per thread at three
       // waves per SIMD 14.8 ms per target step, at five 11.6, this shape 10.2)
@@ -1312,7 +1339,7 @@ __global__ void simulate_continuous_kernel(const DevModel m, uint64_t seed, uint
   states[(size_t)m.root * ld + j] = (uint8_t)draw_index(philox_uniform(seed, g, 1), m.cum_pi, S);
   for (int node = m.nn - 2; node >= 0; --node) {
     const int x = states[(size_t)m.parent[node] * ld + j];
-    const double u = philox_uniform(seed, g, 2u + (uint32_t)node);
+    const double u = philox_node_uniform(seed, g, (uint32_t)node);
     const size_t mo = (size_t)m.model_of[node];
     const double *V = m.eigV + mo * S * S + (size_t)x * S, *Vi = m.eigVi + mo * S * S, *lam = m.eigLam + mo * S;
     const double rt = r * m.blen[node];

@@ -645,7 +645,9 @@ int orc_map_sites_marginal(int nn, const int* parent, const double* blen, int T,
  * implementations; the product and this oracle share a counter-based scheme instead (Philox2x32-10, Random123):
  *   key = seed_lo ^ seed_hi * 0x9E3779B9 ^ 'CMX2'; counter = (g_lo, g_hi[14:0] | draw << 15) with g the global index of
  *   the simulated site and draw = 0 (rate class), 1 (root state), 2 + node (state at the lower end of branch `node`);
- *   u = ((r0 << 32 | r1) >> 11) * 2^-53;  index = #{ j < n-1 : u >= cum[j] } with cum the running sum.
+ *   draws 0 and 1: u = ((r0 << 32 | r1) >> 11) * 2^-53.  Node draws: the sites 2k and 2k + 1 share the call with counter
+ *   g >> 1 and take r0 resp. r1 as a 32-bit uniform, u = r * 2^-32 (orc_node_uniform) -- they are 99 % of the calls, and a
+ *   device thread holding both sites makes one call for two draws.  index = #{ j < n-1 : u >= cum[j] }, cum the running sum.
  *   (Philox4x32-10 below serves the Mica permutation test.) */
 static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                  uint32_t* out) {
@@ -659,7 +661,7 @@ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-double orc_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
+static inline void philox2x32_10(uint64_t seed, uint64_t g, uint32_t draw, uint32_t* w) {
   uint32_t c0 = (uint32_t)g, c1 = ((uint32_t)(g >> 32) & 0x7fffu) | (draw << 15);
   uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ 0x434d5832u;
   for (int r = 0; r < 10; r++) {
@@ -669,8 +671,19 @@ double orc_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
     c0 = n0;
     k += 0x9E3779B9u;
   }
-  uint64_t bits = (((uint64_t)c0 << 32) | c1) >> 11;
+  w[0] = c0;
+  w[1] = c1;
+}
+double orc_uniform(uint64_t seed, uint64_t g, uint32_t draw) {
+  uint32_t w[2];
+  philox2x32_10(seed, g, draw, w);
+  uint64_t bits = (((uint64_t)w[0] << 32) | w[1]) >> 11;
   return (double)bits * (1.0 / 9007199254740992.0);
+}
+double orc_node_uniform(uint64_t seed, uint64_t g, uint32_t node) {
+  uint32_t w[2];
+  philox2x32_10(seed, g >> 1, 2u + node, w);
+  return (double)w[g & 1] * (1.0 / 4294967296.0);
 }
 
 static int draw_index(double u, const double* p, int n) {
@@ -706,7 +719,7 @@ void orc_simulate(int nn, const int* parent, const double* blen, int T, const in
     st[root] = (uint8_t)draw_index(orc_uniform(seed, g, 1), pi, S);
     for (int node = nn - 2; node >= 0; node--) { /* parents have larger ids (post-order) */
       int x = st[parent[node]];
-      st[node] = (uint8_t)draw_index(orc_uniform(seed, g, 2u + (uint32_t)node), P + ((size_t)node * C + c) * S2 + (size_t)x * S, S);
+      st[node] = (uint8_t)draw_index(orc_node_uniform(seed, g, (uint32_t)node), P + ((size_t)node * C + c) * S2 + (size_t)x * S, S);
       if (taxon_of[node] >= 0) aln[(size_t)taxon_of[node] * n + j] = st[node];
     }
   }
@@ -797,7 +810,7 @@ void orc_simulate_continuous(int nn, const int* parent, const double* blen, int 
     for (int node = nn - 2; node >= 0; node--) {
       int x = st[parent[node]];
       orc_transition(S, lam, V, Vinv, blen[node] * r, P);   /* getPij_t(d * rate) of this very site */
-      st[node] = (uint8_t)draw_index(orc_uniform(seed, g, 2u + (uint32_t)node), P + (size_t)x * S, S);
+      st[node] = (uint8_t)draw_index(orc_node_uniform(seed, g, (uint32_t)node), P + (size_t)x * S, S);
       if (taxon_of[node] >= 0) aln[(size_t)taxon_of[node] * n + j] = st[node];
     }
   }

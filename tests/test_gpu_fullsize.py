@@ -76,7 +76,7 @@ def test_configuration3_null_125x2000_sharding_and_pvalue_rule():
     p, n, s = pv[iu], ns[iu], st[iu]
     ok = ~np.isnan(p)
     k = p[ok] * (n[ok] + 1)
-    assert np.max(np.abs(k - np.rint(k))) < 1e-6 and k.min() >= 1 and (k <= n[ok] + 1).all()
+    assert np.max(np.abs(k - np.rint(k))) < 1e-6 and np.rint(k).min() >= 1 and (np.rint(k) <= n[ok] + 1).all()
     nm = np.minimum(m["norm"][iu[0]], m["norm"][iu[1]])
     top = nm == m["norm"].max()
     assert np.isnan(p[top]).all() and (n[top] == 0).all()
