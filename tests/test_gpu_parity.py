@@ -1053,7 +1053,7 @@ def test_inter_rows_on_the_device_match_the_reference_loop(kind):
         e1.inter_rows(kind, m1, {k: v[:60] for k, v in m2.items()}, engine.InterFilters(independent_comparisons=True), threshold=thr)
 
 
-@pytest.mark.parametrize("T,n1,n2", [(40, 50, 77), (100, 37, 205), (256, 130, 260), (300, 40, 50)])
+@pytest.mark.parametrize("T,n1,n2", [(40, 50, 77), (100, 37, 205), (200, 61, 100), (256, 130, 260), (300, 40, 50)])
 def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
     """The protein path up to 256 taxa (cmx_mica4.hip: plain and weighted instantiation, operand registers for 2 / 4 / 8
     k-steps) and above (eight-wave kernel): column counts that are no multiple of the 12 x 3 tile, runs longer than one
