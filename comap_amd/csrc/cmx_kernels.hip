@@ -1133,7 +1133,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // launch_simulate_blocked checks it), and their states are neighbouring bytes
     j[k] = (size_t)blockIdx.x * SPT * NT + (size_t)(SPT * tid + k);
     on[k] = j[k] < n;
-    const size_t jj = on[k] ? j[k] : n - 1, s = s0 + jj;
+    // (n is even: a thread's two sites are both inside or both outside; the outside ones repeat the last pair)
+    const size_t jj = on[k] ? j[k] : n - 2 + (k & 1), s = s0 + jj;
     j[k] = jj;
     g[k] = g0 + s;
     out[k] = aln + (s / blk) * (size_t)m.T * blk + s % blk;
@@ -1184,8 +1185,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     int x[SPT], idx[SPT];
     double u[SPT];
     const double* cum[SPT];
+    // the states of a thread's two sites are neighbouring bytes at an even address (n, j[0] even): one 16-bit access
+    static_assert(SPT % 2 == 0, "sites in pairs");
+    const uint8_t* sp = states + (size_t)par * n;
 #pragma unroll
-    for (int k = 0; k < SPT; ++k) x[k] = states[(size_t)par * n + j[k]];
+    for (int k = 0; k < SPT; k += 2) {
+      const unsigned xx = *reinterpret_cast<const unsigned short*>(sp + (unsigned)j[k]);
+      x[k] = (int)(xx & 0xffu);
+      x[k + 1] = (int)(xx >> 8);
+    }
 #pragma unroll
     for (int k = 0; k < SPT; k += 2) {
       // (g[k] is even and g[k + 1] its neighbour -- or g[k] again, the clamped slot behind the last site of an odd n)
@@ -1223,11 +1231,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         any |= adv == kSimStep;
       }
     } while (any);
+    uint8_t* sn = states + (size_t)node * n;
 #pragma unroll
-    for (int k = 0; k < SPT; ++k)
+    for (int k = 0; k < SPT; k += 2)
       if (on[k]) {
-        states[(size_t)node * n + j[k]] = (uint8_t)idx[k];
-        if (tx >= 0) out[k][(size_t)tx * blk] = (uint8_t)idx[k];
+        *reinterpret_cast<unsigned short*>(sn + (unsigned)j[k]) = (unsigned short)(idx[k] | (idx[k + 1] << 8));
+        if (tx >= 0) {
+          out[k][(size_t)tx * blk] = (uint8_t)idx[k];
+          out[k + 1][(size_t)tx * blk] = (uint8_t)idx[k + 1];
+        }
       }
     if (more) {
       __syncthreads();   // nobody reads the other buffer any more (it held the previous node)
@@ -1256,7 +1268,7 @@ hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0
     // sites: 0.61 ms against the gather kernel's 0.66); a workgroup's walk over the nodes with two barriers each takes
     // ~0.6 ms however few there are, so below that the gather kernel, one thread per site and no barrier, is quicker
     static const size_t lds_min = [] { const char* e = getenv("CMX_SIM_LDS_MIN"); return e ? (size_t)atoll(e) : (size_t)450000; }();   // (override: A/B timing)
-    if (lds && n >= lds_min && ((g0 + s0) & 1) == 0) {   // (the LDS kernel pairs the sites 2 k, 2 k + 1 of the global numbering)
+    if (lds && n >= lds_min && ((g0 + s0) & 1) == 0 && (n & 1) == 0) {   // (the LDS kernel pairs the sites 2 k, 2 k + 1 of the global numbering)
       // 512 threads with two sites each: 56 registers = eight waves per SIMD (the kernel is bound by vector issue -- half of
       // it Philox's quarter-rate multiplies -- once enough waves hide the LDS round trips: four sites per thread at three
       // waves per SIMD 14.8 ms per target step, at five 11.6, this shape 10.2)
