@@ -1237,8 +1237,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
       if (on[k]) {
         *reinterpret_cast<unsigned short*>(sn + (unsigned)j[k]) = (unsigned short)(idx[k] | (idx[k + 1] << 8));
         if (tx >= 0) {
-          out[k][(size_t)tx * blk] = (uint8_t)idx[k];
-          out[k + 1][(size_t)tx * blk] = (uint8_t)idx[k + 1];
+          if (((blk | (size_t)(uintptr_t)aln) & 1) == 0) {   // (an even rep_ram: the pair sits in one replicate block, at an even address)
+            *reinterpret_cast<unsigned short*>(out[k] + (size_t)tx * blk) = (unsigned short)(idx[k] | (idx[k + 1] << 8));
+          } else {
+            out[k][(size_t)tx * blk] = (uint8_t)idx[k];
+            out[k + 1][(size_t)tx * blk] = (uint8_t)idx[k + 1];
+          }
         }
       }
     if (more) {
