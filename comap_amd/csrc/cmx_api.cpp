@@ -7,7 +7,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,8 +24,50 @@ thread_local std::string g_create_error;
 
 struct DevBuf {
   void* p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0;     // capacity the callers may use (the allocation is kGuardBytes longer under the guard)
+  size_t logical = 0;   // guard only: what the last caller asked for; the canary sits at [logical, logical + kGuardBytes)
 };
+
+// CMX_SCRATCH_GUARD=1 (or cmx_debug_scratch_guard(1)): every scratch buffer, per-wave workspace and temporary is
+// allocated kGuardBytes longer, the bytes after what the caller asked for hold a canary, and scratch() (before it hands a
+// buffer out again), cmx_synchronize, cmx_scratch_check and cmx_ctx_destroy verify it and name the buffer that was
+// written past its end.  Round 3: a scratch buffer sized [nn][rep_ram] for a kernel that writes [nn][nrep * rep_ram] lived
+// through a round of green tests on allocator slack.  Debug mode: every check synchronises the device.
+constexpr size_t kGuardBytes = 4096;
+constexpr int kGuardByte = 0xC5;
+std::atomic<int> g_guard{-1};   // -1: not decided yet (environment read at the first context)
+std::mutex g_guard_mu;
+std::vector<std::string> g_guard_failures;   // buffers found trampled, in the order found (process-wide)
+std::map<std::string, size_t> g_guard_shrink;   // test hook: logical size override per buffer name
+
+bool guard_on() {
+  int g = g_guard.load();
+  if (g < 0) {
+    const char* e = getenv("CMX_SCRATCH_GUARD");
+    g = (e && e[0] == '1') ? 1 : 0;
+    g_guard.store(g);
+  }
+  return g == 1;
+}
+
+void guard_record(const std::string& what) {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guard_failures.push_back(what);
+  std::fprintf(stderr, "CMX_SCRATCH_GUARD: %s\n", what.c_str());
+}
+
+hipError_t guard_arm(void* base, size_t logical) {
+  return hipMemset(static_cast<char*>(base) + logical, kGuardByte, kGuardBytes);
+}
+
+// true when the canary after `logical` bytes is intact; the device must be idle
+bool guard_intact(const void* base, size_t logical, size_t* first_bad) {
+  static thread_local std::vector<unsigned char> h(kGuardBytes);
+  if (hipMemcpy(h.data(), static_cast<const char*>(base) + logical, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  for (size_t i = 0; i < kGuardBytes; ++i)
+    if (h[i] != (unsigned char)kGuardByte) { if (first_bad) *first_bad = i; return false; }
+  return true;
+}
 }  // namespace
 
 struct cmx_ctx {
@@ -38,6 +82,8 @@ struct cmx_ctx {
   size_t ws_bytes = 0;
   std::vector<void*> model_allocs;
   std::map<std::string, DevBuf> scratch;
+  struct GuardedFixed { std::string name; void* p; size_t bytes; };
+  std::vector<GuardedFixed> guarded_fixed;   // CMX_SCRATCH_GUARD: the per-wave workspaces, each with a canary after its last byte
   uint32_t* d_default_masks = nullptr;
   unsigned stat_mean_turn = 0;
   // host copies of asynchronously uploaded parameter blocks (mean vectors, MI bounds): the source of a hipMemcpyAsync must
@@ -85,9 +131,61 @@ cmx_status upload(cmx_ctx* ctx, const std::vector<T>& h, const T** d) {
   return CMX_OK;
 }
 
+// verify every guarded buffer of a context (device idle); the first trampled one is named in ctx->err
+cmx_status guard_verify_all(cmx_ctx* ctx) {
+  if (!guard_on()) return CMX_OK;
+  cmx_status rc = CMX_OK;
+  auto bad = [&](const std::string& name, size_t logical, size_t off) {
+    const std::string msg = "buffer '" + name + "' was written past its end (" + std::to_string(logical) + " bytes asked for, first bad byte at +" + std::to_string(off) + ")";
+    guard_record(msg);
+    if (rc == CMX_OK) { ctx->err = "CMX_SCRATCH_GUARD: " + msg; rc = CMX_ERR_INTERNAL; }
+  };
+  size_t off = 0;
+  for (auto& kv : ctx->scratch)
+    if (kv.second.p && !guard_intact(kv.second.p, kv.second.logical, &off)) {
+      bad("scratch:" + kv.first, kv.second.logical, off);
+      (void)guard_arm(kv.second.p, kv.second.logical);   // report an overflow once, not at every later check
+    }
+  for (auto& f : ctx->guarded_fixed)
+    if (!guard_intact(f.p, f.bytes, &off)) {
+      bad(f.name, f.bytes, off);
+      (void)guard_arm(f.p, f.bytes);
+    }
+  return rc;
+}
+
 // grow-only named scratch buffers (allocated on first use, released with the context)
 cmx_status scratch(cmx_ctx* ctx, const char* name, size_t bytes, void** out) {
   DevBuf& b = ctx->scratch[name];
+  if (guard_on()) {
+    // the previous user's canary is checked before the buffer is handed out again (it may move with the size asked for)
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    size_t off = 0;
+    if (b.p && !guard_intact(b.p, b.logical, &off)) {
+      const std::string msg = std::string("buffer 'scratch:") + name + "' was written past its end (" + std::to_string(b.logical) +
+                              " bytes asked for, first bad byte at +" + std::to_string(off) + ")";
+      guard_record(msg);
+      (void)guard_arm(b.p, b.logical);
+      return fail(ctx, CMX_ERR_INTERNAL, "CMX_SCRATCH_GUARD: " + msg);
+    }
+    size_t logical = bytes ? bytes : 16;
+    {
+      std::lock_guard<std::mutex> lk(g_guard_mu);
+      auto it = g_guard_shrink.find(name);
+      if (it != g_guard_shrink.end() && it->second < logical) logical = it->second;   // test hook: pretend the caller asked for less
+    }
+    if (b.bytes < bytes || !b.p) {
+      if (b.p) HIP_TRY(ctx, hipFree(b.p));
+      b.p = nullptr;
+      b.bytes = 0;
+      HIP_TRY(ctx, hipMalloc(&b.p, (bytes ? bytes : 16) + kGuardBytes));
+      b.bytes = bytes;
+    }
+    b.logical = logical;
+    HIP_TRY(ctx, guard_arm(b.p, b.logical));
+    *out = b.p;
+    return CMX_OK;
+  }
   if (b.bytes < bytes) {
     if (b.p) HIP_TRY(ctx, hipFree(b.p));
     b.p = nullptr;
@@ -101,10 +199,29 @@ cmx_status scratch(cmx_ctx* ctx, const char* name, size_t bytes, void** out) {
 
 struct TmpDev {  // RAII device temporaries for the host-pointer entry points
   std::vector<void*> ptrs;
-  ~TmpDev() { for (void* p : ptrs) (void)hipFree(p); }
+  std::vector<size_t> sizes;   // guard only
+  ~TmpDev() {
+    if (!sizes.empty()) {
+      (void)hipDeviceSynchronize();
+      for (size_t i = 0; i < ptrs.size(); ++i) {
+        size_t off = 0;
+        if (!guard_intact(ptrs[i], sizes[i], &off))
+          guard_record("temporary #" + std::to_string(i) + " of a host-pointer entry point was written past its end (" +
+                       std::to_string(sizes[i]) + " bytes asked for, first bad byte at +" + std::to_string(off) + ")");
+      }
+    }
+    for (void* p : ptrs) (void)hipFree(p);
+  }
   hipError_t alloc(void** p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-    if (e == hipSuccess) ptrs.push_back(*p);
+    if (!bytes) bytes = 16;
+    const bool g = guard_on();
+    hipError_t e = hipMalloc(p, bytes + (g ? kGuardBytes : 0));
+    if (e != hipSuccess) return e;
+    ptrs.push_back(*p);
+    if (g) {
+      sizes.push_back(bytes);
+      e = guard_arm(*p, bytes);
+    }
     return e;
   }
 };
@@ -233,12 +350,22 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       const size_t bC = w * 2 * h.B * h.K * ks * sizeof(double);
       const size_t bP = w * h.dC * h.B * h.K * ks * sizeof(double);
       const size_t bS = w * h.nn * ks, bA = w * h.T * ks;
-      HIP_TRY(ctx, hipMalloc((void**)&ws->D, bD));
-      HIP_TRY(ctx, hipMalloc((void**)&ws->U, bD));
-      HIP_TRY(ctx, hipMalloc((void**)&ws->cnt, bC));
-      HIP_TRY(ctx, hipMalloc((void**)&ws->part, bP));
-      HIP_TRY(ctx, hipMalloc((void**)&ws->st, bS));
-      HIP_TRY(ctx, hipMalloc((void**)&ws->aln, bA));
+      const bool g = guard_on();
+      auto one = [&](const char* nm, void** p, size_t bytes) -> cmx_status {
+        HIP_TRY(ctx, hipMalloc(p, bytes + (g ? kGuardBytes : 0)));
+        if (g) {
+          HIP_TRY(ctx, guard_arm(*p, bytes));
+          ctx->guarded_fixed.push_back({std::string(ws == &ctx->ws ? "workspace:" : "workspace_obs:") + nm, *p, bytes});
+        }
+        return CMX_OK;
+      };
+      cmx_status sa;
+      if ((sa = one("D", (void**)&ws->D, bD)) != CMX_OK) return sa;
+      if ((sa = one("U", (void**)&ws->U, bD)) != CMX_OK) return sa;
+      if ((sa = one("cnt", (void**)&ws->cnt, bC)) != CMX_OK) return sa;
+      if ((sa = one("part", (void**)&ws->part, bP)) != CMX_OK) return sa;
+      if ((sa = one("st", (void**)&ws->st, bS)) != CMX_OK) return sa;
+      if ((sa = one("aln", (void**)&ws->aln, bA)) != CMX_OK) return sa;
       ws->waves = (int)w;
       *bytes += 2 * bD + bC + bP + bS + bA;
       return CMX_OK;
@@ -256,6 +383,8 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
 
 void cmx_ctx_destroy(cmx_ctx* ctx) {
   if (!ctx) return;
+  if (guard_on() && hipSetDevice(ctx->device) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
+    (void)guard_verify_all(ctx);   // destroy cannot fail: findings go to stderr and to cmx_debug_scratch_guard_failures
   for (void* p : ctx->model_allocs) (void)hipFree(p);
   for (auto& kv : ctx->scratch) if (kv.second.p) (void)hipFree(kv.second.p);
   for (Workspace* ws : {&ctx->ws, &ctx->ws_obs}) {
@@ -315,7 +444,40 @@ cmx_status cmx_synchronize(cmx_ctx* ctx) {
   if (!ctx) return CMX_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
-  return CMX_OK;
+  return guard_verify_all(ctx);
+}
+
+cmx_status cmx_scratch_check(cmx_ctx* ctx) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (!guard_on()) return fail(ctx, CMX_ERR_UNSUPPORTED, "the scratch guard is off (CMX_SCRATCH_GUARD=1 or cmx_debug_scratch_guard(1) before the context is created)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  return guard_verify_all(ctx);
+}
+
+int cmx_debug_scratch_guard(int on) {
+  const int was = guard_on() ? 1 : 0;
+  if (on >= 0) g_guard.store(on ? 1 : 0);
+  return was;
+}
+
+size_t cmx_debug_scratch_guard_failures(char* buf, size_t cap, int clear) {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  const size_t n = g_guard_failures.size();
+  if (buf && cap) {
+    std::string all;
+    for (const std::string& f : g_guard_failures) { all += f; all += '\n'; }
+    std::snprintf(buf, cap, "%s", all.c_str());
+  }
+  if (clear) g_guard_failures.clear();
+  return n;
+}
+
+void cmx_debug_scratch_shrink(const char* name, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  if (!name) { g_guard_shrink.clear(); return; }
+  if (bytes == 0) g_guard_shrink.erase(name);
+  else g_guard_shrink[name] = bytes;
 }
 
 // nijt.average = no (cmx_set_mapping_options): counts and norms of the sites just mapped are replaced by those of

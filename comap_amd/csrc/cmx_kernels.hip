@@ -1272,7 +1272,9 @@ hipError_t launch_simulate_blocked(const DevModel& m, uint64_t seed, uint64_t g0
     // sites: 0.61 ms against the gather kernel's 0.66); a workgroup's walk over the nodes with two barriers each takes
     // ~0.6 ms however few there are, so below that the gather kernel, one thread per site and no barrier, is quicker
     static const size_t lds_min = [] { const char* e = getenv("CMX_SIM_LDS_MIN"); return e ? (size_t)atoll(e) : (size_t)450000; }();   // (override: A/B timing)
-    if (lds && n >= lds_min && ((g0 + s0) & 1) == 0 && (n & 1) == 0) {   // (the LDS kernel pairs the sites 2 k, 2 k + 1 of the global numbering)
+    // (the LDS kernel pairs the sites 2 k, 2 k + 1 of the global numbering and stores a pair's symbols as one 16-bit word at
+    // column s0 + j of its replicate block: g0, s0 and n all have to be even, not just g0 + s0)
+    if (lds && n >= lds_min && (g0 & 1) == 0 && (s0 & 1) == 0 && (n & 1) == 0) {
       // 512 threads with two sites each: 56 registers = eight waves per SIMD (the kernel is bound by vector issue -- half of
       // it Philox's quarter-rate multiplies -- once enough waves hide the LDS round trips: four sites per thread at three
       // waves per SIMD 14.8 ms per target step, at five 11.6, this shape 10.2)

@@ -57,6 +57,7 @@ EXPORTS = [
     "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_permutation_test_masks", "cmx_mica_permutation_test_masks_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
     "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups", "cmx_debug_candidate_cursor",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
+    "cmx_scratch_check", "cmx_debug_scratch_guard", "cmx_debug_scratch_guard_failures", "cmx_debug_scratch_shrink",
 ]
 # clustering.distance / clustering.method options of the reference (CoMap/CoMap.cpp:402-428, :460-472)
 DIST_CORRELATION, DIST_COMPENSATION, DIST_EUCLIDIAN = range(3)
@@ -66,6 +67,29 @@ DIST_BY_NAME = {"cor": DIST_CORRELATION, "Correlation": DIST_CORRELATION, "comp"
 LINK_BY_NAME = {"complete": LINK_COMPLETE, "single": LINK_SINGLE, "average": LINK_AVERAGE}
 CLUSTER_MAX_SITES = 5000
 MICA_MI, MICA_MIP, MICA_MIC = range(3)      # null.method_zscore.stat (Mica.cpp:551-559)
+
+
+def scratch_guard(on=None):
+    """CMX_SCRATCH_GUARD (include/comap_mi355x.h): switch the canary guard on/off for contexts created from now on
+    (None = query); returns the previous state"""
+    lib = load_library()
+    return bool(lib.cmx_debug_scratch_guard(ctypes.c_int(-1 if on is None else int(bool(on)))))
+
+
+def scratch_guard_failures(clear=False):
+    """buffers the guard has found written past their end so far (process-wide), one string each"""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.cmx_debug_scratch_guard_failures.restype = ctypes.c_size_t
+    n = lib.cmx_debug_scratch_guard_failures(buf, ctypes.c_size_t(len(buf)), ctypes.c_int(int(clear)))
+    return [l for l in buf.value.decode().split("\n") if l][:n]
+
+
+def scratch_shrink(name, nbytes):
+    """test hook of the guard: pretend scratch buffer `name` is asked for with only nbytes (0 removes, name None removes all)"""
+    lib = load_library()
+    lib.cmx_debug_scratch_shrink.restype = None
+    lib.cmx_debug_scratch_shrink(None if name is None else name.encode(), ctypes.c_size_t(nbytes))
 
 
 def mica_bootstrap_indices(seed, nsites, nrep_cpu, nrep_ram):
@@ -302,6 +326,10 @@ class Engine:
 
     def synchronize(self):
         self._check(self._lib.cmx_synchronize(self._ctx))
+
+    def scratch_check(self):
+        """verify every canary of this context (CMX_SCRATCH_GUARD); raises CmxError naming the buffer written past its end"""
+        self._check(self._lib.cmx_scratch_check(self._ctx))
 
     @staticmethod
     def _stream():

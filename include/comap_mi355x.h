@@ -40,7 +40,8 @@ typedef enum {
   CMX_ERR_INVALID = -1,      /* bad argument (reference: bpp::Exception / DimensionException) */
   CMX_ERR_UNSUPPORTED = -2,  /* e.g. nstates > 64 */
   CMX_ERR_DEVICE = -3,       /* HIP error; no CPU fallback exists */
-  CMX_ERR_NOMEM = -4
+  CMX_ERR_NOMEM = -4,
+  CMX_ERR_INTERNAL = -5      /* a self-check of the engine failed (CMX_SCRATCH_GUARD: a device buffer was written past its end) */
 } cmx_status;
 
 /* statistic kinds: CoMap/Statistics.h:164-329, factory CoMap/CoETools.cpp:535-600 */
@@ -122,6 +123,19 @@ cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info);
 /* transition probabilities the engine uses, for inspection/tests: P[C][B][S][S] (row x -> column y) */
 cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P);
 cmx_status cmx_synchronize(cmx_ctx* ctx);
+/* Scratch guard (debugging aid, no counterpart in the reference).  With CMX_SCRATCH_GUARD=1 in the environment when the
+ * first context is created, or after cmx_debug_scratch_guard(1), every device buffer the engine sizes by hand (named
+ * scratch buffers, per-wave workspaces, temporaries of the host-pointer entry points) is followed by a 4 KiB canary.
+ * The engine verifies a buffer's canary before it hands the buffer out again; cmx_synchronize, cmx_scratch_check and
+ * cmx_ctx_destroy verify all of them.  A trampled canary makes the call fail with CMX_ERR_INTERNAL and cmx_last_error
+ * names the buffer.  Every check synchronises the device: not for timed runs. */
+cmx_status cmx_scratch_check(cmx_ctx* ctx);                 /* CMX_ERR_UNSUPPORTED when the guard is off */
+int cmx_debug_scratch_guard(int on);                        /* on < 0: query only; returns the previous state.  Set BEFORE cmx_ctx_create */
+size_t cmx_debug_scratch_guard_failures(char* buf, size_t cap, int clear);   /* findings so far (process-wide), one per line; returns their number */
+/* test hook: under the guard, pretend the named scratch buffer was asked for with only `bytes` bytes (the allocation keeps
+ * its real size, so the kernel's own writes land on the canary instead of past the allocation).  bytes = 0 removes the
+ * override, name = NULL removes all. */
+void cmx_debug_scratch_shrink(const char* name, size_t bytes);
 /* host-side only (no GPU needed): compile the tree into what the mapping kernel's walk of a rate-class pass reads
  * (comap_amd/csrc/cmx_walk.h) and copy it out for inspection/tests.  nrec: [nvisited][16] node records; ldsched:
  * workspace loads; msched: operator uses, pairs (matrix index in a class block, taxon or -1), in program order.  The walk
