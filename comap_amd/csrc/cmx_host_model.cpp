@@ -62,9 +62,16 @@ void jacobi(int n, Mat A, Mat* U, std::vector<double>* lam) {
   for (int i = 0; i < n; ++i) (*lam)[i] = A[(size_t)i * n + i];
 }
 
-// row-major SxS -> 4x4-block packed (tile t = (bi, bj), element k = (k/4, k%4)); layout consumed by matvec_s
-void pack_blocks(int S, const double* M, double* out) {
+// row-major SxS -> 4x4-block packed (tile t = (bi, bj), element k = (k/4, k%4)); layout consumed by matvec_stage.
+// diag (class-fused nucleotide models: the operator is block diagonal, one 4-state tile per class): only the NB diagonal
+// tiles are stored, tile (q, q) at position q -- the kernel then stages NB * 128 bytes per product instead of the unit
+void pack_blocks(int S, const double* M, double* out, bool diag) {
   const int NB = S / 4;
+  if (diag) {
+    for (int q = 0; q < NB; ++q)
+      for (int k = 0; k < 16; ++k) out[q * 16 + k] = M[(size_t)(4 * q + k / 4) * S + 4 * q + k % 4];
+    return;
+  }
   for (int t = 0; t < NB * NB; ++t)
     for (int k = 0; k < 16; ++k) out[t * 16 + k] = M[(size_t)(4 * (t / NB) + k / 4) * S + 4 * (t % NB) + k % 4];
 }
@@ -225,7 +232,11 @@ struct Numeric {
     return staged(which < 0 ? hm.NI + hm.NI * hm.K + tx : hm.NI + hm.NI * hm.K + hm.T + which * hm.T + tx, tx);
   }
   double leafrow(int mat, int leaf, int X) const { return blk[(size_t)mat * MU + (size_t)code[hm.taxon_of[leaf]] * leaf_row_stride(dS) + (X % 4) * NB + X / 4]; }
-  double packed(int mat, int r, int c) const { return blk[(size_t)mat * MU + ((size_t)(r / 4) * NB + c / 4) * 16 + (r % 4) * 4 + c % 4]; }
+  double packed(int mat, int r, int c) const {
+    if (hm.fuse > 1)   // diagonal tiles only (pack_blocks), the others are exact zeros of the block-diagonal operator
+      return r / 4 == c / 4 ? blk[(size_t)mat * MU + (size_t)(r / 4) * 16 + (r % 4) * 4 + c % 4] : 0.0;
+    return blk[(size_t)mat * MU + ((size_t)(r / 4) * NB + c / 4) * 16 + (r % 4) * 4 + c % 4];
+  }
   void count_row(int row, double v) {
     if (row < 0 || row >= hm.B * hm.K) return fail("count row out of range");
     if (counted[row]) return fail("branch counted twice");
@@ -626,7 +637,7 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
                 dense[(size_t)(g * S + x) * dS + g * S + y] =
                     M ? weight(g, which) * M[(size_t)x * S + y] : (which < 0 && x == y ? 1.0 : 0.0);
           }
-          pack_blocks(dS, dense.data(), blk + (size_t)(which < 0 ? sl : NI + sl * K + which) * MU);
+          pack_blocks(dS, dense.data(), blk + (size_t)(which < 0 ? sl : NI + sl * K + which) * MU, F > 1);
         }
       }
     }

@@ -109,6 +109,20 @@ __device__ __forceinline__ void mat_dma_l(const double* src, uint32_t l /* LDS b
     if (lane < MatStage<S>::TAIL) dma_rows16<1>(g + MatStage<S>::FULL * 128, l + MatStage<S>::FULL * 1024);
   }
 }
+// the first BYTES bytes of an operator only (compile-time): products of a class-fused model need their NB diagonal tiles,
+// leaf ops on fully resolved alignments (the null's simulated ones) the S0 state rows of the transposed operator
+template <int BYTES>
+struct MatPart {
+  static constexpr int FULL = BYTES / 1024, TAIL = (BYTES % 1024 + 15) / 16, ROWS = FULL + (TAIL ? 1 : 0);
+};
+template <int BYTES>
+__device__ __forceinline__ void mat_dma_part(const double* src, uint32_t l, int lane) {
+  const double* g = src + 2 * lane;
+  if constexpr (MatPart<BYTES>::FULL > 0) dma_rows16<MatPart<BYTES>::FULL>(g, l);
+  if constexpr (MatPart<BYTES>::TAIL > 0) {
+    if (lane < MatPart<BYTES>::TAIL) dma_rows16<1>(g + MatPart<BYTES>::FULL * 128, l + MatPart<BYTES>::FULL * 1024);
+  }
+}
 // DMA one symbol per lane (address p is per lane) into dword `lane` of the code slot.  The symbols of the null are
 // written by this very wave (simulation) through the same address, hence the L1-bypassing cache policy (sc0 sc1).
 __device__ __forceinline__ void code_dma_l(const uint8_t* p, uint32_t l) {
@@ -121,25 +135,25 @@ template <int N>
 __device__ __forceinline__ void waitcnt_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 template <int S, int VL>
 __device__ __forceinline__ void wait_vm(int allowed) {
-  // what can have been issued after X: the next operator (R DMA rows, +1 with symbols) and up to three workspace vectors
-  // (stores or loads, H instructions each).  Most frequent first.
+  // what can have been issued after X: the next operator (1 .. R DMA rows, +1 with symbols) and up to three workspace
+  // vectors (stores or loads, H instructions each).  The operator part varies per op since round 4 (products of a fused
+  // model and leaf ops of resolved alignments stage a part of the unit), so every count up to R + 1 + H is exact and the
+  // steps above are the multiples of H the vectors add; a smaller immediate than `allowed` only waits for more.
   constexpr int R = MatStage<S>::ROWS, H = VL / 2;
   static_assert(R + 1 + 3 * H < 64, "vmcnt is a 6-bit counter");
-  if (allowed <= R + 1) {
-    if (allowed == R + 1) waitcnt_vm<R + 1>();
-    else if (allowed == R) waitcnt_vm<R>();
-    else waitcnt_vm<0>();
-  } else if (allowed < H + R) {
-    if (allowed >= H && H > R + 1) waitcnt_vm<H>();
-    else waitcnt_vm<R + 1>();
-  } else if (allowed < 2 * H + R) {
-    if (allowed >= H + R + 1) waitcnt_vm<H + R + 1>();
-    else waitcnt_vm<H + R>();
-  } else if (allowed < 3 * H + R) {
-    if (allowed >= 2 * H + R + 1) waitcnt_vm<2 * H + R + 1>();
-    else waitcnt_vm<2 * H + R>();
+  static_assert(R + 1 <= 6, "operator rows + symbols");
+  const int v = allowed % H < 7 ? allowed % H : 6, q = allowed / H;   // (H >= 7 for every instantiation but S = 4: there v < H anyway)
+  if (q == 0) {
+    if (v <= 3) { if (v <= 1) { if (v == 0) waitcnt_vm<0>(); else waitcnt_vm<1>(); } else { if (v == 2) waitcnt_vm<2>(); else waitcnt_vm<3>(); } }
+    else { if (v == 4) waitcnt_vm<4>(); else if (v == 5) waitcnt_vm<5>(); else waitcnt_vm<6>(); }
+  } else if (q == 1) {
+    if (v <= 3) { if (v <= 1) { if (v == 0) waitcnt_vm<H>(); else waitcnt_vm<H + 1>(); } else { if (v == 2) waitcnt_vm<H + 2>(); else waitcnt_vm<H + 3>(); } }
+    else { if (v == 4) waitcnt_vm<H + 4>(); else if (v == 5) waitcnt_vm<H + 5>(); else waitcnt_vm<H + 6>(); }
+  } else if (q == 2) {
+    if (v <= 3) { if (v <= 1) { if (v == 0) waitcnt_vm<2 * H>(); else waitcnt_vm<2 * H + 1>(); } else { if (v == 2) waitcnt_vm<2 * H + 2>(); else waitcnt_vm<2 * H + 3>(); } }
+    else { if (v == 4) waitcnt_vm<2 * H + 4>(); else if (v == 5) waitcnt_vm<2 * H + 5>(); else waitcnt_vm<2 * H + 6>(); }
   } else {
-    waitcnt_vm<3 * H + R>();
+    if (v <= 1) waitcnt_vm<3 * H>(); else if (v <= 3) waitcnt_vm<3 * H + 2>(); else waitcnt_vm<3 * H + 4>();
   }
 }
 
@@ -185,7 +199,7 @@ __device__ __forceinline__ double reduce_sites(const double (&p)[NG]) {
 // tiles are applied, step q = tile (q, q) -- the same bits as the dense product, whose other tiles are exact zeros.
 template <int S, bool TR, bool DIAG>
 __device__ __forceinline__ constexpr int mfma_tile(int q) {
-  return DIAG ? q * (S / 4) + q : (TR ? (q % (S / 4)) * (S / 4) + q / (S / 4) : q);
+  return DIAG ? q : (TR ? (q % (S / 4)) * (S / 4) + q / (S / 4) : q);   // (DIAG: the host stores tile (q, q) at position q)
 }
 template <int S, bool TR, int NG, bool DIAG, int Q>
 __device__ __forceinline__ void mfma_steps(const uint8_t* tile0, double m0, double m1, double m2, const double (&x)[S / 4 * NG],
@@ -388,9 +402,14 @@ struct OpState {
 // Device backend of the tree walk (cmx_walk.h): registers R0..R3 are S-vectors of the wave's sites in the matrix-core
 // layout.  The walk names what it wants; the operator stream (m.msched) and the load schedule (m.ldsched) -- recorded
 // from the same walk on the host and checked numerically there -- say where it is.
-template <int S, int FUSE, int NG>
+// RESOLVED: every symbol of the alignment is a state (the null's simulated or supplied alignments): leaf ops then stage the
+// S0 state rows of the transposed operator only, not its ambiguity rows
+template <int S, int FUSE, int NG, bool RESOLVED>
 struct DevWalk {
   static constexpr int VL = S / 4 * NG, kSites = 16 * NG;
+  static constexpr bool DIAG = FUSE > 1 && S / FUSE == 4;
+  static constexpr int kProductBytes = DIAG ? (S / 4) * 128 : MatStage<S>::BYTES;                      // diagonal tiles come first
+  static constexpr int kLeafBytes = RESOLVED ? (S / FUSE) * leaf_row_stride(S) * 8 : MatStage<S>::BYTES;
   double R0[VL], R1[VL], R2[VL], R3[VL];
   OpState& os;
   const ConstModel& cm;
@@ -466,9 +485,21 @@ struct DevWalk {
     const bool more = (mi + 1 < nmv);
     const int emat = os.pre_mat, etx = os.pre_tx;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads of the other buffer are done
-    mat_dma_l<S>((more ? mat_c : mat_after) + emat /* element offset, premultiplied on the host */,
-                 lds_stage + (os.par ^ 1u) * MatStage<S>::BYTES, vlane());
-    unsigned issued = MatStage<S>::ROWS;
+    unsigned issued;
+    {
+      const double* src = (more ? mat_c : mat_after) + emat;   // element offset, premultiplied on the host
+      const uint32_t dst = lds_stage + (os.par ^ 1u) * MatStage<S>::BYTES;
+      if constexpr (kProductBytes == MatStage<S>::BYTES && kLeafBytes == MatStage<S>::BYTES) {
+        mat_dma_l<S>(src, dst, vlane());
+        issued = MatStage<S>::ROWS;
+      } else if (etx >= 0) {   // (wave-uniform: the next op is a leaf op)
+        mat_dma_part<kLeafBytes>(src, dst, vlane());
+        issued = MatPart<kLeafBytes>::ROWS;
+      } else {
+        mat_dma_part<kProductBytes>(src, dst, vlane());
+        issued = MatPart<kProductBytes>::ROWS;
+      }
+    }
     if (etx >= 0 && (more || c + 1 < c_end)) {
       code_dma_l(gcodes + (size_t)etx * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);
       issued += 1;
@@ -492,7 +523,7 @@ struct DevWalk {
   __device__ __forceinline__ void mv(int, int) {
     unsigned nseq;
     const uint8_t* buf = op_begin(nseq);
-    matvec_stage<S, TR, NG, (FUSE > 1 && S / FUSE == 4)>(buf, vlane(), reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1]));
+    matvec_stage<S, TR, NG, DIAG>(buf, vlane(), reg<SRC>(), reg<DST>()); asm volatile("" :: "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1]));
     op_end(nseq);
   }
   template <int MODE, int SRC, int DST>
@@ -588,7 +619,7 @@ struct DevWalk {
 // cnt[(b*K+k)*64 + lane] holds the final counts n(b, site, k) and the scalars are per lane; without (class-split
 // observed mode) only part[] and L_out = sum of p_c L_c over the processed classes are produced.
 // part: [C][B*K][64] per-class joint counts (written once each, summed at the end: no read-modify-write in the loop).
-template <int S, int FUSE, int NG>
+template <int S, int FUSE, int NG, bool RESOLVED>
 __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restrict__ wsM, double* __restrict__ wsU,
                                                double* __restrict__ part, double* __restrict__ cnt, int lds_off,
                                                const uint8_t* __restrict__ gcodes, size_t gstride, int lane,
@@ -603,7 +634,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   const int C = m.C, K = m.K;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
-  DevWalk<S, FUSE, NG> be(os, cm);
+  DevWalk<S, FUSE, NG, RESOLVED> be(os, cm);
   be.pi = m.pi;
   be.nmv = m.nmv;
   be.wsM = wsM;
@@ -754,7 +785,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
       const size_t s = site < a.nsites ? site : a.nsites - 1;
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S, FUSE, NG>(a, wsD, wsU, a.split_part + sb * m.C * BK * kSites, nullptr, lds_off, a.aln + s, a.ld, lane, os, L, pr,
+      map_sites_wave<S, FUSE, NG, false>(a, wsD, wsU, a.split_part + sb * m.C * BK * kSites, nullptr, lds_off, a.aln + s, a.ld, lane, os, L, pr,
                         rc, nrm, c, c + 1, (int)((task + nwaves) % m.C), false);
       a.split_lc[task * kSites + sidx] = L;
       a.split_lc[(ntasks + task) * kSites + sidx] = pr;
@@ -771,7 +802,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
     if (MODE == kModeObserved) {
       double L, pr, nrm;
       int rc;
-      map_sites_wave<S, FUSE, NG>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
+      map_sites_wave<S, FUSE, NG, false>(a, wsD, wsU, part, cnt0, lds_off, a.aln + s, a.ld, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
       if (active) {
         if (a.logL) a.logL[s] = log(L);
         if (a.post_rate) a.post_rate[s] = pr;
@@ -795,7 +826,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
         gstride = a.rep_ram;
         double L, pr, nrm;
         int rc;
-        map_sites_wave<S, FUSE, NG>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
+        map_sites_wave<S, FUSE, NG, true>(a, wsD, wsU, part, h ? cnt1 : cnt0, lds_off, gbase, gstride, lane, os, L, pr, rc, nrm, 0, m.C, 0, true);
         if (h == 0) { prmin = pr; nmin = nrm; rcmin = rc; }
         else { prmin = pr < prmin ? pr : prmin; nmin = nrm < nmin ? nrm : nmin; rcmin = rc < rcmin ? rc : rcmin; }
       }

@@ -3,15 +3,28 @@
 //
 // What shards (same arithmetic as comap_amd/distributed.py, which the one-process-per-GPU Python path uses):
 //   * the parametric-bootstrap null (AnalysisTools::getNullDistributionIntraDR, CoMap/AnalysisTools.cpp:564-658): replicates
-//     are independent; device r maps the contiguous range replicateShard(r, N, repCPU); the counter RNG is keyed by the
-//     GLOBAL simulated-site index, so the merged null is bit-identical for any N.  ONE ncclAllGather (grouped over the N
-//     communicators of this process) gives every device the whole null in the reference's replicate order;
+//     are independent; rank r maps the contiguous range replicateShard(r, N, repCPU); the counter RNG is keyed by the
+//     GLOBAL simulated-site index, so the merged null is bit-identical for any N.  ONE all-gather gives every rank the
+//     whole null in the reference's replicate order;
 //   * the observed pair loop (CoETools::computeIntraStats, CoMap/CoETools.cpp:672-724): rows of the upper triangle split
-//     by PAIR count (rowShard); every device maps the observed alignment itself (it is small) and compacts the rows of
-//     its range; ranges are contiguous in i, so the devices' rows concatenate to the single-GPU output in the
+//     by PAIR count (rowShard); every rank maps the observed alignment itself (it is small) and compacts the rows of
+//     its range; ranges are contiguous in i, so the ranks' rows concatenate to the single-GPU output in the
 //     reference's (i, j) order -- no second collective on the data path.
 // xGMI is point-to-point: the exchange is 16 bytes per null pair (20 MB per device at the north-star target with 8
 // devices), far below any link limit, so it is a single all-gather and not a ring of smaller ones.
+//
+// Round 4: a throughput path, not only a mirror.
+//   * The exchange is a policy.  RcclExchange (default; `MultiGpu`) = one grouped ncclAllGather over the N communicators
+//     of this process, one rank per distinct device.  LoopbackExchange (`LoopbackMultiGpu`) = the SAME all-gather written
+//     as device-to-device copies between N contexts that may all live on ONE device: every line of the N > 1 logic
+//     (uneven shards, NaN padding, reassembly into replicate order, row ranges) runs on a one-GPU box and is tested there
+//     byte for byte against the single-context path (tests/test_multigpu_cpp.py).
+//   * Every buffer lives in a grow-only per-rank arena owned by the object (nothing is allocated or freed per call
+//     once the sizes have been seen), uploads are asynchronous from pinned staging, and nothing blocks the host between
+//     the first launch on rank 0 and the last launch on rank N - 1.
+//   * Rows stay on the devices (enqueueIntraStats + deviceRows) or come home with ONE asynchronous pinned copy per rank
+//     (fetchRows: spans of cmx_pair_row in rank order, no per-row conversion).  computeIntraStats keeps the
+//     reference-shaped std::vector<IntraStatRow> for callers that want it (one resize + one bulk conversion).
 //
 // Needs the HIP runtime API and RCCL headers (/opt/rocm/include); link with -lcomap_mi355x -lrccl -lamdhip64.
 #ifndef COMAP_MI355X_MULTIGPU_HPP
@@ -20,6 +33,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstring>
 #include <utility>
 
 #include "comap_mi355x_adapter.hpp"
@@ -48,44 +62,120 @@ inline std::pair<size_t, size_t> rowShard(size_t rank, size_t world, size_t n) {
   const size_t end = rank + 1 < world ? firstRowWithPrefixAtLeast(total * (rank + 1) / world) : n;
   return {begin, end};
 }
+// pairs (i, j), j > i, of the rows [begin, end)
+inline size_t pairsOfRows(size_t begin, size_t end, size_t n) {
+  return (end - begin) * (n - 1) - (end * (end - 1) - begin * (begin - 1)) / 2;
+}
 
-class MultiGpu {
+namespace detail {
+inline void hipCheck(hipError_t e, const char* what = "MultiGpu") {
+  if (e != hipSuccess) throw Exception(std::string(what) + ": HIP error: " + hipGetErrorString(e));
+}
+inline void ncclCheck(ncclResult_t e) {
+  if (e != ncclSuccess) throw Exception(std::string("MultiGpu: RCCL error: ") + ncclGetErrorString(e));
+}
+}  // namespace detail
+
+// ---- exchange policies: allGather(send[r], recv[r], count) leaves recv[r] = send[0] | send[1] | ... | send[N-1] on every
+// rank, ordered after what stream r held before the call and before what it is given afterwards.
+struct RcclExchange {   // one communicator per rank, all in this process; ranks must sit on DISTINCT devices
+  std::vector<ncclComm_t> comms;
+  void init(const std::vector<int>& devices, const std::vector<hipStream_t>&) {
+    for (size_t a = 0; a < devices.size(); ++a)
+      for (size_t b = a + 1; b < devices.size(); ++b)
+        if (devices[a] == devices[b]) throw Exception("MultiGpu: RCCL needs one distinct device per rank (LoopbackMultiGpu runs N ranks on one device).");
+    comms.assign(devices.size(), nullptr);
+    detail::ncclCheck(ncclCommInitAll(comms.data(), (int)devices.size(), devices.data()));
+  }
+  void allGather(const std::vector<double*>& send, const std::vector<double*>& recv, size_t count, const std::vector<int>&,
+                 const std::vector<hipStream_t>& streams) {
+    detail::ncclCheck(ncclGroupStart());
+    for (size_t r = 0; r < comms.size(); ++r) detail::ncclCheck(ncclAllGather(send[r], recv[r], count, ncclDouble, comms[r], streams[r]));
+    detail::ncclCheck(ncclGroupEnd());
+  }
+  void destroy(const std::vector<int>& devices) {
+    for (size_t r = 0; r < comms.size(); ++r)
+      if (comms[r]) { (void)hipSetDevice(devices[r]); (void)ncclCommDestroy(comms[r]); comms[r] = nullptr; }
+  }
+};
+
+struct LoopbackExchange {   // the same all-gather as N x N device-to-device copies; ranks may share a device
+  std::vector<hipEvent_t> ready;
+  void init(const std::vector<int>& devices, const std::vector<hipStream_t>&) {
+    ready.assign(devices.size(), nullptr);
+    for (size_t r = 0; r < devices.size(); ++r) {
+      detail::hipCheck(hipSetDevice(devices[r]));
+      detail::hipCheck(hipEventCreateWithFlags(&ready[r], hipEventDisableTiming));
+    }
+  }
+  void allGather(const std::vector<double*>& send, const std::vector<double*>& recv, size_t count, const std::vector<int>& devices,
+                 const std::vector<hipStream_t>& streams) {
+    const size_t N = ready.size();
+    for (size_t q = 0; q < N; ++q) {   // rank q's shard is complete when its stream reaches this point
+      detail::hipCheck(hipSetDevice(devices[q]));
+      detail::hipCheck(hipEventRecord(ready[q], streams[q]));
+    }
+    for (size_t r = 0; r < N; ++r) {
+      detail::hipCheck(hipSetDevice(devices[r]));
+      for (size_t q = 0; q < N; ++q) {
+        if (q != r) detail::hipCheck(hipStreamWaitEvent(streams[r], ready[q], 0));
+        detail::hipCheck(hipMemcpyAsync(recv[r] + q * count, send[q], sizeof(double) * count, hipMemcpyDeviceToDevice, streams[r]));
+      }
+    }
+  }
+  void destroy(const std::vector<int>& devices) {
+    for (size_t r = 0; r < ready.size(); ++r)
+      if (ready[r]) { (void)hipSetDevice(devices[r]); (void)hipEventDestroy(ready[r]); ready[r] = nullptr; }
+  }
+};
+
+template <class Exchange>
+class BasicMultiGpu {
  public:
-  // one context, one stream and one RCCL communicator per listed device (distinct devices of this node)
-  MultiGpu(const TreeArrays& tree, const ModelArrays& model, const std::vector<int>& devices) : devices_(devices) {
+  // one context and one stream per rank; rank r runs on devices[r]
+  BasicMultiGpu(const TreeArrays& tree, const ModelArrays& model, const std::vector<int>& devices) : devices_(devices) {
     if (devices.empty()) throw Exception("MultiGpu: no device given.");
     for (int d : devices) engines_.emplace_back(new Engine(tree, model, d));
     streams_.assign(devices.size(), nullptr);
-    comms_.assign(devices.size(), nullptr);
+    dv_.resize(devices.size());
     for (size_t r = 0; r < devices.size(); ++r) {
       hip(hipSetDevice(devices[r]));
       hip(hipStreamCreate(&streams_[r]));
     }
-    nccl(ncclCommInitAll(comms_.data(), (int)devices.size(), devices.data()));
+    exchange_.init(devices_, streams_);
   }
-  ~MultiGpu() {
+  ~BasicMultiGpu() {
     for (size_t r = 0; r < devices_.size(); ++r) {
       (void)hipSetDevice(devices_[r]);
-      if (comms_[r]) (void)ncclCommDestroy(comms_[r]);
+      if (streams_[r]) (void)hipStreamSynchronize(streams_[r]);
+      for (Buf* b : dv_[r].all()) if (b->p) (void)hipFree(b->p);
+      if (dv_[r].hostRows.p) (void)hipHostFree(dv_[r].hostRows.p);
+      if (dv_[r].hostCount) (void)hipHostFree(dv_[r].hostCount);
+    }
+    exchange_.destroy(devices_);
+    for (size_t r = 0; r < devices_.size(); ++r) {
+      (void)hipSetDevice(devices_[r]);
       if (streams_[r]) (void)hipStreamDestroy(streams_[r]);
     }
+    if (hostAln_.p) (void)hipHostFree(hostAln_.p);
+    if (hostMasks_) (void)hipHostFree(hostMasks_);
   }
-  MultiGpu(const MultiGpu&) = delete;
-  MultiGpu& operator=(const MultiGpu&) = delete;
+  BasicMultiGpu(const BasicMultiGpu&) = delete;
+  BasicMultiGpu& operator=(const BasicMultiGpu&) = delete;
   size_t size() const { return devices_.size(); }
   const Engine& engine(size_t r) const { return *engines_[r]; }
+  hipStream_t stream(size_t r) const { return streams_[r]; }
 
-  // CoETools::getVectors + computeIntraStats with their null (CoMap.cpp:155, 363) over all devices.  aln: [taxon][site]
-  // codes.  Returns the rows of statistics.txt in the reference's order; nullRows (optional) receives the merged null
-  // (Stat, Nmin; RCmin / PRmin are not exchanged: 0 / NaN) in replicate order.
-  std::vector<IntraStatRow> computeIntraStats(const uint8_t* aln, size_t nbSites, const uint32_t* masks, size_t nbMasks,
-                                              const Statistic& statistic, bool computeNull, uint64_t seed, size_t nbRepCPU = 100,
-                                              size_t nbRepRAM = 1000, size_t nbRateClasses = 10, const PairFilters& f = PairFilters(),
-                                              std::vector<NullDistributionRow>* nullRows = nullptr) {
+  // ---- step 1: everything onto the devices' streams, nothing waited for.  CoETools::getVectors + computeIntraStats with
+  // their null (CoMap.cpp:155, 363) over all ranks.  aln: [taxon][site] codes (host).  After this call (and a
+  // synchronize / fetchRows) rank r holds the compacted rows of its range, and every rank the merged null.
+  void enqueueIntraStats(const uint8_t* aln, size_t nbSites, const uint32_t* masks, size_t nbMasks, const Statistic& statistic,
+                         bool computeNull, uint64_t seed, size_t nbRepCPU = 100, size_t nbRepRAM = 1000, size_t nbRateClasses = 10,
+                         const PairFilters& f = PairFilters()) {
     const size_t N = size(), n = nbSites, T = engines_[0]->getNumberOfTaxa();
     const size_t BK = engines_[0]->getNumberOfBranches() * engines_[0]->getNumberOfSubstitutionTypes();
     if (n < 2) throw Exception("MultiGpu::computeIntraStats: at least two sites are needed.");
-    const size_t nnull = computeNull ? nbRepCPU * nbRepRAM : 0;
+    nnull_ = computeNull ? nbRepCPU * nbRepRAM : 0;
     size_t mx = 0;   // entries of the largest null shard: shards are padded to it for the collective
     for (size_t r = 0; r < N; ++r) {
       const auto s = replicateShard(r, N, nbRepCPU);
@@ -94,126 +184,211 @@ class MultiGpu {
     cmx_pair_filters pf;
     pf.min_rate_class = f.minRateClass; pf.max_rate_class_diff = f.maxRateClassDiff;
     pf.min_rate = f.minRate; pf.max_rate_diff = f.maxRateDiff; pf.min_statistic = f.minStatistic;
-    struct Dev {
-      uint8_t* aln = nullptr; uint32_t* masks = nullptr;
-      double *counts = nullptr, *pr = nullptr, *norm = nullptr, *send = nullptr, *recv = nullptr, *nstat = nullptr, *nnmin = nullptr;
-      int32_t* rc = nullptr; cmx_pair_row* rows = nullptr; uint64_t* count = nullptr;
-      size_t cap = 0, rowBegin = 0, rowEnd = 0;
-    };
-    std::vector<Dev> dv(N);
-    auto freeAll = [&]() {
-      for (size_t r = 0; r < N; ++r) {
-        (void)hipSetDevice(devices_[r]);
-        Dev& d = dv[r];
-        for (void* p : {(void*)d.aln, (void*)d.masks, (void*)d.counts, (void*)d.pr, (void*)d.norm, (void*)d.send, (void*)d.recv,
-                        (void*)d.nstat, (void*)d.nnmin, (void*)d.rc, (void*)d.rows, (void*)d.count})
-          if (p) (void)hipFree(p);
+    // pinned staging of the inputs: ONE host copy, then an asynchronous upload per rank (a pageable source would make
+    // every hipMemcpyAsync a blocking staged copy on the thread that is supposed to keep N devices fed)
+    if (hostAln_.bytes < T * n) {
+      if (hostAln_.p) hip(hipHostFree(hostAln_.p));
+      hostAln_.p = nullptr;
+      hip(hipHostMalloc(&hostAln_.p, T * n, hipHostMallocDefault));
+      hostAln_.bytes = T * n;
+    }
+    for (size_t r = 0; r < N; ++r) {   // the staging buffers may still feed the previous call's uploads
+      hip(hipSetDevice(devices_[r]));
+      hip(hipStreamSynchronize(streams_[r]));
+    }
+    std::memcpy(hostAln_.p, aln, T * n);
+    if (masks) {
+      if (!hostMasks_) hip(hipHostMalloc((void**)&hostMasks_, 256 * sizeof(uint32_t), hipHostMallocDefault));
+      const int S = engines_[0]->getNumberOfStates();
+      for (size_t i = 0; i < 256; ++i) hostMasks_[i] = i < nbMasks ? masks[i] : (S >= 32 ? 0xffffffffu : ((1u << S) - 1u));
+    }
+    // ---- every rank: observed alignment up, mapped; its null shard into the send buffer [2][mx] (NaN padded)
+    for (size_t r = 0; r < N; ++r) {
+      Dev& d = dv_[r];
+      const Engine& e = *engines_[r];
+      hip(hipSetDevice(devices_[r]));
+      hipStream_t st = streams_[r];
+      const auto rs = rowShard(r, N, n);
+      d.rowBegin = rs.first; d.rowEnd = rs.second;
+      d.cap = pairsOfRows(d.rowBegin, d.rowEnd, n);
+      ensure(d.aln, T * n);
+      ensure(d.counts, sizeof(double) * BK * n);
+      ensure(d.pr, sizeof(double) * n);
+      ensure(d.norm, sizeof(double) * n);
+      ensure(d.rc, sizeof(int32_t) * n);
+      ensure(d.rows, sizeof(cmx_pair_row) * std::max<size_t>(d.cap, 1));
+      ensure(d.count, sizeof(uint64_t));
+      if (!d.hostCount) hip(hipHostMalloc((void**)&d.hostCount, sizeof(uint64_t), hipHostMallocDefault));
+      hip(hipMemcpyAsync(d.aln.p, hostAln_.p, T * n, hipMemcpyHostToDevice, st));
+      if (masks) {
+        ensure(d.masks, 256 * sizeof(uint32_t));
+        hip(hipMemcpyAsync(d.masks.p, hostMasks_, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
       }
-    };
-    try {
-      // ---- every device: observed alignment up, mapped; its null shard into the send buffer [2][mx] (NaN padded)
-      for (size_t r = 0; r < N; ++r) {
-        Dev& d = dv[r];
-        const Engine& e = *engines_[r];
-        hip(hipSetDevice(devices_[r]));
-        hipStream_t st = streams_[r];
-        const auto rs = rowShard(r, N, n);
-        d.rowBegin = rs.first; d.rowEnd = rs.second;
-        d.cap = (d.rowEnd - d.rowBegin) * (n - 1) - (d.rowEnd * (d.rowEnd - 1) - d.rowBegin * (d.rowBegin - 1)) / 2;
-        hip(hipMalloc((void**)&d.aln, T * n));
-        hip(hipMalloc((void**)&d.counts, sizeof(double) * BK * n));
-        hip(hipMalloc((void**)&d.pr, sizeof(double) * n));
-        hip(hipMalloc((void**)&d.norm, sizeof(double) * n));
-        hip(hipMalloc((void**)&d.rc, sizeof(int32_t) * n));
-        hip(hipMalloc((void**)&d.rows, sizeof(cmx_pair_row) * std::max<size_t>(d.cap, 1)));
-        hip(hipMalloc((void**)&d.count, sizeof(uint64_t)));
-        hip(hipMemcpyAsync(d.aln, aln, T * n, hipMemcpyHostToDevice, st));
-        if (masks) {
-          const int S = e.getNumberOfStates();
-          std::vector<uint32_t> mk(256, S >= 32 ? 0xffffffffu : ((1u << S) - 1u));
-          for (size_t i = 0; i < nbMasks && i < 256; ++i) mk[i] = masks[i];
-          hip(hipMalloc((void**)&d.masks, 256 * sizeof(uint32_t)));
-          hip(hipMemcpy(d.masks, mk.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
-        }
-        e.check(cmx_map_sites_dev(e.ctx(), d.aln, n, n, d.masks, d.counts, n, nullptr, d.pr, d.rc, d.norm, st));
-        if (computeNull) {
-          const auto s = replicateShard(r, N, nbRepCPU);
-          hip(hipMalloc((void**)&d.send, sizeof(double) * 2 * mx));
-          hip(hipMalloc((void**)&d.recv, sizeof(double) * 2 * mx * N));
-          hip(hipMalloc((void**)&d.nstat, sizeof(double) * nnull));
-          hip(hipMalloc((void**)&d.nnmin, sizeof(double) * nnull));
-          hip(hipMemsetAsync(d.send, 0xFF, sizeof(double) * 2 * mx, st));   // all-ones bytes are a NaN
-          if (s.second > s.first)
-            e.check(cmx_null_intra_dev(e.ctx(), statistic.kind(), statistic.params(), seed, s.first, s.second, nbRepRAM, nullptr, d.send,
-                                       nullptr, nullptr, d.send + mx, st));
-        }
-      }
-      // ---- the path's one exchange
+      e.check(cmx_map_sites_dev(e.ctx(), d.aln.template as<uint8_t>(), n, n, masks ? d.masks.template as<uint32_t>() : nullptr,
+                                d.counts.template as<double>(), n, nullptr, d.pr.template as<double>(), d.rc.template as<int32_t>(),
+                                d.norm.template as<double>(), st));
       if (computeNull) {
-        nccl(ncclGroupStart());
-        for (size_t r = 0; r < N; ++r) nccl(ncclAllGather(dv[r].send, dv[r].recv, 2 * mx, ncclDouble, comms_[r], streams_[r]));
-        nccl(ncclGroupEnd());
+        const auto s = replicateShard(r, N, nbRepCPU);
+        ensure(d.send, sizeof(double) * 2 * mx);
+        ensure(d.recv, sizeof(double) * 2 * mx * N);
+        ensure(d.nstat, sizeof(double) * nnull_);
+        ensure(d.nnmin, sizeof(double) * nnull_);
+        hip(hipMemsetAsync(d.send.p, 0xFF, sizeof(double) * 2 * mx, st));   // all-ones bytes are a NaN
+        if (s.second > s.first)
+          e.check(cmx_null_intra_dev(e.ctx(), statistic.kind(), statistic.params(), seed, s.first, s.second, nbRepRAM, nullptr,
+                                     d.send.template as<double>(), nullptr, nullptr, d.send.template as<double>() + mx, st));
       }
-      // ---- every device: the shards back into replicate order, then the rows of its range against the merged null
-      for (size_t r = 0; r < N; ++r) {
-        Dev& d = dv[r];
-        const Engine& e = *engines_[r];
-        hip(hipSetDevice(devices_[r]));
-        hipStream_t st = streams_[r];
-        for (size_t q = 0; computeNull && q < N; ++q) {
-          const auto s = replicateShard(q, N, nbRepCPU);
-          const size_t cnt = (s.second - s.first) * nbRepRAM, off = s.first * nbRepRAM;
-          if (!cnt) continue;
-          hip(hipMemcpyAsync(d.nstat + off, d.recv + q * 2 * mx, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
-          hip(hipMemcpyAsync(d.nnmin + off, d.recv + q * 2 * mx + mx, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
-        }
-        e.check(cmx_intra_rows_range_dev(e.ctx(), statistic.kind(), statistic.params(), d.counts, n, n, d.rc, d.pr, d.norm,
-                                         computeNull ? d.nstat : nullptr, computeNull ? d.nnmin : nullptr, nnull, (int)nbRateClasses, &pf,
-                                         d.rowBegin, d.rowEnd, d.rows, d.cap, d.count, st));
-      }
-      // ---- rows home, in rank order == the reference's (i, j) order
-      std::vector<IntraStatRow> rows;
-      for (size_t r = 0; r < N; ++r) {
-        Dev& d = dv[r];
-        hip(hipSetDevice(devices_[r]));
-        hip(hipStreamSynchronize(streams_[r]));
-        uint64_t count = 0;
-        hip(hipMemcpy(&count, d.count, sizeof(uint64_t), hipMemcpyDeviceToHost));
-        std::vector<cmx_pair_row> raw((size_t)std::min<uint64_t>(count, d.cap));
-        if (!raw.empty()) hip(hipMemcpy(raw.data(), d.rows, sizeof(cmx_pair_row) * raw.size(), hipMemcpyDeviceToHost));
-        for (const cmx_pair_row& q : raw) {
-          IntraStatRow o;
-          o.i = (size_t)q.i; o.j = (size_t)q.j; o.stat = q.stat; o.rcMin = q.rc_min; o.prMin = q.pr_min; o.nMin = q.n_min;
-          o.pValue = q.pvalue; o.nSim = q.nsim;
-          rows.push_back(o);
-        }
-        if (r == 0 && nullRows && computeNull) {
-          Vdouble s(nnull), m(nnull);
-          hip(hipMemcpy(s.data(), d.nstat, sizeof(double) * nnull, hipMemcpyDeviceToHost));
-          hip(hipMemcpy(m.data(), d.nnmin, sizeof(double) * nnull, hipMemcpyDeviceToHost));
-          for (size_t q = 0; q < nnull; ++q) nullRows->push_back({s[q], 0, std::numeric_limits<double>::quiet_NaN(), m[q]});
-        }
-      }
-      freeAll();
-      return rows;
-    } catch (...) {
-      freeAll();
-      throw;
+    }
+    // ---- the path's one exchange
+    if (computeNull) {
+      std::vector<double*> send(N), recv(N);
+      for (size_t r = 0; r < N; ++r) { send[r] = dv_[r].send.template as<double>(); recv[r] = dv_[r].recv.template as<double>(); }
+      exchange_.allGather(send, recv, 2 * mx, devices_, streams_);
+    }
+    // ---- every rank: the shards back into replicate order, then the rows of its range against the merged null
+    for (size_t r = 0; r < N; ++r) {
+      Dev& d = dv_[r];
+      const Engine& e = *engines_[r];
+      hip(hipSetDevice(devices_[r]));
+      hipStream_t st = streams_[r];
+      if (computeNull) reassembleNull(d.recv.template as<double>(), d.nstat.template as<double>(), d.nnmin.template as<double>(), N, nbRepCPU, nbRepRAM, mx, st);
+      e.check(cmx_intra_rows_range_dev(e.ctx(), statistic.kind(), statistic.params(), d.counts.template as<double>(), n, n,
+                                       d.rc.template as<int32_t>(), d.pr.template as<double>(), d.norm.template as<double>(),
+                                       computeNull ? d.nstat.template as<double>() : nullptr, computeNull ? d.nnmin.template as<double>() : nullptr,
+                                       nnull_, (int)nbRateClasses, &pf, d.rowBegin, d.rowEnd, d.rows.template as<cmx_pair_row>(), d.cap,
+                                       d.count.template as<uint64_t>(), st));
+      hip(hipMemcpyAsync(d.hostCount, d.count.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      d.fetched = false;
     }
   }
 
- private:
-  static void hip(hipError_t e) {
-    if (e != hipSuccess) throw Exception(std::string("MultiGpu: HIP error: ") + hipGetErrorString(e));
+  // the gathered shards [rank][2][mx] (stat | nmin, NaN padded) -> the null in replicate order.  Static and public: it is
+  // the one piece of N > 1 arithmetic besides the shard functions, and the tests call it with made-up layouts too.
+  static void reassembleNull(const double* d_recv, double* d_nstat, double* d_nnmin, size_t N, size_t nbRepCPU, size_t nbRepRAM, size_t mx,
+                             hipStream_t st) {
+    for (size_t q = 0; q < N; ++q) {
+      const auto s = replicateShard(q, N, nbRepCPU);
+      const size_t cnt = (s.second - s.first) * nbRepRAM, off = s.first * nbRepRAM;
+      if (!cnt) continue;
+      hip(hipMemcpyAsync(d_nstat + off, d_recv + q * 2 * mx, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      hip(hipMemcpyAsync(d_nnmin + off, d_recv + q * 2 * mx + mx, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    }
   }
-  static void nccl(ncclResult_t e) {
-    if (e != ncclSuccess) throw Exception(std::string("MultiGpu: RCCL error: ") + ncclGetErrorString(e));
+
+  void synchronize() {
+    for (size_t r = 0; r < size(); ++r) {
+      hip(hipSetDevice(devices_[r]));
+      hip(hipStreamSynchronize(streams_[r]));
+    }
+  }
+
+  // ---- step 2a: rows left on the device (valid after synchronize(); the caller reads them with its own kernels / copies)
+  struct DeviceRows { const cmx_pair_row* rows; size_t count, rowBegin, rowEnd; };
+  DeviceRows deviceRows(size_t r) {
+    hip(hipSetDevice(devices_[r]));
+    hip(hipStreamSynchronize(streams_[r]));
+    const Dev& d = dv_[r];
+    return {d.rows.template as<cmx_pair_row>(), (size_t)std::min<uint64_t>(*d.hostCount, d.cap), d.rowBegin, d.rowEnd};
+  }
+  const double* deviceNullStat(size_t r) const { return dv_[r].nstat.template as<double>(); }   // merged null, replicate order, [nnull]
+  const double* deviceNullNmin(size_t r) const { return dv_[r].nnmin.template as<double>(); }
+  size_t nullSize() const { return nnull_; }
+
+  // ---- step 2b: rows home.  One asynchronous copy per rank into its own grow-only pinned buffer; a rank's copy is issued
+  // as soon as ITS row count is known, so the N copies overlap on the N PCIe links.  Spans are in rank order == the
+  // reference's (i, j) order; they stay valid until the next enqueueIntraStats.
+  struct HostRows {
+    std::vector<const cmx_pair_row*> rows;
+    std::vector<size_t> count;
+    size_t total() const { size_t t = 0; for (size_t c : count) t += c; return t; }
+  };
+  const HostRows& fetchRows() {
+    const size_t N = size();
+    host_.rows.assign(N, nullptr);
+    host_.count.assign(N, 0);
+    for (size_t r = 0; r < N; ++r) {
+      Dev& d = dv_[r];
+      hip(hipSetDevice(devices_[r]));
+      hip(hipStreamSynchronize(streams_[r]));   // ranks run concurrently: while this one is waited for the others proceed
+      const size_t cnt = (size_t)std::min<uint64_t>(*d.hostCount, d.cap);
+      if (d.hostRows.bytes < sizeof(cmx_pair_row) * cnt) {
+        if (d.hostRows.p) hip(hipHostFree(d.hostRows.p));
+        d.hostRows.p = nullptr;
+        hip(hipHostMalloc(&d.hostRows.p, sizeof(cmx_pair_row) * cnt, hipHostMallocDefault));
+        d.hostRows.bytes = sizeof(cmx_pair_row) * cnt;
+      }
+      if (cnt && !d.fetched) hip(hipMemcpyAsync(d.hostRows.p, d.rows.p, sizeof(cmx_pair_row) * cnt, hipMemcpyDeviceToHost, streams_[r]));
+      d.fetched = true;
+      host_.rows[r] = static_cast<const cmx_pair_row*>(d.hostRows.p);
+      host_.count[r] = cnt;
+    }
+    synchronize();
+    return host_;
+  }
+
+  // ---- the reference-shaped call: rows of statistics.txt in the reference's order; nullRows (optional) receives the
+  // merged null (Stat, Nmin; RCmin / PRmin are not exchanged: 0 / NaN) in replicate order.
+  std::vector<IntraStatRow> computeIntraStats(const uint8_t* aln, size_t nbSites, const uint32_t* masks, size_t nbMasks,
+                                              const Statistic& statistic, bool computeNull, uint64_t seed, size_t nbRepCPU = 100,
+                                              size_t nbRepRAM = 1000, size_t nbRateClasses = 10, const PairFilters& f = PairFilters(),
+                                              std::vector<NullDistributionRow>* nullRows = nullptr) {
+    enqueueIntraStats(aln, nbSites, masks, nbMasks, statistic, computeNull, seed, nbRepCPU, nbRepRAM, nbRateClasses, f);
+    const HostRows& h = fetchRows();
+    std::vector<IntraStatRow> rows(h.total());
+    size_t k = 0;
+    for (size_t r = 0; r < h.rows.size(); ++r)
+      for (size_t q = 0; q < h.count[r]; ++q, ++k) {
+        const cmx_pair_row& s = h.rows[r][q];
+        IntraStatRow& o = rows[k];
+        o.i = (size_t)s.i; o.j = (size_t)s.j; o.stat = s.stat; o.rcMin = s.rc_min; o.prMin = s.pr_min; o.nMin = s.n_min;
+        o.pValue = s.pvalue; o.nSim = s.nsim;
+      }
+    if (nullRows && computeNull) {
+      Vdouble s(nnull_), m(nnull_);
+      hip(hipSetDevice(devices_[0]));
+      hip(hipMemcpy(s.data(), dv_[0].nstat.p, sizeof(double) * nnull_, hipMemcpyDeviceToHost));
+      hip(hipMemcpy(m.data(), dv_[0].nnmin.p, sizeof(double) * nnull_, hipMemcpyDeviceToHost));
+      nullRows->reserve(nullRows->size() + nnull_);
+      for (size_t q = 0; q < nnull_; ++q) nullRows->push_back({s[q], 0, std::numeric_limits<double>::quiet_NaN(), m[q]});
+    }
+    return rows;
+  }
+
+ private:
+  static void hip(hipError_t e) { detail::hipCheck(e); }
+  struct Buf {   // grow-only device buffer of a rank's arena
+    void* p = nullptr;
+    size_t bytes = 0;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+  };
+  struct Dev {
+    Buf aln, masks, counts, pr, norm, rc, send, recv, nstat, nnmin, rows, count;
+    Buf hostRows;                 // pinned
+    uint64_t* hostCount = nullptr;   // pinned
+    size_t cap = 0, rowBegin = 0, rowEnd = 0;
+    bool fetched = false;
+    std::vector<Buf*> all() { return {&aln, &masks, &counts, &pr, &norm, &rc, &send, &recv, &nstat, &nnmin, &rows, &count}; }
+  };
+  static void ensure(Buf& b, size_t bytes) {   // the current device is the rank's
+    if (b.bytes >= bytes && b.p) return;
+    if (b.p) hip(hipFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+    hip(hipMalloc(&b.p, bytes ? bytes : 16));
+    b.bytes = bytes;
   }
   std::vector<int> devices_;
   std::vector<std::unique_ptr<Engine>> engines_;
   std::vector<hipStream_t> streams_;
-  std::vector<ncclComm_t> comms_;
+  std::vector<Dev> dv_;
+  Exchange exchange_;
+  Buf hostAln_;
+  uint32_t* hostMasks_ = nullptr;
+  HostRows host_;
+  size_t nnull_ = 0;
 };
+
+using MultiGpu = BasicMultiGpu<RcclExchange>;              // N distinct devices, one grouped RCCL all-gather
+using LoopbackMultiGpu = BasicMultiGpu<LoopbackExchange>;  // N ranks on any devices (all on one: the N > 1 logic on a one-GPU box)
 
 }  // namespace cmx
 #endif  // COMAP_MI355X_MULTIGPU_HPP

@@ -119,8 +119,7 @@ def test_clustering_and_candidate_groups_under_the_guard():
     case = make_case(11, 90, 20, 4)
     eng, om = _eng(case), _om(case)
     g = eng.cluster_null(oc.DIST_CORRELATION, oc.LINK_COMPLETE, 123, 1, 4, 50)      # 3 replicates of 50 sites
-    o = oc.cluster_null(om, oc.DIST_CORRELATION, oc.LINK_COMPLETE, 123, 1, 4, 50)
-    assert len(g) == len(o)
+    assert len(g["merge"]) == 3     # (trees are compared with the oracle in tests/test_gpu_cluster.py, on alignments without duplicate columns)
     counts = eng.map_sites(case["aln"])["counts"]
     eng.cluster_sites(oc.DIST_COMPENSATION, oc.LINK_AVERAGE, counts)
     mp = oracle.map_sites(om, case["aln"])
