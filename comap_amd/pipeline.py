@@ -31,6 +31,7 @@ class IntraAnalysis:
         self.rate_class = torch.empty(self.n, dtype=torch.int32, device=dev)
         self._dense = None
         self._rows = None
+        self._compact = None
         self._null = {}
         self._null_aln = None
 
@@ -115,6 +116,18 @@ class IntraAnalysis:
         self.eng.intra_rows_range_dev(self.kind, self.counts, self.rate_class, self.post_rate, self.norm, null_stat, null_nmin,
                                       self.nclasses, rows, count, row_begin, row_end, filters, threshold=self.threshold)
         return rows, count
+
+
+    def compute_intra_compact(self, null_stat=None, null_nmin=None, row_begin=0, row_end=None):
+        """the unfiltered pair loop as 16-byte records (engine.PAIR_COMPACT) -> (uint8 CUDA tensor, number of pairs)"""
+        from .engine import PAIR_COMPACT
+        row_end = self.n if row_end is None else row_end
+        npairs = sum_pairs(self.n, row_begin, row_end)
+        if self._compact is None or self._compact.numel() < max(npairs, 1) * PAIR_COMPACT.itemsize:
+            self._compact = torch.empty(max(npairs, 1) * PAIR_COMPACT.itemsize, dtype=torch.uint8, device=self.aln.device)
+        self.eng.intra_compact_range_dev(self.kind, self.counts, self.norm, null_stat, null_nmin, self.nclasses, self._compact,
+                                         row_begin, row_end, threshold=self.threshold)
+        return self._compact, npairs
 
 
 def sum_pairs(n, row_begin, row_end):

@@ -277,6 +277,24 @@ cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params
                                     const double* d_null_stat, const double* d_null_nmin, size_t nnull, int nclasses,
                                     const cmx_pair_filters* filters, size_t row_begin, size_t row_end, cmx_pair_row* d_rows,
                                     size_t capacity, uint64_t* d_count, void* stream);
+/* The UNFILTERED pair loop as 16 bytes per pair (round 4): statistic, number of null values of the pair's norm class that
+ * are smaller (CoETools.cpp:712-717) and the size of that class, for the pairs (i, j > i) of the rows [row_begin, row_end)
+ * at their position in the reference's (i, j) order -- which, without filters, is arithmetic, so no counting pass runs.
+ * below = 0xffffffff, nsim = 0: PValue NA (smaller norm outside the Domain, CoETools.cpp:718-720) or no null given.
+ * Everything else a statistics.txt row carries is a function of per-site arrays: cmx_expand_compact_rows (host side, no
+ * GPU) rebuilds the cmx_pair_row array bit for bit.  A job without pair filters brings a third of the bytes home. */
+typedef struct cmx_pair_compact {
+  double stat;
+  uint32_t below, nsim;
+} cmx_pair_compact;
+cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts, size_t n, size_t ldc,
+                                       const double* d_norm, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
+                                       int nclasses, size_t row_begin, size_t row_end, cmx_pair_compact* d_out, size_t capacity,
+                                       void* stream);
+/* host only: rows[k] for the pairs of the rows [row_begin, row_end) in (i, j) order from their compact records and the
+ * per-site arrays; nthreads <= 1: the calling thread alone.  npairs must equal the number of pairs of the row range. */
+cmx_status cmx_expand_compact_rows(size_t n, size_t row_begin, size_t row_end, const int32_t* rate_class, const double* post_rate,
+                                   const double* norm, const cmx_pair_compact* compact, size_t npairs, cmx_pair_row* rows, int nthreads);
 /* host pointers: counts [N][B][K] -> statistic -> (optional) p-values from a null -> compacted rows; only the rows
  * cross PCIe on the way back.  null_stat == NULL: no p-values (pvalue NaN, Nsim 0 in every row). */
 cmx_status cmx_intra_rows(cmx_ctx* ctx, int kind, const double* params, const double* counts, size_t n,

@@ -1,0 +1,85 @@
+"""The 16-byte pair records of the unfiltered pair loop (cmx_pair_compact, include/comap_mi355x.h) and their expansion to
+the 48-byte statistics.txt rows of CoMap/CoETools.cpp:662-722.
+
+CPU: cmx_expand_compact_rows is host code -- positions, minima, the p-value quotient (nsim - below + 1) / (nsim + 1) of
+CoETools.cpp:717 and the NA rule against a plain Python loop, for row ranges and any thread count.
+GPU: records written by the device + expansion == the rows the device compacts itself, byte for byte."""
+import numpy as np
+import pytest
+
+from comap_amd import engine
+from conftest import make_case
+
+
+def _synthetic(n, seed):
+    rng = np.random.default_rng(seed)
+    rc = rng.integers(0, 4, size=n).astype(np.int32)
+    pr = rng.uniform(0.1, 3.0, size=n)
+    nm = rng.uniform(0.0, 5.0, size=n)
+    return rc, pr, nm
+
+
+def _reference_rows(n, rb, re_, rc, pr, nm, rec):
+    rows = []
+    k = 0
+    for i in range(rb, re_):
+        for j in range(i + 1, n):
+            c = rec[k]
+            k += 1
+            if c["below"] == 0xffffffff:
+                pv, ns = np.nan, 0
+            else:
+                ns = int(c["nsim"])
+                pv = float(ns - int(c["below"]) + 1) / float(ns + 1)
+            rows.append((i, j, c["stat"], min(rc[i], rc[j]), ns, min(pr[i], pr[j]), min(nm[i], nm[j]), pv))
+    return np.array(rows, dtype=engine.PAIR_ROW)
+
+
+@pytest.mark.parametrize("n,rb,re_,threads", [(2, 0, 2, 1), (37, 0, 37, 1), (37, 5, 20, 3), (64, 63, 64, 2), (101, 0, 101, 16), (50, 10, 10, 4)])
+def test_expansion_equals_the_reference_row_loop(n, rb, re_, threads):
+    rc, pr, nm = _synthetic(n, n + rb)
+    npairs = (re_ - rb) * (n - 1) - (re_ * (re_ - 1) - rb * (rb - 1)) // 2
+    rng = np.random.default_rng(3)
+    rec = np.zeros(npairs, dtype=engine.PAIR_COMPACT)
+    rec["stat"] = rng.normal(size=npairs)
+    rec["nsim"] = rng.integers(1, 100000, size=npairs)
+    rec["below"] = (rng.random(npairs) * (rec["nsim"] + 1)).astype(np.uint32)
+    na = rng.random(npairs) < 0.1
+    rec["below"][na] = 0xffffffff
+    rec["nsim"][na] = 0
+    got = engine.expand_compact_rows(n, rb, re_, rc, pr, nm, rec, threads)
+    ref = _reference_rows(n, rb, re_, rc, pr, nm, rec)
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_expansion_rejects_a_wrong_record_count():
+    rc, pr, nm = _synthetic(10, 1)
+    with pytest.raises(engine.CmxError):
+        engine.expand_compact_rows(10, 0, 10, rc, pr, nm, np.zeros(44, dtype=engine.PAIR_COMPACT))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nstates", [(engine.STAT_CORRELATION, 20), (engine.STAT_COMPENSATION, 4), (engine.STAT_DISCRETE_MI, 20)])
+def test_device_records_expand_to_the_device_rows(kind, nstates):
+    import torch
+    from comap_amd.pipeline import IntraAnalysis
+    case = make_case(10, 203, nstates, 17 + kind)
+    eng = engine.Engine(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    d_aln = torch.from_numpy(case["aln"]).cuda()
+    ana = IntraAnalysis(eng, d_aln, kind, 6, threshold=0.05)
+    ana.get_vectors()
+    nb = ana.null_distribution(99, 0, 40, 64)
+    n = 203
+    for (rb, re_), with_null in (((0, n), True), ((0, n), False), ((17, 130), True), ((202, 203), True), ((60, 60), True)):
+        ns, nm = (nb["stat"], nb["nmin"]) if with_null else (None, None)
+        rows, count = ana.compute_intra_rows(ns, nm, rb, re_)
+        nrows = int(count.item())
+        ref = rows[:nrows * engine.PAIR_ROW.itemsize].cpu().numpy().view(engine.PAIR_ROW)
+        rec, npairs = ana.compute_intra_compact(ns, nm, rb, re_)
+        assert npairs == nrows
+        rec_h = rec[:npairs * engine.PAIR_COMPACT.itemsize].cpu().numpy().view(engine.PAIR_COMPACT)
+        got = engine.expand_compact_rows(n, rb, re_, ana.rate_class.cpu().numpy(), ana.post_rate.cpu().numpy(), ana.norm.cpu().numpy(),
+                                         rec_h, nthreads=3)
+        assert got.tobytes() == ref.tobytes()
+        if with_null and npairs > 100:
+            assert (rec_h["below"] != 0xffffffff).any() and np.isfinite(got["pvalue"]).any()
