@@ -36,6 +36,9 @@ WORKLOADS = {
     "target": dict(ntaxa=64, nsites=10000, nstates=20, seed=20260101, statistic="Correlation", nrep=lambda n: 1000,
                    rep_ram=10000, nclasses=10, scaling="strong",
                    desc="north-star target: 10000x64 protein JTT92+G4(a=0.5), correlation, 1000 null replicates x 10000"),
+    "cfg2": dict(ntaxa=64, nsites=2000, nstates=20, seed=20260101, statistic="Correlation", nrep=lambda n: 0,
+                 rep_ram=2000, nclasses=10, scaling="strong",
+                 desc="BASELINE configs[1]: 2000x64 protein JTT92+G4(a=0.5), correlation, no null (map + all pairs + rows)"),
     "cfg3": dict(ntaxa=64, nsites=2000, nstates=20, seed=20260101, statistic="Correlation", nrep=lambda n: 125 * n,
                  rep_ram=2000, nclasses=10, scaling="weak",
                  desc="2000x64 protein JTT92+G4(a=0.5), correlation, null 125 rep/GPU x 2000 (configs[2] at 8 GPUs)"),
@@ -99,6 +102,10 @@ def cpu_baseline(w, parent, blen, lot, mdl, Bk, clamp, nrep_total):
     t0 = time.perf_counter()
     st = oracle.pair_stats_intra(kind, m["counts"])
     t_pairs = time.perf_counter() - t0
+    if nrep_total == 0:   # no null (BASELINE configs[1]): mapping + the pair loop is the whole job, nothing is extrapolated
+        pairs = n_obs * (n_obs - 1) / 2
+        return dict(value=pairs / (t_map + t_pairs), unit="site-pair statistics/s", cores=1, kind="port",
+                    sample=f"oracle/oracle.c -O2, 1 thread, the whole workload: map {n_obs} sites {t_map:.2f}s + {int(pairs)} pair stats {t_pairs:.2f}s")
     t0 = time.perf_counter()
     nl = oracle.null_intra(om, kind, 1, 0, nrep_s, ram_s)
     t_null = time.perf_counter() - t0
@@ -269,6 +276,18 @@ def main():
     main_s = torch.cuda.current_stream()
 
     def step(i, timed, aln=None):
+        if nrep_total == 0:   # no null: map, then the pair loop without p-values; the events bracket the mapping stage
+            if timed:
+                ev[i][0].record()
+            ana.get_vectors(aln)
+            if timed:
+                ev[i][1].record()
+            if args.pair_output == "compact":
+                return ana.compute_intra_compact(None, None, row_begin, row_end)
+            if args.pair_output == "rows":
+                return ana.compute_intra_rows(None, None, row_begin, row_end)
+            ana.compute_intra_stats(None, None)
+            return None
         side.wait_stream(main_s)
         with torch.cuda.stream(side):
             ana.get_vectors(aln)
@@ -312,14 +331,14 @@ def main():
     # roofline of the dominant kernel (map_kernel<S, null>): HIP events on the launch stream
     null_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     alg, exe = flops_per_site(info, eng.B, eng.C, eng.S, eng.K)
-    sites_per_launch = 2 * n_local
+    sites_per_launch = 2 * n_local if nrep_total else w["nsites"]
     achieved = sites_per_launch * alg / (null_ms * 1e-3) / 1e12
     ach_exe = sites_per_launch * exe / (null_ms * 1e-3) / 1e12
     # `achieved` / `frac` follow SURVEY 8(d): ALGORITHMIC flops (7 B C S^2 per site, leaf edges counted as dense
     # products) / time / peak.  `frac_executed` counts only the matrix products the kernel issues (leaf edges are row
     # gathers, sibling messages are stored instead of recomputed): the matrix pipe's duty, always lower.
-    sim_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_sim]))
-    kname = f"map_kernel<{eng.S},null>"
+    sim_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_sim])) if nrep_total else 0.0
+    kname = f"map_kernel<{eng.S},null>" if nrep_total else f"map_kernel<{eng.S},observed> (+ map_finalize_kernel when class-split)"
     roofline = dict(bound="mfma", kernel=kname, achieved=achieved, peak=FP64_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
                     launch_ms=null_ms, simulate_ms=sim_ms, sites_per_launch=sites_per_launch, flops_per_site_algorithmic=alg,

@@ -573,11 +573,19 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
   }
   a.counts = d_counts; a.ldc = ldc; a.logL = d_logL; a.post_rate = d_post_rate; a.rate_class = d_rate_class;
   a.norm = d_norm;
-  const size_t ks = (size_t)map_sites_per_wave(ctx->hm.dS);
-  const size_t nblocks = (nsites + ks - 1) / ks;
+  size_t ks = (size_t)map_sites_per_wave(ctx->hm.dS);
+  size_t nblocks = (nsites + ks - 1) / ks;
   const size_t obs_waves = (size_t)max_blocks * kWavesPerBlock;
   if (nblocks * (size_t)ctx->hm.dC <= obs_waves && ctx->hm.dC > 1) {
     // small alignment: one (site block, class) per wave, classes summed by a second kernel (same arithmetic order)
+    // Proteins, when even that leaves most of the chip idle: 16-site blocks (one site group per wave) -- four times the
+    // tasks, a quarter of the matrix work per operator op, and a wave's slices of the workspaces are a quarter as large,
+    // so 4 * obs_waves of them fit the same allocation
+    if (ctx->hm.dS == 20 && ctx->hm.fuse == 1 && ks == 64 && ((nsites + 15) / 16) * (size_t)ctx->hm.dC <= 4 * obs_waves) {
+      ks = 16;
+      nblocks = (nsites + ks - 1) / ks;
+    }
+    a.split_sites = (int)ks;
     const size_t ntasks = nblocks * (size_t)ctx->hm.dC, BK = (size_t)ctx->hm.B * ctx->hm.K;
     // (per caller, like the workspaces: the public observed mapping and the engine's own pipelines may overlap on two streams)
     if ((s = scratch(ctx, full_grid ? "split_part_null" : "split_part_obs", sizeof(double) * ntasks * BK * ks, (void**)&a.split_part)) != CMX_OK) return s;

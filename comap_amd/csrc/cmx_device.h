@@ -102,6 +102,7 @@ struct MapArgs {
   // class-split observed mode: [nblocks][C][B*K][64] per-class counts, [2][nblocks][C][64] p_c L_c and r_c p_c L_c
   double* split_part;
   double* split_lc;
+  int split_sites;         // sites per wave-task of the class-split launch: map_sites_per_wave(S), or 16 for small alignments
   int lds_per_wave;        // bytes of dynamic LDS per wave (set by launch_map)
   // null mode
   int stat_kind;

@@ -139,7 +139,7 @@ __device__ __forceinline__ void wait_vm(int allowed) {
   // vectors (stores or loads, H instructions each).  The operator part varies per op since round 4 (products of a fused
   // model and leaf ops of resolved alignments stage a part of the unit), so every count up to R + 1 + H is exact and the
   // steps above are the multiples of H the vectors add; a smaller immediate than `allowed` only waits for more.
-  constexpr int R = MatStage<S>::ROWS, H = VL / 2;
+  constexpr int R = MatStage<S>::ROWS, H = (VL + 1) / 2;
   static_assert(R + 1 + 3 * H < 64, "vmcnt is a 6-bit counter");
   static_assert(R + 1 <= 6, "operator rows + symbols");
   const int v = allowed % H < 7 ? allowed % H : 6, q = allowed / H;   // (H >= 7 for every instantiation but S = 4: there v < H anyway)
@@ -181,13 +181,20 @@ __device__ __forceinline__ double reduce_sites(const double (&p)[NG]) {
     double k0 = p0 + p2, k1 = p1 + p3;   // site groups 0 / 1 in the lower half of the wave, 2 / 3 in the upper
     swap16(k0, k1);            // even rows: own k0, partner's k0    | odd rows: partner's k1, own k1
     return k0 + k1;            // site group lane >> 4: lane l holds site l
-  } else {
+  } else if constexpr (NG == 2) {
     // two site groups (32 sites per wave): lanes l and l ^ 16 both end with the total of site 16 (l >> 5) + (l & 15)
-    static_assert(NG == 2, "site groups per wave");
     double p0 = p[0], p1 = p[1];
     swap32(p0, p1);            // lanes < 32: own p0, partner's p0   | lanes >= 32: partner's p1, own p1
     double k = p0 + p1, q = k;
     swap16(k, q);              // even rows: k own, q = partner's (odd row) k   | odd rows: k = partner's, q own
+    return k + q;
+  } else {
+    // one site group (16 sites per wave, small alignments): all four lanes l, l ^ 16, l ^ 32, l ^ 48 end with the total of site l & 15
+    static_assert(NG == 1, "site groups per wave");
+    double p0 = p[0], p1 = p0;
+    swap32(p0, p1);            // p0 = the lower half's value everywhere, p1 = the upper half's
+    double k = p0 + p1, q = k;
+    swap16(k, q);
     return k + q;
   }
 }
@@ -275,16 +282,17 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
 // Workspace vectors are stored as [S/2][64 lanes][2 doubles]: one 16-byte access per lane and row, 1 KiB per
 // wave-instruction, the same image in HBM and (for prefetched vectors) in LDS.
 template <int S>
-__device__ __forceinline__ void load_vec(const double* p /* slice base + 2*lane */, double (&v)[S]) {
+__device__ __forceinline__ void load_vec(const double* p /* slice base + 2*lane */, double (&v)[S], int lane = 0) {
 #pragma unroll
   for (int i = 0; i < S / 2; ++i) {
     const d2 t = *reinterpret_cast<const d2*>(p + (size_t)i * 2 * kWave);
     v[2 * i] = t[0];
     v[2 * i + 1] = t[1];
   }
+  if constexpr (S % 2) v[S - 1] = p[(size_t)(S / 2) * 2 * kWave - lane];   // odd length (16-site tasks): a last row of single doubles
 }
 template <int S>
-__device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
+__device__ __forceinline__ void store_vec(double* p, const double (&v)[S], int lane = 0) {
 #pragma unroll
   for (int i = 0; i < S / 2; ++i) {
     d2 t;
@@ -292,6 +300,7 @@ __device__ __forceinline__ void store_vec(double* p, const double (&v)[S]) {
     t[1] = v[2 * i + 1];
     *reinterpret_cast<d2*>(p + (size_t)i * 2 * kWave) = t;
   }
+  if constexpr (S % 2) p[(size_t)(S / 2) * 2 * kWave - lane] = v[S - 1];
 }
 
 // asynchronous HBM -> LDS copy of one workspace vector (S/2 LDS-DMA instructions, no VGPR destination)
@@ -440,7 +449,7 @@ struct DevWalk {
   // site of the lane inside the wave's block (see map_sites_wave)
   __device__ __forceinline__ int vsidx() const {
     const int l = vlane();
-    return NG == 4 ? l : (((l >> 5) << 4) | (l & 15));
+    return NG == 4 ? l : (NG == 2 ? (((l >> 5) << 4) | (l & 15)) : (l & 15));
   }
   template <int I>
   __device__ __forceinline__ double (&reg())[VL] {
@@ -466,8 +475,10 @@ struct DevWalk {
   template <int R>
   __device__ __forceinline__ void kill() {
     double(&r)[VL] = reg<R>();
-    static_assert(VL == 4 || VL == 8 || VL == 16 || VL == 20, "kill() names every element in one statement");
-    if constexpr (VL == 4)
+    static_assert(VL == 4 || VL == 5 || VL == 8 || VL == 16 || VL == 20, "kill() names every element in one statement");
+    if constexpr (VL == 5)
+      asm volatile("" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]));
+    else if constexpr (VL == 4)
       asm volatile("" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]));
     else if constexpr (VL == 8)
       asm volatile("" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7]));
@@ -549,13 +560,19 @@ struct DevWalk {
   // instruction this code issues so that the counted waits of the operator stream let them stay in flight.
   template <int D>
   __device__ __forceinline__ void load(int arr, int slot) {
-    load_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vlane(), reg<D>());
-    os.vs += VL / 2;
+    {
+      const int vl = vlane();
+      load_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vl, reg<D>(), vl);
+    }
+    os.vs += (VL + 1) / 2;
   }
   template <int SRC>
   __device__ __forceinline__ void store(int arr, int slot) {
-    store_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vlane(), reg<SRC>());
-    os.vs += VL / 2;
+    {
+      const int vl = vlane();
+      store_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vl, reg<SRC>(), vl);
+    }
+    os.vs += (VL + 1) / 2;
   }
   template <int D, int SRC> __device__ __forceinline__ void mov() {
 #pragma unroll
@@ -630,7 +647,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   constexpr int kSites = 16 * NG;      // sites per wave (NG site groups of 16; an S-vector is S / 4 * NG doubles per lane)
   // site of this lane inside the wave's block for per-site scalars and arrays: NG = 4: the lane itself; NG = 2: lanes
   // l and l ^ 16 both carry site 16 (l >> 5) + (l & 15) and do the per-site work redundantly (identical values)
-  const int sidx = NG == 4 ? lane : (((lane >> 5) << 4) | (lane & 15));
+  const int sidx = NG == 4 ? lane : (NG == 2 ? (((lane >> 5) << 4) | (lane & 15)) : (lane & 15));
   const int C = m.C, K = m.K;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
@@ -745,13 +762,13 @@ template <int S>
 constexpr int map_lds_fixed() { return 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }   // stage buffers + symbol slots
 // + the simulator's node states (one byte per node and site) when they fit what is left of the CU's LDS share
 
-template <int S, int MODE, int FUSE>
+template <int S, int MODE, int FUSE, int NG = map_ng(S)>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void map_kernel(const MapArgs a) {
-  constexpr int NG = map_ng(S), VL = S / 4 * NG, kSites = 16 * NG;
+  constexpr int VL = S / 4 * NG, kSites = 16 * NG;
   const DevModel& m = a.m;
   const ConstModel cm(m);
   const int lane = threadIdx.x & (kWave - 1);
-  const int sidx = NG == 4 ? lane : (((lane >> 5) << 4) | (lane & 15));   // site of this lane in the wave's block
+  const int sidx = NG == 4 ? lane : (NG == 2 ? (((lane >> 5) << 4) | (lane & 15)) : (lane & 15));   // site of this lane in the wave's block
   // wave index through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform and would keep every
   // per-wave base pointer below as a per-lane 64-bit VGPR pair (spilled, and reloaded from scratch in the hot loop)
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -873,7 +890,13 @@ hipError_t launch_map(const MapArgs& a_in, int mode, int grid_blocks, hipStream_
     else if (mode == kModeObservedSplit) CMX_LAUNCH(S_, kModeObservedSplit, F_); \
     else CMX_LAUNCH(S_, kModeNull, F_);                                     \
   } while (0)
-  if (a.m.S == 20 && a.m.fuse == 1) CMX_LAUNCH_MODES(20, 1);
+  if (a.m.S == 20 && a.m.fuse == 1 && mode == kModeObservedSplit && a.split_sites == 16) {
+    // 16-site wave-tasks (one site group): small alignments, four times the waves
+    const hipError_t ea_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&map_kernel<20, kModeObservedSplit, 1, 1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if (ea_ != hipSuccess) return ea_;
+    hipLaunchKernelGGL((map_kernel<20, kModeObservedSplit, 1, 1>), grid, block, lds, stream, a);
+  } else if (a.m.S == 20 && a.m.fuse == 1) CMX_LAUNCH_MODES(20, 1);
   else if (a.m.S == 20 && a.m.fuse == 5) CMX_LAUNCH_MODES(20, 5);
   else if (a.m.S == 16 && a.m.fuse == 4) CMX_LAUNCH_MODES(16, 4);
   else if (a.m.S == 4 && a.m.fuse == 1) CMX_LAUNCH_MODES(4, 1);
@@ -883,13 +906,20 @@ hipError_t launch_map(const MapArgs& a_in, int mode, int grid_blocks, hipStream_
   return hipGetLastError();
 }
 
-// class-split observed mode: sums the per-class results in class order exactly as map_sites_wave's own epilogue does
-__global__ void map_finalize_kernel(const MapArgs a) {
+// class-split observed mode: sums the per-class results in class order exactly as map_sites_wave's own epilogue does.
+// 64 sites x 16 branch lanes per workgroup (round 4; one thread per site walked B x C dependent loads, 0.2 ms for 2 000
+// sites): thread (site, w) sums the classes of the branches b = w mod 16 and leaves each branch's total in LDS, then the
+// site's first thread adds the squares in branch order -- every sum runs in the order of the plain (b, k, c) loop nest.
+constexpr int kFinBranchLanes = 16, kFinChunk = 128;
+__global__ __launch_bounds__(64 * kFinBranchLanes) void map_finalize_kernel(const MapArgs a) {
   const DevModel& m = a.m;
-  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= a.nsites) return;
-  const size_t kS = 16 * (size_t)map_ng(m.S);   // sites per wave-task of the mapping kernel
-  const size_t sb = s / kS, lane = s % kS, BK = (size_t)m.B * m.K;
+  __shared__ double tots[kFinChunk][64];
+  const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t s = (size_t)blockIdx.x * 64 + tx;
+  const bool live = s < a.nsites;
+  const size_t sc = live ? s : a.nsites - 1;
+  const size_t kS = (size_t)a.split_sites;   // sites per wave-task of the mapping kernel
+  const size_t sb = sc / kS, lane = sc % kS, BK = (size_t)m.B * m.K;
   const size_t nblocks = (a.nsites + kS - 1) / kS, ntasks = nblocks * (size_t)m.C;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
@@ -902,18 +932,26 @@ __global__ void map_finalize_kernel(const MapArgs a) {
   }
   const double* part = a.split_part + sb * m.C * BK * kS + lane;
   double nrm = 0.0;
-  for (int b = 0; b < m.B; ++b) {
-    double tot = 0.0;
-    for (int k = 0; k < m.K; ++k) {
-      const size_t r = (size_t)b * m.K + k;
-      double v = 0.0;
-      for (int c = 0; c < m.C; ++c) v += part[((size_t)c * BK + r) * kS];
-      v /= Lsum;
-      if (a.counts) a.counts[r * a.ldc + s] = v;
-      tot += v;
+  for (int b0 = 0; b0 < m.B; b0 += kFinChunk) {
+    const int be = b0 + kFinChunk < m.B ? b0 + kFinChunk : m.B;
+    for (int b = b0 + w; b < be; b += kFinBranchLanes) {
+      double tot = 0.0;
+      for (int k = 0; k < m.K; ++k) {
+        const size_t r = (size_t)b * m.K + k;
+        double v = 0.0;
+        for (int c = 0; c < m.C; ++c) v += part[((size_t)c * BK + r) * kS];
+        v /= Lsum;
+        if (a.counts && live) a.counts[r * a.ldc + s] = v;
+        tot += v;
+      }
+      tots[b - b0][tx] = tot;
     }
-    nrm = __builtin_fma(tot, tot, nrm);
+    __syncthreads();
+    if (w == 0)
+      for (int b = b0; b < be; ++b) nrm = __builtin_fma(tots[b - b0][tx], tots[b - b0][tx], nrm);
+    __syncthreads();
   }
+  if (w != 0 || !live) return;
   if (a.logL) a.logL[s] = log(Lsum);
   if (a.post_rate) a.post_rate[s] = prsum / Lsum;
   if (a.rate_class) a.rate_class[s] = bestc;
@@ -921,7 +959,7 @@ __global__ void map_finalize_kernel(const MapArgs a) {
 }
 
 hipError_t launch_map_finalize(const MapArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(map_finalize_kernel, dim3((unsigned)((a.nsites + 63) / 64)), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(map_finalize_kernel, dim3((unsigned)((a.nsites + 63) / 64)), dim3(64 * kFinBranchLanes), 0, stream, a);
   return hipGetLastError();
 }
 
