@@ -748,7 +748,7 @@ cmx_status cmx_simulate_continuous(cmx_ctx* ctx, uint64_t seed, uint64_t g0, siz
 
 // ------------------------------------------------------------------------------------------------ pair statistics
 static cmx_status check_kind(cmx_ctx* ctx, int kind) {
-  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_DISCRETE_MI_BOUNDS) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
+  if (kind < CMX_STAT_CORRELATION || kind > CMX_STAT_SCALAR_PRODUCT) return fail(ctx, CMX_ERR_INVALID, "unknown statistic kind");
   return CMX_OK;
 }
 // CorrectedCorrelation: params = the two mean vectors [2][B] in host memory -> device copy (null for other kinds)
@@ -864,6 +864,73 @@ static void to_branch_major(const double* sm, size_t n, size_t BK, std::vector<d
   bm->resize(BK * n);
   for (size_t i = 0; i < n; ++i)
     for (size_t r = 0; r < BK; ++r) (*bm)[r * n + i] = sm[i * BK + r];
+}
+
+// AnalysisTools::compute*Matrix (AnalysisTools.cpp:102-339): the same operand preparation, Gram kernel and epilogues as
+// the pair statistics, with the vector length as the "number of branches" and one "substitution type"
+cmx_status cmx_vector_matrix(cmx_ctx* ctx, int kind, size_t dim, const double* v1, size_t n1, const double* v2, size_t n2,
+                             int independent, double* out) {
+  if (!ctx) return CMX_ERR_INVALID;
+  if (kind != CMX_STAT_SCALAR_PRODUCT && kind != CMX_STAT_COSINUS && kind != CMX_STAT_CORRELATION && kind != CMX_STAT_COVARIANCE)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_vector_matrix: kind must be scalar product, cosinus, correlation or covariance");
+  const bool one = v2 == nullptr;
+  if (one) n2 = n1;
+  if (!v1 || !out || n1 == 0 || n2 == 0 || dim == 0 || dim > 0x7fffffffull) return fail(ctx, CMX_ERR_INVALID, "cmx_vector_matrix: bad arguments");
+  if (independent && (one || n1 != n2))
+    return fail(ctx, CMX_ERR_INVALID, "cmx_vector_matrix: when performing independant comparisons, the two datasets must have the same length");
+  if ((kind == CMX_STAT_CORRELATION || kind == CMX_STAT_COVARIANCE) && dim < 2)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_vector_matrix: correlation / covariance need vectors of at least two elements");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int B = (int)dim, Bp = (B + 3) / 4 * 4;
+  TmpDev tmp;
+  std::vector<double> bm;
+  double *d1 = nullptr, *d2 = nullptr, *d_out = nullptr;
+  to_branch_major(v1, n1, dim, &bm);
+  HIP_TRY(ctx, tmp.alloc((void**)&d1, bm.size() * sizeof(double)));
+  HIP_TRY(ctx, hipMemcpy(d1, bm.data(), bm.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (!one) {
+    to_branch_major(v2, n2, dim, &bm);
+    HIP_TRY(ctx, tmp.alloc((void**)&d2, bm.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(d2, bm.data(), bm.size() * sizeof(double), hipMemcpyHostToDevice));
+  } else d2 = d1;
+  if (independent) {   // AnalysisTools.cpp:150-157: j runs over i alone
+    HIP_TRY(ctx, tmp.alloc((void**)&d_out, n1 * sizeof(double)));
+    HIP_TRY(ctx, launch_pair_diag(kind, 0.0, B, 1, d1, n1, d2, n2, n1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_out, nullptr,
+                                  nullptr, nullptr, nullptr, nullptr));
+    std::vector<double> dg(n1);
+    HIP_TRY(ctx, hipMemcpy(dg.data(), d_out, n1 * sizeof(double), hipMemcpyDeviceToHost));
+    std::fill(out, out + n1 * n2, 0.0);
+    for (size_t i = 0; i < n1; ++i) out[i * n2 + i] = dg[i];
+    return CMX_OK;
+  }
+  const size_t ldx1 = (n1 + 15) / 16 * 16, ldx2 = (n2 + 15) / 16 * 16;
+  double *X1, *s1, *r1, *X2, *s2, *r2;
+  cmx_status s;
+  if ((s = scratch(ctx, "pair_X1", sizeof(double) * Bp * ldx1, (void**)&X1)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pair_s1", sizeof(double) * n1, (void**)&s1)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "pair_r1", sizeof(double) * n1, (void**)&r1)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_pair_prep(kind, 0.0, d1, n1, n1, B, 1, X1, ldx1, Bp, s1, r1, nullptr, nullptr));
+  if (one) { X2 = X1; s2 = s1; r2 = r1; }
+  else {
+    if ((s = scratch(ctx, "pair_X2", sizeof(double) * Bp * ldx2, (void**)&X2)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_s2", sizeof(double) * n2, (void**)&s2)) != CMX_OK) return s;
+    if ((s = scratch(ctx, "pair_r2", sizeof(double) * n2, (void**)&r2)) != CMX_OK) return s;
+    HIP_TRY(ctx, launch_pair_prep(kind, 0.0, d2, n2, n2, B, 1, X2, ldx2, Bp, s2, r2, nullptr, nullptr));
+  }
+  HIP_TRY(ctx, tmp.alloc((void**)&d_out, n1 * n2 * sizeof(double)));
+  // the full rectangle (one-set form too: the reference fills both triangles and the diagonal)
+  HIP_TRY(ctx, launch_pair_gram(kind, B, Bp, X1, s1, r1, n1, ldx1, X2, s2, r2, n2, one ? ldx1 : ldx2, 0, d_out, n2, nullptr));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, d_out, n1 * n2 * sizeof(double), hipMemcpyDeviceToHost));
+  if (one) {
+    // matrix[i][i] = 1 for cosinus / correlation (AnalysisTools.cpp:178, 236); the lower triangle mirrors the upper one
+    // (matrix[i][j] = matrix[j][i] = f(v_i, v_j), j > i)
+    for (size_t i = 0; i < n1; ++i) {
+      if (kind == CMX_STAT_COSINUS || kind == CMX_STAT_CORRELATION) out[i * n1 + i] = 1.0;
+      for (size_t j = 0; j < i; ++j) out[i * n1 + j] = out[j * n1 + i];
+    }
+  }
+  return CMX_OK;
 }
 
 cmx_status cmx_pair_stats(cmx_ctx* ctx, int kind, const double* params, const double* counts1, size_t n1,
@@ -1091,24 +1158,23 @@ static cmx_status null_unfused_dev(cmx_ctx* ctx1, cmx_ctx* ctx2, int kind, const
     cmx_ctx* c = cx[h];
     const std::string tag = std::string("inter") + char('0' + h);
     uint8_t *d_aln, *d_st;
-    int32_t* d_cls;
     if ((s = scratch(ctx1, (tag + "_aln").c_str(), (size_t)c->hm.T * n, (void**)&d_aln)) != CMX_OK) return s;
     // (node states share the alignment's row stride n in simulate_kernel: [nn][n], not [nn][rep_ram] -- sized for rep_ram
     // this overflowed as soon as a call held more than one replicate)
     if ((s = scratch(ctx1, (tag + "_st").c_str(), (size_t)c->hm.nn * n, (void**)&d_st)) != CMX_OK) return s;
-    if ((s = scratch(ctx1, (tag + "_cls").c_str(), sizeof(int32_t) * rep_ram, (void**)&d_cls)) != CMX_OK) return s;
     if ((s = scratch(ctx1, (tag + "_cnt").c_str(), sizeof(double) * BK * n, (void**)&cnt[h])) != CMX_OK) return s;
     if ((s = scratch(ctx1, (tag + "_pr").c_str(), sizeof(double) * n, (void**)&pr[h])) != CMX_OK) return s;
     if ((s = scratch(ctx1, (tag + "_nm").c_str(), sizeof(double) * n, (void**)&nm[h])) != CMX_OK) return s;
     if ((s = scratch(ctx1, (tag + "_rc").c_str(), sizeof(int32_t) * n, (void**)&rc[h])) != CMX_OK) return s;
-    for (size_t r = 0; r < nrep; ++r) {
-      if (d_supplied) {   // batch h of replicate r: [T][rep_ram] -> columns r * rep_ram .. of the [T][n] alignment
+    if (d_supplied) {
+      for (size_t r = 0; r < nrep; ++r)   // batch h of replicate r: [T][rep_ram] -> columns r * rep_ram .. of the [T][n] alignment
         HIP_TRY(ctx1, hipMemcpy2DAsync(d_aln + r * rep_ram, n, d_supplied + ((r * 2 + h) * (size_t)c->hm.T) * rep_ram, rep_ram, rep_ram,
                                        (size_t)c->hm.T, hipMemcpyDeviceToDevice, st));
-        continue;
-      }
-      const uint64_t g0 = ((uint64_t)(rep_begin + r) * 2 + h) * (uint64_t)rep_ram;
-      HIP_TRY(ctx1, launch_simulate(c->dm, seed, g0, rep_ram, d_aln + r * rep_ram, n, d_cls, d_st, st));
+    } else {
+      // ONE launch for all replicates of this side (round 3: one per replicate and side -- 2 000 tiny launches for
+      // nb_rep_CPU = 1000): block r of rep_ram columns holds the global sites ((rep_begin + r) * 2 + h) * rep_ram ..
+      const uint64_t g0 = ((uint64_t)rep_begin * 2 + h) * (uint64_t)rep_ram;
+      HIP_TRY(ctx1, launch_simulate(c->dm, seed, g0, n, d_aln, n, nullptr, d_st, st, rep_ram, 2 * (uint64_t)rep_ram));
     }
     s = map_sites_impl(c, d_aln, n, n, nullptr, cnt[h], n, nullptr, pr[h], rc[h], nm[h], stream, true);
     if (s != CMX_OK) { if (c != ctx1) ctx1->err = c->err; return s; }

@@ -199,7 +199,7 @@ hipError_t launch_cluster_props(int dist_kind, int n, int B, int K, size_t batch
                                 const double* d_norm, const double* d_counts, size_t ldc, size_t site_stride, double* d_sigma,
                                 double* d_stat, double* d_nmin, hipStream_t stream);
 hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
-                           int32_t* d_classes, uint8_t* d_states /*[nn][ld]*/, hipStream_t stream);
+                           int32_t* d_classes, uint8_t* d_states, hipStream_t stream, size_t rep_ram = 0, uint64_t gstep = 0);
 hipError_t launch_simulate_continuous(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, double alpha, double p_inv,
                                       uint8_t* d_aln, size_t ld, double* d_rates, uint8_t* d_states, hipStream_t stream);
 hipError_t launch_pair_prep(int kind, double param, const double* d_counts, size_t n, size_t ldc, int B, int K,

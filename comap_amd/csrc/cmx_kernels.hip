@@ -1076,11 +1076,13 @@ hipError_t launch_group_stats(int kind, double param, int B, int K, const double
 }
 
 // ------------------------------------------------------------------------------------------------ stand-alone simulator
+// rep_ram != 0: the n sites are blocks of rep_ram (the replicates of one side of a null, side by side in the alignment);
+// block r holds the global sites g0 + r * gstep ..  (one launch for all replicates of a side: round 3 launched per replicate)
 __global__ void simulate_kernel(const DevModel m, uint64_t seed, uint64_t g0, size_t n, uint8_t* aln, size_t ld,
-                                int32_t* classes, uint8_t* states) {
+                                int32_t* classes, uint8_t* states, size_t rep_ram, uint64_t gstep) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const uint64_t g = g0 + j;
+  const uint64_t g = rep_ram ? g0 + (uint64_t)(j / rep_ram) * gstep + (uint64_t)(j % rep_ram) : g0 + j;
   const int S = m.S0;
   const int c = draw_index(philox_uniform(seed, g, 0), m.cum_probs, m.C0);
   if (classes) classes[j] = c;
@@ -1096,10 +1098,10 @@ __global__ void simulate_kernel(const DevModel m, uint64_t seed, uint64_t g0, si
 }
 
 hipError_t launch_simulate(const DevModel& m, uint64_t seed, uint64_t g0, size_t n, uint8_t* d_aln, size_t ld,
-                           int32_t* d_classes, uint8_t* d_states, hipStream_t stream) {
+                           int32_t* d_classes, uint8_t* d_states, hipStream_t stream, size_t rep_ram, uint64_t gstep) {
   const int block = 256;
   const int grid = (int)((n + block - 1) / block);
-  hipLaunchKernelGGL(simulate_kernel, dim3(grid), dim3(block), 0, stream, m, seed, g0, n, d_aln, ld, d_classes, d_states);
+  hipLaunchKernelGGL(simulate_kernel, dim3(grid), dim3(block), 0, stream, m, seed, g0, n, d_aln, ld, d_classes, d_states, rep_ram, gstep);
   return hipGetLastError();
 }
 
@@ -1491,7 +1493,7 @@ __global__ void pair_prep_kernel(int kind, double param, const double* __restric
   for (int b = 0; b < B; ++b) {
     double v;
     if (kind == 0 || kind == 4) v = counts[(size_t)b * K * ldc + i] - (mvec ? mvec[b] : 0.0) - mean;
-    else if (kind == 3) v = counts[(size_t)b * K * ldc + i];
+    else if (kind == 3 || kind == 9) v = counts[(size_t)b * K * ldc + i];
     else {
       double t = 0.0;
       for (int k = 0; k < K; ++k) t += counts[((size_t)b * K + k) * ldc + i];
@@ -1534,6 +1536,7 @@ __device__ __forceinline__ double pair_epilogue(int kind, int B, double g, doubl
       return cov / (fi * fj);
     }
     case 4: return g / (B - 1);
+    case 9: return g;
     case 3: return g / (fi * fj);
     case 1: {
       double s3 = si + sj + 2.0 * g;

@@ -33,6 +33,11 @@ __device__ __forceinline__ double pair_stat_strided(int kind, double param, int 
       if (kind == 4) return cov;
       return cov / (sqrt(sxx / (B - 1)) * sqrt(syy / (B - 1)));
     }
+    case 9: {  // scalar product (VectorTools::scalar)
+      double sxy = 0;
+      for (int b = 0; b < B; ++b) sxy += c1[(size_t)b * K * ld1] * c2[(size_t)b * K * ld2];
+      return sxy;
+    }
     case 3: {  // Cosinus
       double sxy = 0, sxx = 0, syy = 0;
       for (int b = 0; b < B; ++b) {

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COMAP_MI355X_LIB", os.path.join(_HERE, "libcomap_mi355x.so"))  # override: diagnostic builds
 
 STAT_CORRELATION, STAT_COMPENSATION, STAT_COSUBSTITUTION, STAT_COSINUS, STAT_COVARIANCE, STAT_DISCRETE_MI, \
-    STAT_CORRECTED_CORRELATION, STAT_EUCLIDIAN_DISTANCE, STAT_DISCRETE_MI_BOUNDS = range(9)
+    STAT_CORRECTED_CORRELATION, STAT_EUCLIDIAN_DISTANCE, STAT_DISCRETE_MI_BOUNDS, STAT_SCALAR_PRODUCT = range(10)
 STAT_BY_NAME = {
     # names of the reference's `statistic=` option (CoMap/CoETools.cpp:540-599)
     "Correlation": STAT_CORRELATION, "Compensation": STAT_COMPENSATION, "Cosubstitution": STAT_COSUBSTITUTION,
@@ -57,7 +57,7 @@ EXPORTS = [
     "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_permutation_test_masks", "cmx_mica_permutation_test_masks_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
     "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups", "cmx_debug_candidate_cursor",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
-    "cmx_intra_compact_range_dev", "cmx_expand_compact_rows",
+    "cmx_intra_compact_range_dev", "cmx_expand_compact_rows", "cmx_vector_matrix",
     "cmx_scratch_check", "cmx_debug_scratch_guard", "cmx_debug_scratch_guard_failures", "cmx_debug_scratch_shrink",
 ]
 # clustering.distance / clustering.method options of the reference (CoMap/CoMap.cpp:402-428, :460-472)
@@ -451,6 +451,18 @@ class Engine:
                                              _sz(rep_begin), _sz(rep_end), _sz(rep_ram), _vp(stat), _vp(rcmin),
                                              _vp(prmin), _vp(nmin)))
         return dict(stat=stat, rcmin=rcmin, prmin=prmin, nmin=nmin)
+
+    def vector_matrix(self, kind, v1, v2=None, independent=False):
+        """AnalysisTools::compute{ScalarProduct,Cosinus,Correlation,Covariance}Matrix (AnalysisTools.cpp:102-339) for plain
+        vectors v1 [n1, dim] (and v2 [n2, dim]); kind = STAT_SCALAR_PRODUCT / STAT_COSINUS / STAT_CORRELATION / STAT_COVARIANCE"""
+        a = np.ascontiguousarray(v1, dtype=np.float64)
+        b = None if v2 is None else np.ascontiguousarray(v2, dtype=np.float64)
+        n1, dim = a.shape
+        n2 = n1 if b is None else b.shape[0]
+        out = np.zeros((n1, n2))
+        self._check(self._lib.cmx_vector_matrix(self._ctx, int(kind), _sz(dim), _vp(a), _sz(n1), _vp(b), _sz(n2),
+                                                ctypes.c_int(int(bool(independent))), _vp(out)))
+        return out
 
     def intra_pvalues(self, stat, norms, nclasses, null_stat, null_nmin):
         stat, norms, ns, nm = _f64(stat), _f64(norms), _f64(null_stat), _f64(null_nmin)

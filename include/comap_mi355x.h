@@ -56,6 +56,8 @@ typedef enum {
   CMX_STAT_CORRECTED_CORRELATION = 6, /* Statistics.h:176-204: correlation after subtracting a per-branch mean vector from
                                         either operand; params = [2][nbranches] (meanVector1_, meanVector2_; CoMap.cpp:350-359
                                         sets both to the mean total substitution vector of the data) */
+  CMX_STAT_SCALAR_PRODUCT = 9,       /* the raw Gram: sum_b v1_b v2_b on the type-0 counts (VectorTools::scalar,
+                                      * AnalysisTools::computeScalarProductMatrix, AnalysisTools.cpp:102-158) */
   CMX_STAT_DISCRETE_MI_BOUNDS = 8    /* Statistics.h:307-327 with ANY bounds vector (DiscreteMutualInformationStatistic(const
                                         Vdouble& bounds)): params = [nbounds, b_0 .. b_{nbounds-1}], non-decreasing; per-branch
                                         totals are binned with Domain(bounds)::getIndex (Domain.cpp:113-122).  The bounds of
@@ -295,6 +297,14 @@ cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* par
  * per-site arrays; nthreads <= 1: the calling thread alone.  npairs must equal the number of pairs of the row range. */
 cmx_status cmx_expand_compact_rows(size_t n, size_t row_begin, size_t row_end, const int32_t* rate_class, const double* post_rate,
                                    const double* norm, const cmx_pair_compact* compact, size_t npairs, cmx_pair_row* rows, int nthreads);
+/* AnalysisTools::compute{ScalarProduct,Cosinus,Correlation,Covariance}Matrix (CoMap/AnalysisTools.h:93-190,
+ * AnalysisTools.cpp:102-339) for plain vectors: v1 [n1][dim], v2 [n2][dim] (NULL: the one-set form) in host memory, any
+ * dimension (nothing here depends on the context's tree or model: a context created without them serves too).
+ * kind: CMX_STAT_SCALAR_PRODUCT / COSINUS / CORRELATION / COVARIANCE.  out [n1][n2] (one-set: [n1][n1], symmetric, the
+ * diagonal as the reference sets it: scalar(v, v), 1, 1, var(v)).  independent != 0 (two-set form only, n1 == n2, else
+ * CMX_ERR_INVALID = the reference's DimensionException): only out[i][i] is computed, the rest is 0. */
+cmx_status cmx_vector_matrix(cmx_ctx* ctx, int kind, size_t dim, const double* v1, size_t n1, const double* v2, size_t n2,
+                             int independent, double* out);
 /* host pointers: counts [N][B][K] -> statistic -> (optional) p-values from a null -> compacted rows; only the rows
  * cross PCIe on the way back.  null_stat == NULL: no p-values (pvalue NaN, Nsim 0 in every row). */
 cmx_status cmx_intra_rows(cmx_ctx* ctx, int kind, const double* params, const double* counts, size_t n,

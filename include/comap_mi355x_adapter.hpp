@@ -46,7 +46,12 @@ class Exception : public std::runtime_error {
 class DimensionException : public Exception {
  public:
   DimensionException(const std::string& where, size_t got, size_t expected)
-      : Exception(where + " dimension " + std::to_string(got) + " != " + std::to_string(expected)) {}
+      : Exception(where + " dimension " + std::to_string(got) + " != " + std::to_string(expected)), got_(got), expected_(expected) {}
+  size_t got() const { return got_; }
+  size_t expected() const { return expected_; }
+
+ private:
+  size_t got_, expected_;
 };
 class OutOfRangeException : public Exception {
  public:
@@ -346,6 +351,28 @@ struct NullDistributionRow { double stat; int32_t rcMin; double prMin, nMin; }; 
 struct ContinuousRates { double gammaAlpha = 1.; double pInvariant = 0.; };
 
 class AnalysisTools {
+  static VVdouble vectorMatrix(const Engine& eng, int kind, const VVdouble& v1, const VVdouble* v2, bool independant, const char* where) {
+    const size_t n1 = v1.size(), n2 = v2 ? v2->size() : n1;
+    if (independant && n1 != n2)
+      throw DimensionException(std::string(where) + "\nWhen performing independant comparisons, the two datasets must have the same length.", n1, n2);
+    VVdouble matrix(n1, Vdouble(n2, 0.0));
+    if (n1 == 0 || n2 == 0) return matrix;
+    const size_t dim = v1[0].size();
+    auto flat = [dim](const VVdouble& v) {
+      Vdouble f(v.size() * dim);
+      for (size_t i = 0; i < v.size(); ++i) {
+        if (v[i].size() != dim) throw DimensionException("AnalysisTools: vectors of different lengths.", v[i].size(), dim);
+        std::copy(v[i].begin(), v[i].end(), f.begin() + i * dim);
+      }
+      return f;
+    };
+    const Vdouble f1 = flat(v1), f2 = v2 ? flat(*v2) : Vdouble();
+    Vdouble out(n1 * n2);
+    eng.check(cmx_vector_matrix(eng.ctx(), kind, dim, f1.data(), n1, v2 ? f2.data() : nullptr, n2, independant ? 1 : 0, out.data()));
+    for (size_t i = 0; i < n1; ++i) std::copy(out.begin() + i * n2, out.begin() + (i + 1) * n2, matrix[i].begin());
+    return matrix;
+  }
+
  public:
   // AnalysisTools.cpp:343-350 (the norms come out of the mapping kernel; recomputed here from the counts on request)
   static Vdouble computeNorms(const ProbabilisticSubstitutionMapping& mapping) {
@@ -362,6 +389,28 @@ class AnalysisTools {
     }
     return v;
   }
+  // ---- AnalysisTools::compute{ScalarProduct,Cosinus,Correlation,Covariance}Matrix (AnalysisTools.h:93-190,
+  // AnalysisTools.cpp:102-339): the matrix of a pairwise function of plain vectors, on the device's Gram kernel
+  // (cmx_vector_matrix).  One-set forms: symmetric, diagonal scalar(v, v) / 1 / 1 / var(v).  Two-set forms with
+  // independantComparisons: the two sets must have the same length (DimensionException as in the reference) and only
+  // matrix[i][i] is computed.  `eng`: any engine (a model-less one serves: nothing here depends on tree or model).
+  static VVdouble computeScalarProductMatrix(const Engine& eng, const VVdouble& vectors) { return vectorMatrix(eng, CMX_STAT_SCALAR_PRODUCT, vectors, nullptr, false, ""); }
+  static VVdouble computeScalarProductMatrix(const Engine& eng, const VVdouble& vectors1, const VVdouble& vectors2, bool independantComparisons) {
+    return vectorMatrix(eng, CMX_STAT_SCALAR_PRODUCT, vectors1, &vectors2, independantComparisons, "AnalysisTools::computeScalarProductMatrix.");
+  }
+  static VVdouble computeCosinusMatrix(const Engine& eng, const VVdouble& vectors) { return vectorMatrix(eng, CMX_STAT_COSINUS, vectors, nullptr, false, ""); }
+  static VVdouble computeCosinusMatrix(const Engine& eng, const VVdouble& vectors1, const VVdouble& vectors2, bool independantComparisons) {
+    return vectorMatrix(eng, CMX_STAT_COSINUS, vectors1, &vectors2, independantComparisons, "AnalysisTools::computeCosinusMatrix.");
+  }
+  static VVdouble computeCorrelationMatrix(const Engine& eng, const VVdouble& vectors) { return vectorMatrix(eng, CMX_STAT_CORRELATION, vectors, nullptr, false, ""); }
+  static VVdouble computeCorrelationMatrix(const Engine& eng, const VVdouble& vectors1, const VVdouble& vectors2, bool independantComparisons) {
+    return vectorMatrix(eng, CMX_STAT_CORRELATION, vectors1, &vectors2, independantComparisons, "AnalysisTools::computeCorrelationMatrix.");
+  }
+  static VVdouble computeCovarianceMatrix(const Engine& eng, const VVdouble& vectors) { return vectorMatrix(eng, CMX_STAT_COVARIANCE, vectors, nullptr, false, ""); }
+  static VVdouble computeCovarianceMatrix(const Engine& eng, const VVdouble& vectors1, const VVdouble& vectors2, bool independantComparisons) {
+    return vectorMatrix(eng, CMX_STAT_COVARIANCE, vectors1, &vectors2, independantComparisons, "AnalysisTools::computeCovarianceMatrix.");
+  }
+
   // AnalysisTools.cpp:564-658.  simstats (optional, one vector per class of rateDomain) receives the statistics as
   // in the reference (pairs whose min norm is out of the domain are dropped, :645-648); rows receives all of them.
   static void getNullDistributionIntraDR(const Engine& eng, const Statistic& statistic, uint64_t seed, size_t repCPU,

@@ -10,6 +10,8 @@
 //   AnalysisTools::getNullDistributionIntraDR CoMap/AnalysisTools.h:248-260    cmx::bpp::AnalysisTools::getNullDistributionIntraDR
 //   AnalysisTools::getNullDistributionInterDR CoMap/AnalysisTools.h:262-275    cmx::bpp::AnalysisTools::getNullDistributionInterDR
 //   AnalysisTools::computeNorms               CoMap/AnalysisTools.h:198        cmx::bpp::AnalysisTools::computeNorms
+//   AnalysisTools::compute{ScalarProduct,Cosinus,Correlation,Covariance}Matrix
+//                                             CoMap/AnalysisTools.h:93-190     cmx::bpp::AnalysisTools::compute...Matrix (8 overloads)
 //
 // A maintainer swaps the engine in with two lines per translation unit:
 //     #include "comap_mi355x_bpp.hpp"
@@ -302,6 +304,32 @@ class AnalysisTools {
     ::bpp::Vdouble n(mapping.getNumberOfSites());
     for (size_t i = 0; i < n.size(); ++i) n[i] = ::bpp::LegacySubstitutionMappingTools::computeNormForSite(mapping, i);
     return n;
+  }
+
+  // CoMap/AnalysisTools.h:93-190, bodies AnalysisTools.cpp:102-339: matrices of a pairwise function of plain vectors (not
+  // called from the reference's main() today; kept because they are public members of the seam).  They need no tree and no
+  // model: one model-less context on device 0, created at the first call.
+  static const cmx::Engine& plainEngine() { static cmx::Engine e(0); return e; }
+  static ::bpp::VVdouble computeScalarProductMatrix(const ::bpp::VVdouble& vectors) { return cmx::AnalysisTools::computeScalarProductMatrix(plainEngine(), vectors); }
+  static ::bpp::VVdouble computeScalarProductMatrix(const ::bpp::VVdouble& vectors1, const ::bpp::VVdouble& vectors2, bool independantComparisons) {
+    return rethrow([&] { return cmx::AnalysisTools::computeScalarProductMatrix(plainEngine(), vectors1, vectors2, independantComparisons); });
+  }
+  static ::bpp::VVdouble computeCosinusMatrix(const ::bpp::VVdouble& vectors) { return cmx::AnalysisTools::computeCosinusMatrix(plainEngine(), vectors); }
+  static ::bpp::VVdouble computeCosinusMatrix(const ::bpp::VVdouble& vectors1, const ::bpp::VVdouble& vectors2, bool independantComparisons) {
+    return rethrow([&] { return cmx::AnalysisTools::computeCosinusMatrix(plainEngine(), vectors1, vectors2, independantComparisons); });
+  }
+  static ::bpp::VVdouble computeCorrelationMatrix(const ::bpp::VVdouble& vectors) { return cmx::AnalysisTools::computeCorrelationMatrix(plainEngine(), vectors); }
+  static ::bpp::VVdouble computeCorrelationMatrix(const ::bpp::VVdouble& vectors1, const ::bpp::VVdouble& vectors2, bool independantComparisons) {
+    return rethrow([&] { return cmx::AnalysisTools::computeCorrelationMatrix(plainEngine(), vectors1, vectors2, independantComparisons); });
+  }
+  static ::bpp::VVdouble computeCovarianceMatrix(const ::bpp::VVdouble& vectors) { return cmx::AnalysisTools::computeCovarianceMatrix(plainEngine(), vectors); }
+  static ::bpp::VVdouble computeCovarianceMatrix(const ::bpp::VVdouble& vectors1, const ::bpp::VVdouble& vectors2, bool independantComparisons) {
+    return rethrow([&] { return cmx::AnalysisTools::computeCovarianceMatrix(plainEngine(), vectors1, vectors2, independantComparisons); });
+  }
+  // the adapter's DimensionException as the reference's (bpp::DimensionException, AnalysisTools.cpp:139-147)
+  template <class F> static ::bpp::VVdouble rethrow(F f) {
+    try { return f(); }
+    catch (const cmx::DimensionException& e) { throw ::bpp::DimensionException(e.what(), e.got(), e.expected()); }
   }
 
   // CoMap/AnalysisTools.h:248-260, body AnalysisTools.cpp:564-658.  The engine simulates under the likelihood's own tree /

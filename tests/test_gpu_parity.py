@@ -1238,3 +1238,49 @@ def test_mica_four_wave_nucleotide_kernel_against_oracle(T, n1, n2):
     rel_close(gi["mi"][iu], oi["mi"][iu], 1e-6, 1e-10)
     rel_close(gi["hjoint"][iu], oi["hjoint"][iu], 1e-6, 1e-10)
     assert np.isnan(gi["mi"][np.tril_indices(n2)]).all() and np.isnan(gi["hjoint"][np.tril_indices(n2)]).all()
+
+
+@pytest.mark.parametrize("dim,n1,n2", [(5, 7, 4), (125, 70, 33), (64, 130, 130), (2, 3, 3)])
+def test_analysis_tools_vector_matrices(dim, n1, n2):
+    """AnalysisTools::compute{ScalarProduct,Cosinus,Correlation,Covariance}Matrix (CoMap/AnalysisTools.cpp:102-339) on the
+    Gram kernel (cmx_vector_matrix) against the definitions (VectorTools::scalar / cos / cor / cov, unbiased), for the
+    one-set forms (symmetric, the reference's diagonal), the two-set forms and independantComparisons; a model-less
+    context serves"""
+    rng = np.random.default_rng(dim * 1000 + n1)
+    a, b = rng.normal(size=(n1, dim)), rng.normal(loc=0.3, size=(n2, dim))
+    eng = engine.Engine()
+
+    def ref(kind, x, y):
+        if kind == engine.STAT_SCALAR_PRODUCT:
+            return x @ y.T
+        if kind == engine.STAT_COSINUS:
+            return (x @ y.T) / np.outer(np.linalg.norm(x, axis=1), np.linalg.norm(y, axis=1))
+        xc, yc = x - x.mean(1, keepdims=True), y - y.mean(1, keepdims=True)
+        cov = (xc @ yc.T) / (dim - 1)
+        if kind == engine.STAT_COVARIANCE:
+            return cov
+        return cov / np.outer(np.sqrt((xc ** 2).sum(1) / (dim - 1)), np.sqrt((yc ** 2).sum(1) / (dim - 1)))
+
+    for kind in (engine.STAT_SCALAR_PRODUCT, engine.STAT_COSINUS, engine.STAT_CORRELATION, engine.STAT_COVARIANCE):
+        one = eng.vector_matrix(kind, a)
+        r = ref(kind, a, a)
+        if kind in (engine.STAT_COSINUS, engine.STAT_CORRELATION):
+            assert np.all(np.diag(one) == 1.0)                      # matrix[i][i] = 1 (AnalysisTools.cpp:178, 236)
+        assert np.array_equal(one, one.T)                           # matrix[i][j] = matrix[j][i]
+        rel_close(one, r, 1e-9, 1e-12)
+        two = eng.vector_matrix(kind, a, b)
+        rel_close(two, ref(kind, a, b), 1e-9, 1e-12)
+        if n1 == n2:
+            ind = eng.vector_matrix(kind, a, b, independent=True)
+            assert np.all(ind[~np.eye(n1, dtype=bool)] == 0.0)      # only j = i is computed (AnalysisTools.cpp:150-157)
+            rel_close(np.diag(ind), np.diag(ref(kind, a, b)), 1e-9, 1e-12)
+        else:
+            with pytest.raises(engine.CmxError, match="independant comparisons"):
+                eng.vector_matrix(kind, a, b, independent=True)
+    # the scalar product is a pair statistic like the others (the raw Gram of the type-0 counts)
+    case = make_case(9, 40, 20, 3)
+    e2 = _engine(case)
+    m = e2.map_sites(case["aln"])
+    st = e2.pair_stats(engine.STAT_SCALAR_PRODUCT, m["counts"])
+    iu = np.triu_indices(40, 1)
+    rel_close(st[iu], (m["counts"][:, :, 0] @ m["counts"][:, :, 0].T)[iu], 1e-9, 1e-300)
