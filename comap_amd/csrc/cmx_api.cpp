@@ -320,6 +320,18 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
       if ((s = upload(ctx, ms, &dms)) != CMX_OK) return s;
       d.msched = dms;
       d.nmv = (int)(h.msched.size() / 2);
+      d.msched_r = nullptr;
+      d.nmv_r = 0;
+      if (!h.msched_r.empty()) {   // the cherry-table walk's stream, prepared the same way
+        std::vector<int> mr(h.msched_r);
+        for (size_t i = 0; i < mr.size(); i += 2) mr[i] *= unit;
+        const size_t nr = mr.size();
+        for (size_t i = 0; i < 4; ++i) mr.push_back(mr[i % nr]);
+        const int* dmr = nullptr;
+        if ((s = upload(ctx, mr, &dmr)) != CMX_OK) return s;
+        d.msched_r = dmr;
+        d.nmv_r = (int)(h.msched_r.size() / 2);
+      }
     }
     UP(nrec); UP(simg); UP(simord);
     d.nsimg = (int)(h.simg.size() / 16);
@@ -409,6 +421,8 @@ cmx_status cmx_get_info(const cmx_ctx* ctx, cmx_info* info) {
   info->device_states = ctx->hm.dS; info->device_classes = ctx->hm.dC;
   info->products_per_pass = (int32_t)ctx->hm.n_products; info->leaf_ops_per_pass = (int32_t)ctx->hm.n_leaf_ops;
   info->ws_loads_per_pass = (int32_t)ctx->hm.n_loads; info->ws_stores_per_pass = (int32_t)ctx->hm.n_stores;
+  info->products_per_pass_null = (int32_t)ctx->hm.n_products_r; info->leaf_ops_per_pass_null = (int32_t)ctx->hm.n_leaf_ops_r;
+  info->cherry_tables = ctx->hm.msched_r.empty() ? 0 : ctx->hm.ncherry;
   return CMX_OK;
 }
 

@@ -53,6 +53,8 @@ struct DevModel {
   const int* msched;       // operator uses in program order: pairs (element offset in the class block, taxon or -1),
                            // followed by copies of its first two pairs (the op two ahead is read without a wrap test)
   int nmv;                 // number of pairs
+  const int* msched_r;     // the cherry-table walk's stream (class-fused nucleotide models, resolved alignments: the null), or null
+  int nmv_r;
   const int* ldsched;      // [nloads + 2] workspace loads: bit 31 prefetchable, bit 30 array (0 M, 1 U), low 24 bits slot
   // simulator: running sums of the rows of P, [C][nn][S(x)][S], and a 32-entry guide table per row (see draw_guided)
   const double* CP;

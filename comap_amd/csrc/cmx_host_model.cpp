@@ -110,6 +110,10 @@ void build_records(HostModel* hm) {
   std::vector<char> inlined(nd, 0);
   for (int n = 0; n < nn; ++n)
     if (!is_leaf(n) && n != root && is_leaf(ch[n][0]) && is_leaf(ch[n][1])) inlined[n] = 1;
+  hm->cherry_of.assign(nn, -1);
+  hm->ncherry = 0;
+  for (int n = 0; n < nn; ++n)
+    if (inlined[n]) hm->cherry_of[n] = hm->ncherry++;
   auto kind = [&](int e) { return is_leaf(e) ? (int)KIND_LEAF : (inlined[e] ? (int)KIND_CHERRY : (int)KIND_STORED); };
   // post-order of the visited nodes (explicit stack: caterpillar trees are deep)
   std::vector<int> visited, parent_d(nd, -1);
@@ -158,7 +162,9 @@ void build_records(HostModel* hm) {
 
 namespace {
 // ---- Recorder: the operator stream (matrix index in a class block, taxon or -1) and the workspace loads of a pass
+template <bool CT>
 struct Recorder {
+  static constexpr bool kCherryTables = CT;
   HostModel* hm;
   long t = 0;
   std::vector<long> store_time[2];
@@ -171,14 +177,23 @@ struct Recorder {
     const int tx = hm->taxon_of[leaf];
     return which < 0 ? hm->NI + hm->NI * hm->K + tx : hm->NI + hm->NI * hm->K + hm->T + which * hm->T + tx;
   }
-  void op(int mat, int tx) { hm->msched.push_back(mat); hm->msched.push_back(tx); ++t; }
+  void op(int mat, int tx) {
+    std::vector<int>& ms = CT ? hm->msched_r : hm->msched;
+    ms.push_back(mat); ms.push_back(tx); ++t;
+  }
+  void leaf_op() { (CT ? hm->n_leaf_ops_r : hm->n_leaf_ops)++; }
   void rec(int v, int (&r)[16]) const { for (int i = 0; i < 16; ++i) r[i] = hm->nrec[(size_t)v * 16 + i]; }
-  template <int D> void lset(int leaf, int which) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); hm->n_leaf_ops++; }
-  template <int S, int D> void lmul(int leaf, int which) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); hm->n_leaf_ops++; }
-  template <int S> void ldot(int leaf, int which, int) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); hm->n_leaf_ops++; }
-  template <int S, int D, bool TR> void mv(int node, int which) { op(mat_internal(node, which), -1); hm->n_products++; }
-  template <int D> void load(int arr, int slot) { loads.push_back({arr, slot, t++, store_time[arr][slot]}); hm->n_loads++; }
-  template <int S> void store(int arr, int slot) { store_time[arr][slot] = t++; hm->n_stores++; }
+  template <int D> void lset(int leaf, int which) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); leaf_op(); }
+  template <int S, int D> void lmul(int leaf, int which) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); leaf_op(); }
+  template <int S> void ldot(int leaf, int which, int) { op(mat_leaf(leaf, which), hm->taxon_of[leaf]); leaf_op(); }
+  // cherry-table ops: the table's matrix index, both taxa in the stream entry
+  int mat_cherry(int node, int table) const { return hm->cherry_base + hm->cherry_of[node] * (1 + 3 * hm->K) + table; }
+  int tx_cherry(int l1, int l2) const { return 0x40000000 | hm->taxon_of[l1] | (hm->taxon_of[l2] << 15); }
+  template <int D> void cset(int node, int l1, int l2) { op(mat_cherry(node, 0), tx_cherry(l1, l2)); leaf_op(); }
+  template <int S> void cdot(int node, int l1, int l2, int table, int) { op(mat_cherry(node, table), tx_cherry(l1, l2)); leaf_op(); }
+  template <int S, int D, bool TR> void mv(int node, int which) { op(mat_internal(node, which), -1); (CT ? hm->n_products_r : hm->n_products)++; }
+  template <int D> void load(int arr, int slot) { loads.push_back({arr, slot, t++, store_time[arr][slot]}); if (!CT) hm->n_loads++; }
+  template <int S> void store(int arr, int slot) { store_time[arr][slot] = t++; if (!CT) hm->n_stores++; }
   template <int D, int S> void mov() {}
   template <int D, int S> void mul() {}
   void mulup() {}
@@ -190,7 +205,9 @@ struct Recorder {
 
 // ---- Numeric: the pass in plain doubles for one site, operators read from HostModel::MAT in their device layouts
 // and selected by the recorded stream exactly as the device selects them; every register starts as NaN.
+template <bool CT>
 struct Numeric {
+  static constexpr bool kCherryTables = CT;
   const HostModel& hm;
   int dS, NB;
   size_t MU;
@@ -218,9 +235,10 @@ struct Numeric {
   void fail(const std::string& m) { if (err.empty()) err = "tree-walk self-check failed: " + m; }
   void rec(int v, int (&r)[16]) const { for (int i = 0; i < 16; ++i) r[i] = hm.nrec[(size_t)v * 16 + i]; }
   // the operator the stream stages for this op; `want` = what the walk asked for
+  const std::vector<int>& stream() const { return CT ? hm.msched_r : hm.msched; }
   int staged(int want_mat, int want_tx) {
-    if (2 * mi + 1 >= hm.msched.size()) { fail("more operator uses than the stream holds"); return -1; }
-    const int mat = hm.msched[2 * mi], tx = hm.msched[2 * mi + 1];
+    if (2 * mi + 1 >= stream().size()) { fail("more operator uses than the stream holds"); return -1; }
+    const int mat = stream()[2 * mi], tx = stream()[2 * mi + 1];
     ++mi;
     if (mat < 0 || mat >= hm.MC) { fail("operator index out of range"); return -1; }
     if (mat != want_mat || tx != want_tx) { fail("op " + std::to_string(mi - 1) + " finds the wrong operator staged"); return -1; }
@@ -230,6 +248,26 @@ struct Numeric {
     if (leaf < 0 || leaf >= hm.nn || hm.taxon_of[leaf] < 0) { fail("leaf op on a non-leaf"); return -1; }
     const int tx = hm.taxon_of[leaf];
     return staged(which < 0 ? hm.NI + hm.NI * hm.K + tx : hm.NI + hm.NI * hm.K + hm.T + which * hm.T + tx, tx);
+  }
+  // cherry tables: row = 4 * symbol(l1) + symbol(l2), columns as in a leaf row
+  int cherry_mat(int node, int l1, int l2, int table) {
+    if (node < 0 || node >= hm.nn || hm.cherry_of[node] < 0 || table < 0 || table > 3 * hm.K) { fail("cherry op on a node without tables"); return -1; }
+    return staged(hm.cherry_base + hm.cherry_of[node] * (1 + 3 * hm.K) + table, 0x40000000 | hm.taxon_of[l1] | (hm.taxon_of[l2] << 15));
+  }
+  double cherryrow(int mat, int l1, int l2, int X) const {
+    return blk[(size_t)mat * MU + (size_t)(4 * code[hm.taxon_of[l1]] + code[hm.taxon_of[l2]]) * leaf_row_stride(dS) + (X % 4) * NB + X / 4];
+  }
+  template <int D> void cset(int node, int l1, int l2) {
+    const int mat = cherry_mat(node, l1, l2, 0);
+    if (mat < 0) return;
+    for (int x = 0; x < dS; ++x) R[D][x] = cherryrow(mat, l1, l2, x);
+  }
+  template <int S> void cdot(int node, int l1, int l2, int table, int row) {
+    const int mat = cherry_mat(node, l1, l2, table);
+    if (mat < 0) return;
+    double s = 0;
+    for (int x = 0; x < dS; ++x) s += R[S][x] * cherryrow(mat, l1, l2, x);
+    count_row(row, s);
   }
   double leafrow(int mat, int leaf, int X) const { return blk[(size_t)mat * MU + (size_t)code[hm.taxon_of[leaf]] * leaf_row_stride(dS) + (X % 4) * NB + X / 4]; }
   double packed(int mat, int r, int c) const {
@@ -295,12 +333,17 @@ struct Numeric {
 // records -> operator stream + load schedule (with prefetchability) by a dry run of the walk
 void record_walk(HostModel* hm) {
   hm->msched.clear();
+  hm->msched_r.clear();
   hm->ldsched.clear();
-  hm->n_loads = hm->n_stores = hm->n_products = hm->n_leaf_ops = 0;
-  Recorder rc(hm);
+  hm->n_loads = hm->n_stores = hm->n_products = hm->n_leaf_ops = hm->n_products_r = hm->n_leaf_ops_r = 0;
+  if (hm->cherry_base > 0) {   // the cherry-table walk's own operator stream (same loads and stores)
+    Recorder<true> rt(hm);
+    walk_pass(rt, hm->NV, hm->K);
+  }
+  Recorder<false> rc(hm);
   walk_pass(rc, hm->NV, hm->K);
   for (size_t j = 0; j < rc.loads.size(); ++j) {
-    const Recorder::Ld& e = rc.loads[j];
+    const Recorder<false>::Ld& e = rc.loads[j];
     unsigned w = (unsigned)e.slot | (e.arr ? 0x40000000u : 0u);
     // prefetchable: its producer store is issued before the previous load (where the prefetch is issued)
     if (j > 0 && e.src >= 0 && e.src < rc.loads[j - 1].t) w |= 0x80000000u;
@@ -314,11 +357,20 @@ std::string verify_walk(const HostModel& hm) {
   const int S = hm.S, F = hm.fuse, K = hm.K, nn = hm.nn, B = hm.B, root = hm.root;
   const size_t S2 = (size_t)S * S;
   if ((int)hm.nrec.size() != hm.NV * 16) return "tree-walk self-check failed: record table size";
-  Numeric nm(hm);
+  Numeric<false> nm(hm);
   walk_pass(nm, hm.NV, K);
   if (!nm.err.empty()) return nm.err;
   if (2 * nm.mi != hm.msched.size()) return "tree-walk self-check failed: unused operators in the stream";
   if (nm.fi != hm.ldsched.size()) return "tree-walk self-check failed: unused workspace loads in the schedule";
+  // the cherry-table walk: same site, same reference
+  Numeric<true> nt(hm);
+  const bool tables = !hm.msched_r.empty();
+  if (tables) {
+    walk_pass(nt, hm.NV, K);
+    if (!nt.err.empty()) return nt.err + " (cherry-table walk)";
+    if (2 * nt.mi != hm.msched_r.size()) return "tree-walk self-check failed: unused operators in the cherry-table stream";
+    if (nt.fi != hm.ldsched.size()) return "tree-walk self-check failed: the cherry-table walk loads other workspace vectors";
+  }
   const std::vector<int>& code = nm.code;
   std::vector<double> ref((size_t)B * K, 0.0), Lref(F, 0.0);
   auto kids = [&](int n) { std::vector<int> v; for (int e = hm.first_child[n]; e >= 0; e = hm.next_sib[e]) v.push_back(e); return v; };
@@ -361,6 +413,14 @@ std::string verify_walk(const HostModel& hm) {
   for (size_t r = 0; r < ref.size(); ++r) {
     if (!nm.counted[r]) return "tree-walk self-check failed: a branch is never counted";
     if (!close(nm.cnt[r], ref[r])) return "tree-walk self-check failed: joint count of branch " + std::to_string(r / K) + " differs from the direct computation";
+  }
+  if (tables) {
+    for (int g = 0; g < F && g < hm.C; ++g)
+      if (!close(nt.Lg[g], Lref[g])) return "tree-walk self-check failed: site likelihood of the cherry-table walk differs from the direct computation";
+    for (size_t r = 0; r < ref.size(); ++r) {
+      if (!nt.counted[r]) return "tree-walk self-check failed: the cherry-table walk never counts a branch";
+      if (!close(nt.cnt[r], ref[r])) return "tree-walk self-check failed: cherry-table count of branch " + std::to_string(r / K) + " differs from the direct computation";
+    }
   }
   return std::string();
 }
@@ -422,6 +482,11 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   hm->NI = (int)hm->int_post.size();
   if (!hm->plain) {
     build_records(hm);
+    // cherry tables only for the class-fused nucleotide layout (16 symbol pairs; 400 for proteins would not fit a stage buffer)
+    // (a fused model without a single cherry still gets the second stream -- identical to the first: the null's kernel
+    // instantiation reads it unconditionally)
+    hm->cherry_base = (S == 4 && C >= 4) ? hm->NI + hm->NI * K + T + K * T : 0;
+    if (hm->cherry_base == 0) hm->ncherry = 0;
     record_walk(hm);
   }
   {  // simulator: nodes by depth, four of a level at a time (a level's draws only need the level above); a short group is
@@ -578,7 +643,8 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
   //   [.., + T)                  P of leaf edges transposed, [z][x] = P[x][z] (per-lane row gather by observed symbol)
   //   [.., + K*T)                P o N^k of leaf edges transposed, index k*T + taxon
   const int NI = hm->NI;
-  const int MC = hm->plain ? 0 : NI + NI * K + T + K * T;
+  //   [.., + ncherry*(1+3K))     cherry tables of the class-fused nucleotide layout (cmx_walk.h), 16 rows (symbol pair) each
+  const int MC = hm->plain ? 0 : NI + NI * K + T + K * T + hm->ncherry * (1 + 3 * K);
   hm->MC = MC;
   hm->fuse = (S == 4 && C >= 4) ? (C == 4 ? 4 : 5) : 1;
   const int F = hm->fuse;
@@ -639,6 +705,49 @@ std::string build_host_model(const cmx_model* model, const cmx_tree* tree, HostM
           }
           pack_blocks(dS, dense.data(), blk + (size_t)(which < 0 ? sl : NI + sl * K + which) * MU, F > 1);
         }
+      }
+    }
+    // cherry tables: row 4 s1 + s2 (symbols of the cherry's leaves l1, l2), column X = (class g, state x) stored like a
+    // leaf row; class weights are folded into the count operators as everywhere in the fused layout
+    for (int n = 0; n < nn && hm->ncherry > 0; ++n) {
+      if (hm->cherry_of[n] < 0) continue;
+      int l1 = -1, l2 = -1;
+      for (int e = hm->first_child[n]; e >= 0; e = hm->next_sib[e]) { if (l1 < 0) l1 = e; else l2 = e; }
+      double* tab = blk + (size_t)(hm->cherry_base + hm->cherry_of[n] * (1 + 3 * K)) * MU;
+      for (int g = 0; g < F; ++g) {
+        const int c = dc * F + g;
+        for (int s1 = 0; s1 < S; ++s1)
+          for (int s2 = 0; s2 < S; ++s2)
+            for (int x = 0; x < S; ++x) {
+              const int X = g * S + x, pos = (X % 4) * (dS / 4) + X / 4;
+              const size_t at = (size_t)(4 * s1 + s2) * leaf_row_stride(dS) + pos;
+              if (c >= C) {   // padding class: identity transitions, zero weight -- message = [x == s1 == s2], no counts
+                tab[at] = (x == s1 && x == s2) ? 1.0 : 0.0;
+                for (int q = 1; q <= 3 * K; ++q) tab[(size_t)q * MU + at] = 0.0;
+                continue;
+              }
+              const double w = hm->probs[c];
+              const double* Pn = &hm->P[((size_t)c * B + n) * S2];
+              const double* P1 = &hm->P[((size_t)c * B + l1) * S2];
+              const double* P2 = &hm->P[((size_t)c * B + l2) * S2];
+              double m = 0.0;
+              for (int y = 0; y < S; ++y) m += Pn[(size_t)x * S + y] * P1[(size_t)y * S + s1] * P2[(size_t)y * S + s2];
+              tab[at] = m;
+              for (int k = 0; k < K; ++k) {
+                const double* Jn = &hm->PN[(((size_t)c * B + n) * K + k) * S2];
+                const double* J1 = &hm->PN[(((size_t)c * B + l1) * K + k) * S2];
+                const double* J2 = &hm->PN[(((size_t)c * B + l2) * K + k) * S2];
+                double tj = 0.0, t1 = 0.0, t2 = 0.0;
+                for (int y = 0; y < S; ++y) {
+                  tj += Jn[(size_t)x * S + y] * P1[(size_t)y * S + s1] * P2[(size_t)y * S + s2];
+                  t1 += Pn[(size_t)x * S + y] * J1[(size_t)y * S + s1] * P2[(size_t)y * S + s2];
+                  t2 += Pn[(size_t)x * S + y] * P1[(size_t)y * S + s1] * J2[(size_t)y * S + s2];
+                }
+                tab[(size_t)(1 + k) * MU + at] = w * tj;
+                tab[(size_t)(1 + K + k) * MU + at] = w * t1;
+                tab[(size_t)(1 + 2 * K + k) * MU + at] = w * t2;
+              }
+            }
       }
     }
   }

@@ -43,8 +43,15 @@ struct HostModel {
   std::vector<int> nrec;    // [NV][16] per-visited-node records (cmx_walk.h)
   std::vector<int> msched;  // operator uses of one class pass in program order: (matrix index, taxon or -1) pairs
   std::vector<int> ldsched; // workspace loads of one class pass: bit 31 prefetchable, bit 30 array, low 24 bits slot
-  // per class pass, for traffic / flop accounting
-  size_t n_loads = 0, n_stores = 0, n_products = 0, n_leaf_ops = 0;
+  // Cherry tables (cmx_walk.h; class-fused nucleotide models only): an inlined cherry's message and outside visit as rows
+  // of 1 + 3 K tables indexed by its two leaves' symbols, for fully resolved alignments (the null's).  The tables follow
+  // the leaf operators in a class block (matrix index cherry_base + cherry_of[node] * (1 + 3 K) + table); the walk that
+  // uses them has its own operator stream.  ncherry = 0: no tables (proteins, nucleotide models with < 4 classes).
+  std::vector<int> cherry_of;   // [nn] cherry index of an inlined cherry node, else -1
+  int ncherry = 0, cherry_base = 0;
+  std::vector<int> msched_r;    // operator stream of the cherry-table walk; entry (matrix, taxon | 0x40000000 | tx1 | tx2 << 15 | -1)
+  // per class pass, for traffic / flop accounting (_r: the cherry-table walk)
+  size_t n_loads = 0, n_stores = 0, n_products = 0, n_leaf_ops = 0, n_products_r = 0, n_leaf_ops_r = 0;
 };
 
 // The walk of a rate-class pass lives in cmx_walk.h.  build_records: the per-node records it reads; record_walk: the

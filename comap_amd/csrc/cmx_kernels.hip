@@ -278,6 +278,38 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
   return reduce_sites<NG>(part);
 }
 
+// Row of a cherry table (cmx_walk.h): the row is named by the symbols of the cherry's two leaves, 4 * symbol(l1) + symbol(l2)
+// (fully resolved alignments only: both symbols are states of the 4-letter alphabet), the columns are a leaf row's.
+template <int S, int MODE, int NG>
+__device__ __forceinline__ double cherry_apply(const uint8_t* buf, const uint8_t* codes1, const uint8_t* codes2, int lane,
+                                               const double (&in)[S / 4 * NG], double (&out)[S / 4 * NG]) {
+  constexpr int NB = S / 4;
+  double part[NG];
+  unsigned c1[NG], c2[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) { c1[g] = codes1[g * (256 / NG)]; c2[g] = codes2[g * (256 / NG)]; }
+  const double* r[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const unsigned row = ((c1[g] & 3u) << 2) | (c2[g] & 3u);
+    r[g] = reinterpret_cast<const double*>(buf + row * (leaf_row_stride(S) * 8)) + (lane >> 4) * NB;
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    part[g] = 0.0;
+    double v[NB];
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) v[sb] = r[g][sb];
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) {
+      if (MODE == LEAF_SET) out[sb * NG + g] = v[sb];
+      else part[g] = __builtin_fma(in[sb * NG + g], v[sb], part[g]);
+    }
+  }
+  if (MODE != LEAF_DOT) return 0.0;
+  return reduce_sites<NG>(part);
+}
+
 // ------------------------------------------------------------------------------------------------ small helpers
 // Workspace vectors are stored as [S/2][64 lanes][2 doubles]: one 16-byte access per lane and row, 1 KiB per
 // wave-instruction, the same image in HBM and (for prefetched vectors) in LDS.
@@ -390,9 +422,10 @@ __device__ __forceinline__ void sload_rec(cmx_cint p, cmx_i16& r) {
 struct ConstModel {
   cmx_cint taxon_of, parent, nrec, msched, ldsched;
   cmx_cdbl pi, rates, probs, cum_pi, cum_probs;
-  __device__ __forceinline__ explicit ConstModel(const DevModel& m)
+  // tables: the cherry-table walk's operator stream (class-fused nucleotide models on resolved alignments)
+  __device__ __forceinline__ explicit ConstModel(const DevModel& m, bool tables = false)
       : taxon_of((cmx_cint)m.taxon_of), parent((cmx_cint)m.parent), nrec((cmx_cint)m.nrec),
-        msched((cmx_cint)m.msched), ldsched((cmx_cint)m.ldsched), pi((cmx_cdbl)m.pi), rates((cmx_cdbl)m.rates),
+        msched((cmx_cint)(tables ? m.msched_r : m.msched)), ldsched((cmx_cint)m.ldsched), pi((cmx_cdbl)m.pi), rates((cmx_cdbl)m.rates),
         probs((cmx_cdbl)m.probs), cum_pi((cmx_cdbl)m.cum_pi), cum_probs((cmx_cdbl)m.cum_probs) {}
 };
 // Operator-stream bookkeeping of a wave (wave-uniform, lives across site blocks).  vs counts the VMEM instructions this
@@ -419,6 +452,13 @@ struct DevWalk {
   static constexpr bool DIAG = FUSE > 1 && S / FUSE == 4;
   static constexpr int kProductBytes = DIAG ? (S / 4) * 128 : MatStage<S>::BYTES;                      // diagonal tiles come first
   static constexpr int kLeafBytes = RESOLVED ? (S / FUSE) * leaf_row_stride(S) * 8 : MatStage<S>::BYTES;
+#ifndef CMX_NO_CHERRY_TABLES
+#define CMX_NO_CHERRY_TABLES 0     // 1: A/B builds without the cherry tables (scripts/ab_libs.sh)
+#endif
+  static constexpr bool kCherryTables = RESOLVED && DIAG && !CMX_NO_CHERRY_TABLES;   // cmx_walk.h: cset / cdot instead of a cherry's operator ops
+  static constexpr int kCherryBytes = 16 * leaf_row_stride(S) * 8;   // a table's 16 rows (one per symbol pair)
+  static constexpr int kCherryFlag = 0x40000000;                     // stream entry: taxon of l1 | taxon of l2 << 15 | flag
+  static_assert(kCherryBytes <= MatStage<S>::BYTES, "a cherry table fits a stage buffer");
   double R0[VL], R1[VL], R2[VL], R3[VL];
   OpState& os;
   const ConstModel& cm;
@@ -428,8 +468,8 @@ struct DevWalk {
   double *wsM, *wsU, *pcnt;
   const uint8_t* gcodes;
   size_t gstride;
-  uint8_t *stage, *cslot;
-  uint32_t lds_stage, lds_codes;
+  uint8_t *stage, *cslot, *cslot2;
+  uint32_t lds_stage, lds_codes, lds_codes2;
   int lane, c, c_end;
   double pc;
   double Lg[FUSE];
@@ -503,17 +543,28 @@ struct DevWalk {
       if constexpr (kProductBytes == MatStage<S>::BYTES && kLeafBytes == MatStage<S>::BYTES) {
         mat_dma_l<S>(src, dst, vlane());
         issued = MatStage<S>::ROWS;
-      } else if (etx >= 0) {   // (wave-uniform: the next op is a leaf op)
-        mat_dma_part<kLeafBytes>(src, dst, vlane());
-        issued = MatPart<kLeafBytes>::ROWS;
+      } else if (etx >= 0) {   // (wave-uniform: the next op is a leaf op -- or a cherry-table op)
+        if (kCherryTables && (etx & kCherryFlag)) {
+          mat_dma_part<kCherryBytes>(src, dst, vlane());
+          issued = MatPart<kCherryBytes>::ROWS;
+        } else {
+          mat_dma_part<kLeafBytes>(src, dst, vlane());
+          issued = MatPart<kLeafBytes>::ROWS;
+        }
       } else {
         mat_dma_part<kProductBytes>(src, dst, vlane());
         issued = MatPart<kProductBytes>::ROWS;
       }
     }
     if (etx >= 0 && (more || c + 1 < c_end)) {
-      code_dma_l(gcodes + (size_t)etx * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);
-      issued += 1;
+      if (kCherryTables && (etx & kCherryFlag)) {
+        code_dma_l(gcodes + (size_t)(etx & 0x7fff) * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);
+        code_dma_l(gcodes + (size_t)((etx >> 15) & 0x7fff) * gstride, lds_codes2 + (os.par ^ 1u) * kCodeSlotBytes);
+        issued += 2;
+      } else {
+        code_dma_l(gcodes + (size_t)etx * gstride, lds_codes + (os.par ^ 1u) * kCodeSlotBytes);
+        issued += 1;
+      }
     }
     {  // entry two ops ahead; the stream carries its first two entries again after the last (no wrap test)
       const int i2 = more ? mi + 2 : 1;
@@ -551,6 +602,23 @@ struct DevWalk {
   template <int SRC, int D> __device__ __forceinline__ void lmul(int, int) { (void)leaf<LEAF_MUL, SRC, D>(); }
   template <int SRC> __device__ __forceinline__ void ldot(int, int, int row) {
     const double tot = leaf<LEAF_DOT, SRC, SRC>();
+    pcnt[(size_t)row * kSites + vsidx()] = pc * tot;
+  }
+  // cherry-table ops (cmx_walk.h): the table staged like a leaf operator, its row named by two symbols
+  template <int MODE, int SRC, int DST>
+  __device__ __forceinline__ double cherry(void) {
+    unsigned nseq;
+    const uint8_t* buf = op_begin(nseq);
+    const int vl = vlane();
+    const double tot = cherry_apply<S, MODE, NG>(buf, cslot + os.par * kCodeSlotBytes + 4 * (vl & 15), cslot2 + os.par * kCodeSlotBytes + 4 * (vl & 15),
+                                                 vl, reg<SRC>(), reg<DST>());
+    asm volatile("" :: "v"(tot), "v"(reg<DST>()[0]), "v"(reg<DST>()[VL - 1]));
+    op_end(nseq);
+    return tot;
+  }
+  template <int D> __device__ __forceinline__ void cset(int, int, int) { (void)cherry<LEAF_SET, D, D>(); }
+  template <int SRC> __device__ __forceinline__ void cdot(int, int, int, int, int row) {
+    const double tot = cherry<LEAF_DOT, SRC, SRC>();
     pcnt[(size_t)row * kSites + vsidx()] = pc * tot;
   }
   // workspace vector -> register: plain global loads straight into the destination register, which the walk has
@@ -643,7 +711,8 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
                                                OpState& os, double& L_out, double& pr_out, int& rc_out,
                                                double& norm_out, int c_begin, int c_end, int c_after, bool finalize) {
   const DevModel& m = a.m;
-  const ConstModel cm(m);
+  constexpr bool kTables = DevWalk<S, FUSE, NG, RESOLVED>::kCherryTables;   // (the launcher guarantees m.msched_r then)
+  const ConstModel cm(m, kTables);
   constexpr int kSites = 16 * NG;      // sites per wave (NG site groups of 16; an S-vector is S / 4 * NG doubles per lane)
   // site of this lane inside the wave's block for per-site scalars and arrays: NG = 4: the lane itself; NG = 2: lanes
   // l and l ^ 16 both carry site 16 (l >> 5) + (l & 15) and do the per-site work redundantly (identical values)
@@ -653,15 +722,17 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   int bestc = 0;
   DevWalk<S, FUSE, NG, RESOLVED> be(os, cm);
   be.pi = m.pi;
-  be.nmv = m.nmv;
+  be.nmv = kTables ? m.nmv_r : m.nmv;
   be.wsM = wsM;
   be.wsU = wsU;
   be.gcodes = gcodes;
   be.gstride = gstride;
   be.stage = cmx_smem + lds_off;                                 // two operator buffers
   be.cslot = be.stage + 2 * MatStage<S>::BYTES;                  // two symbol slots
+  be.cslot2 = be.cslot + 2 * kCodeSlotBytes;                     // ... and two for the second leaf of a cherry-table op
   be.lds_stage = lds_addr(be.stage);                             // wave-uniform LDS byte addresses (SGPRs)
   be.lds_codes = lds_addr(be.cslot);
+  be.lds_codes2 = lds_addr(be.cslot2);
   be.lane = lane;
   be.c_end = c_end;
   {  // symbols of op 0 if it is a leaf op (the previous site block could not request them).  Everything this wave
@@ -669,7 +740,12 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     const int tx0 = cm.msched[1];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tx0 >= 0) {
-      code_dma(gcodes + (size_t)tx0 * gstride, be.cslot + os.par * kCodeSlotBytes);
+      if (kTables && (tx0 & 0x40000000)) {
+        code_dma(gcodes + (size_t)(tx0 & 0x7fff) * gstride, be.cslot + os.par * kCodeSlotBytes);
+        code_dma(gcodes + (size_t)((tx0 >> 15) & 0x7fff) * gstride, be.cslot2 + os.par * kCodeSlotBytes);
+      } else {
+        code_dma(gcodes + (size_t)tx0 * gstride, be.cslot + os.par * kCodeSlotBytes);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
@@ -759,14 +835,16 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
 // site groups of 16 per wave: 4 (64 sites, two waves per SIMD) or 2 (32 sites: the four live S-vectors take 80 registers
 // instead of 160 and three waves fit a SIMD; operators are then staged per 32 sites)
 template <int S>
-constexpr int map_lds_fixed() { return 2 * MatStage<S>::BYTES + 2 * kCodeSlotBytes; }   // stage buffers + symbol slots
+constexpr int map_lds_fixed() { return 2 * MatStage<S>::BYTES + 4 * kCodeSlotBytes; }   // stage buffers + symbol slots (two leaves)
 // + the simulator's node states (one byte per node and site) when they fit what is left of the CU's LDS share
 
 template <int S, int MODE, int FUSE, int NG = map_ng(S)>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void map_kernel(const MapArgs a) {
   constexpr int VL = S / 4 * NG, kSites = 16 * NG;
   const DevModel& m = a.m;
-  const ConstModel cm(m);
+  // the null's alignments are fully resolved: class-fused nucleotide models walk them with the cherry tables' stream
+  constexpr bool kTables = MODE == kModeNull && DevWalk<S, FUSE, NG, true>::kCherryTables;
+  const ConstModel cm(m, kTables);
   const int lane = threadIdx.x & (kWave - 1);
   const int sidx = NG == 4 ? lane : (NG == 2 ? (((lane >> 5) << 4) | (lane & 15)) : (lane & 15));   // site of this lane in the wave's block
   // wave index through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform and would keep every
@@ -884,6 +962,8 @@ hipError_t launch_map(const MapArgs& a_in, int mode, int grid_blocks, hipStream_
     if (ea_ != hipSuccess) return ea_;                                                                        \
     hipLaunchKernelGGL((map_kernel<S_, MODE_, F_>), grid, block, lds, stream, a);                             \
   } while (0)
+  // (the null instantiations of the class-fused layouts read the cherry-table walk's stream)
+  if (mode == kModeNull && a.m.fuse > 1 && a.m.msched_r == nullptr) return hipErrorInvalidValue;
 #define CMX_LAUNCH_MODES(S_, F_)                                            \
   do {                                                                      \
     if (mode == kModeObserved) CMX_LAUNCH(S_, kModeObserved, F_);           \

@@ -43,13 +43,26 @@ enum { FLAG_PSEUDO = 1,       // zero-length branch of a split multifurcation
 enum { WS_M = 0, WS_U = 1 };  // workspace arrays: messages of the inside pass, outside messages
 enum { OPER_P = -1 };         // which operator of a branch: OPER_P = transition matrix, k >= 0 = count operator k
 
+// Cherry tables (round 4; class-fused nucleotide models on fully resolved alignments, i.e. the null's): with four states a
+// cherry's two symbols take 16 values, so everything an inlined cherry contributes is a row of a 16-row table indexed by
+// (symbol of l1, symbol of l2) -- its message M_c = P_c (M_l1 o M_l2) (table 0), and, as dot products with its outside
+// message U_c, the counts of its own branch (table 1 + k: J_c^k (M_l1 o M_l2)) and of its two leaf branches (tables
+// 1 + K + k and 1 + 2 K + k: P_c (J_l1^k o M_l2), P_c (M_l1 o J_l2^k)).  A backend with kCherryTables = true gets
+// cset / cdot instead of the 3 operator ops of a cherry's message and the 5 + 3 K of its outside visit: one gather each.
+//
 // Backend concept (all members force-inlined on the device):
+//   static constexpr bool kCherryTables;  cset<D>(node, l1, l2)  [D = table 0 row];  cdot<S>(node, l1, l2, table, row)  [count]
 //   rec(v, int (&r)[16])
 //   lset<D>(leaf, which); lmul<S, D>(leaf, which)  [D = S o row];  ldot<S>(leaf, which, row)  [count]
 //   mv<S, D, TR>(node, which)  [D = M S or M^T S];  load<D>(arr, slot); store<S>(arr, slot)
 //   mov<D, S>(); mul<D, S>() [D *= S]; mulup() [R1 *= R3, R2 *= R3]; setpi<D>(); rootl<S>(); dot3(row); kill<R>()
 template <class BE>
 CMX_HD void walk_cherry_message(BE& be, int node, int l1, int l2) {   // M of an inlined cherry -> R1, through R3
+  if constexpr (BE::kCherryTables) {
+    be.template kill<1>();
+    be.template cset<1>(node, l1, l2);
+    return;
+  }
   be.template kill<3>();
   be.template lset<3>(l1, OPER_P);
   be.template lmul<3, 3>(l2, OPER_P);
@@ -85,6 +98,18 @@ CMX_HD void walk_child_dispose(BE& be, const int (&r)[16], int K) {
   } else if (kind == KIND_STORED && !(SIDE && (r[REC_FLAGS] & FLAG_HAND))) {
     be.template store<UR>(WS_U, r[o + CH_SLOT]);
   } else {
+    if constexpr (BE::kCherryTables) {
+      if (kind == KIND_CHERRY) {
+        // the cherry's whole outside visit: three dot products of its outside message with table rows per substitution type
+        const int l1 = r[o + CH_L1], l2 = r[o + CH_L2];
+        for (int k = 0; k < K; ++k) {
+          be.template cdot<UR>(node, l1, l2, 1 + k, node * K + k);
+          be.template cdot<UR>(node, l1, l2, 1 + K + k, l1 * K + k);
+          be.template cdot<UR>(node, l1, l2, 1 + 2 * K + k, l2 * K + k);
+        }
+        return;
+      }
+    }
     // cherry: its visit happens here, with U in R0; handed-over child: U stays in R0 for the next node
     be.template mov<0, UR>();
     if (kind == KIND_CHERRY) {
@@ -126,6 +151,8 @@ CMX_HD void walk_pass(BE& be, int NV, int K) {
         be.template lset<0>(r[REC_A + CH_NODE], OPER_P);
       } else if (ka == KIND_STORED) {
         be.template load<0>(WS_M, r[REC_A + CH_SLOT]);
+      } else if constexpr (BE::kCherryTables) {
+        be.template cset<0>(r[REC_A + CH_NODE], r[REC_A + CH_L1], r[REC_A + CH_L2]);
       } else {
         be.template lset<3>(r[REC_A + CH_L1], OPER_P);
         be.template lmul<3, 3>(r[REC_A + CH_L2], OPER_P);

@@ -184,7 +184,8 @@ class _Info(ctypes.Structure):
                                                "ninternal", "device", "cu_count", "waves")] + \
                [("workspace_bytes", ctypes.c_size_t)] + \
                [(n, ctypes.c_int32) for n in ("device_states", "device_classes", "products_per_pass", "leaf_ops_per_pass",
-                                              "ws_loads_per_pass", "ws_stores_per_pass")]
+                                              "ws_loads_per_pass", "ws_stores_per_pass", "products_per_pass_null",
+                                              "leaf_ops_per_pass_null", "cherry_tables")]
 
 
 _lib = None

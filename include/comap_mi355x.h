@@ -115,6 +115,9 @@ typedef struct {
    * loaded from / stored to the per-wave workspace -- what roofline accounting needs */
   int32_t device_states, device_classes;
   int32_t products_per_pass, leaf_ops_per_pass, ws_loads_per_pass, ws_stores_per_pass;
+  /* the walk of the null's (fully resolved) alignments when it differs: class-fused nucleotide models take an inlined
+   * cherry's message and outside visit from tables indexed by its two symbols (0 = same walk as above) */
+  int32_t products_per_pass_null, leaf_ops_per_pass_null, cherry_tables;
 } cmx_info;
 
 const char* cmx_version(void);
