@@ -65,14 +65,18 @@ def build_inputs(w):
     return parent, blen, lot, mdl, Bk, clamp
 
 
-def flops_per_site(info, B, C, S, K):
+def flops_per_site(info, B, C, S, K, null=False):
     """algorithmic: SURVEY 8(d), F_map = 7 B C S^2 (K = 1) -- every branch, leaf branches included, priced as dense
     products.  executed: what the kernel issues on the matrix cores (info = cmx_get_info: products of one device-class
-    pass over device states; leaf branches are row gathers, sibling messages are stored, not recomputed)."""
+    pass over device states; leaf branches are row gathers, sibling messages are stored, not recomputed; null: the walk of
+    the null's resolved alignments, where class-fused nucleotide models take cherries from tables)."""
     algorithmic = 7.0 * B * C * S * S
     dS, dC = info["device_states"], info["device_classes"]
     fuse = max(1, dS // S)   # class-fused nucleotide model: block-diagonal operators, only the diagonal tiles are applied
-    executed = dC * (info["products_per_pass"] * 2.0 * dS * dS / fuse + info["leaf_ops_per_pass"] * 2.0 * dS)
+    tables = null and info.get("cherry_tables", 0) > 0
+    products = info["products_per_pass_null"] if tables else info["products_per_pass"]
+    leaf_ops = info["leaf_ops_per_pass_null"] if tables else info["leaf_ops_per_pass"]
+    executed = dC * (products * 2.0 * dS * dS / fuse + leaf_ops * 2.0 * dS)
     return algorithmic, executed
 
 
@@ -330,7 +334,7 @@ def main():
 
     # roofline of the dominant kernel (map_kernel<S, null>): HIP events on the launch stream
     null_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    alg, exe = flops_per_site(info, eng.B, eng.C, eng.S, eng.K)
+    alg, exe = flops_per_site(info, eng.B, eng.C, eng.S, eng.K, null=nrep_total > 0)
     sites_per_launch = 2 * n_local if nrep_total else w["nsites"]
     achieved = sites_per_launch * alg / (null_ms * 1e-3) / 1e12
     ach_exe = sites_per_launch * exe / (null_ms * 1e-3) / 1e12
@@ -383,7 +387,9 @@ def main():
                            pair_output=args.pair_output, observed_rows_this_gpu=[row_begin, row_end],
                            cu_count=info["cu_count"], mapping_waves=info["waves"],
                            walk_per_pass=dict(products=info["products_per_pass"], leaf_ops=info["leaf_ops_per_pass"],
-                                              ws_loads=info["ws_loads_per_pass"], ws_stores=info["ws_stores_per_pass"])),
+                                              ws_loads=info["ws_loads_per_pass"], ws_stores=info["ws_stores_per_pass"],
+                                              cherry_tables=info["cherry_tables"], products_null=info["products_per_pass_null"],
+                                              leaf_ops_null=info["leaf_ops_per_pass_null"])),
                roofline=roofline)
 
     # same step, host memory to host memory (SURVEY 8(d) / BASELINE.md section 3: the contract's clock; never `value`): the

@@ -209,8 +209,11 @@ cmx_status cmx_null_simulate_dev(cmx_ctx* ctx, uint64_t seed, size_t rep_begin, 
  * (AnalysisTools.cpp:587-653): per replicate two batches of rep_ram simulated sites are mapped and site j of
  * batch 1 is scored against site j of batch 2.  Outputs have (rep_end-rep_begin)*rep_ram entries, the four
  * columns of AnalysisTools.cpp:642.  supplied (optional): [rep_end-rep_begin][2][T][rep_ram] alignments to map
- * instead of simulating (deterministic cross-implementation checks).  Sharding replicates over GPUs gives results
- * independent of the number of shards. */
+ * instead of simulating (deterministic cross-implementation checks).  Supplied alignments must be FULLY RESOLVED (every
+ * code a state, as a simulator's output is): the null's kernel stages only the state rows of a leaf operator and, for
+ * class-fused nucleotide models, takes cherries from tables indexed by their two symbols.  The host-pointer entry checks
+ * it (CMX_ERR_INVALID); with the device-pointer entry it is the caller's contract.  Sharding replicates over GPUs gives
+ * results independent of the number of shards. */
 cmx_status cmx_null_intra(cmx_ctx* ctx, int kind, const double* params, uint64_t seed, size_t rep_begin,
                           size_t rep_end, size_t rep_ram, const uint8_t* supplied, double* stat, int32_t* rcmin,
                           double* prmin, double* nmin);
