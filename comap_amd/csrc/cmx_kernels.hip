@@ -140,7 +140,7 @@ __device__ __forceinline__ void wait_vm(int allowed) {
   // model and leaf ops of resolved alignments stage a part of the unit), so every count up to R + 1 + H is exact and the
   // steps above are the multiples of H the vectors add; a smaller immediate than `allowed` only waits for more.
   constexpr int R = MatStage<S>::ROWS, H = (VL + 1) / 2;
-  static_assert(R + 1 + 3 * H < 64, "vmcnt is a 6-bit counter");
+  static_assert(R + 1 + 2 * H < 64, "vmcnt is a 6-bit counter");
   static_assert(R + 1 <= 6, "operator rows + symbols");
   const int v = allowed % H < 7 ? allowed % H : 6, q = allowed / H;   // (H >= 7 for every instantiation but S = 4: there v < H anyway)
   if (q == 0) {
@@ -149,11 +149,13 @@ __device__ __forceinline__ void wait_vm(int allowed) {
   } else if (q == 1) {
     if (v <= 3) { if (v <= 1) { if (v == 0) waitcnt_vm<H>(); else waitcnt_vm<H + 1>(); } else { if (v == 2) waitcnt_vm<H + 2>(); else waitcnt_vm<H + 3>(); } }
     else { if (v == 4) waitcnt_vm<H + 4>(); else if (v == 5) waitcnt_vm<H + 5>(); else waitcnt_vm<H + 6>(); }
-  } else if (q == 2) {
+  } else if (q == 2 && 2 * H + 6 < 64) {
     if (v <= 3) { if (v <= 1) { if (v == 0) waitcnt_vm<2 * H>(); else waitcnt_vm<2 * H + 1>(); } else { if (v == 2) waitcnt_vm<2 * H + 2>(); else waitcnt_vm<2 * H + 3>(); } }
     else { if (v == 4) waitcnt_vm<2 * H + 4>(); else if (v == 5) waitcnt_vm<2 * H + 5>(); else waitcnt_vm<2 * H + 6>(); }
   } else {
-    if (v <= 1) waitcnt_vm<3 * H>(); else if (v <= 3) waitcnt_vm<3 * H + 2>(); else waitcnt_vm<3 * H + 4>();
+    // three vectors or more in flight: whatever the counter can still tell apart (it saturates at 63)
+    constexpr int TOP = (3 * H + 4 < 64) ? 3 * H : (2 * H + 6 < 64 ? 2 * H + 6 : 2 * H);
+    waitcnt_vm<TOP>();
   }
 }
 
@@ -312,19 +314,26 @@ __device__ __forceinline__ double cherry_apply(const uint8_t* buf, const uint8_t
 
 // ------------------------------------------------------------------------------------------------ small helpers
 // Workspace vectors are stored as [S/2][64 lanes][2 doubles]: one 16-byte access per lane and row, 1 KiB per
-// wave-instruction, the same image in HBM and (for prefetched vectors) in LDS.
+// wave-instruction, the same image in HBM and (for prefetched vectors) in LDS.  An odd length (16-site tasks: S = 5) ends
+// with a row of single doubles.
+// (Round 4 tried [S][64] with 64-bit accesses: hipcc puts v_mov copies and the s_waitcnt for them right behind the 128-bit
+// loads at 3 of the 5 load sites of map_kernel<20, null> -- the loaded quads do not match the registers the vector's phi
+// with the other arms of the child switch got -- and 64-bit loads remove copies and early waits alike.  Twice the VMEM
+// instructions cost what that saved: target launch 445 -> 450 ms, same box, profiles/r04_ab_workspace_64bit.log.)
 template <int S>
-__device__ __forceinline__ void load_vec(const double* p /* slice base + 2*lane */, double (&v)[S], int lane = 0) {
+__device__ __forceinline__ void load_vec(const double* p /* slice base */, double (&v)[S], int lane) {
+  p += 2 * lane;
 #pragma unroll
   for (int i = 0; i < S / 2; ++i) {
     const d2 t = *reinterpret_cast<const d2*>(p + (size_t)i * 2 * kWave);
     v[2 * i] = t[0];
     v[2 * i + 1] = t[1];
   }
-  if constexpr (S % 2) v[S - 1] = p[(size_t)(S / 2) * 2 * kWave - lane];   // odd length (16-site tasks): a last row of single doubles
+  if constexpr (S % 2) v[S - 1] = p[(size_t)(S / 2) * 2 * kWave - lane];
 }
 template <int S>
-__device__ __forceinline__ void store_vec(double* p, const double (&v)[S], int lane = 0) {
+__device__ __forceinline__ void store_vec(double* p, const double (&v)[S], int lane) {
+  p += 2 * lane;
 #pragma unroll
   for (int i = 0; i < S / 2; ++i) {
     d2 t;
@@ -455,6 +464,7 @@ struct DevWalk {
 #ifndef CMX_NO_CHERRY_TABLES
 #define CMX_NO_CHERRY_TABLES 0     // 1: A/B builds without the cherry tables (scripts/ab_libs.sh)
 #endif
+  static constexpr int kVecInstrs = (VL + 1) / 2;   // VMEM instructions of one workspace vector
   static constexpr bool kCherryTables = RESOLVED && DIAG && !CMX_NO_CHERRY_TABLES;   // cmx_walk.h: cset / cdot instead of a cherry's operator ops
   static constexpr int kCherryBytes = 16 * leaf_row_stride(S) * 8;   // a table's 16 rows (one per symbol pair)
   static constexpr int kCherryFlag = 0x40000000;                     // stream entry: taxon of l1 | taxon of l2 << 15 | flag
@@ -630,17 +640,17 @@ struct DevWalk {
   __device__ __forceinline__ void load(int arr, int slot) {
     {
       const int vl = vlane();
-      load_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vl, reg<D>(), vl);
+      load_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave, reg<D>(), vl);
     }
-    os.vs += (VL + 1) / 2;
+    os.vs += kVecInstrs;
   }
   template <int SRC>
   __device__ __forceinline__ void store(int arr, int slot) {
     {
       const int vl = vlane();
-      store_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave + 2 * vl, reg<SRC>(), vl);
+      store_vec<VL>((arr ? wsU : wsM) + (size_t)slot * VL * kWave, reg<SRC>(), vl);
     }
-    os.vs += (VL + 1) / 2;
+    os.vs += kVecInstrs;
   }
   template <int D, int SRC> __device__ __forceinline__ void mov() {
 #pragma unroll
