@@ -40,6 +40,29 @@ int main(int argc, char** argv) {
       }
       return 0;
     }
+    if (argc == 4 && std::strcmp(argv[1], "matrices") == 0) {   // GPU: <in.bin: int32 n1, n2, dim; f64 v1[n1][dim], v2[n2][dim]> <out.bin>
+      // cmx::AnalysisTools::compute{ScalarProduct,Cosinus,Correlation,Covariance}Matrix (AnalysisTools.h:93-190) on a
+      // model-less engine: for each of the four, the one-set form of v1, the two-set form, and (n1 == n2) the independent one
+      std::ifstream in(argv[2], std::ios::binary);
+      int32_t h[3];
+      rd(in, h, 3);
+      cmx::VVdouble v1(h[0], cmx::Vdouble(h[2])), v2(h[1], cmx::Vdouble(h[2]));
+      for (auto& v : v1) rd(in, v.data(), v.size());
+      for (auto& v : v2) rd(in, v.data(), v.size());
+      cmx::Engine eng(0);
+      std::ofstream out(argv[3], std::ios::binary);
+      auto put = [&](const cmx::VVdouble& m) { for (const auto& r : m) wr(out, r.data(), r.size()); };
+      put(cmx::AnalysisTools::computeScalarProductMatrix(eng, v1)); put(cmx::AnalysisTools::computeScalarProductMatrix(eng, v1, v2, false));
+      put(cmx::AnalysisTools::computeCosinusMatrix(eng, v1)); put(cmx::AnalysisTools::computeCosinusMatrix(eng, v1, v2, false));
+      put(cmx::AnalysisTools::computeCorrelationMatrix(eng, v1)); put(cmx::AnalysisTools::computeCorrelationMatrix(eng, v1, v2, false));
+      put(cmx::AnalysisTools::computeCovarianceMatrix(eng, v1)); put(cmx::AnalysisTools::computeCovarianceMatrix(eng, v1, v2, false));
+      if (h[0] == h[1]) put(cmx::AnalysisTools::computeCorrelationMatrix(eng, v1, v2, true));
+      else {
+        try { cmx::AnalysisTools::computeCorrelationMatrix(eng, v1, v2, true); return 3; }
+        catch (cmx::DimensionException& e) { std::cout << "DimensionException: " << e.what() << "\n"; }
+      }
+      return 0;
+    }
     if (argc == 4 && std::strcmp(argv[1], "run") == 0) {
       std::ifstream in(argv[2], std::ios::binary);
       int32_t h[8];

@@ -214,3 +214,39 @@ def test_cpp_inter_stats_through_the_device_loop(adapter_exe, tmp_path, indep, q
         lines.append("[%d;%d]\t%s\t%d\t%s\t%s\n" % (100 + q["i"], 500 + q["j"], formats.fmt(q["stat"]), q["rc_min"],
                                                        formats.fmt(q["pr_min"]), formats.fmt(q["n_min"])))
     assert r.stdout == "".join(lines)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n1,n2,dim", [(9, 9, 30), (12, 5, 125)])
+def test_cpp_analysis_tools_matrices(adapter_exe, tmp_path, n1, n2, dim):
+    """cmx::AnalysisTools::compute{ScalarProduct,Cosinus,Correlation,Covariance}Matrix (the reference's
+    AnalysisTools.h:93-190 with an engine argument) against the definitions: one-set, two-set and independantComparisons forms,
+    and the reference's DimensionException when the independent form gets sets of different lengths"""
+    rng = np.random.default_rng(n1 * 100 + n2)
+    a, b = rng.normal(size=(n1, dim)), rng.normal(loc=0.2, size=(n2, dim))
+    inp, out = tmp_path / "m.bin", tmp_path / "o.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<3i", n1, n2, dim) + a.tobytes() + b.tobytes())
+    r = subprocess.run([adapter_exe, "matrices", str(inp), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.frombuffer(open(out, "rb").read(), dtype="<f8")
+
+    def cor(x, y, norm=True):
+        xc, yc = x - x.mean(1, keepdims=True), y - y.mean(1, keepdims=True)
+        cov = (xc @ yc.T) / (dim - 1)
+        return cov / np.outer(np.sqrt((xc ** 2).sum(1) / (dim - 1)), np.sqrt((yc ** 2).sum(1) / (dim - 1))) if norm else cov
+    cosm = lambda x, y: (x @ y.T) / np.outer(np.linalg.norm(x, axis=1), np.linalg.norm(y, axis=1))
+    refs = [a @ a.T, a @ b.T, cosm(a, a), cosm(a, b), cor(a, a), cor(a, b), cor(a, a, False), cor(a, b, False)]
+    off = 0
+    for k, ref in enumerate(refs):
+        got = raw[off:off + ref.size].reshape(ref.shape)
+        off += ref.size
+        if k in (2, 4):
+            assert np.all(np.diag(got) == 1.0)
+        rel_close(got, ref, 1e-9, 1e-12)
+    if n1 == n2:
+        ind = raw[off:off + n1 * n2].reshape(n1, n2)
+        assert np.all(ind[~np.eye(n1, dtype=bool)] == 0.0)
+        rel_close(np.diag(ind), np.diag(cor(a, b)), 1e-9, 1e-12)
+    else:
+        assert "DimensionException" in r.stdout and "independant comparisons" in r.stdout
