@@ -360,8 +360,10 @@ cmx_status cmx_ctx_create(const cmx_model* model, const cmx_tree* tree, int devi
     auto alloc_ws = [&](Workspace* ws, size_t w, size_t* bytes) -> cmx_status {
       const size_t ks = (size_t)map_sites_per_wave(h.dS);   // sites per mapping wave
       const size_t bD = w * h.NIW * h.dS * ks * sizeof(double);
-      const size_t bC = w * 2 * h.B * h.K * ks * sizeof(double);
-      const size_t bP = w * h.dC * h.B * h.K * ks * sizeof(double);
+      // (rows of the per-site scratch arrays: the sites of a wave, or 64 lanes for the 48-site experiment layout)
+      const size_t kr = map_ng(h.dS) == 3 ? 64 : ks;
+      const size_t bC = w * 2 * h.B * h.K * kr * sizeof(double);
+      const size_t bP = w * h.dC * h.B * h.K * kr * sizeof(double);
       const size_t bS = w * h.nn * ks, bA = w * h.T * ks;
       const bool g = guard_on();
       auto one = [&](const char* nm, void** p, size_t bytes) -> cmx_status {
@@ -590,7 +592,7 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
   size_t ks = (size_t)map_sites_per_wave(ctx->hm.dS);
   size_t nblocks = (nsites + ks - 1) / ks;
   const size_t obs_waves = (size_t)max_blocks * kWavesPerBlock;
-  if (nblocks * (size_t)ctx->hm.dC <= obs_waves && ctx->hm.dC > 1) {
+  if (nblocks * (size_t)ctx->hm.dC <= obs_waves && ctx->hm.dC > 1 && map_ng(ctx->hm.dS) != 3) {   // (48-site experiment builds: no class split)
     // small alignment: one (site block, class) per wave, classes summed by a second kernel (same arithmetic order)
     // Proteins, when even that leaves most of the chip idle: 16-site blocks (one site group per wave) -- four times the
     // tasks, a quarter of the matrix work per operator op, and a wave's slices of the workspaces are a quarter as large,

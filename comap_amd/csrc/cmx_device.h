@@ -33,7 +33,7 @@ constexpr int map_ng(int S) { return S >= 16 ? CMX_NG : 4; }
 constexpr int map_sites_per_wave(int S) { return 16 * map_ng(S); }
 // (three waves per SIMD were tried for the 16-state class-fused nucleotide layout -- vectors of 32 registers: at 168
 // registers the kernel spills 213 of them and the cfg 4 launch went from 7.7 to 10.7 ms)
-constexpr int map_waves_per_simd(int S) { return S == 4 ? CMX_WAVES_PER_SIMD_S4 : (map_ng(S) == 2 ? 3 : CMX_WAVES_PER_SIMD); }
+constexpr int map_waves_per_simd(int S) { return S == 4 ? CMX_WAVES_PER_SIMD_S4 : ((map_ng(S) == 2 || map_ng(S) == 3) ? 3 : CMX_WAVES_PER_SIMD); }
 
 // Device-resident model + tree program.  All pointers are device pointers.
 struct DevModel {

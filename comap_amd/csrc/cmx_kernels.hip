@@ -183,6 +183,15 @@ __device__ __forceinline__ double reduce_sites(const double (&p)[NG]) {
     double k0 = p0 + p2, k1 = p1 + p3;   // site groups 0 / 1 in the lower half of the wave, 2 / 3 in the upper
     swap16(k0, k1);            // even rows: own k0, partner's k0    | odd rows: partner's k1, own k1
     return k0 + k1;            // site group lane >> 4: lane l holds site l
+  } else if constexpr (NG == 3) {
+    // three site groups (48 sites per wave, three waves per SIMD): the four-group exchange with an empty fourth group;
+    // lanes 48 .. 63 end with nothing of interest
+    double p0 = p[0], p1 = p[1], p2 = p[2], p3 = 0.0;
+    swap32(p0, p2);
+    swap32(p1, p3);
+    double k0 = p0 + p2, k1 = p1 + p3;
+    swap16(k0, k1);
+    return k0 + k1;
   } else if constexpr (NG == 2) {
     // two site groups (32 sites per wave): lanes l and l ^ 16 both end with the total of site 16 (l >> 5) + (l & 15)
     double p0 = p[0], p1 = p[1];
@@ -255,7 +264,7 @@ __device__ __forceinline__ double leaf_apply(const uint8_t* buf, const uint8_t* 
   // group do not depend on anything computed for the previous one
   unsigned code[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) code[g] = codes[g * (256 / NG)];   // one dword per LANE in the slot, group g at 64 / NG * g
+  for (int g = 0; g < NG; ++g) code[g] = codes[g * (NG == 3 ? 64 : 256 / NG)];   // one dword per LANE in the slot, group g at 64 / NG * g (three groups: as four)
   const double* r[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -289,7 +298,7 @@ __device__ __forceinline__ double cherry_apply(const uint8_t* buf, const uint8_t
   double part[NG];
   unsigned c1[NG], c2[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) { c1[g] = codes1[g * (256 / NG)]; c2[g] = codes2[g * (256 / NG)]; }
+  for (int g = 0; g < NG; ++g) { c1[g] = codes1[g * (NG == 3 ? 64 : 256 / NG)]; c2[g] = codes2[g * (NG == 3 ? 64 : 256 / NG)]; }
   const double* r[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -458,6 +467,7 @@ struct OpState {
 template <int S, int FUSE, int NG, bool RESOLVED>
 struct DevWalk {
   static constexpr int VL = S / 4 * NG, kSites = 16 * NG;
+  static constexpr int kRow = NG == 3 ? 64 : kSites;   // lanes per row of the wave's per-site scratch arrays (three groups: lanes 48 .. 63 own unused columns)
   static constexpr bool DIAG = FUSE > 1 && S / FUSE == 4;
   static constexpr int kProductBytes = DIAG ? (S / 4) * 128 : MatStage<S>::BYTES;                      // diagonal tiles come first
   static constexpr int kLeafBytes = RESOLVED ? (S / FUSE) * leaf_row_stride(S) * 8 : MatStage<S>::BYTES;
@@ -499,7 +509,7 @@ struct DevWalk {
   // site of the lane inside the wave's block (see map_sites_wave)
   __device__ __forceinline__ int vsidx() const {
     const int l = vlane();
-    return NG == 4 ? l : (NG == 2 ? (((l >> 5) << 4) | (l & 15)) : (l & 15));
+    return NG >= 3 ? l : (NG == 2 ? (((l >> 5) << 4) | (l & 15)) : (l & 15));
   }
   template <int I>
   __device__ __forceinline__ double (&reg())[VL] {
@@ -525,7 +535,12 @@ struct DevWalk {
   template <int R>
   __device__ __forceinline__ void kill() {
     double(&r)[VL] = reg<R>();
-    static_assert(VL == 4 || VL == 5 || VL == 8 || VL == 16 || VL == 20, "kill() names every element in one statement");
+    static_assert(VL == 4 || VL == 5 || VL == 8 || VL == 12 || VL == 15 || VL == 16 || VL == 20, "kill() names every element in one statement");
+    if constexpr (VL == 12)
+      asm volatile("" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7]), "=v"(r[8]), "=v"(r[9]), "=v"(r[10]), "=v"(r[11]));
+    else if constexpr (VL == 15)
+      asm volatile("" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7]), "=v"(r[8]), "=v"(r[9]), "=v"(r[10]), "=v"(r[11]), "=v"(r[12]), "=v"(r[13]), "=v"(r[14]));
+    else
     if constexpr (VL == 5)
       asm volatile("" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]));
     else if constexpr (VL == 4)
@@ -612,7 +627,7 @@ struct DevWalk {
   template <int SRC, int D> __device__ __forceinline__ void lmul(int, int) { (void)leaf<LEAF_MUL, SRC, D>(); }
   template <int SRC> __device__ __forceinline__ void ldot(int, int, int row) {
     const double tot = leaf<LEAF_DOT, SRC, SRC>();
-    pcnt[(size_t)row * kSites + vsidx()] = pc * tot;
+    pcnt[(size_t)row * kRow + vsidx()] = pc * tot;
   }
   // cherry-table ops (cmx_walk.h): the table staged like a leaf operator, its row named by two symbols
   template <int MODE, int SRC, int DST>
@@ -629,7 +644,7 @@ struct DevWalk {
   template <int D> __device__ __forceinline__ void cset(int, int, int) { (void)cherry<LEAF_SET, D, D>(); }
   template <int SRC> __device__ __forceinline__ void cdot(int, int, int, int, int row) {
     const double tot = cherry<LEAF_DOT, SRC, SRC>();
-    pcnt[(size_t)row * kSites + vsidx()] = pc * tot;
+    pcnt[(size_t)row * kRow + vsidx()] = pc * tot;
   }
   // workspace vector -> register: plain global loads straight into the destination register, which the walk has
   // declared dead (kill) long before -- in the outside pass the two sibling messages of a node are requested before the
@@ -704,7 +719,7 @@ struct DevWalk {
     for (int sb = 0; sb < S / 4; ++sb)
 #pragma unroll
       for (int g = 0; g < NG; ++g) p_[g] = __builtin_fma(R3[sb * NG + g] * R1[sb * NG + g], R2[sb * NG + g], p_[g]);
-    pcnt[(size_t)row * kSites + vsidx()] = pc * reduce_sites<NG>(p_);
+    pcnt[(size_t)row * kRow + vsidx()] = pc * reduce_sites<NG>(p_);
   }
 };
 
@@ -724,9 +739,10 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
   constexpr bool kTables = DevWalk<S, FUSE, NG, RESOLVED>::kCherryTables;   // (the launcher guarantees m.msched_r then)
   const ConstModel cm(m, kTables);
   constexpr int kSites = 16 * NG;      // sites per wave (NG site groups of 16; an S-vector is S / 4 * NG doubles per lane)
+  constexpr int kRow = NG == 3 ? 64 : kSites;   // row length of the wave's per-site scratch arrays
   // site of this lane inside the wave's block for per-site scalars and arrays: NG = 4: the lane itself; NG = 2: lanes
   // l and l ^ 16 both carry site 16 (l >> 5) + (l & 15) and do the per-site work redundantly (identical values)
-  const int sidx = NG == 4 ? lane : (NG == 2 ? (((lane >> 5) << 4) | (lane & 15)) : (lane & 15));
+  const int sidx = NG >= 3 ? lane : (NG == 2 ? (((lane >> 5) << 4) | (lane & 15)) : (lane & 15));
   const int C = m.C, K = m.K;
   double Lsum = 0.0, prsum = 0.0, best = -1.0;
   int bestc = 0;
@@ -766,7 +782,7 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
     const double pc = FUSE > 1 ? 1.0 : cm.probs[c];  // fused: the class probabilities are folded into the count operators
     be.pc = pc;
     be.c = c;
-    be.pcnt = part + (size_t)c * m.B * K * kSites;   // wave-uniform; the lane's site is added at each use
+    be.pcnt = part + (size_t)c * m.B * K * kRow;   // wave-uniform; the lane's site is added at each use
     be.begin_pass();
     walk_pass(be, m.NV, K);
     if constexpr (FUSE == 1) {
@@ -810,23 +826,23 @@ __device__ __forceinline__ void map_sites_wave(const MapArgs& a, double* __restr
       double t[4][RC];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double* pp = part + ((size_t)(c + q) * BK + r0) * kSites + sidx;
+        const double* pp = part + ((size_t)(c + q) * BK + r0) * kRow + sidx;
 #pragma unroll
-        for (int u = 0; u < RC; ++u) t[q][u] = pp[(size_t)(r0 + u < BK ? u : 0) * kSites];
+        for (int u = 0; u < RC; ++u) t[q][u] = pp[(size_t)(r0 + u < BK ? u : 0) * kRow];
       }
 #pragma unroll
       for (int u = 0; u < RC; ++u) v[u] = (((v[u] + t[0][u]) + t[1][u]) + t[2][u]) + t[3][u];
     }
     for (; c < C; ++c) {
-      const double* pp = part + ((size_t)c * BK + r0) * kSites + sidx;
+      const double* pp = part + ((size_t)c * BK + r0) * kRow + sidx;
 #pragma unroll
-      for (int u = 0; u < RC; ++u) v[u] += pp[(size_t)(r0 + u < BK ? u : 0) * kSites];
+      for (int u = 0; u < RC; ++u) v[u] += pp[(size_t)(r0 + u < BK ? u : 0) * kRow];
     }
 #pragma unroll
     for (int u = 0; u < RC; ++u) {
       if (r0 + u < BK) {
         const double q = v[u] / Lsum;
-        cnt[(size_t)(r0 + u) * kSites + sidx] = q;
+        cnt[(size_t)(r0 + u) * kRow + sidx] = q;
         tot += q;
         if (++kk == K) {
           nrm = __builtin_fma(tot, tot, nrm);
@@ -851,12 +867,13 @@ constexpr int map_lds_fixed() { return 2 * MatStage<S>::BYTES + 4 * kCodeSlotByt
 template <int S, int MODE, int FUSE, int NG = map_ng(S)>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void map_kernel(const MapArgs a) {
   constexpr int VL = S / 4 * NG, kSites = 16 * NG;
+  constexpr int kRow = NG == 3 ? 64 : kSites;
   const DevModel& m = a.m;
   // the null's alignments are fully resolved: class-fused nucleotide models walk them with the cherry tables' stream
   constexpr bool kTables = MODE == kModeNull && DevWalk<S, FUSE, NG, true>::kCherryTables;
   const ConstModel cm(m, kTables);
   const int lane = threadIdx.x & (kWave - 1);
-  const int sidx = NG == 4 ? lane : (NG == 2 ? (((lane >> 5) << 4) | (lane & 15)) : (lane & 15));   // site of this lane in the wave's block
+  const int sidx = NG >= 3 ? lane : (NG == 2 ? (((lane >> 5) << 4) | (lane & 15)) : (lane & 15));   // site of this lane in the wave's block
   // wave index through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform and would keep every
   // per-wave base pointer below as a per-lane 64-bit VGPR pair (spilled, and reloaded from scratch in the hot loop)
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -864,9 +881,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   const int nwaves = gridDim.x * kWavesPerBlock;
   double* wsD = a.ws.D + (size_t)wave * m.NIW * VL * kWave;
   double* wsU = a.ws.U + (size_t)wave * m.NIW * VL * kWave;
-  double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kSites;
-  double* cnt1 = cnt0 + (size_t)m.B * m.K * kSites;
-  double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kSites;
+  double* cnt0 = a.ws.cnt + (size_t)wave * 2 * m.B * m.K * kRow;
+  double* cnt1 = cnt0 + (size_t)m.B * m.K * kRow;
+  double* part = a.ws.part + (size_t)wave * m.C * m.B * m.K * kRow;
   // LDS per wave: workspace prefetch buffer (S*64*8 B), two operator stage buffers, two symbol slots
   const int lds_off = wib * a.lds_per_wave;
   const size_t nblocks = (a.nsites + kSites - 1) / kSites;
@@ -902,7 +919,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
   }
   for (size_t sb = wave; sb < nblocks; sb += nwaves) {
     const size_t site = sb * kSites + sidx;
-    const bool active = site < a.nsites;
+    const bool active = site < a.nsites && sidx < kSites;
     const size_t s = active ? site : a.nsites - 1;
     if (MODE == kModeObserved) {
       double L, pr, nrm;
@@ -914,7 +931,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
         if (a.rate_class) a.rate_class[s] = rc;
         if (a.norm) a.norm[s] = nrm;
         if (a.counts)
-          for (int r = 0; r < m.B * m.K; ++r) a.counts[(size_t)r * a.ldc + s] = cnt0[(size_t)r * kSites + sidx];
+          for (int r = 0; r < m.B * m.K; ++r) a.counts[(size_t)r * a.ldc + s] = cnt0[(size_t)r * kRow + sidx];
       }
     } else {
       // null pair q = s: replicate rep, column j; simulated-site index g_h = ((rep*2 + h)*rep_ram + j).
@@ -935,7 +952,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, map_waves_per_simd(S)) void
         if (h == 0) { prmin = pr; nmin = nrm; rcmin = rc; }
         else { prmin = pr < prmin ? pr : prmin; nmin = nrm < nmin ? nrm : nmin; rcmin = rc < rcmin ? rc : rcmin; }
       }
-      const double stat = pair_stat_strided(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + sidx, (size_t)kSites, cnt1 + sidx, (size_t)kSites, a.stat_mean);
+      const double stat = pair_stat_strided(a.stat_kind, a.stat_param, m.B, m.K, cnt0 + sidx, (size_t)kRow, cnt1 + sidx, (size_t)kRow, a.stat_mean);
       if (active) {
         a.null_stat[s] = stat;
         if (a.null_rcmin) a.null_rcmin[s] = rcmin;
