@@ -1053,7 +1053,8 @@ def test_inter_rows_on_the_device_match_the_reference_loop(kind):
         e1.inter_rows(kind, m1, {k: v[:60] for k, v in m2.items()}, engine.InterFilters(independent_comparisons=True), threshold=thr)
 
 
-@pytest.mark.parametrize("T,n1,n2", [(40, 50, 77), (100, 37, 205), (200, 61, 100), (256, 130, 260), (300, 40, 50)])
+@pytest.mark.parametrize("T,n1,n2", [(40, 50, 77), (100, 37, 205), (200, 61, 100), (256, 130, 260), (300, 40, 50), (257, 61, 40), (512, 50, 77),
+                                     (600, 30, 25)])
 def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
     """The protein path up to 256 taxa (cmx_mica4.hip: plain and weighted instantiation, operand registers for 2 / 4 / 8
     k-steps) and above (eight-wave kernel): column counts that are no multiple of the 12 x 3 tile, runs longer than one
@@ -1087,13 +1088,15 @@ def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
     assert np.isnan(gi["mi"][np.tril_indices(n2)]).all() and np.isnan(gi["hjoint"][np.tril_indices(n2)]).all()
 
 
-def test_mica_weighted_kernel_queue_of_large_cells_beyond_one_wave():
+@pytest.mark.parametrize("T", [256, 512])
+def test_mica_weighted_kernel_queue_of_large_cells_beyond_one_wave(T):
     """The weighted instantiation looks cells below 4 096 / 400 = 10.24 taxa up in LDS and queues the larger ones per wave
     for one gather at the end of the tile.  Here every pair of columns has twenty cells of 12 or 13 taxa (the columns are
     the same partition of the 256 taxa into twenty blocks, states permuted per column) and every column two unknowns: a
-    wave's nine pairs queue 180 cells per tile, three rounds of its 64 lanes (the bound is 225)."""
+    wave's nine pairs queue 180 cells per tile, three rounds of its 64 lanes (the bound is 225).  With 512 taxa (the
+    eight-wave kernel serves those) the twenty cells hold 25 or 26 taxa."""
     rng = np.random.default_rng(5)
-    A, T, n1, n2 = 20, 256, 26, 11
+    A, n1, n2 = 20, 26, 11
     block = (np.arange(T) * A // T).astype(np.uint8)
 
     def draw(n):
