@@ -27,6 +27,7 @@ struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;     // capacity the callers may use (the allocation is kGuardBytes longer under the guard)
   size_t logical = 0;   // guard only: what the last caller asked for; the canary sits at [logical, logical + kGuardBytes)
+  bool guarded = false; // allocated with room for the canary (a buffer from before the guard was switched on is not)
 };
 
 // CMX_SCRATCH_GUARD=1 (or cmx_debug_scratch_guard(1)): every scratch buffer, per-wave workspace and temporary is
@@ -143,7 +144,7 @@ cmx_status guard_verify_all(cmx_ctx* ctx) {
   };
   size_t off = 0;
   for (auto& kv : ctx->scratch)
-    if (kv.second.p && !guard_intact(kv.second.p, kv.second.logical, &off)) {
+    if (kv.second.p && kv.second.guarded && !guard_intact(kv.second.p, kv.second.logical, &off)) {
       bad("scratch:" + kv.first, kv.second.logical, off);
       (void)guard_arm(kv.second.p, kv.second.logical);   // report an overflow once, not at every later check
     }
@@ -161,6 +162,11 @@ cmx_status scratch(cmx_ctx* ctx, const char* name, size_t bytes, void** out) {
   if (guard_on()) {
     // the previous user's canary is checked before the buffer is handed out again (it may move with the size asked for)
     HIP_TRY(ctx, hipDeviceSynchronize());
+    if (b.p && !b.guarded) {   // allocated before the guard was switched on: no room for a canary, start over
+      HIP_TRY(ctx, hipFree(b.p));
+      b.p = nullptr;
+      b.bytes = 0;
+    }
     size_t off = 0;
     if (b.p && !guard_intact(b.p, b.logical, &off)) {
       const std::string msg = std::string("buffer 'scratch:") + name + "' was written past its end (" + std::to_string(b.logical) +
@@ -181,6 +187,7 @@ cmx_status scratch(cmx_ctx* ctx, const char* name, size_t bytes, void** out) {
       b.bytes = 0;
       HIP_TRY(ctx, hipMalloc(&b.p, (bytes ? bytes : 16) + kGuardBytes));
       b.bytes = bytes;
+      b.guarded = true;
     }
     b.logical = logical;
     HIP_TRY(ctx, guard_arm(b.p, b.logical));
@@ -193,6 +200,7 @@ cmx_status scratch(cmx_ctx* ctx, const char* name, size_t bytes, void** out) {
     b.bytes = 0;
     HIP_TRY(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
     b.bytes = bytes;
+    b.guarded = false;
   }
   *out = b.p;
   return CMX_OK;

@@ -163,3 +163,20 @@ def test_continuous_rates_and_codon_alphabets_under_the_guard():
     e9.map_sites(a)
     e9.null_intra(0, 4, 0, 3, 31)
     _clean(eng, e9)
+
+
+def test_guard_switched_on_after_buffers_exist():
+    """a scratch buffer from before the guard was switched on has no room for a canary: it is re-created, not checked"""
+    engine.scratch_guard(False)
+    try:
+        case = make_case(9, 80, 20, 2)
+        eng = _eng(case)
+        m = eng.map_sites(case["aln"])
+        a = eng.pair_stats(0, m["counts"])                   # allocates the pair operands without a guard tail
+        engine.scratch_guard(True)
+        b = eng.pair_stats(0, m["counts"])                   # the same buffers, now re-created with their canaries
+        assert np.array_equal(a, b, equal_nan=True)
+        eng.null_intra(0, 3, 0, 3, 31)
+        _clean(eng)
+    finally:
+        engine.scratch_guard(True)
