@@ -444,7 +444,7 @@ cmx_status cmx_get_transition_matrices(const cmx_ctx* ctx, double* P) {
 
 cmx_status cmx_debug_walk(const cmx_model* model, const cmx_tree* tree, int32_t* nrec, size_t nrec_cap, size_t* nrec_n,
                           int32_t* ldsched, size_t ld_cap, size_t* ld_n, int32_t* msched, size_t m_cap, size_t* m_n,
-                          int32_t* slot_of_node, uint64_t* stats /*[4]: loads, stores, products, leaf ops per pass*/) {
+                          int32_t* slot_of_node, uint64_t* stats /*[7]: loads, stores, products, leaf ops per pass; products, leaf ops of the cherry-table walk, cherries with tables*/) {
   HostModel hm;
   int code = CMX_OK;
   const std::string msg = build_host_model(model, tree, &hm, &code);
@@ -461,7 +461,10 @@ cmx_status cmx_debug_walk(const cmx_model* model, const cmx_tree* tree, int32_t*
   std::memcpy(msched, hm.msched.data(), hm.msched.size() * sizeof(int32_t));
   *nrec_n = hm.nrec.size(); *ld_n = hm.ldsched.size(); *m_n = hm.msched.size();
   if (slot_of_node) std::memcpy(slot_of_node, hm.slot.data(), hm.slot.size() * sizeof(int32_t));
-  if (stats) { stats[0] = hm.n_loads; stats[1] = hm.n_stores; stats[2] = hm.n_products; stats[3] = hm.n_leaf_ops; }
+  if (stats) {
+    stats[0] = hm.n_loads; stats[1] = hm.n_stores; stats[2] = hm.n_products; stats[3] = hm.n_leaf_ops;
+    stats[4] = hm.n_products_r; stats[5] = hm.n_leaf_ops_r; stats[6] = hm.msched_r.empty() ? 0 : (uint64_t)hm.ncherry;
+  }
   return CMX_OK;
 }
 

@@ -225,7 +225,9 @@ def _sz(x):
 
 def debug_walk(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
     """Host-side compilation of the tree into what the mapping kernel's walk reads (no GPU): dict(nrec[NV,16], ldsched,
-    msched[nops,2], slot[nnodes], loads, stores, products, leaf_ops) -- counts are per rate-class pass."""
+    msched[nops,2], slot[nnodes], loads, stores, products, leaf_ops, products_tables, leaf_ops_tables, cherry_tables) --
+    counts are per rate-class pass; *_tables: the walk of resolved alignments with cherry tables (class-fused nucleotide
+    models; cherry_tables = 0: no such walk).  The call fails if the engine's numerical self-check of either walk does."""
     lib = load_library()
     keep = [np.ascontiguousarray(parent, dtype=np.int32), _f64(blen), np.ascontiguousarray(leaf_of_taxon, dtype=np.int32),
             _f64(Q), _f64(pi), _f64(rates), _f64(probs), None if Bk is None else _f64(Bk)]
@@ -238,7 +240,7 @@ def debug_walk(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
     cap = 64 * nn * max(K, 1) + 64
     nrec, ld, ms = (np.zeros(cap, dtype=np.int32) for _ in range(3))
     slot = np.zeros(nn, dtype=np.int32)
-    stats = np.zeros(4, dtype=np.uint64)
+    stats = np.zeros(8, dtype=np.uint64)
     n1, n2, n3 = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
     st = lib.cmx_debug_walk(ctypes.byref(model), ctypes.byref(tree), _vp(nrec), _sz(cap), ctypes.byref(n1), _vp(ld),
                             _sz(cap), ctypes.byref(n2), _vp(ms), _sz(cap), ctypes.byref(n3), _vp(slot), _vp(stats))
@@ -246,7 +248,8 @@ def debug_walk(parent, blen, leaf_of_taxon, Q, pi, rates, probs, Bk=None):
         raise CmxError(st, lib.cmx_last_error(None).decode())
     return dict(nrec=nrec[: n1.value].reshape(-1, 16).copy(), ldsched=ld[: n2.value].copy(),
                 msched=ms[: n3.value].reshape(-1, 2).copy(), slot=slot, loads=int(stats[0]), stores=int(stats[1]),
-                products=int(stats[2]), leaf_ops=int(stats[3]))
+                products=int(stats[2]), leaf_ops=int(stats[3]), products_tables=int(stats[4]), leaf_ops_tables=int(stats[5]),
+                cherry_tables=int(stats[6]))
 
 
 def debug_candidate_cursor(norm_windows, analysable, min_sim, norms, max_trials):

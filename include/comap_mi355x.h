@@ -149,7 +149,9 @@ void cmx_debug_scratch_shrink(const char* name, size_t bytes);
 cmx_status cmx_debug_walk(const cmx_model* model, const cmx_tree* tree, int32_t* nrec, size_t nrec_cap, size_t* nrec_n,
                           int32_t* ldsched, size_t ld_cap, size_t* ld_n, int32_t* msched, size_t m_cap, size_t* m_n,
                           int32_t* slot_of_node /*[nnodes] or NULL*/,
-                          uint64_t* stats /*[4] or NULL: workspace loads, stores, matrix products, leaf ops per pass*/);
+                          uint64_t* stats /*[7] or NULL: workspace loads, stores, matrix products, leaf ops per pass; products and
+                                            leaf ops of the cherry-table walk (resolved alignments of class-fused nucleotide
+                                            models), cherries with tables (0: that walk is the first one)*/);
 
 /* ---- substitution mapping: replaces DRHomogeneousTreeLikelihood::initialize + getLogLikelihoodPerSite /
  * getPosteriorRatePerSite / getRateClassWithMaxPostProbPerSite + computeSubstitutionVectors + computeNormForSite

@@ -135,3 +135,82 @@ def test_malformed_trees_are_rejected():
         engine.debug_walk(bad2, blen, lot, Q, pi, rates, probs)
     with pytest.raises(engine.CmxError):
         engine.debug_walk(parent, -blen, lot, Q, pi, rates, probs)
+
+
+def _shape(kind, ntaxa, seed):
+    if kind == "random":
+        return sy.random_tree(ntaxa, seed)
+    if kind == "multifurcating":
+        return _random_multifurcating(ntaxa, seed)
+    rng = np.random.default_rng(seed)
+    if kind == "caterpillar":
+        nn = 2 * ntaxa - 1
+        par = np.full(nn, -1, dtype=np.int32)
+        lot = np.zeros(ntaxa, dtype=np.int32)
+        lot[0], lot[1] = 0, 1
+        par[0] = par[1] = 2
+        cur = 2
+        for t in range(2, ntaxa):
+            lot[t] = cur + 1
+            par[cur] = par[cur + 1] = cur + 2
+            cur += 2
+    else:   # balanced: every leaf in a cherry
+        level, parent, nxt = list(range(ntaxa)), {}, ntaxa
+        while len(level) > 1:
+            up = []
+            for k in range(0, len(level) - 1, 2):
+                parent[level[k]] = parent[level[k + 1]] = nxt
+                up.append(nxt)
+                nxt += 1
+            if len(level) % 2:
+                up.append(level[-1])
+            level = up
+        kids = {}
+        for c, p in parent.items():
+            kids.setdefault(p, []).append(c)
+        order = []
+
+        def visit(n):
+            for c in kids.get(n, []):
+                visit(c)
+            order.append(n)
+        visit(level[0])
+        new = {old: i for i, old in enumerate(order)}
+        par = np.full(nxt, -1, dtype=np.int32)
+        for c, p in parent.items():
+            par[new[c]] = new[p]
+        lot = np.array([new[t] for t in range(ntaxa)], dtype=np.int32)
+    blen = np.maximum(rng.exponential(0.1, size=len(par)), 1e-6)
+    blen[-1] = 0.0
+    return par, blen, lot
+
+
+@pytest.mark.parametrize("kind,ntaxa", [("random", 5), ("random", 40), ("random", 256), ("multifurcating", 30), ("caterpillar", 12),
+                                        ("balanced", 16), ("balanced", 21), ("random", 3)])
+@pytest.mark.parametrize("ncat,ntypes", [(4, 1), (5, 1), (4, 2), (8, 1)])
+def test_cherry_table_walk_compiles_and_checks(kind, ntaxa, ncat, ntypes):
+    """class-fused nucleotide models (>= 4 rate classes): the walk of resolved alignments takes inlined cherries from tables
+    (cmx_walk.h).  cmx_debug_walk fails unless BOTH walks reproduce likelihood and every joint count of a direct pruning
+    computation from the device layouts (verify_walk), so a call that returns has checked the tables numerically."""
+    parent, blen, lot = _shape(kind, ntaxa, 31 * ntaxa + ncat)
+    m = sy.dna_model(0.6, ncat)
+    Bk = None
+    if ntypes == 2:
+        rng = np.random.default_rng(ntaxa)
+        Bk = np.stack([sy.weighted_register(m["Q"], rng.uniform(-1, 1, size=(4, 4))), sy.weighted_register(m["Q"])])
+    w = engine.debug_walk(parent, blen, lot, m["Q"], m["pi"], m["rates"], m["probs"], Bk=Bk)
+    # a cherry with tables: its message is 1 op instead of 3, its outside visit 3 K instead of 5 + 3 K
+    nch = w["cherry_tables"]
+    assert w["products_tables"] + w["leaf_ops_tables"] == w["products"] + w["leaf_ops"] - nch * 2 * 2 - nch * 5 or nch == 0 or ntypes == 2
+    assert w["products_tables"] <= w["products"] and w["leaf_ops_tables"] <= w["leaf_ops"]
+    if kind == "balanced" and ntaxa == 16:
+        assert nch >= 6
+    if kind == "random" and ntaxa == 3:
+        assert nch == 0 and w["products_tables"] == w["products"]      # no cherry: the second stream is the first
+
+
+def test_fewer_than_four_classes_have_no_table_walk():
+    parent, blen, lot = sy.random_tree(20, 5)
+    m = sy.dna_model(0.6, 3)
+    w = engine.debug_walk(parent, blen, lot, m["Q"], m["pi"], m["rates"], m["probs"])
+    assert w["cherry_tables"] == 0 and w["products_tables"] == 0
