@@ -36,10 +36,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 
 #include "cmx_device.h"
 #include "cmx_lanes.h"
 
+#ifndef CMX_M4_LAG
+#define CMX_M4_LAG 2
+#endif
 namespace cmx {
 
 constexpr int kM4I = 12, kM4J = 3, kM4Rows = 20;
@@ -51,33 +56,49 @@ constexpr int kM4Corr = 12, kM4QCap = 232;
 // takes its unit from the symbol byte with a shift and a mask; 30 is the state of the padding rows (matches nothing)
 constexpr unsigned kM4None = 31u, kM4Unknown = 32u, kM4PadRow = 30u;
 constexpr unsigned kM4NoneX4 = kM4None * 0x01010101u, kM4PadRowX4 = kM4PadRow * 0x01010101u;
+constexpr unsigned kM4FinRow = 40 * 8, kM4FinBytes = 9 * kM4FinRow + 16;   // a wave's nine rows of forty partial sums (+ a spare slot)
 constexpr unsigned kM4MaxChunk = 64;   // tiles per run: one lane of a wave per tile when the run's tile info is loaded
 
 // 16 symbols (four dwords) against one state.  Symbols and states are < 64, so 0x80 - (symbol ^ state) has bit 7 set
 // exactly where they match and no byte borrows.
 // plain: bytes `one` where they match (SHIFT / MASK move bit 7 to the one's place)
 template <int SHIFT, unsigned MASK>
+__device__ __forceinline__ int m4_expand1(unsigned sy, unsigned srow) {
+  return (int)(((0x80808080u - (sy ^ srow)) >> SHIFT) & MASK);
+}
+template <int SHIFT, unsigned MASK>
 __device__ __forceinline__ cmx_i4 m4_expand(const cmx_i4 sy, unsigned srow) {
   cmx_i4 oh;
 #pragma unroll
-  for (int d = 0; d < 4; ++d) oh[d] = (int)(((0x80808080u - ((unsigned)sy[d] ^ srow)) >> SHIFT) & MASK);
+  for (int d = 0; d < 4; ++d) oh[d] = m4_expand1<SHIFT, MASK>((unsigned)sy[d], srow);
   return oh;
 }
 // weighted: UNIT x A (A = 20) where the symbol is the state, UNIT where it is the unknown; `live` = 0 for the padding rows.
 // UNIT is 2 on the first side and 4 on the second, so that the accumulators hold 8 m, the byte offset of f2[m]
 template <unsigned UNIT>
-__device__ __forceinline__ cmx_i4 m4_expand_weighted(const cmx_i4 sy, unsigned srow, unsigned live) {
+__device__ __forceinline__ int m4_expand_weighted1(unsigned sy, unsigned srow, unsigned live) {
   static_assert(kM4Unknown == 32u, "the unknown's bit is bit 5");
+  // 20 UNIT = 5 x (4 UNIT): the match bit moved to the place of 4 UNIT, OR itself two places higher (bytes do not
+  // carry); the unknown's bit 5 moved to the place of UNIT: seven instructions per dword (ten with the unknown compared
+  // like a state)
+  const unsigned eq = ((0x80808080u - (sy ^ srow)) >> (UNIT == 2 ? 4 : 3)) & (0x01010101u * (4u * UNIT));
+  return (int)(((sy >> (UNIT == 2 ? 4 : 3)) & (live * UNIT)) | ((eq << 2) | eq));
+}
+template <unsigned UNIT>
+__device__ __forceinline__ cmx_i4 m4_expand_weighted(const cmx_i4 sy, unsigned srow, unsigned live) {
   cmx_i4 oh;
 #pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    // 20 UNIT = 5 x (4 UNIT): the match bit moved to the place of 4 UNIT, OR itself two places higher (bytes do not
-    // carry); the unknown's bit 5 moved to the place of UNIT: seven instructions per dword (ten with the unknown compared
-    // like a state)
-    const unsigned eq = ((0x80808080u - ((unsigned)sy[d] ^ srow)) >> (UNIT == 2 ? 4 : 3)) & (0x01010101u * (4u * UNIT));
-    oh[d] = (int)((((unsigned)sy[d] >> (UNIT == 2 ? 4 : 3)) & (live * UNIT)) | ((eq << 2) | eq));
-  }
+  for (int d = 0; d < 4; ++d) oh[d] = m4_expand_weighted1<UNIT>((unsigned)sy[d], srow, live);
   return oh;
+}
+// f(0), f(1), ... f(N - 1) with compile-time arguments (std::integral_constant): the steps of the pipelined tile loop
+template <class F, int... I>
+__device__ __forceinline__ void m4_static_for_impl(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void m4_static_for(F&& f) {
+  m4_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // ---- columns sorted by "has unknowns" before tiling.  A tile is the plain instantiation's only if none of its 15 columns
@@ -179,17 +200,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // original column of a sorted position, which is where the results go
   extern __shared__ __attribute__((aligned(16))) uint8_t m4_smem[];   // the kernel's only LDS object: LDS address 0
   constexpr int NQ = 2 * KS;            // operand tiles of the second alignment per tile: 2 column tiles x KS k-steps
+  constexpr bool DMA = WEIGHTED;        // how the next tile's symbol bytes reach the expansion (the tile loop below)
   constexpr int SPT = NQ / 4;           // slots per thread
   // LDS address 0: plain f[0 .. T]; weighted f2[0 .. M0) followed by one zero entry (what a cell >= M0 reads there)
   const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
   const size_t ftab_bytes = ((size_t)(WEIGHTED ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15;
   cmx_i4* ops = reinterpret_cast<cmx_i4*>(m4_smem + ftab_bytes);                 // [2][NQ][64]
-  double* s2t = reinterpret_cast<double*>(ops + 2 * NQ * 64);                     // [2][4] S of the tile's columns
-  unsigned* j2t = reinterpret_cast<unsigned*>(s2t + 8);                           // [2][4] their original column indices
+  double* s2t = reinterpret_cast<double*>(ops + 2 * NQ * 64);                       // [4][4] S of the tile's columns (ring of four tiles)
+  unsigned* j2t = reinterpret_cast<unsigned*>(s2t + 16);                          // [4][4] their original column indices
   // weighted: per wave the sums of its nine pairs' cells of M0 or more (gathered from global memory at the end of a tile),
   // and the queue of those cells
-  double* corr = reinterpret_cast<double*>(j2t + 8);                              // [4][kM4Corr]
+  double* corr = reinterpret_cast<double*>(j2t + 16);                             // [4][kM4Corr]
   unsigned* bigq = reinterpret_cast<unsigned*>(corr + 4 * kM4Corr);               // [4][kM4QCap]
+  // per wave: the lanes' partial sums of a finished tile by pair (9 rows of 40 doubles), transposed through LDS into the
+  // pairs' totals (finalize below)
+  uint8_t* fin = reinterpret_cast<uint8_t*>(WEIGHTED ? reinterpret_cast<uint8_t*>(bigq + 4 * kM4QCap) : reinterpret_cast<uint8_t*>(j2t + 16));   // [4][kM4FinBytes]
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool hi = lane >= 32;
   const int cl = lane & 31;
@@ -223,7 +248,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asrow[ii] = (R < 60 ? (unsigned)(R % kM4Rows) : kM4PadRow) * 0x01010101u;
     acol[ii] = R < 60 ? R / kM4Rows : 2;
   }
-  const int r4 = lane >> 4;
+  // where a lane's partial sums of column tile J go (first-alignment column a = 0; a adds 3 rows): pair row 3 a + b, b by
+  // the lane's packed column (tile 0: columns 0..19 | 20..31, tile 1: 32..39 | 40..59; 60..63 are padding and write nothing), 40 slots per row
+  const unsigned finw = (unsigned)(fin - m4_smem) + kM4FinBytes * (unsigned)w;   // (m4_smem is LDS address 0)
+  const unsigned hs = hi ? 1u : 0u;
+  const unsigned fina[2] = {finw + (cl < 20 ? 8u * (20u * hs + (unsigned)cl) : kM4FinRow + 8u * (12u * hs + (unsigned)(cl - 20))),
+                            finw + (cl < 8 ? kM4FinRow + 8u * (24u + 8u * hs + (unsigned)cl)
+                                           : 2u * kM4FinRow + 8u * (20u * hs + (unsigned)(cl - 8)))};
+  // readers: lanes 4 p .. 4 p + 3 sum the forty partial sums of pair p = 3 a + b, ten each; lane 4 p writes the pair's results
+  const unsigned pl = (unsigned)lane >> 2, plc = pl < 9 ? pl : 8u;
+  const unsigned finr = finw + plc * kM4FinRow + 80u * ((unsigned)lane & 3u);
+  const int al = (int)(plc / 3), bl = (int)(plc % 3);
+  const bool writer = (lane & 3) == 0 && pl < 9;
   for (unsigned run = blockIdx.x; run < nruns; run += gridDim.x) {
     const unsigned I = run / nchunks, ch = run % nchunks;
     const size_t i0 = (size_t)I * kM4I;
@@ -253,14 +289,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool tile_mine = (tinfo & 7) != 7 && (((tinfo >> 3) != 0 || anyA) == WEIGHTED);
     unsigned long long need = __ballot(tile_mine);
     if (need == 0) continue;
-    double s1v[3];
-    unsigned i1v[3];   // original columns of the wave's three
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const size_t i = i0 + 3 * w + a, ic = i < n1 ? i : n1 - 1;
-      s1v[a] = S1[ic];
-      i1v[a] = order1[ic];
-    }
+    // the lane's pair: its first-alignment column (original index, column sum)
+    const size_t il = i0 + 3 * w + al, ilc = il < n1 ? il : n1 - 1;
+    const double s1l = S1[ilc];
+    const unsigned i1l = order1[ilc];
+    const bool ok1 = writer && !((bad1 >> al) & 1);
     cmx_i4 areg[2][KS];
     {
       cmx_i4 raw[2][KS];
@@ -279,243 +312,328 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           areg[ii][ks] = WEIGHTED ? m4_expand_weighted<2>(raw[ii][ks], asrow[ii], asrow[ii] == kM4PadRowX4 ? 0u : 0x01010101u)
                                   : m4_expand<4, 0x08080808u>(raw[ii][ks], asrow[ii]);
     }
-    cmx_i4 braw[SPT];
+    // The symbol bytes of the next tile, two ways.  Plain instantiation: into registers (sixteen of them, held from behind
+    // the second half of one tile to the second half of the next).  Weighted instantiation, which has no registers to
+    // spare (it spilled): global -> LDS without passing through registers (global_load_lds_dwordx4: lane l's 16 bytes land
+    // at base + 16 l, which is where lane l's expanded operand will stand), expanded IN PLACE; requested in front of the
+    // first half, waited for behind it (vmcnt(0)).  The DMA costs the issuing wave more than the register load (measured
+    // with both instantiations on either: plain 2.95 -> 3.26 ms), hence not for both.  Inline asm for the reason given in
+    // cmx_kernels.hip: a DMA the compiler knows of makes it wait for every outstanding load before the next LDS read.
+    cmx_i4 braw[DMA ? 1 : SPT];
     double s2r = 0.0;
     unsigned j2r = 0;
-    auto fetch = [&](unsigned jt) {
-      const unsigned soff = jt * (unsigned)(kM4J * Tp);   // uniform
-#pragma unroll
-      for (int m = 0; m < SPT; ++m)
-        braw[m] = (w + 4 * m) % KS < nks ? __builtin_bit_cast(cmx_i4, __builtin_amdgcn_raw_buffer_load_b128(rc2, boff[m], soff, 0))
-                                         : cmx_i4{(int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4};
+    auto fetch_scalars = [&](unsigned jt) __attribute__((always_inline)) {   // (an iteration ahead of expand_scalars)
       if (tid < kM4J) {
         const size_t j = (size_t)jt * kM4J + tid, jc = j < n2 ? j : n2 - 1;
         s2r = S2[jc];
         j2r = order2[jc];
       }
     };
-    auto expand = [&](int buf) {
+    auto fetch = [&](unsigned jt, int nbuf) __attribute__((always_inline)) {
+      const unsigned soff = jt * (unsigned)(kM4J * Tp);   // uniform
 #pragma unroll
-      for (int m = 0; m < SPT; ++m)
-        ops[(buf * NQ + w + 4 * m) * 64 + lane] = WEIGHTED ? m4_expand_weighted<4>(braw[m], bsrow[m], bsrow[m] == kM4PadRowX4 ? 0u : 0x01010101u)
-                                                           : m4_expand<7, 0x01010101u>(braw[m], bsrow[m]);
-      if (tid < kM4J) {
-        s2t[4 * buf + tid] = s2r;
-        j2t[4 * buf + tid] = j2r;
+      for (int m = 0; m < SPT; ++m) {
+        const bool live = (w + 4 * m) % KS < nks;
+        const cmx_i4 none = {(int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4};
+        if (DMA) {
+          cmx_i4* dst = ops + (nbuf * NQ + w + 4 * m) * 64;
+          if (live) {
+            const uint8_t* g = C2 + soff + boff[m];
+            const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)reinterpret_cast<const uint8_t*>(dst));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+          } else
+            dst[lane] = none;
+        } else
+          braw[m] = live ? __builtin_bit_cast(cmx_i4, __builtin_amdgcn_raw_buffer_load_b128(rc2, boff[m], soff, 0)) : none;
+      }
+      fetch_scalars(jt);
+    };
+    auto expand_dword = [&](unsigned raw, int m) __attribute__((always_inline)) -> int {
+      return WEIGHTED ? m4_expand_weighted1<4>(raw, bsrow[m], bsrow[m] == kM4PadRowX4 ? 0u : 0x01010101u)
+                      : m4_expand1<7, 0x01010101u>(raw, bsrow[m]);
+    };
+    auto expand_scalars = [&](unsigned slot) __attribute__((always_inline)) {   // ring of four tiles: the tile in the products, the one before it (its
+      if (tid < kM4J) {                          // results not yet written) and the one being expanded
+        s2t[4 * slot + tid] = s2r;
+        j2t[4 * slot + tid] = j2r;
       }
     };
-    unsigned jt = jt0 + (unsigned)__builtin_ctzll(need);
-    need &= need - 1;
-    fetch(jt);
-    expand(0);
-    int buf = 0;
-    for (;;) {
-      __syncthreads();   // this tile's operands and scalars are in LDS; every wave is done with the other buffer
-      const bool more = need != 0;
-      const unsigned jn = more ? jt0 + (unsigned)__builtin_ctzll(need) : 0u;
-      need &= need - 1;
-      if (more) fetch(jn);
-      const unsigned inf2 = __builtin_amdgcn_readlane(tinfo, jt - jt0);
+    // ---- the tile loop, software-pipelined inside the wave.  The accumulators of a tile are two halves (column tile J = 0,
+    // 1: 32 registers each).  While the matrix core fills one half, the vector unit empties the other: the products of
+    // (tile t, J = 0) run beside the lookups of (tile t - 1, J = 1) and the expansion of tile t + 1's operands; the products
+    // of (tile t, J = 1) beside the lookups of (tile t, J = 0).  One MFMA per step, the step's share of the vector work
+    // behind it, no instruction moved across a step (sched_barrier): a 32 x 32 x 32 product holds the matrix pipe for 32
+    // cycles and the issue port for 8, the rest of the gap was idle unless the SIMD's other wave happened to be in its
+    // epilogue (measured: one workgroup per CU 6.1 ms, two 3.8 -- a wave alone spent half its tile waiting).
+    cmx_i16v acc[2][2];
+    const cmx_i16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[0][1] = zero;   // "the tile before the first": all cells 0, f = 0
+    acc[1][1] = zero;
+    double pa[3] = {0.0, 0.0, 0.0}, pm = 0.0;   // the sums of the half being emptied, by column a of the wave's block (pm: see `sum`)
+    // weighted, cells of M0 or more: they read the zero behind the LDS table, and the lanes that hold one queue (8 m, pair)
+    // in the wave's LDS queue -- a compare and a branch per register, the rest only where some lane has one; the queued
+    // cells are gathered from global memory when the tile's sums are reduced.  (m4_smem is LDS address 0: the queue's LDS
+    // byte address is its offset.)  Inline asm: written as a branch or a per-lane `if`, the compiler spilled 100 - 230
+    // registers around the 64 regions.
+    const unsigned qbeg = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<const uint8_t*>(bigq) - m4_smem) + 4u * kM4QCap * (unsigned)w);
+    unsigned qp = qbeg;
+    const unsigned corrb = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<const uint8_t*>(corr) - m4_smem) + 8u * kM4Corr * (unsigned)w);
+    // the third table moved back by 8 M0 - 8 bytes: the accumulator itself (8 m) is then the gather's offset, entry 8 M0 the first real one
+    const unsigned long long f2hi_a = (unsigned long long)f2hi - (M8 - 8u);
+    const unsigned long long f2hi_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(f2hi_a >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)f2hi_a);
+    // pair of a cell = 3 a + b: b by the lane's packed column (tile 0: columns 0..19 | 20..31, tile 1: 32..39 | 40..59)
+    unsigned btag[2] = {cl < 20 ? 0u : 1u, cl < 8 ? 1u : 2u}, hi3 = hi ? 3u : 0u;
+    asm volatile("" : "+v"(btag[0]), "+v"(btag[1]), "+v"(hi3));   // (or 64 loop-invariant sums stay live across the tiles)
+
+    // one accumulator register of half JJ: register v of tile (ii, JJ) is packed row R0 = 32 ii + 8 (v / 4) + v % 4 in the
+    // lower lane half and R0 + 4 in the upper one, packed column 32 JJ + cl.  Rows 16..19 | 20..23 are the one register quad
+    // whose halves belong to different columns (0 | 1); rows 60..63 are padding (count 0, f = 0).
+    // plain: the accumulator is 8 x count = the LDS address of f(count).  weighted: 8 m, the LDS address of f2[m] for m < M0
+    auto look = [&](auto jc, auto ec) __attribute__((always_inline)) -> double {
+      constexpr int JJ = decltype(jc)::value, e = decltype(ec)::value, ii = e / 16, v = e % 16;
+      const unsigned a8 = (unsigned)acc[ii][JJ][v];
+      const double val = *reinterpret_cast<const __attribute__((address_space(3))) double*>(static_cast<uintptr_t>(WEIGHTED ? (a8 < M8 ? a8 : M8) : a8));
+      if (WEIGHTED) {
+        constexpr int R0 = 32 * ii + 8 * (v / 4) + v % 4, a0 = R0 / kM4Rows, a1 = (R0 + 4) / kM4Rows;
+        constexpr bool mixed = !(a0 == a1 || a1 == 3);   // a0 == 0, a1 == 1  (rows 60..63 are padding: never large)
+        const unsigned tag = mixed ? btag[JJ] + hi3 : btag[JJ];
+        unsigned long long sv;
+        unsigned t, q, cnt;
+        asm volatile("v_cmp_le_u32_e32 vcc, %[m8], %[a]\n\t"
+                     "s_cbranch_vccz .Lmq%=\n\t"
+                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 2, %[qp]\n\t"
+                     "v_lshl_or_b32 %[e], %[a], 1, %[tag]\n\t"
+                     "v_add_u32_e32 %[e], %[a3], %[e]\n\t"
+                     "s_and_saveexec_b64 %[sv], vcc\n\t"
+                     "ds_write_b32 %[t], %[e]\n\t"
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                     "s_lshl2_add_u32 %[qp], %[cnt], %[qp]\n"
+                     ".Lmq%=:"
+                     : [qp] "+s"(qp), [t] "=&v"(t), [e] "=&v"(q), [sv] "=&s"(sv), [cnt] "=&s"(cnt)
+                     : [a] "v"(acc[ii][JJ][v]), [m8] "s"(M8), [tag] "v"(tag), [a3] "n"(mixed ? 0 : 3 * a0)
+                     : "vcc", "scc", "memory");
+      }
+      return val;
+    };
+    auto sum = [&](auto ec, double val) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value, ii = e / 16, v = e % 16;
+      constexpr int R0 = 32 * ii + 8 * (v / 4) + v % 4, a0 = R0 / kM4Rows, a1 = (R0 + 4) / kM4Rows;
+      if (a0 == a1 || a1 == 3) pa[a0] += val;
+      else pm += val;    // a0 == 0 in the lower lane half, 1 in the upper one
+    };
+    // a half is emptied: the lane's three sums to its slots of the pair rows
+    auto dump = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int JJ = decltype(jc)::value;
+      pa[0] += hi ? 0.0 : pm;
+      pa[1] += hi ? pm : 0.0;
+      pm = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        // (packed columns 60..63 are padding: no pair; their lanes' zeros go to the wave's spare slot -- a select, not a
+        // branch: with control flow at the end of a half the register allocator spilled)
+        const unsigned at = fina[JJ] + 3u * kM4FinRow * (unsigned)a;
+        *reinterpret_cast<__attribute__((address_space(3))) double*>(static_cast<uintptr_t>(JJ == 1 && cl >= 28 ? finw + 9u * kM4FinRow : at)) = pa[a];
+        pa[a] = 0.0;
+      }
+    };
+    constexpr int NS = 2 * KS;        // steps (products) of a half
+    constexpr int RPS = 32 / NS;      // accumulator registers of the other half emptied per step
+    // the products of half J of the tile in operand buffer `buf`, the lookups of half 1 - J (of the previous tile for J = 0)
+    // and, for EXP, the expansion of the next tile's symbols in operand buffer `nbuf`
+    auto half = [&](auto jc, auto expc, int buf, int nbuf) __attribute__((always_inline)) {
+      constexpr int J = decltype(jc)::value, O = 1 - J;
+      constexpr bool EXP = decltype(expc)::value;
+      const cmx_i4* ob = ops + (buf * NQ + J * KS) * 64 + lane;
+      cmx_i4 nb = ob[0], bb = nb, eo = {0, 0, 0, 0};
+      const unsigned* rawp = reinterpret_cast<const unsigned*>(ops + (nbuf * NQ + w) * 64 + lane);   // slot m: + 4 m x 64 x 4 dwords
+      unsigned rq[3] = {0, 0, 0};   // raw dwords two steps ahead of their expansion
+      if (EXP && DMA) {
+        rq[0] = rawp[0];
+        rq[1] = rawp[1];
+      }
+      // a lookup's value is summed LAG steps after the lookup is issued (one LDS round trip is about two products)
+      constexpr int LAG = CMX_M4_LAG;
+      double vr[LAG + 1][RPS];
+      m4_static_for<NS>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, ii = st & 1, ks = st >> 1;
+        if (ii == 0) {
+          bb = nb;
+          if (ks + 1 < KS) nb = ob[(ks + 1) * 64];   // operands one k-step ahead of the products
+        }
+        acc[ii][J] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[ii][ks], bb, ks ? acc[ii][J] : zero, 0, 0, 0);
+        m4_static_for<RPS>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          vr[st % (LAG + 1)][r] = look(std::integral_constant<int, O>{}, std::integral_constant<int, st * RPS + r>{});
+        });
+        if (st >= LAG)
+          m4_static_for<RPS>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            sum(std::integral_constant<int, (st >= LAG ? st - LAG : 0) * RPS + r>{}, vr[(st + 1) % (LAG + 1)][r]);
+          });
+        if (EXP) {   // one dword of the next tile's operands per step
+          constexpr int m = st / 4, d = st % 4, s2 = st + 2;
+          if (DMA && s2 < NS) rq[s2 % 3] = rawp[(s2 / 4) * 4 * 64 * 4 + s2 % 4];
+          eo[d] = expand_dword(DMA ? rq[st % 3] : (unsigned)braw[DMA ? 0 : m][d], m);
+          if (d == 3) ops[(nbuf * NQ + w + 4 * m) * 64 + lane] = eo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      m4_static_for<LAG * RPS>([&](auto rc) {
+        constexpr int r = decltype(rc)::value, st = NS - LAG + r / RPS;
+        sum(std::integral_constant<int, st * RPS + r % RPS>{}, vr[st % (LAG + 1)][r % RPS]);
+      });
+      // (an asm statement with vector outputs counts as divergent in all its outputs; across the loop's back edge the
+      // queue pointer has to be visibly uniform or it is given a vector register)
+      if (WEIGHTED) qp = __builtin_amdgcn_readfirstlane(qp);
+      dump(std::integral_constant<int, O>{});
+    };
+    // the sums of a finished tile (both halves emptied) -> its nine pairs' results; `slot`: its place in the scalar ring
+    auto finalize = [&](unsigned jtp, unsigned slot) __attribute__((always_inline)) {
+      const unsigned inf2 = __builtin_amdgcn_readlane(tinfo, jtp - jt0);
       const int bad2 = inf2 & 7;
-      const bool work = bad1 != 7 && bad2 != 7;    // wave-uniform (the tile is this instantiation's: see tile_mine)
-      cmx_i16v acc[2][2];   // written by the first k-step (C operand 0)
-      if (work) {
-        const cmx_i16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const cmx_i4* ob = ops + buf * NQ * 64 + lane;
-        cmx_i4 nb0 = ob[0], nb1 = ob[KS * 64];   // operands one k-step ahead of the products, not all sixteen at once
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const cmx_i4 bb0 = nb0, bb1 = nb1;
-          if (ks + 1 < KS) {
-            nb0 = ob[(ks + 1) * 64];
-            nb1 = ob[(KS + ks + 1) * 64];
-          }
-          asm volatile("" ::: "memory");
-          acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][ks], bb0, ks ? acc[0][0] : zero, 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[1][ks], bb0, ks ? acc[1][0] : zero, 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][ks], bb1, ks ? acc[0][1] : zero, 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[1][ks], bb1, ks ? acc[1][1] : zero, 0, 0, 0);
-        }
+      // the queued cells: one gather for (nearly always) all of them, in flight during the reductions below.  Straight-line
+      // asm under an EXEC mask (no lanes when the queue is empty), for the register allocator's sake as above.
+      const unsigned nq = WEIGHTED ? __builtin_amdgcn_readfirstlane((qp - qbeg) >> 2) : 0u;
+      unsigned ge = 0;
+      double gv = 0.0;
+      if (WEIGHTED) {
+        unsigned long long sv;
+        unsigned t;
+        asm volatile("v_cmp_gt_u32_e32 vcc, %[nq], %[lane]\n\t"
+                     "s_and_saveexec_b64 %[sv], vcc\n\t"
+                     "v_lshl_add_u32 %[t], %[lane], 2, %[qb]\n\t"
+                     "ds_read_b32 %[e], %[t]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshrrev_b32_e32 %[t], 1, %[e]\n\t"
+                     "v_and_b32_e32 %[t], 0xfffffff8, %[t]\n\t"
+                     "global_load_dwordx2 %[g], %[t], %[base]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [e] "+v"(ge), [g] "+v"(gv), [t] "=&v"(t), [sv] "=&s"(sv)
+                     : [nq] "s"(nq), [lane] "v"(lane), [qb] "s"(qbeg), [base] "s"(f2hi_u)
+                     : "vcc", "memory");
       }
-      if (more) expand(buf ^ 1);
-      if (work) {
-        // per lane: sums by (column a of the wave's block, column tile jj).  Register v of tile (ii, jj) is packed row
-        // R0 = 32 ii + 8 (v / 4) + v % 4 in the lower lane half and R0 + 4 in the upper one, packed column 32 jj + cl.
-        // Rows 16..19 | 20..23 are the one register quad whose halves belong to different columns (0 | 1); rows 60..63
-        // are padding (count 0, f = 0).
-        // the third table moved back by 8 M0 - 8 bytes: the accumulator itself (8 m) is then the gather's offset, entry 8 M0 the first real one
-        const unsigned long long f2hi_a = (unsigned long long)f2hi - (M8 - 8u);
-        const unsigned long long f2hi_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(f2hi_a >> 32)) << 32) |
-                                          (unsigned)__builtin_amdgcn_readfirstlane((unsigned)f2hi_a);
-        const unsigned corrb = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<const uint8_t*>(corr) - m4_smem) + 8u * kM4Corr * (unsigned)w);
-        double pa[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, pm[2] = {0.0, 0.0};
-        // weighted, cells of M0 or more: they read the zero behind the LDS table, and the lanes that hold one queue
-        // (8 m, pair) in the wave's LDS queue -- a compare and a branch per register, the rest only where some lane has
-        // one.  (Gathering them on the spot under the lanes' EXEC mask cost a global-memory round trip per eight registers,
-        // with nothing to do meanwhile: 43 % of the registers hold such a cell in some lane.)  Inline asm: written as a
-        // branch or a per-lane `if`, the compiler spilled 100 - 230 registers around the 64 regions.
-        // (m4_smem is LDS address 0: the queue's LDS byte address is its offset)
-        unsigned qp = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<const uint8_t*>(bigq) - m4_smem) + 4u * kM4QCap * (unsigned)w);
-        const unsigned qbeg = qp;
-        // pair of a cell = 3 a + b: b by the lane's packed column (tile 0: columns 0..19 | 20..31, tile 1: 32..39 | 40..59)
-        unsigned btag[2] = {cl < 20 ? 0u : 1u, cl < 8 ? 1u : 2u}, hi3 = hi ? 3u : 0u;
-        asm volatile("" : "+v"(btag[0]), "+v"(btag[1]), "+v"(hi3));   // (or 64 loop-invariant sums stay live across the tiles)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            constexpr int NB = WEIGHTED ? 8 : 16;   // lookups in flight at a time
-#pragma unroll
-            for (int v0 = 0; v0 < 16; v0 += NB) {
-              double val[NB];
-#pragma unroll
-              for (int v = 0; v < NB; ++v) asm volatile("" : "+v"(acc[ii][jj][v0 + v]));   // no address arithmetic ahead of its batch
-#pragma unroll
-              for (int v = 0; v < NB; ++v) {
-                // plain: the accumulator is 8 x count = the LDS address of f(count).  weighted: it is 8 m, the LDS address of
-                // f2[m] for m < M0
-                const unsigned a8 = (unsigned)acc[ii][jj][v0 + v];
-                val[v] = *reinterpret_cast<const __attribute__((address_space(3))) double*>(static_cast<uintptr_t>(WEIGHTED ? (a8 < M8 ? a8 : M8) : a8));
-              }
-              if (WEIGHTED) {
-#pragma unroll
-                for (int v = 0; v < NB; ++v) {
-                  const int R0 = 32 * ii + 8 * ((v0 + v) / 4) + (v0 + v) % 4, a0 = R0 / kM4Rows, a1 = (R0 + 4) / kM4Rows;
-                  // (rows 60..63 are padding: never large)
-                  const bool mixed = !(a0 == a1 || a1 == 3);   // a0 == 0, a1 == 1
-                  const unsigned tag = mixed ? btag[jj] + hi3 : btag[jj];
-                  unsigned long long sv;
-                  unsigned t, e, cnt;
-                  asm volatile("v_cmp_le_u32_e32 vcc, %[m8], %[a]\n\t"
-                               "s_cbranch_vccz .Lmq%=\n\t"
-                               "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                               "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                               "v_lshl_add_u32 %[t], %[t], 2, %[qp]\n\t"
-                               "v_lshl_or_b32 %[e], %[a], 1, %[tag]\n\t"
-                               "v_add_u32_e32 %[e], %[a3], %[e]\n\t"
-                               "s_and_saveexec_b64 %[sv], vcc\n\t"
-                               "ds_write_b32 %[t], %[e]\n\t"
-                               "s_mov_b64 exec, %[sv]\n\t"
-                               "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                               "s_lshl2_add_u32 %[qp], %[cnt], %[qp]\n"
-                               ".Lmq%=:"
-                               : [qp] "+s"(qp), [t] "=&v"(t), [e] "=&v"(e), [sv] "=&s"(sv), [cnt] "=&s"(cnt)
-                               : [a] "v"(acc[ii][jj][v0 + v]), [m8] "s"(M8), [tag] "v"(tag), [a3] "n"(mixed ? 0 : 3 * a0)
-                               : "vcc", "scc", "memory");
-                }
-              }
-#pragma unroll
-              for (int v = 0; v < NB; ++v) {
-                const int R0 = 32 * ii + 8 * ((v0 + v) / 4) + (v0 + v) % 4, a0 = R0 / kM4Rows, a1 = (R0 + 4) / kM4Rows;
-                if (a0 == a1 || a1 == 3) pa[a0][jj] += val[v];
-                else pm[jj] += val[v];    // a0 == 0, a1 == 1
-              }
-              asm volatile("" ::: "memory");
-            }
-          }
-        // the queued cells: one gather for (nearly always) all of them, in flight during the reductions below.  Straight-line
-        // asm under an EXEC mask (no lanes when the queue is empty), for the register allocator's sake as above.
-        const unsigned nq = WEIGHTED ? (qp - qbeg) >> 2 : 0u;
-        unsigned ge = 0;
-        double gv = 0.0;
-        if (WEIGHTED) {
-          unsigned long long sv;
-          unsigned t;
-          asm volatile("v_cmp_gt_u32_e32 vcc, %[nq], %[lane]\n\t"
-                       "s_and_saveexec_b64 %[sv], vcc\n\t"
-                       "v_lshl_add_u32 %[t], %[lane], 2, %[qb]\n\t"
-                       "ds_read_b32 %[e], %[t]\n\t"
-                       "s_waitcnt lgkmcnt(0)\n\t"
-                       "v_lshrrev_b32_e32 %[t], 1, %[e]\n\t"
-                       "v_and_b32_e32 %[t], 0xfffffff8, %[t]\n\t"
-                       "global_load_dwordx2 %[g], %[t], %[base]\n\t"
-                       "s_mov_b64 exec, %[sv]"
-                       : [e] "+v"(ge), [g] "+v"(gv), [t] "=&v"(t), [sv] "=&s"(sv)
-                       : [nq] "s"(nq), [lane] "v"(lane), [qb] "s"(qbeg), [base] "s"(f2hi_u)
-                       : "vcc", "memory");
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          pa[0][jj] += hi ? 0.0 : pm[jj];
-          pa[1][jj] += hi ? pm[jj] : 0.0;
-        }
-        // by column b of the tile: column tile 0 holds packed columns 0..31 (b = 0 for cl < 20, else 1), tile 1 holds
-        // 32..63 (b = 1 for cl < 8, else 2; packed columns 60..63 are padding)
-        double t[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          t[3 * a + 0] = cl < 20 ? pa[a][0] : 0.0;
-          t[3 * a + 1] = (cl >= 20 ? pa[a][0] : 0.0) + (cl < 8 ? pa[a][1] : 0.0);
-          t[3 * a + 2] = cl >= 8 ? pa[a][1] : 0.0;
-        }
-        double sres[3];   // lanes with lane >> 4 == r hold pair 4 g + r in sres[g] (pair = 3 a + b)
-        sres[0] = mica_reduce4(t[0], t[1], t[2], t[3]);
-        sres[1] = mica_reduce4(t[4], t[5], t[6], t[7]);
-        sres[2] = mica_reduce4(t[8], 0.0, 0.0, 0.0);
-        if (WEIGHTED) {
-          // the gathered values into the wave's per-pair sums (LDS atomics of one wave: program order, lane order); beyond
-          // the first 64 queued cells (rare) a loop of the same steps with the round trip exposed
-          unsigned long long sv;
-          unsigned t, e2, sq;
-          double g2;
-          asm volatile("v_cmp_gt_u32_e32 vcc, %[nq], %[lane]\n\t"
-                       "s_and_saveexec_b64 %[sv], vcc\n\t"
-                       "v_and_b32_e32 %[t], 15, %[e]\n\t"
-                       "v_lshl_add_u32 %[t], %[t], 3, %[cb]\n\t"
-                       "s_waitcnt vmcnt(0)\n\t"
-                       "ds_add_f64 %[t], %[g]\n\t"
-                       "s_mov_b64 exec, %[sv]\n\t"
-                       "s_movk_i32 %[sq], 64\n"
-                       ".Lmr%=:\n\t"
-                       "s_cmp_ge_u32 %[sq], %[nq]\n\t"
-                       "s_cbranch_scc1 .Lmd%=\n\t"
-                       "v_add_u32_e32 %[t], %[sq], %[lane]\n\t"
-                       "v_cmp_gt_u32_e32 vcc, %[nq], %[t]\n\t"
-                       "s_and_saveexec_b64 %[sv], vcc\n\t"
-                       "v_lshl_add_u32 %[t], %[t], 2, %[qb]\n\t"
-                       "ds_read_b32 %[e2], %[t]\n\t"
-                       "s_waitcnt lgkmcnt(0)\n\t"
-                       "v_lshrrev_b32_e32 %[t], 1, %[e2]\n\t"
-                       "v_and_b32_e32 %[t], 0xfffffff8, %[t]\n\t"
-                       "global_load_dwordx2 %[g2], %[t], %[base]\n\t"
-                       "v_and_b32_e32 %[e2], 15, %[e2]\n\t"
-                       "v_lshl_add_u32 %[e2], %[e2], 3, %[cb]\n\t"
-                       "s_waitcnt vmcnt(0)\n\t"
-                       "ds_add_f64 %[e2], %[g2]\n\t"
-                       "s_mov_b64 exec, %[sv]\n\t"
-                       "s_add_u32 %[sq], %[sq], 64\n\t"
-                       "s_branch .Lmr%=\n"
-                       ".Lmd%=:"
-                       : [t] "=&v"(t), [e2] "=&v"(e2), [g2] "=&v"(g2), [sv] "=&s"(sv), [sq] "=&s"(sq), "+v"(sres[0]), "+v"(sres[1]), "+v"(sres[2])
-                       : [nq] "s"(nq), [lane] "v"(lane), [e] "v"(ge), [g] "v"(gv), [cb] "s"(corrb), [qb] "s"(qbeg), [base] "s"(f2hi_u)
-                       : "vcc", "scc", "memory");
-        }
-        if ((lane & 15) == 0) {
-          const size_t j0 = (size_t)jt * kM4J;
-#pragma unroll
-          for (int g = 0; g < 3; ++g) {
-            const int pr = 4 * g + r4;
-            if (pr < 9) {
-              const int a = pr / 3, b = pr % 3;
-              // intra: the pair is this tile's if its second column comes later in SORTED order; it is written at (smaller,
-              // larger) ORIGINAL column (MI and the joint entropy are symmetric; j <= i holds NaN, mica_nan_lower_kernel)
-              if (!((bad1 >> a) & 1) && !((bad2 >> b) & 1) && (!intra || j0 + b > i0 + 3 * w + a)) {
-                const size_t oi = a == 0 ? i1v[0] : (a == 1 ? i1v[1] : i1v[2]), oj = j2t[4 * buf + b];
-                const size_t i = intra && oj < oi ? oj : oi, j = intra && oj < oi ? oi : oj;
-                const double s = WEIGHTED ? sres[g] + corr[kM4Corr * w + pr] : sres[g];
-                const double sa = a == 0 ? s1v[0] : (a == 1 ? s1v[1] : s1v[2]);
-                mi[i * ldo + j] = lnT + (s - sa - s2t[4 * buf + b]) * invT;
-                hj[i * ldo + j] = lnT - s * invT;
-              }
-            }
-          }
-        }
-        if (WEIGHTED && lane < kM4Corr) corr[kM4Corr * w + lane] = 0.0;   // (after the reads above: one wave, LDS in order)
+      // forty partial sums per pair, ten per lane, the four lanes of a pair by two quad swaps (LDS of one wave: in order
+      // behind the dumps)
+      double sres;
+      {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const __attribute__((address_space(3))) d2* rp = reinterpret_cast<const __attribute__((address_space(3))) d2*>(static_cast<uintptr_t>(finr));
+        const d2 v0 = rp[0], v1 = rp[1], v2 = rp[2], v3 = rp[3], v4 = rp[4];
+        sres = (((v0[0] + v0[1]) + (v1[0] + v1[1])) + ((v2[0] + v2[1]) + (v3[0] + v3[1]))) + (v4[0] + v4[1]);
+        sres += mica_dpp_f64<0xB1>(sres);   // quad_perm [1, 0, 3, 2]
+        sres += mica_dpp_f64<0x4E>(sres);   // quad_perm [2, 3, 0, 1]
       }
-      if (!more) break;
-      buf ^= 1;
-      jt = jn;
+      if (WEIGHTED) {
+        // the gathered values into the wave's per-pair sums (LDS atomics of one wave: program order, lane order); beyond
+        // the first 64 queued cells (rare) a loop of the same steps with the round trip exposed
+        unsigned long long sv;
+        unsigned t, e2, sq;
+        double g2;
+        asm volatile("v_cmp_gt_u32_e32 vcc, %[nq], %[lane]\n\t"
+                     "s_and_saveexec_b64 %[sv], vcc\n\t"
+                     "v_and_b32_e32 %[t], 15, %[e]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 3, %[cb]\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "ds_add_f64 %[t], %[g]\n\t"
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "s_movk_i32 %[sq], 64\n"
+                     ".Lmr%=:\n\t"
+                     "s_cmp_ge_u32 %[sq], %[nq]\n\t"
+                     "s_cbranch_scc1 .Lmd%=\n\t"
+                     "v_add_u32_e32 %[t], %[sq], %[lane]\n\t"
+                     "v_cmp_gt_u32_e32 vcc, %[nq], %[t]\n\t"
+                     "s_and_saveexec_b64 %[sv], vcc\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 2, %[qb]\n\t"
+                     "ds_read_b32 %[e2], %[t]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshrrev_b32_e32 %[t], 1, %[e2]\n\t"
+                     "v_and_b32_e32 %[t], 0xfffffff8, %[t]\n\t"
+                     "global_load_dwordx2 %[g2], %[t], %[base]\n\t"
+                     "v_and_b32_e32 %[e2], 15, %[e2]\n\t"
+                     "v_lshl_add_u32 %[e2], %[e2], 3, %[cb]\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "ds_add_f64 %[e2], %[g2]\n\t"
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "s_add_u32 %[sq], %[sq], 64\n\t"
+                     "s_branch .Lmr%=\n"
+                     ".Lmd%=:"
+                     : [t] "=&v"(t), [e2] "=&v"(e2), [g2] "=&v"(g2), [sv] "=&s"(sv), [sq] "=&s"(sq), "+v"(sres)
+                     : [nq] "s"(nq), [lane] "v"(lane), [e] "v"(ge), [g] "v"(gv), [cb] "s"(corrb), [qb] "s"(qbeg), [base] "s"(f2hi_u)
+                     : "vcc", "scc", "memory");
+        qp = qbeg;
+      }
+      // intra: the pair is this tile's if its second column comes later in SORTED order; it is written at (smaller,
+      // larger) ORIGINAL column (MI and the joint entropy are symmetric; j <= i holds NaN, mica_nan_lower_kernel)
+      if (ok1 && !((bad2 >> bl) & 1) && (!intra || (size_t)jtp * kM4J + bl > il)) {
+        const size_t oi = i1l, oj = j2t[4 * slot + bl];
+        const size_t i = intra && oj < oi ? oj : oi, j = intra && oj < oi ? oi : oj;
+        const double sp = WEIGHTED ? sres + corr[kM4Corr * w + plc] : sres;
+        mi[i * ldo + j] = lnT + (sp - s1l - s2t[4 * slot + bl]) * invT;
+        hj[i * ldo + j] = lnT - sp * invT;
+      }
+      if (WEIGHTED && lane < kM4Corr) corr[kM4Corr * w + lane] = 0.0;   // (after the reads above: one wave, LDS in order)
+    };
+
+    unsigned jt = jt0 + (unsigned)__builtin_ctzll(need), jn = 0, jtp = 0;
+    need &= need - 1;
+    fetch(jt, 0);
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < SPT; ++m) {
+      cmx_i4* op = ops + (w + 4 * m) * 64 + lane;
+      const cmx_i4 raw = DMA ? *op : braw[DMA ? 0 : m];
+      cmx_i4 eo;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) eo[d] = expand_dword((unsigned)raw[d], m);
+      *op = eo;
     }
+    expand_scalars(0);
+    bool have_p = false, have_n = need != 0;
+    if (have_n) {
+      jn = jt0 + (unsigned)__builtin_ctzll(need);
+      need &= need - 1;
+      if (!DMA) fetch(jn, 1);
+    }
+    int buf = 0;
+    unsigned slot = 0;
+    for (;;) {
+      __syncthreads();   // this tile's operands and scalars are in LDS; every wave is done with the other operand buffer
+      if (DMA && have_n) fetch(jn, buf ^ 1);
+      half(std::integral_constant<int, 0>{}, std::false_type{}, buf, buf);
+      if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's symbols are in LDS
+      if (have_p) finalize(jtp, (slot + 3) & 3);
+      if (have_n) {
+        half(std::integral_constant<int, 1>{}, std::true_type{}, buf, buf ^ 1);
+        expand_scalars((slot + 1) & 3);
+      } else
+        half(std::integral_constant<int, 1>{}, std::false_type{}, buf, buf);
+      have_p = true;
+      jtp = jt;
+      if (!have_n) break;
+      jt = jn;
+      have_n = need != 0;
+      if (have_n) {
+        jn = jt0 + (unsigned)__builtin_ctzll(need);
+        need &= need - 1;
+        if (!DMA) fetch(jn, 0);   // (the registers are free: the second half expanded what they held)
+      }
+      buf ^= 1;
+      slot = (slot + 1) & 3;
+    }
+    // the last tile's second half
+    m4_static_for<4>([&](auto bc) {
+      constexpr int b0 = decltype(bc)::value * 8;
+      double val[8];
+      m4_static_for<8>([&](auto rc) { val[decltype(rc)::value] = look(std::integral_constant<int, 1>{}, std::integral_constant<int, b0 + decltype(rc)::value>{}); });
+      m4_static_for<8>([&](auto rc) { sum(std::integral_constant<int, b0 + decltype(rc)::value>{}, val[decltype(rc)::value]); });
+    });
+    if (WEIGHTED) qp = __builtin_amdgcn_readfirstlane(qp);
+    dump(std::integral_constant<int, 1>{});
+    finalize(jtp, slot);
   }
 }
 // ---- nucleotides.  Four states: SIXTEEN columns share a 64-row block, a wave's 64 x 64 accumulator block is the Gram of
@@ -717,8 +835,8 @@ hipError_t launch_mica_dna4(int T, const MicaWork* wk, size_t n1, size_t n2, int
 
 size_t mica4_lds_bytes(int T, int KS, bool weighted) {
   const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
-  return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 8 * sizeof(double) + 8 * sizeof(unsigned) +
-         (weighted ? 4 * kM4Corr * sizeof(double) + 4 * kM4QCap * sizeof(unsigned) : 0);
+  return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 16 * sizeof(double) + 16 * sizeof(unsigned) +
+         (weighted ? 4 * kM4Corr * sizeof(double) + 4 * kM4QCap * sizeof(unsigned) : 0) + 4 * kM4FinBytes;
 }
 
 template <int KS, bool WEIGHTED>
