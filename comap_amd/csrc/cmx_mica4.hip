@@ -50,7 +50,9 @@ namespace cmx {
 constexpr int kM4I = 12, kM4J = 3, kM4Rows = 20;
 // The cells of a pair sum to 400 T, so at most 400 T / M0 <= 25 of them reach M0 = 4096 at T <= 256: a wave's nine pairs
 // queue at most 225 cells per tile.
-constexpr int kM4Corr = 12, kM4QCap = 232;
+constexpr int kM4Corr = 12;
+// (sixteen k-steps = up to 512 taxa: 50 such cells per pair, 450 per wave and tile)
+constexpr int m4_qcap(int KS) { return KS > 8 ? 464 : 232; }
 // Symbol codes of the SORTED column arrays the protein kernels read (mica_gather_columns_kernel recodes them): states
 // 0..19, "no row" 31 (padding taxa and columns), the unknown 32 -- a bit of its own, so that the weighted expansion
 // takes its unit from the symbol byte with a shift and a mask; 30 is the state of the padding rows (matches nothing)
@@ -191,7 +193,7 @@ __global__ void mica_nan_lower_kernel(size_t n, double* __restrict__ mi, double*
 }
 
 template <int KS, bool WEIGHTED>   // k-steps of 32 taxa: Tp <= 32 KS
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mica_mfma4_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 : 2, KS > 8 ? 1 : 2))) void mica_mfma4_kernel(
     int T, int Tp, const uint8_t* __restrict__ C1, size_t n1, const unsigned* __restrict__ info1, const double* __restrict__ S1,
     const uint8_t* __restrict__ C2, size_t n2, const unsigned* __restrict__ info2, const double* __restrict__ S2,
     const unsigned* __restrict__ order1, const unsigned* __restrict__ order2, const double* __restrict__ ftab_g, int intra,
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) uint8_t m4_smem[];   // the kernel's only LDS object: LDS address 0
   constexpr int NQ = 2 * KS;            // operand tiles of the second alignment per tile: 2 column tiles x KS k-steps
   constexpr bool DMA = WEIGHTED;        // how the next tile's symbol bytes reach the expansion (the tile loop below)
+  constexpr bool FINI = !WEIGHTED;      // a finished tile's results are made beside the next tile's products (the tile loop below)
   constexpr int SPT = NQ / 4;           // slots per thread
   // LDS address 0: plain f[0 .. T]; weighted f2[0 .. M0) followed by one zero entry (what a cell >= M0 reads there)
   const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // weighted: per wave the sums of its nine pairs' cells of M0 or more (gathered from global memory at the end of a tile),
   // and the queue of those cells
   double* corr = reinterpret_cast<double*>(j2t + 16);                             // [4][kM4Corr]
+  constexpr int kM4QCap = m4_qcap(KS);
   unsigned* bigq = reinterpret_cast<unsigned*>(corr + 4 * kM4Corr);               // [4][kM4QCap]
   // per wave: the lanes' partial sums of a finished tile by pair (9 rows of 40 doubles), transposed through LDS into the
   // pairs' totals (finalize below)
@@ -440,59 +444,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         pa[a] = 0.0;
       }
     };
-    constexpr int NS = 2 * KS;        // steps (products) of a half
-    constexpr int RPS = 32 / NS;      // accumulator registers of the other half emptied per step
-    // the products of half J of the tile in operand buffer `buf`, the lookups of half 1 - J (of the previous tile for J = 0)
-    // and, for EXP, the expansion of the next tile's symbols in operand buffer `nbuf`
-    auto half = [&](auto jc, auto expc, int buf, int nbuf) __attribute__((always_inline)) {
-      constexpr int J = decltype(jc)::value, O = 1 - J;
-      constexpr bool EXP = decltype(expc)::value;
-      const cmx_i4* ob = ops + (buf * NQ + J * KS) * 64 + lane;
-      cmx_i4 nb = ob[0], bb = nb, eo = {0, 0, 0, 0};
-      const unsigned* rawp = reinterpret_cast<const unsigned*>(ops + (nbuf * NQ + w) * 64 + lane);   // slot m: + 4 m x 64 x 4 dwords
-      unsigned rq[3] = {0, 0, 0};   // raw dwords two steps ahead of their expansion
-      if (EXP && DMA) {
-        rq[0] = rawp[0];
-        rq[1] = rawp[1];
-      }
-      // a lookup's value is summed LAG steps after the lookup is issued (one LDS round trip is about two products)
-      constexpr int LAG = CMX_M4_LAG;
-      double vr[LAG + 1][RPS];
-      m4_static_for<NS>([&](auto sc) {
-        constexpr int st = decltype(sc)::value, ii = st & 1, ks = st >> 1;
-        if (ii == 0) {
-          bb = nb;
-          if (ks + 1 < KS) nb = ob[(ks + 1) * 64];   // operands one k-step ahead of the products
-        }
-        acc[ii][J] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[ii][ks], bb, ks ? acc[ii][J] : zero, 0, 0, 0);
-        m4_static_for<RPS>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          vr[st % (LAG + 1)][r] = look(std::integral_constant<int, O>{}, std::integral_constant<int, st * RPS + r>{});
-        });
-        if (st >= LAG)
-          m4_static_for<RPS>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            sum(std::integral_constant<int, (st >= LAG ? st - LAG : 0) * RPS + r>{}, vr[(st + 1) % (LAG + 1)][r]);
-          });
-        if (EXP) {   // one dword of the next tile's operands per step
-          constexpr int m = st / 4, d = st % 4, s2 = st + 2;
-          if (DMA && s2 < NS) rq[s2 % 3] = rawp[(s2 / 4) * 4 * 64 * 4 + s2 % 4];
-          eo[d] = expand_dword(DMA ? rq[st % 3] : (unsigned)braw[DMA ? 0 : m][d], m);
-          if (d == 3) ops[(nbuf * NQ + w + 4 * m) * 64 + lane] = eo;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      m4_static_for<LAG * RPS>([&](auto rc) {
-        constexpr int r = decltype(rc)::value, st = NS - LAG + r / RPS;
-        sum(std::integral_constant<int, st * RPS + r % RPS>{}, vr[st % (LAG + 1)][r % RPS]);
-      });
-      // (an asm statement with vector outputs counts as divergent in all its outputs; across the loop's back edge the
-      // queue pointer has to be visibly uniform or it is given a vector register)
-      if (WEIGHTED) qp = __builtin_amdgcn_readfirstlane(qp);
-      dump(std::integral_constant<int, O>{});
-    };
-    // the sums of a finished tile (both halves emptied) -> its nine pairs' results; `slot`: its place in the scalar ring
-    auto finalize = [&](unsigned jtp, unsigned slot) __attribute__((always_inline)) {
+    // ---- the sums of a finished tile (both halves emptied and dumped) -> its nine pairs' results.  `slot`: the tile's place in
+    // the scalar ring.  Weighted instantiation: in a row between the halves (its queue of large cells is the finished tile's
+    // until it is emptied here).
+    auto finalize_row = [&](unsigned jtp, unsigned slot) __attribute__((always_inline)) {
       const unsigned inf2 = __builtin_amdgcn_readlane(tinfo, jtp - jt0);
       const int bad2 = inf2 & 7;
       // the queued cells: one gather for (nearly always) all of them, in flight during the reductions below.  Straight-line
@@ -577,7 +532,103 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       if (WEIGHTED && lane < kM4Corr) corr[kM4Corr * w + lane] = 0.0;   // (after the reads above: one wave, LDS in order)
     };
+    // Plain instantiation: in four pieces at four steps of the NEXT tile's second half (the LDS round trips and the stores
+    // behind products: in a row they were 620 of a tile's 3 870 cycles).  `have`: there is such a tile (not in a run's first
+    // iteration).  Forty partial sums per pair, ten per lane (LDS of one wave: in order behind the dumps), in two rounds.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 f_v0 = {0.0, 0.0}, f_v1 = f_v0, f_v2 = f_v0;
+    double f_sres = 0.0, f_s2 = 0.0;
+    unsigned f_oj = 0;
+    auto fin = [&](auto pc, unsigned jtp, unsigned slot, bool have) __attribute__((always_inline)) {
+      constexpr int P = decltype(pc)::value;
+      const __attribute__((address_space(3))) d2* rp = reinterpret_cast<const __attribute__((address_space(3))) d2*>(static_cast<uintptr_t>(finr));
+      if (P == 0) {
+        f_v0 = rp[0];
+        f_v1 = rp[1];
+        f_v2 = rp[2];
+      } else if (P == 1) {
+        f_sres = ((f_v0[0] + f_v0[1]) + (f_v1[0] + f_v1[1])) + (f_v2[0] + f_v2[1]);
+        f_v0 = rp[3];
+        f_v1 = rp[4];
+        f_oj = j2t[4 * slot + bl];   // and the pair's scalars
+        f_s2 = s2t[4 * slot + bl];
+      } else if (P == 2) {
+        f_sres += (f_v0[0] + f_v0[1]) + (f_v1[0] + f_v1[1]);
+        f_sres += mica_dpp_f64<0xB1>(f_sres);   // the four lanes of a pair: quad_perm [1, 0, 3, 2],
+        f_sres += mica_dpp_f64<0x4E>(f_sres);   // [2, 3, 0, 1]
+      } else {
+        const unsigned inf2 = __builtin_amdgcn_readlane(tinfo, jtp - jt0);
+        const int bad2 = inf2 & 7;
+        // intra: as above
+        if (have && ok1 && !((bad2 >> bl) & 1) && (!intra || (size_t)jtp * kM4J + bl > il)) {
+          const size_t oi = i1l, oj = f_oj;
+          const size_t i = intra && oj < oi ? oj : oi, j = intra && oj < oi ? oi : oj;
+          mi[i * ldo + j] = lnT + (f_sres - s1l - f_s2) * invT;
+          hj[i * ldo + j] = lnT - f_sres * invT;
+        }
+      }
+    };
+    auto finalize = [&](unsigned jtp, unsigned slot) __attribute__((always_inline)) {
+      if (FINI) m4_static_for<4>([&](auto pc) { fin(pc, jtp, slot, true); });
+      else finalize_row(jtp, slot);
+    };
 
+    constexpr int NS = 2 * KS;        // steps (products) of a half
+    constexpr int RPS = 32 / NS;      // accumulator registers of the other half emptied per step
+    // the products of half J of the tile in operand buffer `buf`, the lookups of half 1 - J (of the previous tile for J = 0)
+    // and, for EXP, the expansion of the next tile's symbols in operand buffer `nbuf`
+    auto half = [&](auto jc, auto expc, auto finc, int buf, int nbuf, unsigned jtp, unsigned pslot, bool have_p) __attribute__((always_inline)) {
+      constexpr int J = decltype(jc)::value, O = 1 - J;
+      constexpr bool EXP = decltype(expc)::value, FIN = decltype(finc)::value;
+      const cmx_i4* ob = ops + (buf * NQ + J * KS) * 64 + lane;
+      cmx_i4 nb = ob[0], bb = nb, eo = {0, 0, 0, 0};
+      const unsigned* rawp = reinterpret_cast<const unsigned*>(ops + (nbuf * NQ + w) * 64 + lane);   // slot m: + 4 m x 64 x 4 dwords
+      unsigned rq[3] = {0, 0, 0};   // raw dwords two steps ahead of their expansion
+      if (EXP && DMA) {
+        rq[0] = rawp[0];
+        rq[1] = rawp[1];
+      }
+      // a lookup's value is summed LAG steps after the lookup is issued (one LDS round trip is about two products)
+      constexpr int LAG = CMX_M4_LAG;
+      double vr[LAG + 1][RPS];
+      m4_static_for<NS>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, ii = st & 1, ks = st >> 1;
+        if (ii == 0) {
+          bb = nb;
+          if (ks + 1 < KS) nb = ob[(ks + 1) * 64];   // operands one k-step ahead of the products
+        }
+        acc[ii][J] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[ii][ks], bb, ks ? acc[ii][J] : zero, 0, 0, 0);
+        m4_static_for<RPS>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          vr[st % (LAG + 1)][r] = look(std::integral_constant<int, O>{}, std::integral_constant<int, st * RPS + r>{});
+        });
+        if (st >= LAG)
+          m4_static_for<RPS>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            sum(std::integral_constant<int, (st >= LAG ? st - LAG : 0) * RPS + r>{}, vr[(st + 1) % (LAG + 1)][r]);
+          });
+        if (FIN)   // a piece of the previous tile's results at every fourth of the half
+          m4_static_for<4>([&](auto pc) {
+            if (decltype(pc)::value * NS / 4 == st) fin(pc, jtp, pslot, have_p);
+          });
+        if (EXP) {   // one dword of the next tile's operands per step
+          constexpr int m = st / 4, d = st % 4, s2 = st + 2;
+          if (DMA && s2 < NS) rq[s2 % 3] = rawp[(s2 / 4) * 4 * 64 * 4 + s2 % 4];
+          eo[d] = expand_dword(DMA ? rq[st % 3] : (unsigned)braw[DMA ? 0 : m][d], m);
+          if (d == 3) ops[(nbuf * NQ + w + 4 * m) * 64 + lane] = eo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      m4_static_for<LAG * RPS>([&](auto rc) {
+        constexpr int r = decltype(rc)::value, st = NS - LAG + r / RPS;
+        sum(std::integral_constant<int, st * RPS + r % RPS>{}, vr[st % (LAG + 1)][r % RPS]);
+      });
+      // (an asm statement with vector outputs counts as divergent in all its outputs; across the loop's back edge the
+      // queue pointer has to be visibly uniform or it is given a vector register)
+      if (WEIGHTED) qp = __builtin_amdgcn_readfirstlane(qp);
+      dump(std::integral_constant<int, O>{});
+    };
+    // the sums of a finished tile (both halves emptied) -> its nine pairs' results; `slot`: its place in the scalar ring
     unsigned jt = jt0 + (unsigned)__builtin_ctzll(need), jn = 0, jtp = 0;
     need &= need - 1;
     fetch(jt, 0);
@@ -600,26 +651,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     int buf = 0;
     unsigned slot = 0;
+    const std::false_type no{};
+    const std::true_type yes{};
+    const std::integral_constant<int, 0> h0{};
+    const std::integral_constant<int, 1> h1{};
     for (;;) {
       __syncthreads();   // this tile's operands and scalars are in LDS; every wave is done with the other operand buffer
-      if (DMA && have_n) fetch(jn, buf ^ 1);
-      half(std::integral_constant<int, 0>{}, std::false_type{}, buf, buf);
-      if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's symbols are in LDS
-      if (have_p) finalize(jtp, (slot + 3) & 3);
-      if (have_n) {
-        half(std::integral_constant<int, 1>{}, std::true_type{}, buf, buf ^ 1);
-        expand_scalars((slot + 1) & 3);
-      } else
-        half(std::integral_constant<int, 1>{}, std::false_type{}, buf, buf);
-      have_p = true;
-      jtp = jt;
-      if (!have_n) break;
-      jt = jn;
-      have_n = need != 0;
-      if (have_n) {
-        jn = jt0 + (unsigned)__builtin_ctzll(need);
-        need &= need - 1;
-        if (!DMA) fetch(jn, 0);   // (the registers are free: the second half expanded what they held)
+      const unsigned pslot = (slot + 3) & 3;
+      if (DMA) {
+        // weighted: request the next tile's symbols | first half | wait | previous tile's results | second half + expansion
+        if (have_n) fetch(jn, buf ^ 1);
+        half(h0, no, no, buf, buf, 0u, 0u, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's symbols are in LDS
+        if (have_p) finalize(jtp, pslot);
+        if (have_n) {
+          half(h1, yes, no, buf, buf ^ 1, 0u, 0u, false);
+          expand_scalars((slot + 1) & 3);
+        } else
+          half(h1, no, no, buf, buf, 0u, 0u, false);
+        have_p = true;
+        jtp = jt;
+        if (!have_n) break;
+        jt = jn;
+        have_n = need != 0;
+        if (have_n) {
+          jn = jt0 + (unsigned)__builtin_ctzll(need);
+          need &= need - 1;
+        }
+      } else {
+        // plain: first half + expansion of the next tile (its symbols are in registers) | request the tile after it |
+        // second half + the previous tile's results
+        if (have_n) {
+          half(h0, yes, no, buf, buf ^ 1, 0u, 0u, false);
+          expand_scalars((slot + 1) & 3);
+        } else
+          half(h0, no, no, buf, buf, 0u, 0u, false);
+        const unsigned jcur = jt;
+        const bool had_n = have_n;
+        if (have_n) {
+          jt = jn;
+          have_n = need != 0;
+          if (have_n) {
+            jn = jt0 + (unsigned)__builtin_ctzll(need);
+            need &= need - 1;
+            fetch(jn, 0);   // (the registers are free: the first half expanded what they held)
+          }
+        }
+        half(h1, no, yes, buf, buf, jtp, pslot, have_p);
+        have_p = true;
+        jtp = jcur;
+        if (!had_n) break;
       }
       buf ^= 1;
       slot = (slot + 1) & 3;
@@ -836,7 +917,7 @@ hipError_t launch_mica_dna4(int T, const MicaWork* wk, size_t n1, size_t n2, int
 size_t mica4_lds_bytes(int T, int KS, bool weighted) {
   const int M0 = 400 * T + 1 < kMicaLdsF2 ? 400 * T + 1 : kMicaLdsF2;
   return (((size_t)(weighted ? M0 + 1 : T + 1) * 8 + 15) & ~(size_t)15) + (size_t)2 * 2 * KS * 64 * sizeof(cmx_i4) + 16 * sizeof(double) + 16 * sizeof(unsigned) +
-         (weighted ? 4 * kM4Corr * sizeof(double) + 4 * kM4QCap * sizeof(unsigned) : 0) + 4 * kM4FinBytes;
+         (weighted ? 4 * kM4Corr * sizeof(double) + 4 * m4_qcap(KS) * sizeof(unsigned) : 0) + 4 * kM4FinBytes;
 }
 
 template <int KS, bool WEIGHTED>
@@ -884,7 +965,7 @@ static hipError_t launch_mica4_ks(int T, int Tp, const MicaWork* wk, size_t n1, 
 // proteins, Tp <= 256 (eight k-steps of operand registers), byte offsets within 31 bits; the caller serves the pairs with
 // partial ambiguity codes
 bool mica4_serves(int A, int Tp, size_t n1, size_t n2) {
-  return A == 20 && Tp <= 256 && (std::max(n1, n2) + kMicaCodePad) * (size_t)Tp < 0x7fffffffull;
+  return A == 20 && Tp <= 512 && (std::max(n1, n2) + kMicaCodePad) * (size_t)Tp < 0x7fffffffull;
 }
 
 hipError_t launch_mica4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,
@@ -899,7 +980,10 @@ hipError_t launch_mica4(int T, const MicaWork* wk, size_t n1, size_t n2, int int
   const int Tp = wk->Tp;
   if (Tp <= 64) return launch_mica4_ks<2>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
   if (Tp <= 128) return launch_mica4_ks<4>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
-  return launch_mica4_ks<8>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
+  if (Tp <= 256) return launch_mica4_ks<8>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
+  // 257 .. 512 taxa: sixteen k-steps of operand registers, one workgroup per CU (the pipelined tile loop keeps a lone wave's
+  // matrix core and vector unit busy together)
+  return launch_mica4_ks<16>(T, Tp, wk, n1, n2, intra, d_mi, d_hj, ldo, chunk, grid, stream);
 }
 
 }  // namespace cmx
