@@ -4,16 +4,22 @@
 //   * persistent workgroups of FOUR waves (one per SIMD), each walking a run of tiles of 12 columns of the first
 //     alignment x 3 columns of the second; wave w owns the 3 x 3 pairs of its block of three first-alignment columns;
 //   * the first alignment's operands held in REGISTERS for the whole run: three columns x 20 states = 60 of the 64 rows
-//     of a block (no pseudo-state row for the unknowns: see below), 8 k-steps x 2 row tiles x 4 registers, expanded
+//     of a block (no pseudo-state row for the unknowns: see below), up to 8 k-steps x 2 row tiles x 4 registers (16 k-steps
+//     = 512 taxa at one workgroup per CU), expanded
 //     once per run straight from the symbol bytes.  The k-loop reads only the second alignment's operands from LDS
 //     (2 ds_read_b128 per 4 MFMAs) -- the 8-wave kernel (cmx_kernels.hip, mica_mfma3_kernel) expanded all twelve operand
 //     tiles of every tile again, and its busiest SIMDs spent more issue cycles on that than on the matrix products;
 //   * the first operand's "one" is 8, the second's 1: an accumulator holds 8 x count, which IS the LDS address of
 //     f(count) (the table sits at LDS address 0) -- no shift and no add in front of the 64 lookups per lane;
-//   * the second alignment's symbol bytes of the NEXT tile are fetched while the current tile's products run and are
-//     expanded into the other operand buffer before the current tile's epilogue: one barrier per tile, no wait on memory;
+//   * the tile loop software-pipelined INSIDE the wave (round 4; the loop itself is commented where it stands): a tile's
+//     accumulators are two halves, the matrix core fills one while the vector unit empties the other, the next tile's
+//     operands are expanded a dword per step beside the products, and one barrier per tile is all the workgroup shares;
+//   * a wave's nine pair totals by an LDS transpose: every lane dumps its three partial sums per half into the pair's row
+//     of forty, four lanes per pair read ten each (round 3 selected nine values per lane and reduce-scattered them over
+//     the wave: a quarter of the kernel's time);
 //   * 20 rows per column put the column boundaries on the accumulator registers' row quads (rows 20 and 60 fall between
-//     the two lane halves of a register, row 40 between registers): one select pair per tile column instead of eleven.
+//     the two lane halves of a register, row 40 between registers): every accumulator register belongs to one column of the
+//     wave's block, but for one quad per half that belongs to one by lane half.
 //
 // UNKNOWNS (gap, X: symbols compatible with every state -- what real alignments are full of) take the same road in a second
 // instantiation (WEIGHTED).  The fractional counts of resolveUnknowns = true are c_ab = N_ab + (N_aG + N_Gb) / A + N_GG / A^2
