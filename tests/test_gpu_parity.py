@@ -1056,8 +1056,8 @@ def test_inter_rows_on_the_device_match_the_reference_loop(kind):
 @pytest.mark.parametrize("T,n1,n2", [(40, 50, 77), (100, 37, 205), (200, 61, 100), (256, 130, 260), (300, 40, 50), (257, 61, 40), (512, 50, 77),
                                      (600, 30, 25)])
 def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
-    """The protein path up to 256 taxa (cmx_mica4.hip: plain and weighted instantiation, operand registers for 2 / 4 / 8
-    k-steps) and above (eight-wave kernel): column counts that are no multiple of the 12 x 3 tile, runs longer than one
+    """The protein path up to 512 taxa (cmx_mica4.hip: plain and weighted instantiation, operand registers for 2 / 4 / 8 /
+    16 k-steps, the last at one workgroup per CU) and above (eight-wave kernel): column counts that are no multiple of the 12 x 3 tile, runs longer than one
     chunk of tiles (n2 = 205, 260), columns with unknowns scattered so that blocks and tiles mix clean and gapped
     columns, some columns all unknown, one column with a partial ambiguity code; rectangle and intra layout."""
     rng = np.random.default_rng(T + n1)
@@ -1088,30 +1088,32 @@ def test_mica_four_wave_kernels_mixed_blocks_against_oracle(T, n1, n2):
     assert np.isnan(gi["mi"][np.tril_indices(n2)]).all() and np.isnan(gi["hjoint"][np.tril_indices(n2)]).all()
 
 
-@pytest.mark.parametrize("T", [256, 512])
-def test_mica_weighted_kernel_queue_of_large_cells_beyond_one_wave(T):
+@pytest.mark.parametrize("T,blocks", [(256, 20), (512, 20), (512, 40)])
+def test_mica_weighted_kernel_queue_of_large_cells_beyond_one_wave(T, blocks):
     """The weighted instantiation looks cells below 4 096 / 400 = 10.24 taxa up in LDS and queues the larger ones per wave
-    for one gather at the end of the tile.  Here every pair of columns has twenty cells of 12 or 13 taxa (the columns are
-    the same partition of the 256 taxa into twenty blocks, states permuted per column) and every column two unknowns: a
-    wave's nine pairs queue 180 cells per tile, three rounds of its 64 lanes (the bound is 225).  With 512 taxa (the
-    eight-wave kernel serves those) the twenty cells hold 25 or 26 taxa."""
+    for one gather when the tile's sums are reduced.  Here every pair of columns has twenty cells of 12 or 13 taxa (the
+    columns are the same partition of the 256 taxa into twenty blocks, states permuted per column) and every column two
+    unknowns: a wave's nine pairs queue 180 cells per tile, three rounds of its 64 lanes (the bound is 225).  With 512 taxa
+    (sixteen k-steps, queue of 464) twenty cells of 25 or 26 taxa, or -- forty blocks, the first column's state by block
+    modulo 20, the second's by block / 2 -- FORTY cells of 12 or 13 taxa per pair: 360 queued cells per wave and tile."""
     rng = np.random.default_rng(5)
     A, n1, n2 = 20, 26, 11
-    block = (np.arange(T) * A // T).astype(np.uint8)
+    block = np.arange(T) * blocks // T
 
-    def draw(n):
-        a = np.stack([rng.permutation(A).astype(np.uint8)[block] for _ in range(n)], axis=1)
+    def draw(n, key):
+        a = np.stack([rng.permutation(A).astype(np.uint8)[key] for _ in range(n)], axis=1)
         for c in range(n):
             a[rng.choice(T, 2, replace=False), c] = A
         return np.ascontiguousarray(a)
 
-    a1, a2 = draw(n1), draw(n2)
+    a1, a2 = draw(n1, block % A), draw(n2, block * A // blocks)
     eng = engine.Engine()
     g = eng.mi_columns(a1, a2, A)
     o = oracle.mi_columns(a1, a2, A, oracle.default_masks(A))
     rel_close(g["mi"], o["mi"], 1e-6, 1e-10)
     rel_close(g["hjoint"], o["hjoint"], 1e-6, 1e-10)
-    assert o["mi"].min() > 2.5          # (nearly the full ln 20: the cells are what the test says)
+    # (blocks = 20: nearly the full ln 20; 40: each state of one column meets two of the other, ln 20 - ln 2)
+    assert o["mi"].min() > (2.5 if blocks == 20 else 1.9)
     g2 = eng.mi_columns(a1, a2, A)
     assert np.array_equal(g["mi"], g2["mi"]) and np.array_equal(g["hjoint"], g2["hjoint"])   # same bits run to run
 
