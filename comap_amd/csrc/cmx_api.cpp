@@ -1766,6 +1766,7 @@ cmx_status cmx_mi_columns_dev(cmx_ctx* ctx, int nalpha, int ntaxa, const uint32_
       if ((s = scratch(ctx, "mica_order1", sizeof(unsigned) * n1, (void**)&w.order1)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_Cs1", (size_t)w.Tp * (n1 + kMicaCodePad), (void**)&w.Cs1)) != CMX_OK) return s;
       if ((s = scratch(ctx, "mica_Ss1", sizeof(double) * n1, (void**)&w.Ss1)) != CMX_OK) return s;
+      if (mica4_serves(nalpha, w.Tp, n1, intra ? n1 : n2) && (s = scratch(ctx, "mica_img2", mica4_image_bytes(w.Tp, intra ? n1 : n2), &w.img2)) != CMX_OK) return s;
       if (!intra) {
         if ((s = scratch(ctx, "mica_info2", sizeof(unsigned) * ((n2 + 11) / 12 * 4 + 4), (void**)&w.info2)) != CMX_OK) return s;
         if ((s = scratch(ctx, "mica_order2", sizeof(unsigned) * n2, (void**)&w.order2)) != CMX_OK) return s;

@@ -267,11 +267,13 @@ struct MicaWork {
   unsigned *order1, *order2; // [n] original column of a sorted position (columns without unknowns first, stable)
   uint8_t *Cs1, *Cs2;        // [n + kMicaCodePad][Tp] symbol bytes in sorted order
   double *Ss1, *Ss2;         // [n] column sums in sorted order
+  void* img2;                // mica4_image_bytes(Tp, n2): the second alignment's expanded operands by tile (cmx_mica4.hip)
   int Tp;                  // T rounded up to a multiple of 32 (taxa per MFMA step)
 };
 bool mica_needs_onehot(int A, int Tp);   // whether launch_mi_columns reads MicaWork::H1 / H2 for this alphabet
 // cmx_mica4.hip: the four-wave protein kernel (unknowns included; partial ambiguity codes are not served)
 bool mica4_serves(int A, int Tp, size_t n1, size_t n2);
+size_t mica4_image_bytes(int Tp, size_t n2);
 hipError_t launch_mica4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,
                         hipStream_t stream);
 // the four-wave nucleotide kernel (unknowns included; partial ambiguity codes are not served)

@@ -2944,7 +2944,7 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
         const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&mica_mfma3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (ea != hipSuccess) return ea;
       }
-      if (mica4_serves(A, Tp, n1, n2) && work->info1 && !mica_eight_wave_tiles()) {
+      if (mica4_serves(A, Tp, n1, n2) && work->info1 && work->img2 && !mica_eight_wave_tiles()) {
         // up to 256 taxa: the four-wave kernel (cmx_mica4.hip), unknowns included
         const hipError_t e4 = launch_mica4(T, work, n1, n2, intra, d_mi, d_hj, ldo, stream);
         if (e4 != hipSuccess) return e4;

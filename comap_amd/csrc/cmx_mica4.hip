@@ -11,9 +11,11 @@
 //     tiles of every tile again, and its busiest SIMDs spent more issue cycles on that than on the matrix products;
 //   * the first operand's "one" is 8, the second's 1: an accumulator holds 8 x count, which IS the LDS address of
 //     f(count) (the table sits at LDS address 0) -- no shift and no add in front of the 64 lookups per lane;
+//   * the second alignment's operands expanded ONCE per call into an image of the tiles' LDS buffers (mica4_image_kernel),
+//     so that a workgroup loads operands, not symbols (round 4);
 //   * the tile loop software-pipelined INSIDE the wave (round 4; the loop itself is commented where it stands): a tile's
-//     accumulators are two halves, the matrix core fills one while the vector unit empties the other, the next tile's
-//     operands are expanded a dword per step beside the products, and one barrier per tile is all the workgroup shares;
+//     accumulators are two halves, the matrix core fills one while the vector unit empties the other, and one barrier per
+//     tile is all the workgroup shares;
 //   * a wave's nine pair totals by an LDS transpose: every lane dumps its three partial sums per half into the pair's row
 //     of forty, four lanes per pair read ten each (round 3 selected nine values per lane and reduce-scattered them over
 //     the wave: a quarter of the kernel's time);
@@ -71,32 +73,26 @@ constexpr unsigned kM4MaxChunk = 64;   // tiles per run: one lane of a wave per 
 // exactly where they match and no byte borrows.
 // plain: bytes `one` where they match (SHIFT / MASK move bit 7 to the one's place)
 template <int SHIFT, unsigned MASK>
-__device__ __forceinline__ int m4_expand1(unsigned sy, unsigned srow) {
-  return (int)(((0x80808080u - (sy ^ srow)) >> SHIFT) & MASK);
-}
-template <int SHIFT, unsigned MASK>
 __device__ __forceinline__ cmx_i4 m4_expand(const cmx_i4 sy, unsigned srow) {
   cmx_i4 oh;
 #pragma unroll
-  for (int d = 0; d < 4; ++d) oh[d] = m4_expand1<SHIFT, MASK>((unsigned)sy[d], srow);
+  for (int d = 0; d < 4; ++d) oh[d] = (int)(((0x80808080u - ((unsigned)sy[d] ^ srow)) >> SHIFT) & MASK);
   return oh;
 }
 // weighted: UNIT x A (A = 20) where the symbol is the state, UNIT where it is the unknown; `live` = 0 for the padding rows.
 // UNIT is 2 on the first side and 4 on the second, so that the accumulators hold 8 m, the byte offset of f2[m]
 template <unsigned UNIT>
-__device__ __forceinline__ int m4_expand_weighted1(unsigned sy, unsigned srow, unsigned live) {
-  static_assert(kM4Unknown == 32u, "the unknown's bit is bit 5");
-  // 20 UNIT = 5 x (4 UNIT): the match bit moved to the place of 4 UNIT, OR itself two places higher (bytes do not
-  // carry); the unknown's bit 5 moved to the place of UNIT: seven instructions per dword (ten with the unknown compared
-  // like a state)
-  const unsigned eq = ((0x80808080u - (sy ^ srow)) >> (UNIT == 2 ? 4 : 3)) & (0x01010101u * (4u * UNIT));
-  return (int)(((sy >> (UNIT == 2 ? 4 : 3)) & (live * UNIT)) | ((eq << 2) | eq));
-}
-template <unsigned UNIT>
 __device__ __forceinline__ cmx_i4 m4_expand_weighted(const cmx_i4 sy, unsigned srow, unsigned live) {
+  static_assert(kM4Unknown == 32u, "the unknown's bit is bit 5");
   cmx_i4 oh;
 #pragma unroll
-  for (int d = 0; d < 4; ++d) oh[d] = m4_expand_weighted1<UNIT>((unsigned)sy[d], srow, live);
+  for (int d = 0; d < 4; ++d) {
+    // 20 UNIT = 5 x (4 UNIT): the match bit moved to the place of 4 UNIT, OR itself two places higher (bytes do not
+    // carry); the unknown's bit 5 moved to the place of UNIT: seven instructions per dword (ten with the unknown compared
+    // like a state)
+    const unsigned eq = ((0x80808080u - ((unsigned)sy[d] ^ srow)) >> (UNIT == 2 ? 4 : 3)) & (0x01010101u * (4u * UNIT));
+    oh[d] = (int)((((unsigned)sy[d] >> (UNIT == 2 ? 4 : 3)) & (live * UNIT)) | ((eq << 2) | eq));
+  }
   return oh;
 }
 // f(0), f(1), ... f(N - 1) with compile-time arguments (std::integral_constant): the steps of the pipelined tile loop
@@ -198,17 +194,41 @@ __global__ void mica_nan_lower_kernel(size_t n, double* __restrict__ mi, double*
   }
 }
 
+// ---- the second alignment's operands, expanded ONCE per call: the image of a tile is what the tile's operand buffer holds in
+// LDS -- [2 KS operand tiles q][64 lanes] x 16 bytes; q = column tile q / KS, k-step q % KS; lane: packed column 32 (q / KS)
+// + (lane & 31) = column C / 20 of the tile's three, state C % 20 (C >= 60: padding), taxa 32 (q % KS) + 16 (lane >> 5) ..
+// + 15 -- so that the workgroups load operands instead of symbols and spend no vector instruction on expanding them (a
+// tile was expanded once per block of twelve first-alignment columns: 417 times at cfg 5, 64 of the plain instantiation's
+// ~200 vector instructions per wave and tile).  16 KB per tile at 256 taxa, one image per instantiation (the weights
+// differ); the workgroups that run together walk the same chunk of tiles (run order in the kernel), so the image is read
+// from L2.
+template <int KS, bool WEIGHTED>
+__global__ __launch_bounds__(256) void mica4_image_kernel(int Tp, const uint8_t* __restrict__ C2, cmx_i4* __restrict__ img) {
+  constexpr int NQ = 2 * KS;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, cl = lane & 31, nks = Tp / 32;
+  const size_t jt = blockIdx.x;
+  for (int q = w; q < NQ; q += 4) {
+    const int C = 32 * (q / KS) + cl;
+    const unsigned srow = (C < 60 ? (unsigned)(C % kM4Rows) : kM4PadRow) * 0x01010101u;
+    cmx_i4 raw = {(int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4};
+    // (the symbol arrays carry columns of padding behind the last one: no clamp)
+    if (q % KS < nks) raw = *reinterpret_cast<const cmx_i4*>(C2 + (jt * kM4J + (C < 60 ? C / kM4Rows : 2)) * (size_t)Tp + 32 * (q % KS) + 16 * (lane >> 5));
+    img[(jt * NQ + q) * 64 + lane] = WEIGHTED ? m4_expand_weighted<4>(raw, srow, srow == kM4PadRowX4 ? 0u : 0x01010101u)
+                                              : m4_expand<7, 0x01010101u>(raw, srow);
+  }
+}
+
 template <int KS, bool WEIGHTED>   // k-steps of 32 taxa: Tp <= 32 KS
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 : 2, KS > 8 ? 1 : 2))) void mica_mfma4_kernel(
     int T, int Tp, const uint8_t* __restrict__ C1, size_t n1, const unsigned* __restrict__ info1, const double* __restrict__ S1,
-    const uint8_t* __restrict__ C2, size_t n2, const unsigned* __restrict__ info2, const double* __restrict__ S2,
+    const cmx_i4* __restrict__ img2, size_t n2, const unsigned* __restrict__ info2, const double* __restrict__ S2,
     const unsigned* __restrict__ order1, const unsigned* __restrict__ order2, const double* __restrict__ ftab_g, int intra,
     double* __restrict__ mi, double* __restrict__ hj, size_t ldo, unsigned nJ, unsigned chunk, unsigned nchunks, unsigned nruns) {
-  // C1 / C2 / S1 / S2 / info1 / info2 are in SORTED column order (mica_sort_columns_kernel); order1 / order2 name the
-  // original column of a sorted position, which is where the results go
+  // C1 / S1 / S2 / info1 / info2 and the columns behind img2 are in SORTED column order (mica_sort_columns_kernel); order1 /
+  // order2 name the original column of a sorted position, which is where the results go
   extern __shared__ __attribute__((aligned(16))) uint8_t m4_smem[];   // the kernel's only LDS object: LDS address 0
   constexpr int NQ = 2 * KS;            // operand tiles of the second alignment per tile: 2 column tiles x KS k-steps
-  constexpr bool DMA = WEIGHTED;        // how the next tile's symbol bytes reach the expansion (the tile loop below)
+  constexpr bool DMA = WEIGHTED;        // how the next tile's operands reach LDS (the tile loop below)
   constexpr bool FINI = !WEIGHTED;      // a finished tile's results are made beside the next tile's products (the tile loop below)
   constexpr int SPT = NQ / 4;           // slots per thread
   // LDS address 0: plain f[0 .. T]; weighted f2[0 .. M0) followed by one zero entry (what a cell >= M0 reads there)
@@ -236,19 +256,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
   const unsigned M8 = 8u * (unsigned)M0;
   const double lnT = log((double)T), invT = 1.0 / (double)T;
   const int nks = Tp / 32;
-  // the second alignment's symbol bytes through a buffer descriptor: lane offset in a VGPR, tile offset in an SGPR
-  const __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(C2), 0, 0x7fffffff, 0x00020000);
+  // the second alignment's operand image (mica4_image_kernel) through a buffer descriptor: this thread's 16 bytes of operand
+  // tile q = w + 4 m in a VGPR offset, the tile in an SGPR offset
+  const __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cmx_i4*>(img2), 0, 0x7fffffff, 0x00020000);
+  const unsigned ioff = (unsigned)((w * 64 + lane) * 16);
   // f2[m] for m >= M0: the third table holds a zero and then f2[M0 ..]; byte offset max(8 m - (8 M0 - 8), 0)
   const char* f2hi = reinterpret_cast<const char*>(ftab_g + (T + 1) + (400 * T + 1));
-  // this thread's slots of the second alignment's operand tiles: q = w + 4 m -> column tile q / KS, k-step q % KS;
-  // packed column 32 (q / KS) + cl = column C / 20 of the tile, state C % 20 (C >= 60: padding)
-  unsigned bsrow[SPT], boff[SPT];
-#pragma unroll
-  for (int m = 0; m < SPT; ++m) {
-    const int q = w + 4 * m, C = 32 * (q / KS) + cl;
-    bsrow[m] = (C < 60 ? (unsigned)(C % kM4Rows) : kM4PadRow) * 0x01010101u;
-    boff[m] = (unsigned)((C < 60 ? C / kM4Rows : 2) * Tp + 32 * (q % KS) + 16 * (lane >> 5));   // from the tile's first column
-  }
   // first alignment: row tile ii, packed row 32 ii + cl
   unsigned asrow[2];
   int acol[2];
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
   const int al = (int)(plc / 3), bl = (int)(plc % 3);
   const bool writer = (lane & 3) == 0 && pl < 9;
   for (unsigned run = blockIdx.x; run < nruns; run += gridDim.x) {
-    const unsigned I = run / nchunks, ch = run % nchunks;
+    const unsigned nI = nruns / nchunks, I = run % nI, ch = run / nI;   // workgroups running together share a chunk of tiles
     const size_t i0 = (size_t)I * kM4I;
     unsigned jt0 = ch * chunk;
     const unsigned jt1 = jt0 + chunk < nJ ? jt0 + chunk : nJ;
@@ -322,13 +335,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
           areg[ii][ks] = WEIGHTED ? m4_expand_weighted<2>(raw[ii][ks], asrow[ii], asrow[ii] == kM4PadRowX4 ? 0u : 0x01010101u)
                                   : m4_expand<4, 0x08080808u>(raw[ii][ks], asrow[ii]);
     }
-    // The symbol bytes of the next tile, two ways.  Plain instantiation: into registers (sixteen of them, held from behind
-    // the second half of one tile to the second half of the next).  Weighted instantiation, which has no registers to
-    // spare (it spilled): global -> LDS without passing through registers (global_load_lds_dwordx4: lane l's 16 bytes land
-    // at base + 16 l, which is where lane l's expanded operand will stand), expanded IN PLACE; requested in front of the
-    // first half, waited for behind it (vmcnt(0)).  The DMA costs the issuing wave more than the register load (measured
-    // with both instantiations on either: plain 2.95 -> 3.26 ms), hence not for both.  Inline asm for the reason given in
-    // cmx_kernels.hip: a DMA the compiler knows of makes it wait for every outstanding load before the next LDS read.
+    // The operands of the next tile, two ways.  Plain instantiation: into registers (sixteen of them, held from behind the
+    // first half of one tile to the first half of the next, where they are stored to the other operand buffer four
+    // registers every fourth step).  Weighted instantiation, which has no registers to spare (it spilled): global -> LDS
+    // without passing through registers (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, the image's order),
+    // requested in front of the first half, waited for behind it (vmcnt(0)).  The DMA costs the issuing wave more than the
+    // register load (measured with both instantiations on either: plain 2.95 -> 3.26 ms), hence not for both.  Inline asm
+    // for the reason given in cmx_kernels.hip: a DMA the compiler knows of makes it wait for every outstanding load before
+    // the next LDS read.
     cmx_i4 braw[DMA ? 1 : SPT];
     double s2r = 0.0;
     unsigned j2r = 0;
@@ -340,37 +354,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
       }
     };
     auto fetch = [&](unsigned jt, int nbuf) __attribute__((always_inline)) {
-      const unsigned soff = jt * (unsigned)(kM4J * Tp);   // uniform
+      const unsigned soff = jt * (unsigned)(NQ * 1024);   // uniform
 #pragma unroll
       for (int m = 0; m < SPT; ++m) {
-        const bool live = (w + 4 * m) % KS < nks;
-        const cmx_i4 none = {(int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4, (int)kM4NoneX4};
         if (DMA) {
-          cmx_i4* dst = ops + (nbuf * NQ + w + 4 * m) * 64;
-          if (live) {
-            const uint8_t* g = C2 + soff + boff[m];
-            const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)reinterpret_cast<const uint8_t*>(dst));
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
-          } else
-            dst[lane] = none;
+          const cmx_i4* dst = ops + (nbuf * NQ + w + 4 * m) * 64;
+          const uint8_t* g = reinterpret_cast<const uint8_t*>(img2) + soff + ioff + 4096u * (unsigned)m;
+          const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)reinterpret_cast<const uint8_t*>(dst));
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
         } else
-          braw[m] = live ? __builtin_bit_cast(cmx_i4, __builtin_amdgcn_raw_buffer_load_b128(rc2, boff[m], soff, 0)) : none;
+          braw[m] = __builtin_bit_cast(cmx_i4, __builtin_amdgcn_raw_buffer_load_b128(rc2, ioff + 4096u * (unsigned)m, soff, 0));
       }
       fetch_scalars(jt);
     };
-    auto expand_dword = [&](unsigned raw, int m) __attribute__((always_inline)) -> int {
-      return WEIGHTED ? m4_expand_weighted1<4>(raw, bsrow[m], bsrow[m] == kM4PadRowX4 ? 0u : 0x01010101u)
-                      : m4_expand1<7, 0x01010101u>(raw, bsrow[m]);
-    };
     auto expand_scalars = [&](unsigned slot) __attribute__((always_inline)) {   // ring of four tiles: the tile in the products, the one before it (its
-      if (tid < kM4J) {                          // results not yet written) and the one being expanded
+      if (tid < kM4J) {                          // results not yet written) and the one being loaded
         s2t[4 * slot + tid] = s2r;
         j2t[4 * slot + tid] = j2r;
       }
     };
     // ---- the tile loop, software-pipelined inside the wave.  The accumulators of a tile are two halves (column tile J = 0,
     // 1: 32 registers each).  While the matrix core fills one half, the vector unit empties the other: the products of
-    // (tile t, J = 0) run beside the lookups of (tile t - 1, J = 1) and the expansion of tile t + 1's operands; the products
+    // (tile t, J = 0) run beside the lookups of (tile t - 1, J = 1) and the next tile's operands on their way to LDS; the products
     // of (tile t, J = 1) beside the lookups of (tile t, J = 0).  One MFMA per step, the step's share of the vector work
     // behind it, no instruction moved across a step (sched_barrier): a 32 x 32 x 32 product holds the matrix pipe for 32
     // cycles and the issue port for 8, the rest of the gap was idle unless the SIMD's other wave happened to be in its
@@ -582,18 +587,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
     constexpr int NS = 2 * KS;        // steps (products) of a half
     constexpr int RPS = 32 / NS;      // accumulator registers of the other half emptied per step
     // the products of half J of the tile in operand buffer `buf`, the lookups of half 1 - J (of the previous tile for J = 0)
-    // and, for EXP, the expansion of the next tile's symbols in operand buffer `nbuf`
+    // and, for EXP, the next tile's operands from registers into operand buffer `nbuf`
     auto half = [&](auto jc, auto expc, auto finc, int buf, int nbuf, unsigned jtp, unsigned pslot, bool have_p) __attribute__((always_inline)) {
       constexpr int J = decltype(jc)::value, O = 1 - J;
       constexpr bool EXP = decltype(expc)::value, FIN = decltype(finc)::value;
       const cmx_i4* ob = ops + (buf * NQ + J * KS) * 64 + lane;
-      cmx_i4 nb = ob[0], bb = nb, eo = {0, 0, 0, 0};
-      const unsigned* rawp = reinterpret_cast<const unsigned*>(ops + (nbuf * NQ + w) * 64 + lane);   // slot m: + 4 m x 64 x 4 dwords
-      unsigned rq[3] = {0, 0, 0};   // raw dwords two steps ahead of their expansion
-      if (EXP && DMA) {
-        rq[0] = rawp[0];
-        rq[1] = rawp[1];
-      }
+      cmx_i4 nb = ob[0], bb = nb;
       // a lookup's value is summed LAG steps after the lookup is issued (one LDS round trip is about two products)
       constexpr int LAG = CMX_M4_LAG;
       double vr[LAG + 1][RPS];
@@ -617,12 +616,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
           m4_static_for<4>([&](auto pc) {
             if (decltype(pc)::value * NS / 4 == st) fin(pc, jtp, pslot, have_p);
           });
-        if (EXP) {   // one dword of the next tile's operands per step
-          constexpr int m = st / 4, d = st % 4, s2 = st + 2;
-          if (DMA && s2 < NS) rq[s2 % 3] = rawp[(s2 / 4) * 4 * 64 * 4 + s2 % 4];
-          eo[d] = expand_dword(DMA ? rq[st % 3] : (unsigned)braw[DMA ? 0 : m][d], m);
-          if (d == 3) ops[(nbuf * NQ + w + 4 * m) * 64 + lane] = eo;
-        }
+        if (EXP && st % 4 == 3) ops[(nbuf * NQ + w + 4 * (st / 4)) * 64 + lane] = braw[DMA ? 0 : st / 4];   // operand tile w + 4 m, m = st / 4
         __builtin_amdgcn_sched_barrier(0);
       });
       m4_static_for<LAG * RPS>([&](auto rc) {
@@ -639,14 +633,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
     need &= need - 1;
     fetch(jt, 0);
     if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else {
 #pragma unroll
-    for (int m = 0; m < SPT; ++m) {
-      cmx_i4* op = ops + (w + 4 * m) * 64 + lane;
-      const cmx_i4 raw = DMA ? *op : braw[DMA ? 0 : m];
-      cmx_i4 eo;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) eo[d] = expand_dword((unsigned)raw[d], m);
-      *op = eo;
+      for (int m = 0; m < SPT; ++m) ops[(w + 4 * m) * 64 + lane] = braw[DMA ? 0 : m];
     }
     expand_scalars(0);
     bool have_p = false, have_n = need != 0;
@@ -665,16 +654,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
       __syncthreads();   // this tile's operands and scalars are in LDS; every wave is done with the other operand buffer
       const unsigned pslot = (slot + 3) & 3;
       if (DMA) {
-        // weighted: request the next tile's symbols | first half | wait | previous tile's results | second half + expansion
+        // weighted: request the next tile's operands | first half | previous tile's results | second half | wait
         if (have_n) fetch(jn, buf ^ 1);
         half(h0, no, no, buf, buf, 0u, 0u, false);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's symbols are in LDS
         if (have_p) finalize(jtp, pslot);
-        if (have_n) {
-          half(h1, yes, no, buf, buf ^ 1, 0u, 0u, false);
-          expand_scalars((slot + 1) & 3);
-        } else
-          half(h1, no, no, buf, buf, 0u, 0u, false);
+        half(h1, no, no, buf, buf, 0u, 0u, false);
+        if (have_n) expand_scalars((slot + 1) & 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's operands are in LDS (in front of the barrier)
         have_p = true;
         jtp = jt;
         if (!have_n) break;
@@ -685,7 +671,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
           need &= need - 1;
         }
       } else {
-        // plain: first half + expansion of the next tile (its symbols are in registers) | request the tile after it |
+        // plain: first half + the next tile's operands from registers to LDS | request the tile after it |
         // second half + the previous tile's results
         if (have_n) {
           half(h0, yes, no, buf, buf ^ 1, 0u, 0u, false);
@@ -700,7 +686,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
           if (have_n) {
             jn = jt0 + (unsigned)__builtin_ctzll(need);
             need &= need - 1;
-            fetch(jn, 0);   // (the registers are free: the first half expanded what they held)
+            fetch(jn, 0);   // (the registers are free: the first half stored what they held)
           }
         }
         half(h1, no, yes, buf, buf, jtp, pslot, have_p);
@@ -936,8 +922,11 @@ static hipError_t launch_mica4_one(int T, int Tp, const MicaWork* wk, size_t n1,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  // the second alignment's operand image of this instantiation (its two halves of wk->img2)
+  cmx_i4* img = reinterpret_cast<cmx_i4*>(wk->img2) + (WEIGHTED ? (size_t)nJ * 2 * KS * 64 : 0);
+  hipLaunchKernelGGL((mica4_image_kernel<KS, WEIGHTED>), dim3(nJ), dim3(256), 0, stream, Tp, intra ? wk->Cs1 : wk->Cs2, img);
   hipLaunchKernelGGL((mica_mfma4_kernel<KS, WEIGHTED>), dim3(grid < nruns ? grid : nruns), dim3(256), lds, stream, T, Tp, wk->Cs1, n1,
-                     wk->info1, wk->Ss1, intra ? wk->Cs1 : wk->Cs2, n2, intra ? wk->info1 : wk->info2, intra ? wk->Ss1 : wk->Ss2,
+                     wk->info1, wk->Ss1, img, n2, intra ? wk->info1 : wk->info2, intra ? wk->Ss1 : wk->Ss2,
                      wk->order1, intra ? wk->order1 : wk->order2, wk->ftab, intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns);
   return hipGetLastError();
 }
@@ -970,8 +959,11 @@ static hipError_t launch_mica4_ks(int T, int Tp, const MicaWork* wk, size_t n1, 
 
 // proteins, Tp <= 256 (eight k-steps of operand registers), byte offsets within 31 bits; the caller serves the pairs with
 // partial ambiguity codes
+static int mica4_ksteps(int Tp) { return Tp <= 64 ? 2 : (Tp <= 128 ? 4 : (Tp <= 256 ? 8 : 16)); }
+// bytes of MicaWork::img2: two images (plain, weighted) of 2 KS KB per tile of three columns of the second alignment
+size_t mica4_image_bytes(int Tp, size_t n2) { return 2 * ((n2 + kM4J - 1) / kM4J) * (size_t)(2 * mica4_ksteps(Tp)) * 1024; }
 bool mica4_serves(int A, int Tp, size_t n1, size_t n2) {
-  return A == 20 && Tp <= 512 && (std::max(n1, n2) + kMicaCodePad) * (size_t)Tp < 0x7fffffffull;
+  return A == 20 && Tp <= 512 && (std::max(n1, n2) + kMicaCodePad) * (size_t)Tp < 0x7fffffffull && mica4_image_bytes(Tp, n2) / 2 < 0x7fffffffull;
 }
 
 hipError_t launch_mica4(int T, const MicaWork* wk, size_t n1, size_t n2, int intra, double* d_mi, double* d_hj, size_t ldo,
