@@ -295,6 +295,8 @@ def main():
         side.wait_stream(main_s)
         with torch.cuda.stream(side):
             ana.get_vectors(aln)
+            if args.pair_output == "compact":   # the observed pairs' statistics too: they do not wait for the null
+                ana.prefetch_intra_gram(row_begin, row_end)
         # the null: simulate (own kernel, full occupancy) then map + score; the events bracket the mapping launch alone
         nb = ana.null_distribution(w["seed"] + 7, rep_begin, rep_end, ram, map_events=ev[i] if timed else None,
                                    sim_events=ev_sim[i] if timed else None)

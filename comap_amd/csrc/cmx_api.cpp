@@ -100,6 +100,8 @@ struct cmx_ctx {
   std::vector<uint8_t> perm_tab_host;
   unsigned long long perm_F_L = 0;
   int perm_F_T = 0, perm_F_sh = -1;
+  // cmx_intra_gram_prefetch_dev: the Gram blocks kept for the next cmx_intra_compact_range_dev with the same arguments
+  struct GramKept { bool valid = false; int kind = 0; const double* counts = nullptr; size_t n = 0, ldc = 0, row_begin = 0, row_end = 0; const double* stat = nullptr; } gram_kept;
   const double *va_P = nullptr, *va_N1 = nullptr, *va_NC = nullptr;   // their operators, uploaded at first use
   const double *va_PN = nullptr, *va_pi = nullptr;                     // plain path: joint counts and frequencies, padded
   const int *va_first = nullptr, *va_next = nullptr;
@@ -1433,6 +1435,47 @@ cmx_status cmx_intra_rows_range_dev(cmx_ctx* ctx, int kind, const double* params
   return CMX_OK;
 }
 
+// the row blocks of the pair loop: <= 256 MiB of statistics, whole 64-row tiles
+static size_t pair_row_block(size_t n, size_t rows) {
+  size_t RB = ((size_t)256 << 20) / (8 * n) / 64 * 64;
+  return std::max<size_t>(64, std::min<size_t>(RB, (rows + 63) / 64 * 64));
+}
+
+cmx_status cmx_intra_gram_prefetch_dev(cmx_ctx* ctx, int kind, const double* d_counts, size_t n, size_t ldc, size_t row_begin,
+                                       size_t row_end, void* stream) {
+  cmx_status s = need_model(ctx);
+  if (s != CMX_OK) return s;
+  if ((s = check_kind(ctx, kind)) != CMX_OK) return s;
+  if (!d_counts || n == 0 || ldc < n || n > 0x7fffffffull || row_begin > row_end || row_end > n)
+    return fail(ctx, CMX_ERR_INVALID, "cmx_intra_gram_prefetch: bad arguments");
+  ctx->gram_kept.valid = false;
+  const HostModel& h = ctx->hm;
+  const size_t rows = row_end - row_begin;
+  // statistics with parameters (mean vectors, thresholds, bounds) and distances: left to the later call
+  if (rows == 0 || h.B < 2 || kind == CMX_STAT_CORRECTED_CORRELATION || kind == CMX_STAT_DISCRETE_MI || kind == CMX_STAT_DISCRETE_MI_BOUNDS ||
+      kind == CMX_STAT_EUCLIDIAN_DISTANCE)
+    return CMX_OK;
+  const size_t RB = pair_row_block(n, rows), nblk = (rows + RB - 1) / RB;
+  if (nblk * RB * n * sizeof(double) > ((size_t)2 << 30)) return CMX_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int Bp = (h.B + 3) / 4 * 4;
+  const size_t ldx = (n + 15) / 16 * 16;
+  // (scratch of its own: the null's scoring may be using the pair loop's on another stream)
+  double *X = nullptr, *sv = nullptr, *rv = nullptr, *kept = nullptr;
+  if ((s = scratch(ctx, "gram_X1", sizeof(double) * Bp * ldx, (void**)&X)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "gram_s1", sizeof(double) * n, (void**)&sv)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "gram_r1", sizeof(double) * n, (void**)&rv)) != CMX_OK) return s;
+  if ((s = scratch(ctx, "gram_kept", sizeof(double) * nblk * RB * n, (void**)&kept)) != CMX_OK) return s;
+  HIP_TRY(ctx, launch_pair_prep(kind, 0.0, d_counts, n, ldc, h.B, h.K, X, ldx, Bp, sv, rv, nullptr, st));
+  for (size_t i0 = row_begin; i0 < row_end; i0 += RB) {
+    const size_t rb = std::min(RB, row_end - i0);
+    HIP_TRY(ctx, launch_pair_gram(kind, h.B, Bp, X + i0, sv + i0, rv + i0, rb, ldx, X, sv, rv, n, ldx, 2, kept + (i0 - row_begin) * n, n, st, 1, 0, 0, 0, i0));
+  }
+  ctx->gram_kept = {true, kind, d_counts, n, ldc, row_begin, row_end, kept};
+  return CMX_OK;
+}
+
 cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* params, const double* d_counts, size_t n, size_t ldc,
                                        const double* d_norm, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
                                        int nclasses, size_t row_begin, size_t row_end, cmx_pair_compact* d_out, size_t capacity,
@@ -1453,6 +1496,11 @@ cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* par
   if (row_begin == row_end) return CMX_OK;
   // the same operand, null index and row blocks as cmx_intra_rows_range_dev; the pass after each Gram block writes the
   // records at their arithmetic position (no filters: no counting pass, no scan)
+  // the Gram blocks may be there already (cmx_intra_gram_prefetch_dev with these arguments): then only the record pass runs
+  const cmx_ctx::GramKept gk0 = ctx->gram_kept;
+  ctx->gram_kept.valid = false;
+  const double* kept = gk0.valid && gk0.kind == kind && gk0.counts == d_counts && gk0.n == n && gk0.ldc == ldc && gk0.row_begin == row_begin &&
+                               gk0.row_end == row_end ? gk0.stat : nullptr;
   const double param = (kind == CMX_STAT_DISCRETE_MI) ? (params ? params[0] : 0.99) : 0.0;
   const double* d_mean = nullptr;
   if ((s = stat_mean_vectors(ctx, kind, params, &d_mean, stream)) != CMX_OK) return s;
@@ -1462,7 +1510,8 @@ cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* par
   uint32_t* mcls = nullptr;
   uint8_t* mbad = nullptr;
   size_t mldx = 0;
-  if (kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
+  if (kept) {
+  } else if (kind == CMX_STAT_DISCRETE_MI_BOUNDS) {
     MiBounds mb;
     if ((s = mi_bounds(ctx, params, &mb, stream)) != CMX_OK) return s;
     if ((s = mi_classify(ctx, mb, d_counts, n, ldc, "1", &mcls, &mbad, &mldx, stream)) != CMX_OK) return s;
@@ -1474,15 +1523,16 @@ cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* par
   }
   NullTable nt{};
   if (with_null && (s = prepare_null(ctx, d_norm, n, nclasses, d_null_stat, d_null_nmin, nnull, st, &nt)) != CMX_OK) return s;
-  size_t RB = ((size_t)256 << 20) / (8 * n) / 64 * 64;
-  RB = std::max<size_t>(64, std::min<size_t>(RB, (row_end - row_begin + 63) / 64 * 64));
-  double* blk_stat;
-  if ((s = scratch(ctx, "blk_stat", sizeof(double) * RB * n, (void**)&blk_stat)) != CMX_OK) return s;
+  const size_t RB = pair_row_block(n, row_end - row_begin);
+  double* blk_stat = nullptr;
+  if (!kept && (s = scratch(ctx, "blk_stat", sizeof(double) * RB * n, (void**)&blk_stat)) != CMX_OK) return s;
   for (size_t i0 = row_begin; i0 < row_end; i0 += RB) {
     const size_t rb = std::min(RB, row_end - i0);
-    if (mcls) HIP_TRY(ctx, launch_mi_pairs_block(h.B, mcls + i0, mbad + i0, rb, mldx, mcls, mbad, n, mldx, 2, blk_stat, n, i0, st));
+    const double* blk = kept ? kept + (i0 - row_begin) * n : blk_stat;
+    if (kept) {
+    } else if (mcls) HIP_TRY(ctx, launch_mi_pairs_block(h.B, mcls + i0, mbad + i0, rb, mldx, mcls, mbad, n, mldx, 2, blk_stat, n, i0, st));
     else HIP_TRY(ctx, launch_pair_gram(gk, h.B, Bp, X + i0, sv + i0, rv + i0, rb, ldx, X, sv, rv, n, ldx, 2, blk_stat, n, st, 1, 0, 0, 0, i0));
-    HIP_TRY(ctx, launch_pair_compact(blk_stat, n, n, d_norm, with_null ? &nt : nullptr, d_out, capacity, st, i0, rb, row_begin));
+    HIP_TRY(ctx, launch_pair_compact(blk, n, n, d_norm, with_null ? &nt : nullptr, d_out, capacity, st, i0, rb, row_begin));
   }
   return CMX_OK;
 }

@@ -57,7 +57,7 @@ EXPORTS = [
     "cmx_mica_permutation_test", "cmx_mica_permutation_test_dev", "cmx_mica_permutation_test_masks", "cmx_mica_permutation_test_masks_dev", "cmx_mica_average_mi", "cmx_mica_average_mi_dev", "cmx_mica_zscore_null", "cmx_mica_zscore_null_dev",
     "cmx_group_stats", "cmx_group_stats_dev", "cmx_candidate_groups", "cmx_debug_candidate_cursor",
     "cmx_hclust", "cmx_hclust_dev", "cmx_cluster_sites", "cmx_cluster_sites_dev", "cmx_cluster_null",
-    "cmx_intra_compact_range_dev", "cmx_expand_compact_rows", "cmx_vector_matrix",
+    "cmx_intra_compact_range_dev", "cmx_intra_gram_prefetch_dev", "cmx_expand_compact_rows", "cmx_vector_matrix",
     "cmx_scratch_check", "cmx_debug_scratch_guard", "cmx_debug_scratch_guard_failures", "cmx_debug_scratch_shrink",
 ]
 # clustering.distance / clustering.method options of the reference (CoMap/CoMap.cpp:402-428, :460-472)
@@ -733,6 +733,13 @@ class Engine:
         self._check(self._lib.cmx_intra_compact_range_dev(
             self._ctx, int(kind), _vp(params), _vp(counts), _sz(n), _sz(counts.stride(0)), _vp(norm), _vp(null_stat), _vp(null_nmin),
             _sz(nnull), int(nclasses), _sz(row_begin), _sz(row_end), _vp(out), _sz(out.numel() // PAIR_COMPACT.itemsize), self._stream()))
+
+    def intra_gram_prefetch_dev(self, kind, counts, n, row_begin=0, row_end=None):
+        """enqueue the statistics of the observed pairs of rows [row_begin, row_end) on the current stream and keep them for the
+        next intra_compact_range_dev with the same arguments (cmx_intra_gram_prefetch_dev: beside the null, not behind it)"""
+        row_end = int(n) if row_end is None else int(row_end)
+        self._check(self._lib.cmx_intra_gram_prefetch_dev(self._ctx, int(kind), _vp(counts), _sz(n), _sz(counts.stride(0)),
+                                                          _sz(row_begin), _sz(row_end), self._stream()))
 
     def intra_rows_range_dev(self, kind, counts, rate_class, post_rate, norm, null_stat, null_nmin, nclasses, rows, count,
                              row_begin=0, row_end=None, filters=None, threshold=0.99, mean_vectors=None):

@@ -118,6 +118,12 @@ class IntraAnalysis:
         return rows, count
 
 
+    def prefetch_intra_gram(self, row_begin=0, row_end=None):
+        """The statistics of the observed pairs do not depend on the null: a caller that maps the observed alignment on a side
+        stream can enqueue them there too, behind get_vectors; compute_intra_compact with the same row range then only looks
+        the p-values up and writes the records (its stream ordered behind this one's)."""
+        self.eng.intra_gram_prefetch_dev(self.kind, self.counts, self.n, row_begin, self.n if row_end is None else row_end)
+
     def compute_intra_compact(self, null_stat=None, null_nmin=None, row_begin=0, row_end=None):
         """the unfiltered pair loop as 16-byte records (engine.PAIR_COMPACT) -> (uint8 CUDA tensor, number of pairs)"""
         from .engine import PAIR_COMPACT

@@ -301,6 +301,16 @@ cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* par
                                        const double* d_norm, const double* d_null_stat, const double* d_null_nmin, size_t nnull,
                                        int nclasses, size_t row_begin, size_t row_end, cmx_pair_compact* d_out, size_t capacity,
                                        void* stream);
+/* Optional first half of cmx_intra_compact_range_dev, for a caller that maps the observed alignment beside the null (the
+ * reference runs CoETools::computeIntraStats' null, CoETools.cpp:836-872, before its pair loop, :672-724; the statistics
+ * of the observed pairs do not depend on it): the operand preparation and the Gram blocks of the rows [row_begin, row_end)
+ * are enqueued on `stream` NOW and kept (rows x n doubles) for the next cmx_intra_compact_range_dev with the same kind,
+ * d_counts, n, ldc and row range, which then only runs its record pass; any other call to it discards them.  The vectors
+ * behind d_counts must not change in between, and that next call's stream must be ordered behind this one's.  Kept only
+ * when it fits 2 GiB and for statistics without parameters; otherwise nothing happens here and the later call does all
+ * the work.  Returns CMX_OK either way. */
+cmx_status cmx_intra_gram_prefetch_dev(cmx_ctx* ctx, int kind, const double* d_counts, size_t n, size_t ldc, size_t row_begin,
+                                       size_t row_end, void* stream);
 /* host only: rows[k] for the pairs of the rows [row_begin, row_end) in (i, j) order from their compact records and the
  * per-site arrays; nthreads <= 1: the calling thread alone.  npairs must equal the number of pairs of the row range. */
 cmx_status cmx_expand_compact_rows(size_t n, size_t row_begin, size_t row_end, const int32_t* rate_class, const double* post_rate,

@@ -83,3 +83,41 @@ def test_device_records_expand_to_the_device_rows(kind, nstates):
         assert got.tobytes() == ref.tobytes()
         if with_null and npairs > 100:
             assert (rec_h["below"] != 0xffffffff).any() and np.isfinite(got["pvalue"]).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nstates", [(engine.STAT_CORRELATION, 20), (engine.STAT_COMPENSATION, 4), (engine.STAT_DISCRETE_MI, 20)])
+def test_prefetched_gram_gives_the_same_records(kind, nstates):
+    """cmx_intra_gram_prefetch_dev: the observed pairs' statistics enqueued ahead (on a side stream, beside the null) and
+    kept for the next record pass with the same arguments.  Same bytes as without; consumed by one call; ignored when the
+    row range differs; a statistic with a parameter (DiscreteMI's threshold) is not kept at all (the calls still agree)."""
+    import torch
+    from comap_amd.pipeline import IntraAnalysis
+    case = make_case(10, 310, nstates, 5 + kind)
+    eng = engine.Engine(case["parent"], case["blen"], case["lot"], case["Q"], case["pi"], case["rates"], case["probs"])
+    d_aln = torch.from_numpy(case["aln"]).cuda()
+    ana = IntraAnalysis(eng, d_aln, kind, 6, threshold=0.05)
+    n = 310
+    side = torch.cuda.Stream()
+    main_s = torch.cuda.current_stream()
+
+    def records(rb, re_, ns, nm):
+        rec, npairs = ana.compute_intra_compact(ns, nm, rb, re_)
+        return rec[:npairs * engine.PAIR_COMPACT.itemsize].cpu().numpy().tobytes()
+
+    for rb, re_ in ((0, n), (33, 290), (309, 310)):
+        side.wait_stream(main_s)
+        with torch.cuda.stream(side):
+            ana.get_vectors()
+            ana.prefetch_intra_gram(rb, re_)
+        nb = ana.null_distribution(7, 0, 30, 64)
+        main_s.wait_stream(side)
+        with_kept = records(rb, re_, nb["stat"], nb["nmin"])
+        plain = records(rb, re_, nb["stat"], nb["nmin"])        # the kept blocks were consumed: this one computes its own
+        from comap_amd.pipeline import sum_pairs
+        assert with_kept == plain and len(plain) == sum_pairs(n, rb, re_) * engine.PAIR_COMPACT.itemsize
+        # kept for another range: ignored, and dropped
+        ana.prefetch_intra_gram(0, n)
+        torch.cuda.synchronize()
+        assert records(rb, re_, nb["stat"], nb["nmin"]) == plain
+        assert records(0, n, None, None) == records(0, n, None, None)
