@@ -353,6 +353,19 @@ def main():
     # index, Gram, p-value lookup, filters, compacted rows; the observed alignment's mapping runs beside the null); at N > 1
     # the all-gather too
     roofline["rest_of_step_ms"] = ms_per_step - null_ms - sim_ms
+    if nrep_total:
+        # In the timed steps the observed alignment's mapping and the observed pairs' Gram run on the side stream beside this
+        # launch and share its CUs (they cost a protein null nothing measurable, the short nucleotide null of cfg4 up to a
+        # tenth).  Outside the timed region: the same launch with nothing beside it -- the kernel's own figure.
+        roofline["concurrent_in_timed_steps"] = "observed mapping + observed pairs' Gram (side stream)"
+        torch.cuda.synchronize()
+        ev_alone = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
+        for e2 in ev_alone:
+            ana.null_distribution(w["seed"] + 7, rep_begin, rep_end, ram, map_events=e2)
+        torch.cuda.synchronize()
+        alone_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_alone]))
+        roofline["launch_ms_alone"] = alone_ms
+        roofline["frac_alone"] = sites_per_launch * alg / (alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
     for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
         try:
             t = json.load(open(tf))

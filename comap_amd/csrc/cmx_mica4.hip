@@ -50,9 +50,6 @@
 #include "cmx_device.h"
 #include "cmx_lanes.h"
 
-#ifndef CMX_M4_LAG
-#define CMX_M4_LAG 2
-#endif
 namespace cmx {
 
 constexpr int kM4I = 12, kM4J = 3, kM4Rows = 20;
@@ -594,7 +591,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
       const cmx_i4* ob = ops + (buf * NQ + J * KS) * 64 + lane;
       cmx_i4 nb = ob[0], bb = nb;
       // a lookup's value is summed LAG steps after the lookup is issued (one LDS round trip is about two products)
-      constexpr int LAG = CMX_M4_LAG;
+      constexpr int LAG = 2;   // (1 .. 4 measured alike)
       double vr[LAG + 1][RPS];
       m4_static_for<NS>([&](auto sc) {
         constexpr int st = decltype(sc)::value, ii = st & 1, ks = st >> 1;
