@@ -584,6 +584,7 @@ static cmx_status map_sites_impl(cmx_ctx* ctx, const uint8_t* d_aln, size_t nsit
   if (s != CMX_OK) return s;
   if (!d_aln || nsites == 0 || ld < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: bad alignment arguments");
   if (d_counts && ldc < nsites) return fail(ctx, CMX_ERR_INVALID, "cmx_map_sites: ldc < nsites");
+  if (d_counts && d_counts == ctx->gram_kept.counts) ctx->gram_kept.valid = false;   // the vectors the kept Gram blocks were made from are rewritten
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->hm.plain) {
     // alphabets other than 4 / 20 states (codon models): likelihood, rates and every mapping option from the plain kernels.

@@ -305,8 +305,8 @@ cmx_status cmx_intra_compact_range_dev(cmx_ctx* ctx, int kind, const double* par
  * reference runs CoETools::computeIntraStats' null, CoETools.cpp:836-872, before its pair loop, :672-724; the statistics
  * of the observed pairs do not depend on it): the operand preparation and the Gram blocks of the rows [row_begin, row_end)
  * are enqueued on `stream` NOW and kept (rows x n doubles) for the next cmx_intra_compact_range_dev with the same kind,
- * d_counts, n, ldc and row range, which then only runs its record pass; any other call to it discards them.  The vectors
- * behind d_counts must not change in between, and that next call's stream must be ordered behind this one's.  Kept only
+ * d_counts, n, ldc and row range, which then only runs its record pass; any other call to it, and a mapping call that
+ * writes to d_counts, discards them.  The vectors behind d_counts must not change in between by other means, and that next call's stream must be ordered behind this one's.  Kept only
  * when it fits 2 GiB and for statistics without parameters; otherwise nothing happens here and the later call does all
  * the work.  Returns CMX_OK either way. */
 cmx_status cmx_intra_gram_prefetch_dev(cmx_ctx* ctx, int kind, const double* d_counts, size_t n, size_t ldc, size_t row_begin,

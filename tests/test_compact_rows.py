@@ -121,3 +121,13 @@ def test_prefetched_gram_gives_the_same_records(kind, nstates):
         torch.cuda.synchronize()
         assert records(rb, re_, nb["stat"], nb["nmin"]) == plain
         assert records(0, n, None, None) == records(0, n, None, None)
+    # Gram blocks kept, then the vectors rewritten by another mapping call into the same buffer: the kept blocks are dropped
+    aln2 = d_aln.clone()
+    aln2[:, 0:100] = d_aln[:, 100:200]
+    ana.get_vectors()
+    ana.prefetch_intra_gram(0, n)
+    ana.get_vectors(aln2)
+    changed = records(0, n, None, None)
+    assert changed == records(0, n, None, None)
+    ana.get_vectors()
+    assert changed != records(0, n, None, None)
