@@ -2436,6 +2436,64 @@ __global__ __launch_bounds__(256) void mica_onehot_kernel(int A, int T, int Tp, 
   }
 }
 
+// The same classification without the one-hot matrices (what the packed kernels need: codes, flags, column sums), 64 columns
+// per workgroup: the alignment is [taxon][column], the codes [column][taxon].  mica_onehot_kernel reads a column with
+// 256 one-byte loads from 256 cache lines (and counts with 256 LDS atomics on 21 addresses); here a wave reads 64 columns
+// of one taxon in one line, counts per (column, state), and a tile of 64 taxa x 64 columns is turned in LDS so that the
+// codes leave as 64-byte rows too.  S is summed in the same state order: the same bits.
+__global__ __launch_bounds__(256) void mica_codes_kernel(int A, int T, int Tp, const uint32_t* __restrict__ masks,
+                                                         const uint8_t* __restrict__ aln, size_t ld, uint8_t* __restrict__ codes,
+                                                         uint8_t* __restrict__ flag, uint8_t* __restrict__ gap, double* __restrict__ S,
+                                                         int* __restrict__ anyflag, size_t n, size_t npad /* columns behind n that get "no row" codes */) {
+  constexpr int kRow = 68;               // bytes per taxon of the tile: 17 dwords, so that a column is read conflict-free
+  constexpr int kCnt = 35;               // counts per column (states, the unknown; odd stride)
+  __shared__ __attribute__((aligned(4))) uint8_t tile[64 * kRow];
+  __shared__ int cnt[64 * kCnt];
+  __shared__ int amb[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t i0 = (size_t)blockIdx.x * 64, i = i0 + lane;
+  const uint32_t full = (1u << A) - 1u;
+  for (int k = threadIdx.x; k < 64 * kCnt; k += 256) cnt[k] = 0;
+  if (threadIdx.x < 64) amb[threadIdx.x] = 0;
+  __syncthreads();
+  for (int tc = 0; tc < Tp; tc += 64) {
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {       // wave w: taxa tc + 4 r + w, one column per lane
+      const int tl = 4 * r + w, t = tc + tl;
+      unsigned c = 63u;
+      if (t < T && i < n) {
+        c = aln[(size_t)t * ld + i];
+        if (c >= (unsigned)A) {
+          if ((masks[c] & full) == full) c = (unsigned)A;     // unknown: pseudo-state
+          else { amb[lane] = 1; c = 63u; }
+        }
+        if (c <= (unsigned)A) atomicAdd(&cnt[lane * kCnt + (int)c], 1);
+      }
+      tile[tl * kRow + lane] = (uint8_t)c;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {       // wave w: columns 4 r + w, one taxon per lane
+      const int col = 4 * r + w;
+      if (i0 + col < n + npad && tc + lane < Tp) codes[(i0 + col) * (size_t)Tp + tc + lane] = tile[lane * kRow + col];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 64 && i < n) {
+    const int* cc = cnt + lane * kCnt;
+    double s = 0.0;
+    const double g = (double)cc[A] / (double)A;
+    for (int a = 0; a < A; ++a) {
+      const double c = (double)cc[a] + g;
+      if (c > 0.0) s += c * log(c);
+    }
+    S[i] = s;
+    flag[i] = (uint8_t)amb[lane];
+    gap[i] = (uint8_t)(cc[A] > 0 ? 1 : 0);
+    if (amb[lane]) atomicOr(anyflag, 1);
+  }
+}
+
 // f[c] = c ln c for the integer counts 0..T, followed by f2[m] = (m / A^2) ln(m / A^2) for m = 0..A^2 T: the fractional
 // count of a pair with unknowns is c_ab = N_ab + (N_aA + N_Ab) / A + N_AA / A^2 = m / A^2 with the INTEGER
 // m = A^2 N_ab + A (N_aA + N_Ab) + N_AA, so those pairs need no logarithm at run time either
@@ -2931,11 +2989,19 @@ hipError_t launch_mi_columns(int A, int T, const uint32_t* d_masks, const uint8_
     const int Tp = work->Tp;
     const bool needH = mica_needs_onehot(A, Tp);   // the packed protein kernels expand the symbol bytes themselves
     hipLaunchKernelGGL(mica_ftable_kernel, dim3((unsigned)((A * A * T) / 256 + 1)), dim3(256), 0, stream, T, A, work->ftab, work->anyflag);
-    hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)(n1 + kMicaCodePad)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, needH ? work->H1 : nullptr, work->C1, work->flag1,
-                       work->gap1, work->S1, work->anyflag, n1);
-    if (!intra)
-      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)(n2 + kMicaCodePad)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln2, ld2, needH ? work->H2 : nullptr, work->C2,
-                         work->flag2, work->gap2, work->S2, work->anyflag, n2);
+    if (needH) {
+      hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)(n1 + kMicaCodePad)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, work->H1, work->C1, work->flag1,
+                         work->gap1, work->S1, work->anyflag, n1);
+      if (!intra)
+        hipLaunchKernelGGL(mica_onehot_kernel, dim3((unsigned)(n2 + kMicaCodePad)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln2, ld2, work->H2, work->C2,
+                           work->flag2, work->gap2, work->S2, work->anyflag, n2);
+    } else {   // codes, flags and column sums only: 64 columns per workgroup
+      hipLaunchKernelGGL(mica_codes_kernel, dim3((unsigned)((n1 + kMicaCodePad + 63) / 64)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln1, ld1, work->C1, work->flag1,
+                         work->gap1, work->S1, work->anyflag, n1, (size_t)kMicaCodePad);
+      if (!intra)
+        hipLaunchKernelGGL(mica_codes_kernel, dim3((unsigned)((n2 + kMicaCodePad + 63) / 64)), dim3(256), 0, stream, A, T, Tp, d_masks, d_aln2, ld2, work->C2,
+                           work->flag2, work->gap2, work->S2, work->anyflag, n2, (size_t)kMicaCodePad);
+    }
     dim3 g2((unsigned)((n2 + kMicaTileJ - 1) / kMicaTileJ), (unsigned)((n1 + kMicaTileI - 1) / kMicaTileI));
     const size_t lds2 = (((size_t)(T + 1) * 8 + 15) & ~(size_t)15) + 2 * (kMicaTileI + kMicaTileJ) * 64 * sizeof(cmx_i4);
     if (A == 20 && !mica_one_column_tiles()) {

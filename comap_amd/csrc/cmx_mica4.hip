@@ -107,7 +107,8 @@ __device__ __forceinline__ void m4_static_for(F&& f) {
 // (columns without unknowns first, the others behind them, each group in its original order -- neighbours stay
 // neighbours, so a tile's three output columns still share cache lines) makes the blocks homogeneous but one.
 // order[k] = original column at sorted position k.  One workgroup: a scan over n flags.
-__global__ __launch_bounds__(1024) void mica_sort_columns_kernel(const uint8_t* __restrict__ gap, size_t n, unsigned* __restrict__ order) {
+__global__ __launch_bounds__(1024) void mica_sort_columns_kernel(const uint8_t* __restrict__ gap, size_t n, unsigned* __restrict__ order,
+                                                                unsigned* __restrict__ anygap /* 1: some column has unknowns */) {
   __shared__ unsigned wsum[16], base[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // first pass: number of columns without unknowns
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(1024) void mica_sort_columns_kernel(const uint8_t* 
     for (int k = 0; k < 16; ++k) t += wsum[k];
     base[0] = 0;        // next position among the columns without unknowns
     base[1] = t;        // next position among the others
+    *anygap = t < n ? 1u : 0u;
   }
   __syncthreads();
   for (size_t i0 = 0; i0 < n; i0 += 1024) {
@@ -220,7 +222,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
     int T, int Tp, const uint8_t* __restrict__ C1, size_t n1, const unsigned* __restrict__ info1, const double* __restrict__ S1,
     const cmx_i4* __restrict__ img2, size_t n2, const unsigned* __restrict__ info2, const double* __restrict__ S2,
     const unsigned* __restrict__ order1, const unsigned* __restrict__ order2, const double* __restrict__ ftab_g, int intra,
-    double* __restrict__ mi, double* __restrict__ hj, size_t ldo, unsigned nJ, unsigned chunk, unsigned nchunks, unsigned nruns) {
+    double* __restrict__ mi, double* __restrict__ hj, size_t ldo, unsigned nJ, unsigned chunk, unsigned nchunks, unsigned nruns,
+    const unsigned* __restrict__ anygap1, const unsigned* __restrict__ anygap2) {
+  // no column with unknowns anywhere: nothing for the weighted instantiation to do (its walk over the runs to find that out
+  // was 0.03 ms of a 2.6 ms call)
+  if (WEIGHTED && *anygap1 == 0 && *anygap2 == 0) return;
   // C1 / S1 / S2 / info1 / info2 and the columns behind img2 are in SORTED column order (mica_sort_columns_kernel); order1 /
   // order2 name the original column of a sorted position, which is where the results go
   extern __shared__ __attribute__((aligned(16))) uint8_t m4_smem[];   // the kernel's only LDS object: LDS address 0
@@ -924,7 +930,8 @@ static hipError_t launch_mica4_one(int T, int Tp, const MicaWork* wk, size_t n1,
   hipLaunchKernelGGL((mica4_image_kernel<KS, WEIGHTED>), dim3(nJ), dim3(256), 0, stream, Tp, intra ? wk->Cs1 : wk->Cs2, img);
   hipLaunchKernelGGL((mica_mfma4_kernel<KS, WEIGHTED>), dim3(grid < nruns ? grid : nruns), dim3(256), lds, stream, T, Tp, wk->Cs1, n1,
                      wk->info1, wk->Ss1, img, n2, intra ? wk->info1 : wk->info2, intra ? wk->Ss1 : wk->Ss2,
-                     wk->order1, intra ? wk->order1 : wk->order2, wk->ftab, intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns);
+                     wk->order1, intra ? wk->order1 : wk->order2, wk->ftab, intra, d_mi, d_hj, ldo, nJ, chunk, nchunks, nruns,
+                     wk->info1 + (n1 + 11) / 12 * 4, intra ? wk->info1 + (n1 + 11) / 12 * 4 : wk->info2 + (n2 + 11) / 12 * 4);
   return hipGetLastError();
 }
 
@@ -935,13 +942,14 @@ static hipError_t launch_mica4_ks(int T, int Tp, const MicaWork* wk, size_t n1, 
   const unsigned nchunks = (nJ + chunk - 1) / chunk, nruns = nI * nchunks;
   // block info, padded to whole tiles (blocks past the end: all three columns "not served")
   const size_t nb1 = (size_t)nI * (kM4I / 3), nb2 = nJ;
-  hipLaunchKernelGGL(mica_sort_columns_kernel, dim3(1), dim3(1024), 0, stream, wk->gap1, n1, wk->order1);
+  // (the info arrays have four words to spare behind the blocks of the four-wave tiling: the first holds "some column has unknowns")
+  hipLaunchKernelGGL(mica_sort_columns_kernel, dim3(1), dim3(1024), 0, stream, wk->gap1, n1, wk->order1, wk->info1 + (n1 + 11) / 12 * 4);
   hipLaunchKernelGGL(mica_gather_columns_kernel, dim3((unsigned)(n1 + kMicaCodePad)), dim3(256), 0, stream, wk->order1, n1, Tp, wk->C1, wk->S1,
                      wk->Cs1, wk->Ss1);
   hipLaunchKernelGGL(mica_blockinfo_kernel, dim3((unsigned)((nb1 + 255) / 256)), dim3(256), 0, stream, wk->order1, wk->flag1, wk->gap1, n1, nb1,
                      wk->info1);
   if (!intra) {
-    hipLaunchKernelGGL(mica_sort_columns_kernel, dim3(1), dim3(1024), 0, stream, wk->gap2, n2, wk->order2);
+    hipLaunchKernelGGL(mica_sort_columns_kernel, dim3(1), dim3(1024), 0, stream, wk->gap2, n2, wk->order2, wk->info2 + (n2 + 11) / 12 * 4);
     hipLaunchKernelGGL(mica_gather_columns_kernel, dim3((unsigned)(n2 + kMicaCodePad)), dim3(256), 0, stream, wk->order2, n2, Tp, wk->C2, wk->S2,
                        wk->Cs2, wk->Ss2);
     hipLaunchKernelGGL(mica_blockinfo_kernel, dim3((unsigned)((nb2 + 255) / 256)), dim3(256), 0, stream, wk->order2, wk->flag2, wk->gap2, n2, nb2,
