@@ -34,6 +34,8 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <memory>
+#include <thread>
 #include <utility>
 
 #include "comap_mi355x_adapter.hpp"
@@ -137,10 +139,14 @@ class BasicMultiGpu {
     if (devices.empty()) throw Exception("MultiGpu: no device given.");
     for (int d : devices) engines_.emplace_back(new Engine(tree, model, d));
     streams_.assign(devices.size(), nullptr);
+    side_.assign(devices.size(), nullptr);
+    sideDone_.assign(devices.size(), nullptr);
     dv_.resize(devices.size());
     for (size_t r = 0; r < devices.size(); ++r) {
       hip(hipSetDevice(devices[r]));
       hip(hipStreamCreate(&streams_[r]));
+      hip(hipStreamCreate(&side_[r]));   // the observed alignment's mapping (and Gram) beside the null: independent work
+      hip(hipEventCreateWithFlags(&sideDone_[r], hipEventDisableTiming));
     }
     exchange_.init(devices_, streams_);
   }
@@ -148,14 +154,18 @@ class BasicMultiGpu {
     for (size_t r = 0; r < devices_.size(); ++r) {
       (void)hipSetDevice(devices_[r]);
       if (streams_[r]) (void)hipStreamSynchronize(streams_[r]);
+      if (side_[r]) (void)hipStreamSynchronize(side_[r]);
       for (Buf* b : dv_[r].all()) if (b->p) (void)hipFree(b->p);
       if (dv_[r].hostRows.p) (void)hipHostFree(dv_[r].hostRows.p);
+      if (dv_[r].hostSite.p) (void)hipHostFree(dv_[r].hostSite.p);
       if (dv_[r].hostCount) (void)hipHostFree(dv_[r].hostCount);
     }
     exchange_.destroy(devices_);
     for (size_t r = 0; r < devices_.size(); ++r) {
       (void)hipSetDevice(devices_[r]);
       if (streams_[r]) (void)hipStreamDestroy(streams_[r]);
+      if (side_[r]) (void)hipStreamDestroy(side_[r]);
+      if (sideDone_[r]) (void)hipEventDestroy(sideDone_[r]);
     }
     if (hostAln_.p) (void)hipHostFree(hostAln_.p);
     if (hostMasks_) (void)hipHostFree(hostMasks_);
@@ -163,6 +173,11 @@ class BasicMultiGpu {
   BasicMultiGpu(const BasicMultiGpu&) = delete;
   BasicMultiGpu& operator=(const BasicMultiGpu&) = delete;
   size_t size() const { return devices_.size(); }
+  // Rows wanted on the HOST and no pair filter set: let the devices write the 16-byte records of
+  // cmx_intra_compact_range_dev (a third of the bytes over PCIe, no counting pass) and rebuild the 48-byte rows on the host
+  // (cmx_expand_compact_rows: bit for bit the rows the devices would have written).  deviceRows() has no rows to show in
+  // that mode and throws.  computeIntraStats() switches it on by itself; off by default for enqueueIntraStats().
+  void enableCompactTransfer(bool on = true) { compactWanted_ = on; }
   const Engine& engine(size_t r) const { return *engines_[r]; }
   hipStream_t stream(size_t r) const { return streams_[r]; }
 
@@ -195,6 +210,7 @@ class BasicMultiGpu {
     for (size_t r = 0; r < N; ++r) {   // the staging buffers may still feed the previous call's uploads
       hip(hipSetDevice(devices_[r]));
       hip(hipStreamSynchronize(streams_[r]));
+      hip(hipStreamSynchronize(side_[r]));
     }
     std::memcpy(hostAln_.p, aln, T * n);
     if (masks) {
@@ -216,17 +232,38 @@ class BasicMultiGpu {
       ensure(d.pr, sizeof(double) * n);
       ensure(d.norm, sizeof(double) * n);
       ensure(d.rc, sizeof(int32_t) * n);
-      ensure(d.rows, sizeof(cmx_pair_row) * std::max<size_t>(d.cap, 1));
+      // the unfiltered loop as 16-byte records when the rows are wanted on the host (enableCompactTransfer)
+      d.compact = compactWanted_ && f.minRateClass <= 0 && f.maxRateClassDiff < 0 && !(f.minRate > 0.) && f.maxRateDiff < 0. &&
+                  !(f.minStatistic > 0.);
+      ensure(d.rows, (d.compact ? sizeof(cmx_pair_compact) : sizeof(cmx_pair_row)) * std::max<size_t>(d.cap, 1));
       ensure(d.count, sizeof(uint64_t));
       if (!d.hostCount) hip(hipHostMalloc((void**)&d.hostCount, sizeof(uint64_t), hipHostMallocDefault));
-      hip(hipMemcpyAsync(d.aln.p, hostAln_.p, T * n, hipMemcpyHostToDevice, st));
+      // the observed alignment on the side stream: up, mapped, (records mode) its pairs' Gram blocks kept for the record
+      // pass and the per-site arrays the host expansion needs on their way home -- all beside the null on the main stream
+      hipStream_t sd = side_[r];
+      hip(hipMemcpyAsync(d.aln.p, hostAln_.p, T * n, hipMemcpyHostToDevice, sd));
       if (masks) {
         ensure(d.masks, 256 * sizeof(uint32_t));
-        hip(hipMemcpyAsync(d.masks.p, hostMasks_, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        hip(hipMemcpyAsync(d.masks.p, hostMasks_, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, sd));
       }
       e.check(cmx_map_sites_dev(e.ctx(), d.aln.template as<uint8_t>(), n, n, masks ? d.masks.template as<uint32_t>() : nullptr,
                                 d.counts.template as<double>(), n, nullptr, d.pr.template as<double>(), d.rc.template as<int32_t>(),
-                                d.norm.template as<double>(), st));
+                                d.norm.template as<double>(), sd));
+      if (d.compact) {
+        e.check(cmx_intra_gram_prefetch_dev(e.ctx(), statistic.kind(), d.counts.template as<double>(), n, n, d.rowBegin, d.rowEnd, sd));
+        const size_t sb = n * (sizeof(int32_t) + 2 * sizeof(double));
+        if (d.hostSite.bytes < sb) {
+          if (d.hostSite.p) hip(hipHostFree(d.hostSite.p));
+          d.hostSite.p = nullptr;
+          hip(hipHostMalloc(&d.hostSite.p, sb, hipHostMallocDefault));
+          d.hostSite.bytes = sb;
+        }
+        char* hs = static_cast<char*>(d.hostSite.p);   // [n] posterior rate | [n] norm | [n] rate class
+        hip(hipMemcpyAsync(hs, d.pr.p, sizeof(double) * n, hipMemcpyDeviceToHost, sd));
+        hip(hipMemcpyAsync(hs + sizeof(double) * n, d.norm.p, sizeof(double) * n, hipMemcpyDeviceToHost, sd));
+        hip(hipMemcpyAsync(hs + 2 * sizeof(double) * n, d.rc.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, sd));
+      }
+      hip(hipEventRecord(sideDone_[r], sd));
       if (computeNull) {
         const auto s = replicateShard(r, N, nbRepCPU);
         ensure(d.send, sizeof(double) * 2 * mx);
@@ -251,13 +288,22 @@ class BasicMultiGpu {
       const Engine& e = *engines_[r];
       hip(hipSetDevice(devices_[r]));
       hipStream_t st = streams_[r];
+      hip(hipStreamWaitEvent(st, sideDone_[r], 0));   // the observed alignment's vectors (and kept Gram blocks) are there
       if (computeNull) reassembleNull(d.recv.template as<double>(), d.nstat.template as<double>(), d.nnmin.template as<double>(), N, nbRepCPU, nbRepRAM, mx, st);
-      e.check(cmx_intra_rows_range_dev(e.ctx(), statistic.kind(), statistic.params(), d.counts.template as<double>(), n, n,
-                                       d.rc.template as<int32_t>(), d.pr.template as<double>(), d.norm.template as<double>(),
-                                       computeNull ? d.nstat.template as<double>() : nullptr, computeNull ? d.nnmin.template as<double>() : nullptr,
-                                       nnull_, (int)nbRateClasses, &pf, d.rowBegin, d.rowEnd, d.rows.template as<cmx_pair_row>(), d.cap,
-                                       d.count.template as<uint64_t>(), st));
-      hip(hipMemcpyAsync(d.hostCount, d.count.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      if (d.compact)
+        e.check(cmx_intra_compact_range_dev(e.ctx(), statistic.kind(), statistic.params(), d.counts.template as<double>(), n, n,
+                                            d.norm.template as<double>(), computeNull ? d.nstat.template as<double>() : nullptr,
+                                            computeNull ? d.nnmin.template as<double>() : nullptr, nnull_, (int)nbRateClasses, d.rowBegin,
+                                            d.rowEnd, d.rows.template as<cmx_pair_compact>(), d.cap, st));
+      else {
+        e.check(cmx_intra_rows_range_dev(e.ctx(), statistic.kind(), statistic.params(), d.counts.template as<double>(), n, n,
+                                         d.rc.template as<int32_t>(), d.pr.template as<double>(), d.norm.template as<double>(),
+                                         computeNull ? d.nstat.template as<double>() : nullptr, computeNull ? d.nnmin.template as<double>() : nullptr,
+                                         nnull_, (int)nbRateClasses, &pf, d.rowBegin, d.rowEnd, d.rows.template as<cmx_pair_row>(), d.cap,
+                                         d.count.template as<uint64_t>(), st));
+        hip(hipMemcpyAsync(d.hostCount, d.count.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      }
+      d.nSites = n;
       d.fetched = false;
     }
   }
@@ -278,6 +324,7 @@ class BasicMultiGpu {
   void synchronize() {
     for (size_t r = 0; r < size(); ++r) {
       hip(hipSetDevice(devices_[r]));
+      hip(hipStreamSynchronize(side_[r]));
       hip(hipStreamSynchronize(streams_[r]));
     }
   }
@@ -288,6 +335,7 @@ class BasicMultiGpu {
     hip(hipSetDevice(devices_[r]));
     hip(hipStreamSynchronize(streams_[r]));
     const Dev& d = dv_[r];
+    if (d.compact) throw Exception("MultiGpu::deviceRows: the devices hold 16-byte records (enableCompactTransfer), not rows.");
     return {d.rows.template as<cmx_pair_row>(), (size_t)std::min<uint64_t>(*d.hostCount, d.cap), d.rowBegin, d.rowEnd};
   }
   const double* deviceNullStat(size_t r) const { return dv_[r].nstat.template as<double>(); }   // merged null, replicate order, [nnull]
@@ -310,19 +358,39 @@ class BasicMultiGpu {
       Dev& d = dv_[r];
       hip(hipSetDevice(devices_[r]));
       hip(hipStreamSynchronize(streams_[r]));   // ranks run concurrently: while this one is waited for the others proceed
-      const size_t cnt = (size_t)std::min<uint64_t>(*d.hostCount, d.cap);
-      if (d.hostRows.bytes < sizeof(cmx_pair_row) * cnt) {
+      const size_t cnt = d.compact ? d.cap : (size_t)std::min<uint64_t>(*d.hostCount, d.cap);   // (records mode: every pair)
+      const size_t each = d.compact ? sizeof(cmx_pair_compact) : sizeof(cmx_pair_row);
+      if (d.hostRows.bytes < each * cnt) {
         if (d.hostRows.p) hip(hipHostFree(d.hostRows.p));
         d.hostRows.p = nullptr;
-        hip(hipHostMalloc(&d.hostRows.p, sizeof(cmx_pair_row) * cnt, hipHostMallocDefault));
-        d.hostRows.bytes = sizeof(cmx_pair_row) * cnt;
+        hip(hipHostMalloc(&d.hostRows.p, each * cnt, hipHostMallocDefault));
+        d.hostRows.bytes = each * cnt;
       }
-      if (cnt && !d.fetched) hip(hipMemcpyAsync(d.hostRows.p, d.rows.p, sizeof(cmx_pair_row) * cnt, hipMemcpyDeviceToHost, streams_[r]));
-      d.fetched = true;
+      if (cnt && !d.fetched) hip(hipMemcpyAsync(d.hostRows.p, d.rows.p, each * cnt, hipMemcpyDeviceToHost, streams_[r]));
       host_.rows[r] = static_cast<const cmx_pair_row*>(d.hostRows.p);
       host_.count[r] = cnt;
     }
     synchronize();
+    // records mode: the 48-byte rows rebuilt from the records and the per-site arrays (host threads, no GPU)
+    for (size_t r = 0; r < N; ++r) {
+      Dev& d = dv_[r];
+      if (d.compact && !d.fetched && host_.count[r]) {
+        if (d.expandedCap < host_.count[r]) {
+          d.expanded.reset(new cmx_pair_row[host_.count[r]]);
+          d.expandedCap = host_.count[r];
+        }
+        const char* hs = static_cast<const char*>(d.hostSite.p);
+        const size_t n = d.nSites;
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt == 0 ? 1u : (nt > 16 ? 16u : nt);
+        const cmx_status st = cmx_expand_compact_rows(n, d.rowBegin, d.rowEnd, reinterpret_cast<const int32_t*>(hs + 2 * sizeof(double) * n),
+                                                      reinterpret_cast<const double*>(hs), reinterpret_cast<const double*>(hs + sizeof(double) * n),
+                                                      static_cast<const cmx_pair_compact*>(d.hostRows.p), host_.count[r], d.expanded.get(), (int)nt);
+        if (st != CMX_OK) throw Exception("MultiGpu::fetchRows: cmx_expand_compact_rows failed.");
+      }
+      if (d.compact) host_.rows[r] = d.expanded.get();
+      d.fetched = true;
+    }
     return host_;
   }
 
@@ -332,7 +400,15 @@ class BasicMultiGpu {
                                               const Statistic& statistic, bool computeNull, uint64_t seed, size_t nbRepCPU = 100,
                                               size_t nbRepRAM = 1000, size_t nbRateClasses = 10, const PairFilters& f = PairFilters(),
                                               std::vector<NullDistributionRow>* nullRows = nullptr) {
-    enqueueIntraStats(aln, nbSites, masks, nbMasks, statistic, computeNull, seed, nbRepCPU, nbRepRAM, nbRateClasses, f);
+    const bool was = compactWanted_;
+    compactWanted_ = true;   // only host rows are asked for here
+    try {
+      enqueueIntraStats(aln, nbSites, masks, nbMasks, statistic, computeNull, seed, nbRepCPU, nbRepRAM, nbRateClasses, f);
+    } catch (...) {
+      compactWanted_ = was;
+      throw;
+    }
+    compactWanted_ = was;
     const HostRows& h = fetchRows();
     std::vector<IntraStatRow> rows(h.total());
     size_t k = 0;
@@ -363,10 +439,13 @@ class BasicMultiGpu {
   };
   struct Dev {
     Buf aln, masks, counts, pr, norm, rc, send, recv, nstat, nnmin, rows, count;
-    Buf hostRows;                 // pinned
+    Buf hostRows;                 // pinned: the rows, or (records mode) the 16-byte records
+    Buf hostSite;                 // pinned, records mode: posterior rate | norm | rate class of every site
+    std::unique_ptr<cmx_pair_row[]> expanded;   // records mode: the rows rebuilt on the host
+    size_t expandedCap = 0, nSites = 0;
     uint64_t* hostCount = nullptr;   // pinned
     size_t cap = 0, rowBegin = 0, rowEnd = 0;
-    bool fetched = false;
+    bool fetched = false, compact = false;
     std::vector<Buf*> all() { return {&aln, &masks, &counts, &pr, &norm, &rc, &send, &recv, &nstat, &nnmin, &rows, &count}; }
   };
   static void ensure(Buf& b, size_t bytes) {   // the current device is the rank's
@@ -378,7 +457,9 @@ class BasicMultiGpu {
   }
   std::vector<int> devices_;
   std::vector<std::unique_ptr<Engine>> engines_;
-  std::vector<hipStream_t> streams_;
+  std::vector<hipStream_t> streams_, side_;
+  std::vector<hipEvent_t> sideDone_;
+  bool compactWanted_ = false;
   std::vector<Dev> dv_;
   Exchange exchange_;
   Buf hostAln_;

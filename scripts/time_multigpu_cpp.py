@@ -36,5 +36,8 @@ if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
                            src, "-o", exe, "-L", os.path.dirname(E.LIB_PATH), "-lcomap_mi355x", "-L", "/opt/rocm/lib", "-lrccl", "-lamdhip64",
                            "-Wl,-rpath," + os.path.dirname(E.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
-for args in (["1", str(reps)], ["2", str(reps), "loopback"]):
-    print(subprocess.check_output([exe, "time", path] + args, text=True).strip(), flush=True)
+for records in (False, True):   # rows written by the devices / 16-byte records + rows rebuilt on the host (enableCompactTransfer)
+    env = dict(os.environ, **({"CMX_MG_RECORDS": "1"} if records else {}))
+    env.pop("CMX_MG_RECORDS", None) if not records else None
+    for args in (["1", str(reps)], ["2", str(reps), "loopback"]):
+        print(("records " if records else "rows    ") + subprocess.check_output([exe, "time", path] + args, text=True, env=env).strip(), flush=True)

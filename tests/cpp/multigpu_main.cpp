@@ -105,8 +105,9 @@ int main(int argc, char** argv) {
           std::printf("{\"ranks\": %d, \"exchange\": \"%s\", \"ms_per_step_mean\": %.3f, \"ms_per_step_best\": %.3f, \"pairs_per_s\": %.4e}\n", nranks,
                       loop ? "loopback" : "rccl", sum / reps, best, pairs / (sum / reps * 1e-3));
         };
-        if (loop) { cmx::LoopbackMultiGpu mg(t, m, std::vector<int>(nranks, 0)); run(mg); }
-        else { std::vector<int> dv(nranks); for (int d = 0; d < nranks; ++d) dv[d] = d; cmx::MultiGpu mg(t, m, dv); run(mg); }
+        const bool records = std::getenv("CMX_MG_RECORDS") != nullptr;   // 16-byte records over PCIe, rows rebuilt on the host
+        if (loop) { cmx::LoopbackMultiGpu mg(t, m, std::vector<int>(nranks, 0)); mg.enableCompactTransfer(records); run(mg); }
+        else { std::vector<int> dv(nranks); for (int d = 0; d < nranks; ++d) dv[d] = d; cmx::MultiGpu mg(t, m, dv); mg.enableCompactTransfer(records); run(mg); }
         return 0;
       }
       const int nranks = std::atoi(argv[4]);
@@ -119,8 +120,26 @@ int main(int argc, char** argv) {
         if (first[q].i != rows[q].i || first[q].j != rows[q].j || std::memcmp(&first[q].stat, &rows[q].stat, 8) || first[q].nSim != rows[q].nSim ||
             std::memcmp(&first[q].pValue, &rows[q].pValue, 8))
           throw cmx::Exception("second call on the warm arena differs from the first");
-      // rows left on the devices == rows fetched home; every rank holds the same merged null
+      // (computeIntraStats asks for host rows only: the devices wrote 16-byte records and the host rebuilt the rows.)  The same
+      // analysis in rows mode: rows left on the devices == rows fetched home == the rows rebuilt from the records; every rank
+      // holds the same merged null
+      bool threw = false;
+      try { (void)mg.deviceRows(0); } catch (const cmx::Exception&) { threw = true; }
+      if (!threw) throw cmx::Exception("deviceRows in records mode did not throw");
+      mg.enqueueIntraStats(aln.data(), N, nullptr, 0, stat, true, seed, h[5], h[6], h[7]);
       const auto& hr = mg.fetchRows();
+      {
+        size_t k = 0;
+        for (int r = 0; r < nranks; ++r)
+          for (size_t q = 0; q < hr.count[r]; ++q, ++k) {
+            const cmx_pair_row& a = hr.rows[r][q];
+            if (k >= rows.size() || static_cast<size_t>(a.i) != rows[k].i || static_cast<size_t>(a.j) != rows[k].j || std::memcmp(&a.stat, &rows[k].stat, 8) ||
+                std::memcmp(&a.pvalue, &rows[k].pValue, 8) || a.nsim != rows[k].nSim || a.rc_min != rows[k].rcMin ||
+                std::memcmp(&a.pr_min, &rows[k].prMin, 8) || std::memcmp(&a.n_min, &rows[k].nMin, 8))
+              throw cmx::Exception("rows mode differs from records mode");
+          }
+        if (k != rows.size()) throw cmx::Exception("rows mode: row count differs from records mode");
+      }
       std::vector<double> n0(nul.size()), nr(nul.size());
       for (int r = 0; r < nranks; ++r) {
         const auto d = mg.deviceRows(r);
