@@ -332,3 +332,29 @@ def test_rows_of_tiny_alignments_and_tiny_nulls(n):
                 assert np.isnan(rows["pvalue"]).all() and (rows["nsim"] == 0).all()
         none, cnt0 = eng.intra_rows(0, r["counts"], r["rate_class"], r["post_rate"], r["norm"], capacity=0)
         assert cnt0 == cnt and len(none) == 0
+
+
+def test_kept_gram_blocks_over_several_row_blocks_at_7000_sites():
+    """cmx_intra_gram_prefetch_dev with more than one row block of the pair loop (256 MiB / 8 n = 4 736 rows at 7 000 sites:
+    two blocks for the whole triangle, and a row range that starts inside the first and ends inside the second): the record
+    pass over the kept blocks writes the bytes of the pass that computes its own."""
+    import torch
+    from comap_amd.pipeline import IntraAnalysis, sum_pairs
+    parent, blen, lot = sy.random_tree(24, 77)
+    mdl = sy.dna_model(0.5, 4)
+    eng = engine.Engine(parent, blen, lot, mdl["Q"], mdl["pi"], mdl["rates"], mdl["probs"])
+    n = 7000
+    aln, _ = eng.simulate(5, 0, n)
+    d_aln = torch.from_numpy(aln).cuda()
+    ana = IntraAnalysis(eng, d_aln, engine.STAT_CORRELATION, 8)
+    ana.get_vectors()
+    nb = ana.null_distribution(3, 0, 20, 500)
+    for rb, re_ in ((0, n), (3000, 6500)):
+        rec, npairs = ana.compute_intra_compact(nb["stat"], nb["nmin"], rb, re_)
+        assert npairs == sum_pairs(n, rb, re_)
+        own = rec[:npairs * engine.PAIR_COMPACT.itemsize].clone()
+        ana.prefetch_intra_gram(rb, re_)
+        rec, _ = ana.compute_intra_compact(nb["stat"], nb["nmin"], rb, re_)
+        assert torch.equal(rec[:npairs * engine.PAIR_COMPACT.itemsize], own)
+        h = own[:16 * 1000].cpu().numpy().view(engine.PAIR_COMPACT)
+        assert np.isfinite(h["stat"]).all() and (h["below"] != 0xffffffff).any()
