@@ -340,12 +340,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 8 ? 1 
     }
     // The operands of the next tile, two ways.  Plain instantiation: into registers (sixteen of them, held from behind the
     // first half of one tile to the first half of the next, where they are stored to the other operand buffer four
-    // registers every fourth step).  Weighted instantiation, which has no registers to spare (it spilled): global -> LDS
-    // without passing through registers (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, the image's order),
-    // requested in front of the first half, waited for behind it (vmcnt(0)).  The DMA costs the issuing wave more than the
-    // register load (measured with both instantiations on either: plain 2.95 -> 3.26 ms), hence not for both.  Inline asm
-    // for the reason given in cmx_kernels.hip: a DMA the compiler knows of makes it wait for every outstanding load before
-    // the next LDS read.
+    // registers every fourth step).  Weighted instantiation: global -> LDS without passing through registers
+    // (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, the image's order), requested in front of the first
+    // half, waited for in front of the next barrier (vmcnt(0)).  Each on the other's road is slower, measured same box: the
+    // plain one on DMA 2.95 -> 3.26 ms (the DMA costs the issuing wave more than a register load), the weighted one on
+    // registers 4.48 -> 4.75 ms (256 registers, 12 spilled).  Inline asm for the reason given in cmx_kernels.hip: a DMA the
+    // compiler knows of makes it wait for every outstanding load before the next LDS read.
     cmx_i4 braw[DMA ? 1 : SPT];
     double s2r = 0.0;
     unsigned j2r = 0;
